@@ -1,0 +1,190 @@
+/*
+ * ugs.h - C-ABI of the MI355X-native usearch_global / UCLUST search hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI;
+ * its seam is three C++ classes wired by a factory:
+ *
+ *   class Searcher        /root/reference/src/searcher.h:21-96   (Search(SeqInfo*))
+ *   class Aligner         /root/reference/src/aligner.h:23-115   (GlobalAligner::Align)
+ *   class HitMgr/HitSink  /root/reference/src/hitmgr.h:16-95, hitsink.h:30-62
+ *   MakeDBSearcher()      /root/reference/src/makedbsearcher.cpp:75-236
+ *
+ * The per-query, synchronous, pointer-chasing interface cannot feed a GPU, so the
+ * replacement sits at the same seam but is batched: plain C, caller-owned buffers,
+ * integer return codes (0 = ok, <0 = error; never exit()), no C++/torch types.
+ * One handle = one GPU = one HIP stream; a handle is used by one host thread at a
+ * time; handles on different GPUs are independent.
+ *
+ * There is NO CPU fallback behind this ABI: every entry point that computes needs a
+ * gfx950 device and fails with UGS_E_NODEVICE otherwise.
+ */
+#ifndef UGS_H
+#define UGS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGS_ABI_VERSION 1
+
+/* error codes */
+#define UGS_OK            0
+#define UGS_E_ARG        -1   /* bad argument / unsupported option value            */
+#define UGS_E_NODEVICE   -2   /* no usable gfx950 device (there is no CPU fallback)  */
+#define UGS_E_HIP        -3   /* HIP runtime error (see ugs_last_error)             */
+#define UGS_E_NOMEM      -4
+#define UGS_E_CAPACITY   -5   /* caller-provided output buffer too small             */
+#define UGS_E_ENVELOPE   -6   /* input outside the device path's supported envelope  */
+
+/*
+ * Snapshot of every option that reaches the hot path.  The reference
+ * reads these ad hoc deep in hot code (oget_*); here they are frozen once.
+ *   id            -id as the reference stores it for ranking: float  (udbusortedsearcher.cpp:101)
+ *   id_accept     -id as the accepter compares it: the option table stores floats
+ *                 (opts.cpp:265), so this is (double)(float)id       (accepter.cpp:35-39)
+ *   max_accepts / max_rejects                                         (terminator.cpp:8-45)
+ *   big           -big: DB size above which the "Big" ranker is used  (udbusortedsearcher.cpp:44)
+ *   bump_pct      -bump                                               (udbusortedsearcher.cpp:278)
+ *   stepwords     -stepwords                                          (wordparams.cpp:179-191)
+ *   band, minhsp, xdrop_nw, hsp_word_len                              (alnheuristics.cpp:26-62)
+ *   match, mismatch (nt) ; aa uses BLOSUM62                           (alnparams.cpp:333,380-384)
+ *   dbmask        0 = upper-case only, 1 = fastnucleo/fastamino       (makeudb.cpp:11-25)
+ */
+typedef struct ugs_params {
+  int32_t  is_nucleo;
+  int32_t  word_len;       /* UDB word length: 8 nt / 5 aa            */
+  float    id;
+  double   id_accept;
+  int32_t  id_set;         /* 0 = -id absent: no identity filter (accepter.cpp:35 tests ofilled) */
+  int32_t  strand_both;
+  int32_t  max_accepts;
+  int32_t  max_rejects;
+  uint32_t big;
+  uint32_t bump_pct;
+  uint32_t stepwords;
+  int32_t  band;
+  int32_t  minhsp;
+  float    xdrop_nw;
+  float    match;
+  float    mismatch;
+  int32_t  hsp_word_len;   /* 5 nt / 3 aa                              */
+  int32_t  dbmask;
+} ugs_params;
+
+/*
+ * One accepted hit == one AlignResult appended to HitMgr (hitmgr.cpp:161-183), with
+ * the fields AlignResult::FillLo derives from the path (arscorer.cpp:201-296).
+ * Coordinates are 0-based positions of the first/last aligned (M) column.
+ * The alignment path is run-length encoded in the cigar pool: one uint32 per run,
+ * (length << 2) | op with op 0=M 1=D 2=I, in alignment order INCLUDING terminal gaps
+ * (what CompressPath prints into .uc, comppath.cpp:7-48).
+ */
+typedef struct ugs_hit {
+  uint32_t query;        /* index into the batch                           */
+  uint32_t target;       /* DB sequence index (uc column 2)                */
+  uint32_t ids;          /* m_IdCount                                      */
+  uint32_t mism;         /* m_MismatchCount                                */
+  uint32_t gaps_int;     /* m_IntGapCount (gap columns between first/last M) */
+  uint32_t aln_len;      /* m_AlnLength  (terminal gaps excluded)          */
+  uint32_t opens;        /* GetGapOpenCount (arscorer.cpp:554-569)         */
+  uint32_t qlo, qhi, tlo, thi;
+  uint32_t ql, tl;       /* sequence lengths                               */
+  uint32_t strand;       /* 0 = plus, 1 = query reverse-complemented       */
+  uint64_t cigar_off;    /* into the cigar pool, in uint32 units           */
+  uint32_t cigar_len;    /* number of runs                                 */
+  uint32_t cols;         /* total path columns incl. terminal gaps         */
+} ugs_hit;
+
+typedef struct ugs_db ugs_db;       /* opaque: masked DB + UDB index resident in HBM */
+typedef struct ugs_batch ugs_batch; /* opaque: one query batch resident in HBM       */
+
+/* Fill *p with the reference defaults for usearch_global (o_defaults.inc, terminator.cpp:26-31). */
+int ugs_params_init(ugs_params *p, int is_nucleo, double id);
+
+int ugs_abi_version(void);
+int ugs_device_count(void);
+
+/*
+ * Replaces LoadUDB + UDBData::FromSeqDB (loaddb.cpp:100-125, udbbuild.cpp:303-398):
+ * `seqs` are the raw DB letters (as read from FASTA, concatenated, no terminators),
+ * offs[nseq+1] their boundaries.  Masking (fastmask.cpp:88-158) and the word index are
+ * built here and stay resident on `device`.
+ */
+int ugs_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs,
+                  uint32_t nseq, int device, ugs_db **out);
+void ugs_db_destroy(ugs_db *db);
+/* introspection used by tests/bench: number of index postings, slots, bytes in HBM */
+int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint64_t *hbm_bytes);
+
+/*
+ * Replaces the Thread() loop calling Searcher::Search per query (search.cpp:51-87,
+ * searcher.cpp:122-161): search a whole batch; hits come back grouped by query in
+ * query order, each group sorted as HitMgr::Sort orders them (hitmgr.cpp:477-483).
+ * nhits_per_query[nq] receives the group sizes.  Returns UGS_E_CAPACITY if hits_cap or
+ * cigar_cap (uint32 units) is too small (hits_cap = nq * max_accepts * (1+strand_both)
+ * always suffices).
+ */
+int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
+                     ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                     uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used);
+
+/*
+ * Staged form of the same call, for callers that keep batches resident in HBM
+ * (bench.py times ugs_batch_search + ugs_batch_sync only):
+ *   upload  = H2D of letters/offsets
+ *   search  = enqueue the ranking + alignment kernels on the handle's stream
+ *   sync    = wait for the stream
+ *   fetch   = D2H of hit records + cigar runs, grouped/sorted as ugs_search_batch
+ */
+int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_letters, ugs_batch **out);
+void ugs_batch_destroy(ugs_batch *b);
+int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t *qoffs, uint32_t nq);
+int ugs_batch_search(ugs_batch *b);
+int ugs_batch_sync(ugs_batch *b);
+int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                    uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used);
+/*
+ * Per-stage device time of the last ugs_batch_search (HIP events on the handle's own
+ * stream), and the algorithmic work it did: postings the reference
+ * semantics requires reading, letters of query + aligned candidates, DP cells.
+ */
+typedef struct ugs_batch_stats {
+  float    ms_rank;          /* ranking kernel(s)                         */
+  float    ms_align;         /* alignment kernel                          */
+  float    ms_total;
+  uint64_t postings;         /* sum over queries of P(q)                  */
+  uint64_t query_letters;
+  uint64_t target_letters;   /* letters of candidates actually aligned    */
+  uint64_t pairs_aligned;
+  uint64_t dp_cells;
+  uint64_t hits;
+} ugs_batch_stats;
+int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st);
+
+/*
+ * Stage-level entry point used by the parity tests: the ranked candidate list of every
+ * query exactly as the reference's candidate loop would walk it
+ * (udbusortedsearcherbig.cpp:113-134 / udbusortedsearcher.cpp:138-151), truncated to
+ * the first k = max_accepts + max_rejects - 1 entries per strand.
+ * cand[(q*nstrand + s)*k + j] = target index, cnt[...] = word count, n[q*nstrand+s] = entries.
+ */
+int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap);
+
+/*
+ * Text writers replacing OutputSink::OutputBlast6 / OutputUC / OutputUCNoHits
+ * (blast6out.cpp:27-80, outputuc.cpp:10-93).  Write at most cap bytes (incl. NUL) of one
+ * line (with trailing '\n') into buf; return the length that was / would be written.
+ */
+int ugs_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
+int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
+                      const char *qlabel, const char *tlabel, char *buf, int cap);
+int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
+
+const char *ugs_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGS_H */

@@ -1,0 +1,1379 @@
+/*
+ * ugs_oracle.c - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's usearch_global hot path.
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).  Scores are float like the reference (all reachable values are
+ * exact half-integers).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use this file; the product (usearch12_amd/) never does.
+ *
+ * Pinned against the compiled unmodified reference (oracle/_ref/usearch12) through the
+ * golden fixtures in tests/golden/ (tests/test_oracle_golden.py).
+ */
+#include "ugs_oracle.h"
+
+#include <ctype.h>
+#include <limits.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned char byte;
+
+#define INVALID_LETTER 0xffu
+#define BAD_WORD 0xffffffffu
+#define MINUS_INFINITY (-9e9f)          /* mx.h:12 */
+#define MAXREPS 8                       /* hspfinder.h:10 */
+#define TB_DM 0x01                      /* tracebit.h:4-7 */
+#define TB_IM 0x02
+#define TB_MD 0x04
+#define TB_MI 0x08
+
+/* ------------------------------------------------------------------ tables */
+
+static byte g_c2l_nt[256], g_c2l_aa[256];
+static byte g_match_nt[256][256], g_match_aa[256][256];
+static float g_subst_nt_default[256][256];
+static float g_subst_aa[256][256];
+static byte g_comp[256];
+static int g_tables_done = 0;
+static pthread_mutex_t g_tables_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* BLOSUM62, NCBI 1/2-bit units, standard order; values as blosum62.cpp:22-49 holds them */
+static const char B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX*";
+static const signed char B62[24][24] = {
+  { 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0,-2,-1, 0,-4},
+  {-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3,-1, 0,-1,-4},
+  {-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3, 3, 0,-1,-4},
+  {-2,-2, 1, 6,-3, 0, 2,-1,-1,-3,-4,-1,-3,-3,-1, 0,-1,-4,-3,-3, 4, 1,-1,-4},
+  { 0,-3,-3,-3, 9,-3,-4,-3,-3,-1,-1,-3,-1,-2,-3,-1,-1,-2,-2,-1,-3,-3,-2,-4},
+  {-1, 1, 0, 0,-3, 5, 2,-2, 0,-3,-2, 1, 0,-3,-1, 0,-1,-2,-1,-2, 0, 3,-1,-4},
+  {-1, 0, 0, 2,-4, 2, 5,-2, 0,-3,-3, 1,-2,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1,-4},
+  { 0,-2, 0,-1,-3,-2,-2, 6,-2,-4,-4,-2,-3,-3,-2, 0,-2,-2,-3,-3,-1,-2,-1,-4},
+  {-2, 0, 1,-1,-3, 0, 0,-2, 8,-3,-3,-1,-2,-1,-2,-1,-2,-2, 2,-3, 0, 0,-1,-4},
+  {-1,-3,-3,-3,-1,-3,-3,-4,-3, 4, 2,-3, 1, 0,-3,-2,-1,-3,-1, 3,-3,-3,-1,-4},
+  {-1,-2,-3,-4,-1,-2,-3,-4,-3, 2, 4,-2, 2, 0,-3,-2,-1,-2,-1, 1,-4,-3,-1,-4},
+  {-1, 2, 0,-1,-3, 1, 1,-2,-1,-3,-2, 5,-1,-3,-1, 0,-1,-3,-2,-2, 0, 1,-1,-4},
+  {-1,-1,-2,-3,-1, 0,-2,-3,-2, 1, 2,-1, 5, 0,-2,-1,-1,-1,-1, 1,-3,-1,-1,-4},
+  {-2,-3,-3,-3,-2,-3,-3,-3,-1, 0, 0,-3, 0, 6,-4,-2,-2, 1, 3,-1,-3,-3,-1,-4},
+  {-1,-2,-2,-1,-3,-1,-1,-2,-2,-3,-3,-1,-2,-4, 7,-1,-1,-4,-3,-2,-2,-1,-2,-4},
+  { 1,-1, 1, 0,-1, 0, 0, 0,-1,-2,-2, 0,-1,-2,-1, 4, 1,-3,-2,-2, 0, 0, 0,-4},
+  { 0,-1, 0,-1,-1,-1,-1,-2,-2,-1,-1,-1,-1,-2,-1, 1, 5,-2,-2, 0,-1,-1, 0,-4},
+  {-3,-3,-4,-4,-2,-2,-3,-2,-2,-3,-2,-3,-1, 1,-4,-3,-2,11, 2,-3,-4,-3,-2,-4},
+  {-2,-2,-2,-3,-2,-1,-2,-3, 2,-1,-1,-2,-1, 3,-3,-2,-2, 2, 7,-1,-3,-2,-1,-4},
+  { 0,-3,-3,-3,-1,-2,-2,-3,-3, 3, 1,-2, 1,-1,-2,-2, 0,-3,-1, 4,-3,-2,-1,-4},
+  {-2,-1, 3, 4,-3, 0, 1,-1, 0,-3,-4, 0,-3,-3,-2, 0,-1,-4,-3,-3, 4, 1,-1,-4},
+  {-1, 0, 0, 1,-3, 3, 4,-2, 0,-3,-3, 1,-1,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1,-4},
+  { 0,-1,-1,-1,-2,-1,-1,-1,-1,-1,-1,-1,-1,-1,-2, 0, 0,-2,-1,-1,-1,-1,-1,-4},
+  {-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4, 1},
+};
+
+/* setnucmx.cpp:11-99: ACGTU (either case) score match/mismatch by letter identity
+ * (T==U); every other byte scores 0 (the N loop writes zeros; the '?' loop is a no-op) */
+static void fill_subst_nt(float mx[256][256], float match, float mismatch)
+{
+  static const char alpha[] = "ACGTU";
+  memset(mx, 0, sizeof(float) * 256 * 256);
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      float v = (g_c2l_nt[(byte)alpha[i]] == g_c2l_nt[(byte)alpha[j]]) ? match : mismatch;
+      byte ui = (byte)alpha[i], uj = (byte)alpha[j];
+      byte li = (byte)tolower(ui), lj = (byte)tolower(uj);
+      mx[ui][uj] = v; mx[ui][lj] = v; mx[li][uj] = v; mx[li][lj] = v;
+    }
+}
+
+static void init_tables(void)
+{
+  pthread_mutex_lock(&g_tables_lock);
+  if (g_tables_done) { pthread_mutex_unlock(&g_tables_lock); return; }
+
+  /* alpha.cpp:529-790, 1309-1567 */
+  memset(g_c2l_nt, 0xff, 256);
+  memset(g_c2l_aa, 0xff, 256);
+  g_c2l_nt['A'] = g_c2l_nt['a'] = 0; g_c2l_nt['C'] = g_c2l_nt['c'] = 1;
+  g_c2l_nt['G'] = g_c2l_nt['g'] = 2; g_c2l_nt['T'] = g_c2l_nt['t'] = 3;
+  g_c2l_nt['U'] = g_c2l_nt['u'] = 3;
+  {
+    static const char aa[] = "ACDEFGHIKLMNPQRSTVWY";
+    for (int i = 0; i < 20; ++i) {
+      g_c2l_aa[(byte)aa[i]] = (byte)i;
+      g_c2l_aa[(byte)tolower(aa[i])] = (byte)i;
+    }
+  }
+
+  /* alpha2.cpp:54-69 (IUPAC codes), :90-150 (bits) */
+  byte nucbit[256], iupac[256];
+  memset(nucbit, 0, 256); memset(iupac, 0, 256);
+  nucbit['A'] = nucbit['a'] = 1; nucbit['C'] = nucbit['c'] = 2;
+  nucbit['G'] = nucbit['g'] = 4; nucbit['T'] = nucbit['t'] = 8; nucbit['U'] = nucbit['u'] = 8;
+  for (int c = 0; c < 256; ++c) iupac[c] = nucbit[c];
+  {
+    static const struct { char code; const char *chars; } codes[] = {
+      {'M', "AC"}, {'R', "AG"}, {'W', "AT"}, {'S', "CG"}, {'Y', "CT"}, {'K', "GT"},
+      {'V', "ACG"}, {'H', "ACT"}, {'D', "AGT"}, {'B', "CGT"}, {'X', "GATC"}, {'N', "GATC"}};
+    for (unsigned k = 0; k < sizeof(codes) / sizeof(codes[0]); ++k) {
+      byte bits = 0;
+      for (const char *p = codes[k].chars; *p; ++p) bits |= nucbit[(byte)*p];
+      iupac[(byte)codes[k].code] = bits;
+      iupac[(byte)tolower(codes[k].code)] = bits;
+    }
+  }
+
+  /* alpha2.cpp:220-300 Init_MatchMxs */
+  for (int i = 0; i < 256; ++i)
+    for (int j = 0; j < 256; ++j) {
+      int ai = isalpha(i) != 0, aj = isalpha(j) != 0;
+      if (!ai || !aj) {
+        int gi = (i == '-' || i == '.'), gj = (j == '-' || j == '.');
+        g_match_nt[i][j] = g_match_aa[i][j] = (byte)(gi && gj);
+        continue;
+      }
+      if (toupper(i) == toupper(j)) { g_match_nt[i][j] = g_match_aa[i][j] = 1; continue; }
+      g_match_aa[i][j] = (byte)(toupper(i) == 'X' || toupper(j) == 'X');
+      int eqij = (nucbit[i] & iupac[j]) != 0;
+      int eqji = (nucbit[j] & iupac[i]) != 0;
+      g_match_nt[i][j] = (byte)(eqij || eqji);
+    }
+  g_match_aa['B']['N'] = g_match_aa['N']['B'] = 1;
+  g_match_aa['B']['D'] = g_match_aa['D']['B'] = 1;
+  g_match_aa['Z']['Q'] = g_match_aa['Q']['Z'] = 1;
+  g_match_aa['Z']['E'] = g_match_aa['E']['Z'] = 1;
+
+  fill_subst_nt(g_subst_nt_default, 1.0f, -2.0f);
+
+  /* blosum62.cpp:51-84: both cases of the 24 symbols, everything else 0 */
+  memset(g_subst_aa, 0, sizeof(g_subst_aa));
+  for (int i = 0; i < 24; ++i)
+    for (int j = 0; j < 24; ++j) {
+      float v = (float)B62[i][j];
+      byte ui = (byte)B62_ORDER[i], uj = (byte)B62_ORDER[j];
+      byte li = (byte)tolower(ui), lj = (byte)tolower(uj);
+      g_subst_aa[ui][uj] = v; g_subst_aa[ui][lj] = v; g_subst_aa[li][uj] = v; g_subst_aa[li][lj] = v;
+    }
+
+  /* alpha.cpp:3005-3265 g_CharToCompChar: '?' (= keep the char) for anything unlisted;
+   * note lower-case 'u' is NOT listed */
+  memset(g_comp, '?', 256);
+  {
+    static const char from[] = "ABCDGHKMNRSTUVWXY";
+    static const char to[]   = "TVGHCDMKNYSAABWXR";
+    for (int k = 0; from[k]; ++k) {
+      g_comp[(byte)from[k]] = (byte)to[k];
+      if (from[k] != 'U') g_comp[(byte)tolower(from[k])] = (byte)tolower(to[k]);
+    }
+  }
+  g_tables_done = 1;
+  pthread_mutex_unlock(&g_tables_lock);
+}
+
+/* ------------------------------------------------------------------ params */
+
+void orc_params_init(ugs_params *p, int is_nucleo, double id)
+{
+  memset(p, 0, sizeof(*p));
+  p->is_nucleo = is_nucleo;
+  p->word_len = is_nucleo ? 8 : 5;           /* udbparams.cpp:235-261 */
+  p->id = (float)id;
+  p->id_accept = (double)(float)id;      /* options are stored as float: opts.cpp:265 */
+  p->id_set = 1;
+  p->strand_both = 0;
+  p->max_accepts = 1;                        /* terminator.cpp:26-31 */
+  p->max_rejects = 32;
+  p->big = 100000;                           /* o_defaults.inc */
+  p->bump_pct = 50;
+  p->stepwords = 8;
+  p->band = 16;
+  p->minhsp = 16;
+  p->xdrop_nw = 8.0f;
+  p->match = 1.0f;
+  p->mismatch = -2.0f;
+  p->hsp_word_len = is_nucleo ? 5 : 3;       /* alnheuristics.cpp:36,44 */
+  p->dbmask = 1;
+}
+
+/* ------------------------------------------------------------------ db */
+
+typedef struct {
+  unsigned Loi, Loj, Len;
+  float Score;
+} HSP;
+
+typedef struct {
+  /* gap penalties, alnparams.h */
+  float OpenA, OpenB, ExtA, ExtB, LOpenA, LOpenB, LExtA, LExtB, ROpenA, ROpenB, RExtA, RExtB;
+} AlnPen;
+
+struct orc_db {
+  ugs_params p;
+  uint32_t nseq;
+  char *seqs;           /* masked copy */
+  uint64_t *offs;
+  uint32_t alpha;       /* 4 / 20 */
+  uint64_t slots;
+  uint64_t *row_off;    /* slots+1 */
+  uint32_t *postings;
+  const byte *c2l;
+  float (*subst)[256];
+  float subst_nt_custom[256][256];
+  const byte (*match)[256];
+  AlnPen ap;            /* alnparams.cpp:380-384 */
+  /* alnheuristics.cpp:26-62 */
+  float MinGlobalHSPFractId, MinGlobalHSPScore, XDropGlobalHSP;
+  unsigned MinGlobalHSPLength, BandRadius, HSPw, HSPWordCount;
+  int big;              /* udbusortedsearcher.cpp:39-58 latch (DB is static here) */
+  orc_stats stats;
+  uint32_t maxlen;
+};
+
+/* fastmask.cpp:88-158 FastMaskSeq, soft mask (hardmask off), in place */
+void orc_fastmask(char *seq_, uint32_t L)
+{
+  byte *Seq = (byte *)seq_;
+  for (unsigned i = 0; i < L; ++i) Seq[i] = (byte)toupper(Seq[i]);
+  if (L < 2) return;
+  const unsigned k1 = 5, j1 = 2, k2 = 5, j2 = 1;
+  byte Lastc = '?';
+  unsigned Start = UINT_MAX;
+  for (unsigned i = 0; i < L; ++i) {
+    byte c = (byte)toupper(Seq[i]);
+    if (c != Lastc || i + 1 == L) {
+      unsigned n1 = i - Start;               /* unsigned wrap with Start==UINT_MAX intended */
+      if (n1 >= k1)
+        for (unsigned j = Start + j1; j < i; ++j) Seq[j] = (byte)tolower(Seq[j]);
+      Start = i;
+    }
+    Lastc = c;
+  }
+  for (unsigned StartPos = 0; StartPos <= 1; ++StartPos) {
+    unsigned LastPair = UINT_MAX;
+    unsigned Start2 = UINT_MAX;
+    for (unsigned i = StartPos; i < L - 1; i += 2) {
+      byte c1 = (byte)toupper(Seq[i]), c2 = (byte)toupper(Seq[i + 1]);
+      unsigned Pair = ((unsigned)c1 << 8) + c2;
+      if (Pair != LastPair) {
+        unsigned n2 = i - Start2;
+        if (n2 >= k2)
+          for (unsigned j = Start2 + 2 * j2; j < i; ++j) Seq[j] = (byte)tolower(Seq[j]);
+        Start2 = i;
+      }
+      LastPair = Pair;
+    }
+  }
+}
+
+/* seqinfo.cpp:292-323 */
+void orc_revcomp(const char *seq, uint32_t len, char *out)
+{
+  init_tables();
+  for (uint32_t i = 0; i < len; ++i) {
+    byte c = (byte)seq[i];
+    byte rc = g_comp[c];
+    if (rc == '?') rc = c;
+    out[len - i - 1] = (char)rc;
+  }
+}
+
+/* udbparams.cpp:540-555 SeqToWordNoPattern */
+static inline uint32_t seq_to_word(const orc_db *db, const byte *s)
+{
+  uint32_t w = 0;
+  for (int i = 0; i < db->p.word_len; ++i) {
+    byte c = s[i];
+    if (c >= 'a' && c <= 'z') return BAD_WORD;   /* islower, C locale */
+    unsigned l = db->c2l[c];
+    if (l == INVALID_LETTER) return BAD_WORD;
+    w = w * db->alpha + l;
+  }
+  return w;
+}
+
+/* udbbuild.cpp:303-398 FromSeqDB + :256-284 AddSeqNoncoded: each target once per
+ * distinct valid word, rows ascending by target index */
+static int build_index(orc_db *db)
+{
+  uint64_t slots = 1;
+  for (int i = 0; i < db->p.word_len; ++i) slots *= db->alpha;
+  db->slots = slots;
+  db->row_off = (uint64_t *)calloc(slots + 1, sizeof(uint64_t));
+  uint32_t *stamp = (uint32_t *)calloc(slots, sizeof(uint32_t));
+  if (!db->row_off || !stamp) return UGS_E_NOMEM;
+  const int W = db->p.word_len;
+  for (int pass = 0; pass < 2; ++pass) {
+    uint64_t *fill = NULL;
+    if (pass == 1) {
+      uint64_t tot = 0;
+      for (uint64_t s = 0; s < slots; ++s) { uint64_t c = db->row_off[s + 1]; db->row_off[s + 1] = tot; tot += c; }
+      /* now row_off[s+1] = start of row s; shift */
+      for (uint64_t s = 0; s < slots; ++s) db->row_off[s] = db->row_off[s + 1];
+      db->row_off[slots] = tot;
+      db->postings = (uint32_t *)malloc((tot ? tot : 1) * sizeof(uint32_t));
+      fill = (uint64_t *)malloc(slots * sizeof(uint64_t));
+      if (!db->postings || !fill) return UGS_E_NOMEM;
+      memcpy(fill, db->row_off, slots * sizeof(uint64_t));
+      memset(stamp, 0, slots * sizeof(uint32_t));
+    }
+    for (uint32_t t = 0; t < db->nseq; ++t) {
+      const byte *s = (const byte *)db->seqs + db->offs[t];
+      uint64_t L = db->offs[t + 1] - db->offs[t];
+      if (L < (uint64_t)W) continue;
+      for (uint64_t pos = 0; pos + W <= L; ++pos) {
+        uint32_t w = seq_to_word(db, s + pos);
+        if (w == BAD_WORD) continue;
+        if (stamp[w] == t + 1) continue;
+        stamp[w] = t + 1;
+        if (pass == 0) db->row_off[w + 1]++;
+        else db->postings[fill[w]++] = t;
+      }
+    }
+    if (pass == 1) free(fill);
+    else {
+      /* after pass 0 row_off[s+1] holds the size of row s */
+    }
+  }
+  free(stamp);
+  return UGS_OK;
+}
+
+int orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                  orc_db **out)
+{
+  init_tables();
+  orc_db *db = (orc_db *)calloc(1, sizeof(orc_db));
+  if (!db) return UGS_E_NOMEM;
+  db->p = *p;
+  db->nseq = nseq;
+  uint64_t tot = offs[nseq];
+  db->seqs = (char *)malloc(tot ? tot : 1);
+  db->offs = (uint64_t *)malloc((nseq + 1) * sizeof(uint64_t));
+  memcpy(db->seqs, seqs, tot);
+  memcpy(db->offs, offs, (nseq + 1) * sizeof(uint64_t));
+  db->alpha = p->is_nucleo ? 4 : 20;
+  db->c2l = p->is_nucleo ? g_c2l_nt : g_c2l_aa;
+  db->match = p->is_nucleo ? (const byte(*)[256])g_match_nt : (const byte(*)[256])g_match_aa;
+  if (p->is_nucleo) {
+    fill_subst_nt(db->subst_nt_custom, p->match, p->mismatch);
+    db->subst = db->subst_nt_custom;
+  } else
+    db->subst = g_subst_aa;
+  /* makeudb.cpp:11-25 MaskDB -> seqdb.cpp:415 Mask (in place) */
+  uint32_t maxlen = 0;
+  for (uint32_t t = 0; t < nseq; ++t) {
+    uint32_t L = (uint32_t)(offs[t + 1] - offs[t]);
+    if (L > maxlen) maxlen = L;
+    if (p->dbmask) orc_fastmask(db->seqs + offs[t], L);
+    else for (uint32_t i = 0; i < L; ++i) db->seqs[offs[t] + i] = (char)toupper((byte)db->seqs[offs[t] + i]);
+  }
+  db->maxlen = maxlen;
+  /* alnparams.cpp:380-384 Init4 */
+  float Open = p->is_nucleo ? -10.0f : -17.0f, Ext = -1.0f, TO = -0.5f, TE = -0.5f;
+  db->ap.OpenA = db->ap.OpenB = Open;
+  db->ap.LOpenA = db->ap.LOpenB = db->ap.ROpenA = db->ap.ROpenB = TO;
+  db->ap.ExtA = db->ap.ExtB = Ext;
+  db->ap.LExtA = db->ap.LExtB = db->ap.RExtA = db->ap.RExtB = TE;
+  /* alnheuristics.cpp:26-62 */
+  db->XDropGlobalHSP = p->xdrop_nw;
+  db->BandRadius = (unsigned)p->band;
+  db->MinGlobalHSPLength = (unsigned)p->minhsp;
+  db->HSPw = (unsigned)p->hsp_word_len;
+  float idf = p->id_set ? p->id : 0.5f;     /* oget_fltd(OPT_id, 0.5) */
+  if (p->is_nucleo) {
+    db->MinGlobalHSPFractId = idf > 0.75f ? idf : 0.75f;
+    db->MinGlobalHSPScore = db->MinGlobalHSPFractId * db->MinGlobalHSPLength * p->match;
+  } else {
+    float MinDiag = 9e9f;
+    static const char aa[] = "ACDEFGHIKLMNPQRSTVWY";
+    for (int i = 0; i < 20; ++i) {
+      float s = db->subst[(byte)aa[i]][(byte)aa[i]];
+      if (s < MinDiag) MinDiag = s;
+    }
+    db->MinGlobalHSPFractId = idf > 0.5f ? idf : 0.5f;
+    db->MinGlobalHSPScore = db->MinGlobalHSPFractId * MinDiag * db->MinGlobalHSPLength;
+  }
+  db->HSPWordCount = 1;
+  for (unsigned i = 0; i < db->HSPw; ++i) db->HSPWordCount *= db->alpha;
+  db->big = nseq > p->big;                  /* udbusortedsearcher.cpp:44 */
+  int rc = build_index(db);
+  if (rc != UGS_OK) { orc_db_destroy(db); return rc; }
+  *out = db;
+  return UGS_OK;
+}
+
+void orc_db_destroy(orc_db *db)
+{
+  if (!db) return;
+  free(db->seqs); free(db->offs); free(db->row_off); free(db->postings); free(db);
+}
+
+const char *orc_db_masked(const orc_db *db) { return db->seqs; }
+uint64_t orc_db_slots(const orc_db *db) { return db->slots; }
+const uint64_t *orc_db_row_off(const orc_db *db) { return db->row_off; }
+const uint32_t *orc_db_postings(const orc_db *db) { return db->postings; }
+void orc_get_stats(const orc_db *db, orc_stats *st) { *st = db->stats; }
+
+/* ------------------------------------------------------------------ per-thread workspace */
+
+typedef struct {
+  orc_db *db;
+  /* ranking */
+  uint32_t *qwords, *quniq; unsigned nqw, nquniq; uint32_t qcap;
+  byte *wordfound;                 /* slots */
+  uint32_t *U;                     /* nseq */
+  uint32_t *top_t, *top_u, *order, *top_t2; /* nseq */
+  uint32_t *cs_sizes, *cs_offsets; uint32_t cs_cap;
+  unsigned ntop;                   /* candidates in final order: cand_t/cand_c */
+  uint32_t *cand_t, *cand_c;
+  /* hsp finder */
+  uint32_t *wordsA, *wordsB; unsigned nwA, nwB, capA, capB;
+  unsigned *wcountsA, *wposA;
+  const byte *A, *B; unsigned LA, LB;
+  HSP *hsps; unsigned nhsp, caphsp;
+  HSP **chain; unsigned nchain;
+  /* chainer scratch */
+  unsigned *bp_pos, *bp_idx, *prev; byte *bp_islo; float *cscore; unsigned *list;
+  /* dp */
+  float *Mrow, *Drow; byte *TB; unsigned dpLA, dpLB; size_t tbcap, rowcap;
+  char *path, *subpath; size_t pathcap;
+  /* per-thread output */
+  orc_stats st;
+} Work;
+
+static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (!q) abort(); return q; }
+
+static Work *work_new(orc_db *db)
+{
+  Work *w = (Work *)calloc(1, sizeof(Work));
+  w->db = db;
+  w->wordfound = (byte *)calloc(db->slots, 1);
+  uint32_t n = db->nseq ? db->nseq : 1;
+  w->U = (uint32_t *)calloc(n, 4);
+  w->top_t = (uint32_t *)malloc(n * 4); w->top_u = (uint32_t *)malloc(n * 4);
+  w->order = (uint32_t *)malloc(n * 4); w->top_t2 = (uint32_t *)malloc(n * 4);
+  w->cand_t = (uint32_t *)malloc(n * 4); w->cand_c = (uint32_t *)malloc(n * 4);
+  w->wcountsA = (unsigned *)malloc(db->HSPWordCount * sizeof(unsigned));
+  w->wposA = (unsigned *)malloc((size_t)db->HSPWordCount * MAXREPS * sizeof(unsigned));
+  return w;
+}
+
+static void work_free(Work *w)
+{
+  free(w->qwords); free(w->quniq); free(w->wordfound); free(w->U); free(w->top_t); free(w->top_u);
+  free(w->order); free(w->top_t2); free(w->cs_sizes); free(w->cs_offsets); free(w->cand_t); free(w->cand_c);
+  free(w->wordsA); free(w->wordsB); free(w->wcountsA); free(w->wposA); free(w->hsps); free(w->chain);
+  free(w->bp_pos); free(w->bp_idx); free(w->prev); free(w->bp_islo); free(w->cscore); free(w->list);
+  free(w->Mrow); free(w->Drow); free(w->TB); free(w->path); free(w->subpath); free(w);
+}
+
+/* ------------------------------------------------------------------ ranking */
+
+/* udbsearcher.cpp:128-151 SetQueryWordsAllNoBadNoPattern + :161-194 SetQueryUniqueWords */
+static void set_query_words(Work *w, const byte *q, unsigned L)
+{
+  orc_db *db = w->db;
+  if (w->qcap < L + 1) {
+    w->qcap = L + 1;
+    w->qwords = (uint32_t *)xrealloc(w->qwords, w->qcap * 4);
+    w->quniq = (uint32_t *)xrealloc(w->quniq, w->qcap * 4);
+  }
+  w->nqw = 0;
+  if (L >= (unsigned)db->p.word_len)
+    for (unsigned pos = 0; pos + db->p.word_len <= L; ++pos) {
+      uint32_t word = seq_to_word(db, q + pos);
+      if (word != BAD_WORD) w->qwords[w->nqw++] = word;
+    }
+  w->nquniq = 0;
+  for (unsigned i = 0; i < w->nqw; ++i) {
+    uint32_t word = w->qwords[i];
+    if (!w->wordfound[word]) { w->quniq[w->nquniq++] = word; w->wordfound[word] = 1; }
+  }
+  for (unsigned i = 0; i < w->nqw; ++i) w->wordfound[w->qwords[i]] = 0;
+}
+
+/* wordparams.cpp:60-112 (table from CD-HIT, as the reference holds it) */
+static const double MinWordFractAmino[50] = {
+  0.00, 0.00, 0.00, 0.00, 0.01, 0.01, 0.01, 0.02, 0.02, 0.02, 0.03, 0.04, 0.04, 0.05, 0.06, 0.06, 0.08,
+  0.08, 0.10, 0.10, 0.11, 0.14, 0.14, 0.14, 0.17, 0.17, 0.18, 0.20, 0.21, 0.21, 0.27, 0.28, 0.31, 0.34,
+  0.36, 0.41, 0.43, 0.45, 0.48, 0.54, 0.55, 0.56, 0.64, 0.69, 0.73, 0.75, 0.80, 0.85, 0.90, 0.95};
+
+/* wordparams.cpp:125-135,145-159,167-192 GetWordCountingParams -> Step (MinU unused by Big path) */
+static unsigned word_step(const orc_db *db, unsigned Nu)
+{
+  double FractId = (double)db->p.id;   /* float widened to double, SURVEY A.2 */
+  unsigned Thresh;
+  if (db->p.is_nucleo) {
+    double WordFract = 1 - (1 - FractId) * db->p.word_len;
+    if (WordFract < 0.0) Thresh = 1;
+    else {
+      WordFract *= Nu;
+      Thresh = WordFract < 1.0 ? 1 : (unsigned)WordFract;
+    }
+  } else {
+    if (FractId < 0.5) Thresh = 0;
+    else {
+      unsigned i = (unsigned)((FractId - 0.5) * 100);
+      if (i >= 50) i = 49;
+      Thresh = (unsigned)(MinWordFractAmino[i] * Nu);
+    }
+  }
+  if (db->p.stepwords == 0) return 1;
+  unsigned Step = Thresh / db->p.stepwords;
+  if (Step == 0) Step = 1;
+  return Step;
+}
+
+static void cs_alloc(Work *w, unsigned N)
+{
+  if (w->cs_cap < N) {
+    w->cs_cap = N + 64;
+    w->cs_sizes = (uint32_t *)xrealloc(w->cs_sizes, w->cs_cap * 4);
+    w->cs_offsets = (uint32_t *)xrealloc(w->cs_offsets, w->cs_cap * 4);
+  }
+}
+
+/* countsort.cpp:6-108 CountSortOrderDesc */
+static unsigned count_sort_order_desc(Work *w, const uint32_t *Values, unsigned ValueCount, uint32_t *Order)
+{
+  unsigned MaxValue = 0, NextValue = 0;
+  for (unsigned i = 0; i < ValueCount; ++i) {
+    unsigned v = Values[i];
+    if (v > MaxValue) { NextValue = MaxValue; MaxValue = v; }
+  }
+  unsigned MinValue = NextValue / 2;
+  unsigned N = MaxValue + 1;
+  cs_alloc(w, N);
+  memset(w->cs_sizes, 0, N * 4);
+  for (unsigned i = 0; i < ValueCount; ++i) { unsigned v = Values[i]; if (v < MinValue) continue; ++w->cs_sizes[v]; }
+  unsigned Offset = 0;
+  for (int v = (int)MaxValue; v >= (int)MinValue; --v) { w->cs_offsets[v] = Offset; Offset += w->cs_sizes[v]; }
+  for (unsigned i = 0; i < ValueCount; ++i) {
+    unsigned v = Values[i];
+    if (v < MinValue) continue;
+    Order[w->cs_offsets[v]++] = i;
+  }
+  return w->cs_offsets[MinValue];
+}
+
+/* countsort.cpp:110-191 CountSortSubsetDesc */
+static unsigned count_sort_subset_desc(Work *w, const uint32_t *Values, unsigned ValueCount,
+                                       const uint32_t *Subset, uint32_t *Result)
+{
+  unsigned MaxValue = 0, NextValue = 0;
+  for (unsigned i = 0; i < ValueCount; ++i) {
+    unsigned v = Values[Subset[i]];
+    if (v > MaxValue) { NextValue = MaxValue; MaxValue = v; }
+  }
+  unsigned MinValue = NextValue / 2;
+  unsigned N = MaxValue + 1;
+  cs_alloc(w, N);
+  memset(w->cs_sizes, 0, N * 4);
+  for (unsigned i = 0; i < ValueCount; ++i) { unsigned v = Values[Subset[i]]; if (v < MinValue) continue; ++w->cs_sizes[v]; }
+  unsigned Offset = 0;
+  for (int v = (int)MaxValue; v >= (int)MinValue; --v) { w->cs_offsets[v] = Offset; Offset += w->cs_sizes[v]; }
+  for (unsigned i = 0; i < ValueCount; ++i) {
+    unsigned k = Subset[i];
+    unsigned v = Values[k];
+    if (v < MinValue) continue;
+    Result[w->cs_offsets[v]++] = k;
+  }
+  return w->cs_offsets[MinValue];
+}
+
+/* small path: udbusortedsearcher.cpp:109-120 SetTargetOrder = SetU_NonCoded(1) (:375-410),
+ * SetTopBump(1, bump) (:230-267) or SetTopNoBump (:205-228), CountSortOrderDesc */
+static void rank_small(Work *w, const byte *q, unsigned L)
+{
+  orc_db *db = w->db;
+  set_query_words(w, q, L);
+  w->ntop = 0;
+  const unsigned SeqCount = db->nseq;
+  if (SeqCount == 0) return;
+  memset(w->U, 0, (size_t)SeqCount * 4);
+  for (unsigned i = 0; i < w->nquniq; ++i) {
+    uint32_t word = w->quniq[i];
+    const uint32_t *row = db->postings + db->row_off[word];
+    uint64_t size = db->row_off[word + 1] - db->row_off[word];
+    w->st.postings += size;
+    for (uint64_t j = 0; j < size; ++j) ++w->U[row[j]];
+  }
+  unsigned MinU = 1, TopCount = 0;
+  if (db->p.bump_pct != 0) {
+    double Bump = db->p.bump_pct / 100.0;
+    unsigned MaxCount = 0;
+    for (unsigned t = 0; t < SeqCount; ++t) {
+      unsigned n = w->U[t];
+      if (n >= MinU) {
+        if (n > MaxCount) {
+          unsigned NewMin = (unsigned)(n * Bump);
+          if (NewMin > MinU && NewMin < MaxCount) MinU = NewMin;
+          MaxCount = n;
+        }
+        w->top_u[TopCount] = n; w->top_t[TopCount] = t; ++TopCount;
+      }
+    }
+  } else {
+    for (unsigned t = 0; t < SeqCount; ++t) {
+      unsigned n = w->U[t];
+      if (n >= MinU) { w->top_u[TopCount] = n; w->top_t[TopCount] = t; ++TopCount; }
+    }
+  }
+  unsigned K = count_sort_order_desc(w, w->top_u, TopCount, w->order);
+  for (unsigned k = 0; k < K; ++k) {
+    unsigned i = w->order[k];
+    w->cand_t[k] = w->top_t[i]; w->cand_c[k] = w->top_u[i];
+  }
+  w->ntop = K;
+}
+
+/* Big path: udbusortedsearcherbig.cpp:31-135 scan part + CountSortSubsetDesc, then
+ * udbusortedsearcher.cpp:65-84 OnQueryDoneImpl (clear touched counters) */
+static void rank_big(Work *w, const byte *q, unsigned L)
+{
+  orc_db *db = w->db;
+  w->ntop = 0;
+  if (db->nseq == 0) return;
+  set_query_words(w, q, L);
+  unsigned Step = word_step(db, w->nquniq);
+  unsigned TopCount = 0;
+  for (unsigned i = 0; i < w->nquniq; i += Step) {
+    uint32_t word = w->quniq[i];
+    const uint32_t *row = db->postings + db->row_off[word];
+    uint64_t size = db->row_off[word + 1] - db->row_off[word];
+    w->st.postings += size;
+    for (uint64_t j = 0; j < size; ++j) {
+      uint32_t t = row[j];
+      unsigned c = w->U[t];
+      if (c == 0) w->top_t[TopCount++] = t;
+      w->U[t] = c + 1;
+    }
+  }
+  if (TopCount == 0) return;
+  unsigned K = count_sort_subset_desc(w, w->U, TopCount, w->top_t, w->top_t2);
+  for (unsigned k = 0; k < K; ++k) { w->cand_t[k] = w->top_t2[k]; w->cand_c[k] = w->U[w->top_t2[k]]; }
+  w->ntop = K;
+  for (unsigned i = 0; i < TopCount; ++i) w->U[w->top_t[i]] = 0;
+}
+
+/* ------------------------------------------------------------------ HSP finder */
+
+/* hspfinder.cpp:226-270 SeqToWords: rolling word for EVERY position, invalid letter -> 0 */
+static unsigned hf_seq_to_words(const orc_db *db, const byte *Seq, unsigned L, uint32_t *Words)
+{
+  const unsigned wl = db->HSPw, as = db->alpha;
+  if (L < wl) return 0;
+  const unsigned Hi = db->HSPWordCount / as;
+  uint32_t Word = 0;
+  const byte *Front = Seq, *Back = Seq;
+  for (unsigned i = 0; i + 1 < wl; ++i) {
+    unsigned Letter = db->c2l[*Front++];
+    if (Letter >= as) Letter = 0;
+    Word = Word * as + Letter;
+  }
+  for (unsigned i = wl - 1; i < L; ++i) {
+    unsigned Letter = db->c2l[*Front++];
+    if (Letter >= as) Letter = 0;
+    Word = Word * as + Letter;
+    *Words++ = Word;
+    Letter = db->c2l[*Back++];
+    if (Letter >= as) Letter = 0;
+    Word -= Letter * Hi;
+  }
+  return L - wl + 1;
+}
+
+/* hspfinder.cpp:304-323 SetA */
+static void hf_set_a(Work *w, const byte *A, unsigned LA)
+{
+  orc_db *db = w->db;
+  if (w->capA < LA + 1) { w->capA = LA + 512; w->wordsA = (uint32_t *)xrealloc(w->wordsA, w->capA * 4); }
+  memset(w->wcountsA, 0, db->HSPWordCount * sizeof(unsigned));
+  w->A = A; w->LA = LA;
+  w->nwA = hf_seq_to_words(db, A, LA, w->wordsA);
+  for (unsigned PosA = 0; PosA < w->nwA; ++PosA) {
+    unsigned Word = w->wordsA[PosA];
+    unsigned n = w->wcountsA[Word];
+    if (n == MAXREPS) continue;
+    w->wposA[Word * MAXREPS + n] = PosA;
+    ++w->wcountsA[Word];
+  }
+}
+
+/* hspfinder.cpp:325-331 SetB */
+static void hf_set_b(Work *w, const byte *B, unsigned LB)
+{
+  if (w->capB < LB + 1) { w->capB = LB + 32; w->wordsB = (uint32_t *)xrealloc(w->wordsB, w->capB * 4); }
+  w->B = B; w->LB = LB;
+  w->nwB = hf_seq_to_words(w->db, B, LB, w->wordsB);
+}
+
+/* hspfinder.cpp:594-636 IsGlobalHSP */
+static int is_global_hsp(unsigned ALo, unsigned BLo, unsigned Length, unsigned LA, unsigned LB)
+{
+  (void)Length;
+  if (LA <= LB) {
+    unsigned MaxGap = LA / 4 + 1;
+    if (ALo > BLo && ALo - BLo > MaxGap) return 0;
+    unsigned AR = LA - ALo, BR = LB - BLo;
+    if (AR > BR && AR - BR > MaxGap) return 0;
+  } else {
+    unsigned MaxGap = LB / 4 + 1;
+    if (BLo > ALo && BLo - ALo > MaxGap) return 0;
+    unsigned AR = LA - ALo, BR = LB - BLo;
+    if (BR > AR && BR - AR > MaxGap) return 0;
+  }
+  return 1;
+}
+
+/* ungappedblast.cpp:8-211 UngappedBlast(X, StaggerOk=false, MinLength, MinScore) */
+static void ungapped_blast(Work *w, float X, unsigned MinLength, float MinScore)
+{
+  orc_db *db = w->db;
+  w->nhsp = 0;
+  ++w->st.ungapped_calls;
+  const unsigned wl = db->HSPw;
+  if (w->LB < 2 * wl) return;
+  const byte *A = w->A, *B = w->B;
+  const unsigned LA = w->LA, LB = w->LB;
+  float (*Mx)[256] = db->subst;
+  unsigned BPos = 0;
+  for (;;) {
+    if (BPos >= w->nwB) break;
+    unsigned Word = w->wordsB[BPos];
+    unsigned NA = w->wcountsA[Word];
+    if (NA == 0) { ++BPos; continue; }
+    int found = 0;
+    for (unsigned i = 0; i < NA; ++i) {
+      unsigned APos = w->wposA[Word * MAXREPS + i];
+      unsigned Diag = (LA + BPos) - APos;
+      unsigned BPos2 = BPos + wl - 1, APos2 = APos + wl - 1;
+      if (APos2 >= LA || BPos2 >= LB) continue;
+      float Score = 0;
+      for (unsigned j = 0; j < wl; ++j) Score += Mx[A[APos + j]][B[BPos + j]];
+      float BestScore = Score;
+      unsigned BestBPos2 = BPos2;
+      for (;;) {                                   /* extend right */
+        ++BPos2; if (BPos2 >= LB) break;
+        ++APos2; if (APos2 >= LA) break;
+        Score += Mx[A[APos2]][B[BPos2]];
+        if (Score > BestScore) { BestScore = Score; BestBPos2 = BPos2; }
+        else if (BestScore - Score > X) break;
+      }
+      unsigned APos1 = APos, BPos1 = BPos, BestBPos1 = BPos1;   /* extend left */
+      Score = BestScore;
+      for (;;) {
+        if (BPos1 == 0 || APos1 == 0) break;
+        --BPos1; --APos1;
+        Score += Mx[A[APos1]][B[BPos1]];
+        if (Score > BestScore) { BestScore = Score; BestBPos1 = BPos1; }
+        else if (BestScore - Score > X) break;
+      }
+      unsigned Blo = BestBPos1, Bhi = BestBPos2;
+      unsigned Length = Bhi - Blo + 1;
+      unsigned Alo = (LA + BestBPos1) - Diag;
+      int Ok = (Length >= MinLength && BestScore >= MinScore);
+      Ok = Ok && is_global_hsp(Alo, Blo, Length, LA, LB);
+      if (Ok) {
+        if (w->nhsp + 1 > w->caphsp) {
+          w->caphsp = w->caphsp * 2 + 64;
+          w->hsps = (HSP *)xrealloc(w->hsps, w->caphsp * sizeof(HSP));
+        }
+        HSP *h = &w->hsps[w->nhsp++];
+        h->Loi = Alo; h->Loj = Blo; h->Len = Length; h->Score = BestScore;
+        BPos = Bhi + 1;
+        found = 1;
+        break;
+      }
+    }
+    if (!found) ++BPos;
+  }
+}
+
+/* stable merge sort of break points (glibc qsort with enough memory is a stable
+ * merge sort; comparator chainer.cpp:219-238: Pos asc, Lo before Hi, else equal) */
+static int bp_less(unsigned posa, int loa, unsigned posb, int lob)
+{
+  if (posa != posb) return posa < posb;
+  if (loa != lob) return loa && !lob;
+  return 0;
+}
+
+/* chainer.cpp:352-500 Chain (+ :322-350 FindBestChainLT, :251-270 SetBPs); the
+ * "delete enclosed chains" branch compares a value with itself and never fires (:447-448) */
+static void chain_hsps(Work *w)
+{
+  const unsigned n = w->nhsp;
+  w->nchain = 0;
+  if (n == 0) return;
+  w->chain = (HSP **)xrealloc(w->chain, n * sizeof(HSP *));
+  w->bp_pos = (unsigned *)xrealloc(w->bp_pos, 2 * n * sizeof(unsigned));
+  w->bp_idx = (unsigned *)xrealloc(w->bp_idx, 2 * n * sizeof(unsigned));
+  w->bp_islo = (byte *)xrealloc(w->bp_islo, 2 * n);
+  w->prev = (unsigned *)xrealloc(w->prev, n * sizeof(unsigned));
+  w->cscore = (float *)xrealloc(w->cscore, n * sizeof(float));
+  w->list = (unsigned *)xrealloc(w->list, n * sizeof(unsigned));
+  for (unsigned i = 0; i < n; ++i) {
+    w->bp_pos[2 * i] = w->hsps[i].Loi; w->bp_islo[2 * i] = 1; w->bp_idx[2 * i] = i;
+    w->bp_pos[2 * i + 1] = w->hsps[i].Loi + w->hsps[i].Len - 1; w->bp_islo[2 * i + 1] = 0; w->bp_idx[2 * i + 1] = i;
+  }
+  /* stable insertion sort == stable merge sort result */
+  for (unsigned i = 1; i < 2 * n; ++i) {
+    unsigned p = w->bp_pos[i], ix = w->bp_idx[i]; byte lo = w->bp_islo[i];
+    unsigned j = i;
+    while (j > 0 && bp_less(p, lo, w->bp_pos[j - 1], w->bp_islo[j - 1])) {
+      w->bp_pos[j] = w->bp_pos[j - 1]; w->bp_idx[j] = w->bp_idx[j - 1]; w->bp_islo[j] = w->bp_islo[j - 1];
+      --j;
+    }
+    w->bp_pos[j] = p; w->bp_idx[j] = ix; w->bp_islo[j] = lo;
+  }
+  for (unsigned i = 0; i < n; ++i) w->prev[i] = UINT_MAX;
+  unsigned nlist = 0;
+  for (unsigned b = 0; b < 2 * n; ++b) {
+    unsigned hi = w->bp_idx[b];
+    const HSP *h = &w->hsps[hi];
+    if (!w->bp_islo[b]) continue;
+    unsigned Ahi = h->Loi, Bhi = h->Loj;
+    float BestScore = -9e9f;
+    unsigned BestChain = UINT_MAX;
+    for (unsigned k = 0; k < nlist; ++k) {
+      unsigned ci = w->list[k];
+      const HSP *c = &w->hsps[ci];
+      unsigned cAhi = c->Loi + c->Len - 1, cBhi = c->Loj + c->Len - 1;
+      float cs = w->cscore[ci];
+      if (cAhi < Ahi && cBhi < Bhi && (BestChain == UINT_MAX || cs > BestScore)) { BestChain = ci; BestScore = cs; }
+    }
+    w->list[nlist++] = hi;
+    w->prev[hi] = BestChain;
+    w->cscore[hi] = BestChain == UINT_MAX ? h->Score : w->cscore[BestChain] + h->Score;
+  }
+  unsigned Opt = 0;
+  float OptScore = w->cscore[0];
+  for (unsigned i = 1; i < n; ++i)
+    if (w->cscore[i] > OptScore) { Opt = i; OptScore = w->cscore[i]; }
+  unsigned len = 0;
+  for (unsigned i = Opt; i != UINT_MAX; i = w->prev[i]) ++len;
+  unsigned k = 1;
+  for (unsigned i = Opt; i != UINT_MAX; i = w->prev[i]) w->chain[len - k++] = &w->hsps[i];
+  w->nchain = len;
+}
+
+/* hsp.h:102-126 IsStaggered */
+static int hsp_is_staggered(const HSP *h, unsigned LA, unsigned LB)
+{
+  int Hii = (int)(h->Loi + h->Len - 1), Hij = (int)(h->Loj + h->Len - 1);
+  int TermGapLeftA = (int)h->Loi - (int)h->Loj;
+  int TermGapLeftB = (int)h->Loj - (int)h->Loi;
+  int TermGapRightA = (int)LA - Hii - 1 - ((int)LB - Hij - 1);
+  int TermGapRightB = (int)LB - Hij - 1 - ((int)LA - Hii - 1);
+  if (TermGapLeftA < 0) TermGapLeftA = 0;
+  if (TermGapLeftB < 0) TermGapLeftB = 0;
+  if (TermGapRightB < 0) TermGapRightB = 0;     /* (TermGapRightA is NOT clamped in the reference) */
+  int GapA = TermGapLeftA + TermGapRightA;
+  int GapB = TermGapLeftB + TermGapRightB;
+  if (GapA == 0 || GapB == 0) return 0;
+  double r = (LA < LB ? (double)GapA / LA : (double)GapB / LB);
+  return r > 0.5;
+}
+
+/* getglobalhsps.cpp:9-61 GetGlobalHSPs (+ hspfinder.cpp:537-553 Chain, :561-579 GetHSPIdCount) */
+static unsigned get_global_hsps(Work *w, unsigned MinLength, float *HSPFractId)
+{
+  orc_db *db = w->db;
+  ungapped_blast(w, db->XDropGlobalHSP, MinLength, db->MinGlobalHSPScore);
+  chain_hsps(w);
+  for (unsigned i = 0; i < w->nchain; ++i)
+    if (hsp_is_staggered(w->chain[i], w->LA, w->LB)) { w->nchain = 0; break; }
+  unsigned TotalLength = 0, TotalSame = 0;
+  for (unsigned i = 0; i < w->nchain; ++i) {
+    const HSP *h = w->chain[i];
+    TotalLength += h->Len;
+    for (unsigned k = 0; k < h->Len; ++k)
+      if (db->match[w->A[h->Loi + k]][w->B[h->Loj + k]]) ++TotalSame;
+  }
+  *HSPFractId = TotalLength == 0 ? 0.0f : (float)TotalSame / (float)TotalLength;
+  return w->nchain;
+}
+
+/* ------------------------------------------------------------------ banded Viterbi */
+
+static void dp_alloc(Work *w, unsigned LA, unsigned LB)
+{
+  size_t need_row = (size_t)LB + 8;
+  if (w->rowcap < need_row) {
+    w->rowcap = need_row + 256;
+    w->Mrow = (float *)xrealloc(w->Mrow, w->rowcap * sizeof(float));
+    w->Drow = (float *)xrealloc(w->Drow, w->rowcap * sizeof(float));
+  }
+  size_t need_tb = ((size_t)LA + 1) * ((size_t)LB + 1);
+  if (w->tbcap < need_tb) { w->tbcap = need_tb + 1024; w->TB = (byte *)xrealloc(w->TB, w->tbcap); }
+}
+
+static void path_alloc(Work *w, size_t n)
+{
+  if (w->pathcap < n + 16) {
+    w->pathcap = n + 1024;
+    w->path = (char *)xrealloc(w->path, w->pathcap);
+    w->subpath = (char *)xrealloc(w->subpath, w->pathcap);
+  }
+}
+
+/* diagbox.h:150-171 GetRange_j */
+static void get_range_j(unsigned LA, unsigned LB, unsigned dlo, unsigned dhi, unsigned i,
+                        unsigned *Startj, unsigned *Endj)
+{
+  unsigned s = (dlo + i >= LA) ? dlo + i - LA : 0;
+  if (s >= LB) s = LB - 1;
+  unsigned e = (dhi + i + 1 >= LA) ? dhi + i + 1 - LA : 0;
+  if (e > LB) e = LB;
+  *Startj = s; *Endj = e;
+}
+
+/* viterbifastbandmem.cpp:12-230 ViterbiFastBandMem + tracebackbitmem.cpp:8-73; writes the
+ * path (M/D/I text, NUL-terminated) into out */
+static float viterbi_band(Work *w, const byte *A, unsigned LA, const byte *B, unsigned LB,
+                          unsigned DiagLo, unsigned DiagHi, const AlnPen *AP, char *out)
+{
+  orc_db *db = w->db;
+  dp_alloc(w, LA, LB);
+  float (*Mx)[256] = db->subst;
+  float OpenA = AP->LOpenA, ExtA = AP->LExtA;
+  float *Mrow = w->Mrow + 1, *Drow = w->Drow + 1;   /* Mrow[-1] is addressable */
+  byte *TB = w->TB;
+  const size_t TBS = (size_t)LB + 1;
+  Mrow[-1] = MINUS_INFINITY;
+  for (unsigned j = 0; j <= LB; ++j) { Mrow[j] = MINUS_INFINITY; Drow[j] = MINUS_INFINITY; }
+  uint64_t cells = 0;
+  for (unsigned i = 0; i < LA; ++i) {
+    unsigned Startj, Endj;
+    get_range_j(LA, LB, DiagLo, DiagHi, i, &Startj, &Endj);
+    if (Endj == 0) continue;
+    float OpenB = Startj == 0 ? AP->LOpenB : AP->OpenB;
+    float ExtB = Startj == 0 ? AP->LExtB : AP->ExtB;
+    const float *MxRow = Mx[A[i]];
+    float I0 = MINUS_INFINITY;
+    float M0;
+    if (i == 0) M0 = 0;
+    else M0 = (Startj == 0) ? MINUS_INFINITY : Mrow[(int)Startj - 1];
+    byte *TBrow = TB + (size_t)i * TBS;
+    if (Startj > 0) TBrow[(int)Startj - 1] = TB_IM;
+    cells += Endj - Startj;
+    for (unsigned j = Startj; j < Endj; ++j) {
+      byte b = B[j];
+      byte TraceBits = 0;
+      float SavedM0 = M0;
+      {
+        float xM = M0;
+        if (Drow[j] > xM) { xM = Drow[j]; TraceBits = TB_DM; }
+        if (I0 > xM) { xM = I0; TraceBits = TB_IM; }
+        M0 = Mrow[j];
+        Mrow[j] = xM + MxRow[b];
+      }
+      {
+        float md = SavedM0 + OpenB;
+        Drow[j] += ExtB;
+        if (md >= Drow[j]) { Drow[j] = md; TraceBits |= TB_MD; }
+      }
+      {
+        float mi = SavedM0 + OpenA;
+        I0 += ExtA;
+        if (mi >= I0) { I0 = mi; TraceBits |= TB_MI; }
+      }
+      OpenB = AP->OpenB; ExtB = AP->ExtB;
+      TBrow[j] = TraceBits;
+    }
+    {
+      TBrow[LB] = 0;
+      float md = M0 + AP->ROpenB;
+      Drow[LB] += AP->RExtB;
+      if (md >= Drow[LB]) { Drow[LB] = md; TBrow[LB] = TB_MD; }
+    }
+    M0 = MINUS_INFINITY;
+    OpenA = AP->OpenA; ExtA = AP->ExtA;
+  }
+  unsigned Startj, Endj;
+  get_range_j(LA, LB, DiagLo, DiagHi, LA - 1, &Startj, &Endj);
+  byte *TBrow = TB + (size_t)LA * TBS;
+  float I1 = MINUS_INFINITY;
+  Mrow[(int)Startj - 1] = MINUS_INFINITY;
+  cells += LB;   /* last-row I sweep, SURVEY 8d */
+  for (unsigned j = Startj; j < Endj; ++j) {
+    TBrow[j] = 0;
+    float mi = Mrow[(int)j - 1] + AP->ROpenA;
+    I1 += AP->RExtA;
+    if (mi > I1) { I1 = mi; TBrow[j] = TB_MI; }
+  }
+  float FinalM = Mrow[LB - 1], FinalD = Drow[LB], FinalI = I1;
+  float Score = FinalM; char State = 'M';
+  if (FinalD > Score) { Score = FinalD; State = 'D'; }
+  if (FinalI > Score) { Score = FinalI; State = 'I'; }
+  w->st.dp_cells += cells; ++w->st.dp_calls;
+
+  /* tracebackbitmem.cpp:8-73 */
+  size_t i = LA, j = LB, n = 0;
+  for (;;) {
+    if (i == 0 && j == 0) break;
+    out[n++] = State;
+    byte t;
+    switch (State) {
+    case 'M':
+      t = TB[(i - 1) * TBS + (j - 1)];
+      if (t & TB_DM) State = 'D'; else if (t & TB_IM) State = 'I'; else State = 'M';
+      --i; --j; break;
+    case 'D':
+      t = TB[(i - 1) * TBS + j];
+      State = (t & TB_MD) ? 'M' : 'D';
+      --i; break;
+    default:
+      t = TB[i * TBS + (j - 1)];
+      State = (t & TB_MI) ? 'M' : 'I';
+      --j; break;
+    }
+  }
+  for (size_t k = 0; k < n / 2; ++k) { char c = out[k]; out[k] = out[n - 1 - k]; out[n - 1 - k] = c; }
+  out[n] = 0;
+  return Score;
+}
+
+/* viterbifastbandmem.cpp:232-253 ViterbiFastMainDiagMem */
+static float viterbi_main_diag(Work *w, const byte *A, unsigned LA, const byte *B, unsigned LB,
+                               unsigned BandRadius, const AlnPen *AP, char *out)
+{
+  unsigned DiagLo = LA < LB ? LA : LB;
+  unsigned DiagHi = LA > LB ? LA : LB;
+  if (DiagLo > BandRadius) DiagLo -= BandRadius; else DiagLo = 1;
+  DiagHi += BandRadius;
+  unsigned MaxDiag = LA + LB - 1;
+  if (DiagHi > MaxDiag) DiagHi = MaxDiag;
+  return viterbi_band(w, A, LA, B, LB, DiagLo, DiagHi, AP, out);
+}
+
+/* globalalignmem.cpp:70-112 AlignHSPMem with alnparams.cpp:100-152 AlnParams::Init */
+static void align_hole(Work *w, unsigned Loi, unsigned Loj, unsigned Leni, unsigned Lenj, char *out)
+{
+  orc_db *db = w->db;
+  out[0] = 0;
+  if (Leni == 0) { if (Lenj > 0) { memset(out, 'I', Lenj); out[Lenj] = 0; } return; }
+  if (Lenj == 0) { memset(out, 'D', Leni); out[Leni] = 0; return; }
+  const AlnPen *AP = &db->ap;
+  AlnPen L = *AP;
+  int LeftA = (Loi == 0), LeftB = (Loj == 0);
+  int RightA = (Loi + Leni == w->LA), RightB = (Loj + Lenj == w->LB);
+  L.LOpenA = LeftA ? AP->LOpenA : AP->OpenA;   L.LExtA = LeftA ? AP->LExtA : AP->ExtA;
+  L.LOpenB = LeftB ? AP->LOpenB : AP->OpenB;   L.LExtB = LeftB ? AP->LExtB : AP->ExtB;
+  L.ROpenA = RightA ? AP->ROpenA : AP->OpenA;  L.RExtA = RightA ? AP->RExtA : AP->ExtA;
+  L.ROpenB = RightB ? AP->ROpenB : AP->OpenB;  L.RExtB = RightB ? AP->RExtB : AP->ExtB;
+  /* BandRadius==0 would be the full DP (viterbifastmem.cpp); not reachable at -band 16 */
+  viterbi_main_diag(w, w->A + Loi, Leni, w->B + Loj, Lenj, db->BandRadius, &L, out);
+}
+
+/* globalalignmem.cpp:129-236 GlobalAlign_AllOpts (FullDPAlways=false, FailIfNoHSPs=true).
+ * SetA must have been called for the query; returns 1 and w->path on success. */
+static int global_align(Work *w, const byte *B, unsigned LB, float *HSPFractIdOut)
+{
+  orc_db *db = w->db;
+  const unsigned LA = w->LA;
+  hf_set_b(w, B, LB);
+  path_alloc(w, (size_t)LA + LB + 2);
+  unsigned MinHSPLength = db->MinGlobalHSPLength == 0 ? 32 : db->MinGlobalHSPLength;
+  if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
+  if (MinHSPLength < 16) MinHSPLength = 16;
+  float HSPFractId = -1.0f;
+  unsigned HSPCount = get_global_hsps(w, MinHSPLength, &HSPFractId);
+  if (HSPFractIdOut) *HSPFractIdOut = HSPFractId;
+  if (HSPFractId < db->MinGlobalHSPFractId) return 0;
+  if (HSPCount == 0) {
+    if (db->MinGlobalHSPLength > 0 && LA > 64) return 0;
+    viterbi_main_diag(w, w->A, LA, B, LB, db->BandRadius, &db->ap, w->path);
+    return 1;
+  }
+  char *p = w->path;
+  for (unsigned i = 0; i < HSPCount; ++i) {
+    const HSP *Prev = i == 0 ? NULL : w->chain[i - 1];
+    const HSP *H = w->chain[i];
+    unsigned hLoi, hLoj, hLeni, hLenj;       /* globalalignmem.cpp:25-68 GetHole */
+    if (Prev) {
+      unsigned pHii = Prev->Loi + Prev->Len - 1, pHij = Prev->Loj + Prev->Len - 1;
+      hLoi = pHii + 1; hLoj = pHij + 1; hLeni = H->Loi - pHii - 1; hLenj = H->Loj - pHij - 1;
+    } else { hLoi = 0; hLoj = 0; hLeni = H->Loi; hLenj = H->Loj; }
+    align_hole(w, hLoi, hLoj, hLeni, hLenj, w->subpath);
+    size_t n = strlen(w->subpath);
+    memcpy(p, w->subpath, n); p += n;
+    memset(p, 'M', H->Len); p += H->Len;
+  }
+  {
+    const HSP *Last = w->chain[HSPCount - 1];
+    unsigned hLoi = Last->Loi + Last->Len, hLoj = Last->Loj + Last->Len;
+    align_hole(w, hLoi, hLoj, LA - hLoi, LB - hLoj, w->subpath);
+    size_t n = strlen(w->subpath);
+    memcpy(p, w->subpath, n); p += n;
+  }
+  *p = 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------ hits */
+
+/* arscorer.cpp:201-296 FillLo + :554-569 GetGapOpenCount; path covers both whole sequences */
+static void fill_hit(const orc_db *db, const char *Path, const byte *Q, unsigned QL, const byte *T,
+                     unsigned TL, ugs_hit *h)
+{
+  unsigned FirstM = UINT_MAX, LastM = UINT_MAX, Col = 0;
+  for (; Path[Col]; ++Col) if (Path[Col] == 'M') { if (FirstM == UINT_MAX) FirstM = Col; LastM = Col; }
+  unsigned ColCount = Col;
+  unsigned FirstQ = 0, FirstT = 0;
+  for (unsigned c = 0; c < FirstM && c < ColCount; ++c) {
+    if (Path[c] == 'M' || Path[c] == 'D') ++FirstQ;
+    if (Path[c] == 'M' || Path[c] == 'I') ++FirstT;
+  }
+  unsigned QPos = FirstQ, TPos = FirstT, Ids = 0, Mism = 0, IntGaps = 0, Opens = 0;
+  char Lastc = 'M';
+  for (unsigned c = FirstM; c <= LastM && FirstM != UINT_MAX; ++c) {
+    char ch = Path[c];
+    if (ch == 'M') {
+      if (db->match[Q[QPos]][T[TPos]]) ++Ids; else ++Mism;
+      ++QPos; ++TPos;
+    } else if (ch == 'D') { if (c > FirstM) ++IntGaps; ++QPos; }
+    else { if (c > FirstM) ++IntGaps; ++TPos; }
+    if (ch != 'M' && Lastc == 'M') ++Opens;
+    Lastc = ch;
+  }
+  h->ids = Ids; h->mism = Mism; h->gaps_int = IntGaps; h->opens = Opens;
+  h->aln_len = LastM - FirstM + 1;
+  h->qlo = FirstQ; h->tlo = FirstT; h->qhi = QPos - 1; h->thi = TPos - 1;
+  h->ql = QL; h->tl = TL; h->cols = ColCount;
+}
+
+/* sort.h:85-117 QuickSortOrderRecurse<float, Desc=true> */
+static void qs_order_desc(const float *V, int left, int right, unsigned *Order)
+{
+  int i = left, j = right;
+  float pivot = V[Order[(left + right) / 2]];
+  while (i <= j) {
+    while (V[Order[i]] > pivot) i++;
+    while (V[Order[j]] < pivot) j--;
+    if (i <= j) { unsigned t = Order[i]; Order[i] = Order[j]; Order[j] = t; i++; j--; }
+  }
+  if (left < j) qs_order_desc(V, left, j, Order);
+  if (i < right) qs_order_desc(V, i, right, Order);
+}
+
+typedef struct {
+  ugs_hit *hits; unsigned nhits, cap;
+  uint32_t *cig; uint64_t ncig, cigcap;
+} HitBuf;
+
+static void hb_push(HitBuf *hb, const ugs_hit *h, const char *path)
+{
+  if (hb->nhits + 1 > hb->cap) { hb->cap = hb->cap * 2 + 64; hb->hits = (ugs_hit *)xrealloc(hb->hits, hb->cap * sizeof(ugs_hit)); }
+  ugs_hit *o = &hb->hits[hb->nhits++];
+  *o = *h;
+  o->cigar_off = hb->ncig;
+  uint32_t runs = 0;
+  for (const char *p = path; *p;) {
+    char c = *p; uint32_t n = 0;
+    while (*p == c) { ++p; ++n; }
+    if (hb->ncig + 1 > hb->cigcap) { hb->cigcap = hb->cigcap * 2 + 256; hb->cig = (uint32_t *)xrealloc(hb->cig, hb->cigcap * 4); }
+    hb->cig[hb->ncig++] = (n << 2) | (c == 'M' ? 0u : c == 'D' ? 1u : 2u);
+    ++runs;
+  }
+  o->cigar_len = runs;
+}
+
+/* searcher.cpp:122-161 Search for one strand: SetQueryImpl/Aligner::SetQuery/SearchImpl with the
+ * candidate loop (udbusortedsearcher.cpp:138-151 / udbusortedsearcherbig.cpp:113-134), OnAR
+ * (searcher.cpp:52-61), Accepter::IsAcceptLo (accepter.cpp:27-94, default filters), Terminator
+ * (terminator.cpp:64-100) */
+static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb)
+{
+  orc_db *db = w->db;
+  if (db->big) rank_big(w, q, QL); else rank_small(w, q, QL);
+  hf_set_a(w, q, QL);
+  w->st.query_letters += QL;
+  int AcceptCount = 0, RejectCount = 0;
+  for (unsigned k = 0; k < w->ntop; ++k) {
+    uint32_t t = w->cand_t[k];
+    const byte *T = (const byte *)db->seqs + db->offs[t];
+    unsigned TL = (unsigned)(db->offs[t + 1] - db->offs[t]);
+    w->st.target_letters += TL; ++w->st.pairs_aligned;
+    float fid;
+    int aligned = global_align(w, T, TL, &fid);
+    int Accept = 0;
+    if (aligned) {
+      ugs_hit h; memset(&h, 0, sizeof(h));
+      fill_hit(db, w->path, q, QL, T, TL, &h);
+      Accept = 1;
+      if (db->p.id_set) {
+        double FractId = h.aln_len == 0 ? 0.0 : (double)h.ids / (double)h.aln_len;
+        if (FractId < db->p.id_accept) Accept = 0;
+      }
+      if (Accept) { h.query = qindex; h.target = t; h.strand = (uint32_t)strand; hb_push(hb, &h, w->path); ++w->st.hits; }
+    }
+    if (Accept) ++AcceptCount; else ++RejectCount;
+    if (db->p.max_accepts > 0 && AcceptCount == db->p.max_accepts) break;
+    if (db->p.max_rejects > 0 && RejectCount == db->p.max_rejects) break;
+  }
+}
+
+typedef struct {
+  orc_db *db; const char *qseqs; const uint64_t *qoffs; uint32_t q0, q1;
+  HitBuf hb; uint32_t *nhits; orc_stats st;
+} Job;
+
+static void *job_run(void *arg)
+{
+  Job *J = (Job *)arg;
+  orc_db *db = J->db;
+  Work *w = work_new(db);
+  char *rc = NULL; size_t rccap = 0;
+  for (uint32_t qi = J->q0; qi < J->q1; ++qi) {
+    const byte *q = (const byte *)J->qseqs + J->qoffs[qi];
+    unsigned QL = (unsigned)(J->qoffs[qi + 1] - J->qoffs[qi]);
+    unsigned first = J->hb.nhits;
+    search_strand(w, qi, q, QL, 0, &J->hb);
+    if (db->p.strand_both && db->p.is_nucleo) {
+      if (rccap < QL + 1) { rccap = QL + 256; rc = (char *)xrealloc(rc, rccap); }
+      orc_revcomp((const char *)q, QL, rc);
+      search_strand(w, qi, (const byte *)rc, QL, 1, &J->hb);
+    }
+    unsigned n = J->hb.nhits - first;
+    J->nhits[qi] = n;
+    if (n > 1) {     /* hitmgr.cpp:477-483 Sort by float(FractId) desc */
+      float *sc = (float *)malloc(n * sizeof(float));
+      unsigned *ord = (unsigned *)malloc(n * sizeof(unsigned));
+      ugs_hit *tmp = (ugs_hit *)malloc(n * sizeof(ugs_hit));
+      for (unsigned i = 0; i < n; ++i) {
+        const ugs_hit *h = &J->hb.hits[first + i];
+        sc[i] = (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len);
+        ord[i] = i; tmp[i] = *h;
+      }
+      qs_order_desc(sc, 0, (int)n - 1, ord);
+      for (unsigned i = 0; i < n; ++i) J->hb.hits[first + i] = tmp[ord[i]];
+      free(sc); free(ord); free(tmp);
+    }
+  }
+  J->st = w->st;
+  free(rc);
+  work_free(w);
+  return NULL;
+}
+
+int orc_search_batch(orc_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
+                     ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                     uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used, int nthreads)
+{
+  if (nthreads < 1) nthreads = 1;
+  if ((uint32_t)nthreads > nq && nq > 0) nthreads = (int)nq;
+  Job *jobs = (Job *)calloc((size_t)nthreads, sizeof(Job));
+  pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  for (int k = 0; k < nthreads; ++k) {
+    jobs[k].db = db; jobs[k].qseqs = qseqs; jobs[k].qoffs = qoffs; jobs[k].nhits = nhits_per_query;
+    jobs[k].q0 = (uint32_t)((uint64_t)nq * k / nthreads);
+    jobs[k].q1 = (uint32_t)((uint64_t)nq * (k + 1) / nthreads);
+  }
+  if (nthreads == 1) job_run(&jobs[0]);
+  else {
+    for (int k = 0; k < nthreads; ++k) pthread_create(&th[k], NULL, job_run, &jobs[k]);
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+  }
+  int rc = UGS_OK;
+  uint64_t nh = 0, nc = 0;
+  memset(&db->stats, 0, sizeof(db->stats));
+  for (int k = 0; k < nthreads; ++k) {
+    HitBuf *hb = &jobs[k].hb;
+    if (nh + hb->nhits > hits_cap || nc + hb->ncig > cigar_cap) rc = UGS_E_CAPACITY;
+    if (rc == UGS_OK) {
+      for (unsigned i = 0; i < hb->nhits; ++i) { hits[nh + i] = hb->hits[i]; hits[nh + i].cigar_off += nc; }
+      if (hb->ncig) memcpy(cigar_pool + nc, hb->cig, hb->ncig * 4);
+    }
+    nh += hb->nhits; nc += hb->ncig;
+    orc_stats *a = &db->stats, *b = &jobs[k].st;
+    a->postings += b->postings; a->query_letters += b->query_letters; a->target_letters += b->target_letters;
+    a->pairs_aligned += b->pairs_aligned; a->dp_cells += b->dp_cells; a->hits += b->hits;
+    a->ungapped_calls += b->ungapped_calls; a->dp_calls += b->dp_calls;
+    free(hb->hits); free(hb->cig);
+  }
+  if (cigar_used) *cigar_used = nc;
+  free(jobs); free(th);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ stage entry points */
+
+int orc_rank(orc_db *db, const char *q, uint32_t ql, uint32_t *cand, uint32_t *cnt, uint32_t cap)
+{
+  Work *w = work_new(db);
+  if (db->big) rank_big(w, (const byte *)q, ql); else rank_small(w, (const byte *)q, ql);
+  unsigned n = w->ntop;
+  for (unsigned k = 0; k < n && k < cap; ++k) { cand[k] = w->cand_t[k]; cnt[k] = w->cand_c[k]; }
+  work_free(w);
+  return (int)n;
+}
+
+int orc_align_pair(orc_db *db, const char *q, uint32_t ql, const char *t, uint32_t tl,
+                   char *path, uint32_t cap, float *hsp_fract_id)
+{
+  Work *w = work_new(db);
+  hf_set_a(w, (const byte *)q, ql);
+  int ok = global_align(w, (const byte *)t, tl, hsp_fract_id);
+  if (ok) {
+    size_t n = strlen(w->path);
+    if (n + 1 > cap) ok = -1; else memcpy(path, w->path, n + 1);
+  } else if (cap) path[0] = 0;
+  work_free(w);
+  return ok;
+}
+
+float orc_viterbi_band(orc_db *db, const char *a, uint32_t la, const char *b, uint32_t lb,
+                       uint32_t band, const float *pen, char *path, uint32_t cap, uint64_t *cells)
+{
+  Work *w = work_new(db);
+  AlnPen P;
+  P.OpenA = pen[0]; P.OpenB = pen[1]; P.ExtA = pen[2]; P.ExtB = pen[3];
+  P.LOpenA = pen[4]; P.LOpenB = pen[5]; P.LExtA = pen[6]; P.LExtB = pen[7];
+  P.ROpenA = pen[8]; P.ROpenB = pen[9]; P.RExtA = pen[10]; P.RExtB = pen[11];
+  path_alloc(w, (size_t)la + lb + 2);
+  float s = viterbi_main_diag(w, (const byte *)a, la, (const byte *)b, lb, band, &P, w->path);
+  size_t n = strlen(w->path);
+  if (n + 1 <= cap) memcpy(path, w->path, n + 1); else if (cap) path[0] = 0;
+  if (cells) *cells = w->st.dp_cells;
+  work_free(w);
+  return s;
+}
+
+/* ------------------------------------------------------------------ writers */
+
+/* blast6out.cpp:27-80: qstart..send are 1..QL / 1..TL (global m_HSP = whole sequences,
+ * alignresult.cpp:138-145); with a rev-comp query sstart/send swap (arscorer.cpp:754-757) */
+int orc_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  double PctId = 100.0 * FractId;
+  unsigned TLo = 1, THi = h->tl;
+  if (h->strand) { TLo = h->tl; THi = 1; }
+  return snprintf(buf, (size_t)cap, "%s\t%s\t%.1f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t*\t*\n", qlabel, tlabel,
+                  PctId, h->aln_len, h->mism, h->opens, 1u, h->ql, TLo, THi);
+}
+
+/* outputuc.cpp:45-93 + comppath.cpp:7-48 */
+int orc_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
+                      const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  double PctId = 100.0 * FractId;
+  char strand = !is_nucleo ? '.' : (h->strand ? '-' : '+');
+  int n = snprintf(buf, (size_t)cap, "H\t%u\t%u\t%.1f\t%c\t%u\t%u\t", h->target, h->ql, PctId, strand, 0u, 0u);
+  for (uint32_t k = 0; k < h->cigar_len; ++k) {
+    uint32_t r = cigar_pool[h->cigar_off + k];
+    char op = "MDI"[r & 3];
+    uint32_t len = r >> 2;
+    if (len == 1) n += snprintf(n < cap ? buf + n : NULL, n < cap ? (size_t)(cap - n) : 0, "%c", op);
+    else n += snprintf(n < cap ? buf + n : NULL, n < cap ? (size_t)(cap - n) : 0, "%u%c", len, op);
+  }
+  n += snprintf(n < cap ? buf + n : NULL, n < cap ? (size_t)(cap - n) : 0, "\t%s\t%s\n", qlabel, tlabel);
+  return n;
+}
+
+/* outputuc.cpp:10-23 */
+int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap)
+{
+  return snprintf(buf, (size_t)cap, "N\t*\t%u\t*\t.\t*\t*\t*\t%s\t*\n", ql, qlabel);
+}

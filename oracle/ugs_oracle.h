@@ -1,0 +1,80 @@
+/*
+ * ugs_oracle.h - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the reference's usearch_global hot path, used only as
+ * the parity checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg.  Nothing under usearch12_amd/ may include, link or call this.
+ *
+ * Pinning: validated bit-exact against the compiled, unmodified reference
+ * (oracle/_ref/usearch12, built by oracle/build_ref.sh) on the golden fixtures under
+ * tests/golden/ (see tests/golden/make_golden.py and tests/test_oracle_golden.py).
+ */
+#ifndef UGS_ORACLE_H
+#define UGS_ORACLE_H
+
+#include <stdint.h>
+#include "../include/ugs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_db orc_db;
+
+int  orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs,
+                   uint32_t nseq, orc_db **out);
+void orc_db_destroy(orc_db *db);
+
+/* masked DB letters (same offsets as the input) */
+const char *orc_db_masked(const orc_db *db);
+/* CSR view of the UDB index: row_off[slots+1], postings[row_off[slots]] */
+uint64_t orc_db_slots(const orc_db *db);
+const uint64_t *orc_db_row_off(const orc_db *db);
+const uint32_t *orc_db_postings(const orc_db *db);
+
+/* whole search, nthreads std worker threads over queries; same output contract as ugs_search_batch */
+int orc_search_batch(orc_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
+                     ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                     uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used,
+                     int nthreads);
+
+/* algorithmic work counters of the last orc_search_batch */
+typedef struct orc_stats {
+  uint64_t postings, query_letters, target_letters, pairs_aligned, dp_cells, hits,
+           ungapped_calls, dp_calls;
+} orc_stats;
+void orc_get_stats(const orc_db *db, orc_stats *st);
+
+/* stage: ranked candidate list of one query strand (already reverse-complemented by the
+ * caller if needed), in the order the candidate loop walks it; returns total kept count,
+ * writes min(cap, kept) entries */
+int orc_rank(orc_db *db, const char *q, uint32_t ql, uint32_t *cand, uint32_t *cnt, uint32_t cap);
+
+/* stage: GlobalAligner::Align on one pair.  Returns 1 if aligned (path written as
+ * NUL-terminated M/D/I text into path[cap]), 0 if rejected. hsp_fract_id receives HSPFractId. */
+int orc_align_pair(orc_db *db, const char *q, uint32_t ql, const char *t, uint32_t tl,
+                   char *path, uint32_t cap, float *hsp_fract_id);
+
+/* stage: ViterbiFastMainDiagMem on a hole with explicit 12 gap penalties
+ * pen = {OpenA,OpenB,ExtA,ExtB,LOpenA,LOpenB,LExtA,LExtB,ROpenA,ROpenB,RExtA,RExtB} */
+float orc_viterbi_band(orc_db *db, const char *a, uint32_t la, const char *b, uint32_t lb,
+                       uint32_t band, const float *pen, char *path, uint32_t cap, uint64_t *cells);
+
+/* stage: FastMaskSeq in place */
+void orc_fastmask(char *seq, uint32_t len);
+
+/* reverse complement (seqinfo.cpp:292-323) */
+void orc_revcomp(const char *seq, uint32_t len, char *out);
+
+/* text writers (blast6out.cpp:27-80, outputuc.cpp:10-93) */
+int orc_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
+int orc_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
+                      const char *qlabel, const char *tlabel, char *buf, int cap);
+int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
+
+void orc_params_init(ugs_params *p, int is_nucleo, double id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

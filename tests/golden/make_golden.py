@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the compiled, UNMODIFIED
+reference (oracle/_ref/usearch12, built by oracle/build_ref.sh from /root/reference/src)
+on seeded synthetic inputs.  Runs only where /root/reference exists (the build container).
+
+Committed per case: <case>.b6 and <case>.uc (the reference's -blast6out / -uc text, -threads 1
+so lines are in query order) and one manifest.json with the generator arguments, the
+reference command line and sha256 digests of the generated inputs.  Inputs themselves are
+NOT committed: tests regenerate them from usearch12_amd/synth.py and check the digests.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from usearch12_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "usearch12")
+
+# name -> dict(gen=..., args=..., id=..., strand=..., opts={reference option: value})
+CASES = {
+    "nt_small":    dict(gen="uniform", seed=11, db_n=2000, q_n=300, length=250, aa=False, id=0.97, strand="plus"),
+    "nt_big":      dict(gen="uniform", seed=12, db_n=3000, q_n=300, length=250, aa=False, id=0.97, strand="plus", big=100),
+    "nt_both":     dict(gen="uniform", seed=13, db_n=2000, q_n=300, length=250, aa=False, id=0.97, strand="both"),
+    "nt_bigboth":  dict(gen="uniform", seed=14, db_n=3000, q_n=300, length=250, aa=False, id=0.97, strand="both", big=100),
+    "aa_small":    dict(gen="uniform", seed=15, db_n=3000, q_n=300, length=300, aa=True, id=0.8),
+    "aa_big":      dict(gen="uniform", seed=16, db_n=3000, q_n=300, length=300, aa=True, id=0.8, big=100),
+    "nt_lowid":    dict(gen="uniform", seed=17, db_n=2000, q_n=300, length=250, aa=False, id=0.8, strand="plus", mut=[0.08, 0.01, 0.01]),
+    "nt_lowidbig": dict(gen="uniform", seed=18, db_n=2000, q_n=300, length=250, aa=False, id=0.8, strand="plus", mut=[0.08, 0.01, 0.01], big=100),
+    "nt_short":    dict(gen="uniform", seed=19, db_n=2000, q_n=300, length=60, aa=False, id=0.9, strand="plus", mut=[0.03, 0.01, 0.01]),
+    "nt_big120k":  dict(gen="uniform", seed=20, db_n=120000, q_n=400, length=250, aa=False, id=0.97, strand="plus"),
+    "hard_small":  dict(gen="hard", seed=21, n_fam=300, fam=8, q_n=1200, aa=False, id=0.97, strand="plus"),
+    "hard_big":    dict(gen="hard", seed=22, n_fam=300, fam=8, q_n=1200, aa=False, id=0.97, strand="plus", big=100),
+    "hard_both":   dict(gen="hard", seed=23, n_fam=300, fam=8, q_n=1200, aa=False, id=0.97, strand="both", big=100),
+    "hard_id90":   dict(gen="hard", seed=24, n_fam=300, fam=8, q_n=1200, aa=False, id=0.90, strand="plus", big=100),
+    "hard_id90s":  dict(gen="hard", seed=24, n_fam=300, fam=8, q_n=1200, aa=False, id=0.90, strand="plus"),
+    "hard_acc":    dict(gen="hard", seed=25, n_fam=300, fam=8, q_n=800, aa=False, id=0.95, strand="plus", big=100, maxaccepts=4, maxrejects=16),
+    "hard_acc_s":  dict(gen="hard", seed=25, n_fam=300, fam=8, q_n=800, aa=False, id=0.95, strand="both", maxaccepts=4, maxrejects=16),
+    "hard_aa":     dict(gen="hard", seed=26, n_fam=300, fam=8, q_n=1200, aa=True, id=0.8, big=100),
+    "hard_aa_s":   dict(gen="hard", seed=27, n_fam=300, fam=8, q_n=1200, aa=True, id=0.9),
+}
+
+
+def make_inputs(c):
+    if c["gen"] == "uniform":
+        db = synth.make_db(c["seed"], c["db_n"], c["length"], c["aa"])
+        kw = {}
+        if "mut" in c:
+            kw = dict(p_sub=c["mut"][0], p_del=c["mut"][1], p_ins=c["mut"][2])
+        qs = synth.make_queries(c["seed"], db, c["q_n"], c["length"], c["aa"], **kw)
+    else:
+        db, qs = synth.make_hard(c["seed"], c["n_fam"], c["fam"], c["q_n"], aa=c["aa"])
+    if c.get("strand") == "both":
+        qs = synth.revcomp_some(c["seed"], qs)
+    return db, qs
+
+
+def digest(ss):
+    h = hashlib.sha256()
+    h.update(ss.offs.tobytes())
+    h.update(ss.seqs.tobytes())
+    return h.hexdigest()
+
+
+def ref_cmd(c, qfa, dbfa, prefix):
+    cmd = [REF, "-usearch_global", qfa, "-db", dbfa, "-id", str(c["id"]), "-blast6out", prefix + ".b6",
+           "-uc", prefix + ".uc", "-threads", "1"]
+    if not c["aa"]:
+        cmd += ["-strand", c["strand"]]
+    for opt in ("big", "maxaccepts", "maxrejects"):
+        if opt in c:
+            cmd += ["-" + opt, str(c[opt])]
+    return cmd
+
+
+def main():
+    assert os.path.exists(REF), "build the reference first: oracle/build_ref.sh"
+    manifest = {}
+    only = set(sys.argv[1:])
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, c in CASES.items():
+            if only and name not in only:
+                continue
+            db, qs = make_inputs(c)
+            dbfa, qfa = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa")
+            db.write_fasta(dbfa)
+            qs.write_fasta(qfa)
+            prefix = os.path.join(HERE, name)
+            cmd = ref_cmd(c, qfa, dbfa, prefix)
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            nb6 = sum(1 for _ in open(prefix + ".b6"))
+            manifest[name] = dict(c, db_sha256=digest(db), q_sha256=digest(qs), n_hits=nb6,
+                                  cmd=" ".join(["usearch12"] + [os.path.basename(x) if x.startswith(tmp) else x
+                                                                 for x in cmd[1:]]).replace(HERE + "/", ""))
+            print(name, "hits", nb6)
+    path = os.path.join(HERE, "manifest.json")
+    if only and os.path.exists(path):
+        old = json.load(open(path))
+        old.update(manifest)
+        manifest = old
+    json.dump(manifest, open(path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+"""TEST-ONLY ctypes binding of oracle/liborc.so (the CPU restatement used as parity checker)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from usearch12_amd.abi import Params, HIT_DTYPE, ptr, as_u8, cigar_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+REF_BIN = os.path.join(ORC_DIR, "_ref", "usearch12")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORC_DIR, "liborc.so")
+        src = os.path.join(ORC_DIR, "ugs_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORC_DIR, "liborc.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.orc_db_create.restype = C.c_int
+        L.orc_db_create.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.orc_db_destroy.argtypes = [C.c_void_p]
+        L.orc_db_masked.restype = C.c_void_p
+        L.orc_db_masked.argtypes = [C.c_void_p]
+        L.orc_db_slots.restype = C.c_uint64
+        L.orc_db_slots.argtypes = [C.c_void_p]
+        L.orc_db_row_off.restype = C.c_void_p
+        L.orc_db_row_off.argtypes = [C.c_void_p]
+        L.orc_db_postings.restype = C.c_void_p
+        L.orc_db_postings.argtypes = [C.c_void_p]
+        L.orc_search_batch.restype = C.c_int
+        L.orc_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_rank.restype = C.c_int
+        L.orc_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_align_pair.restype = C.c_int
+        L.orc_align_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                     C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_viterbi_band.restype = C.c_float
+        L.orc_viterbi_band.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.orc_fastmask.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_params_init.argtypes = [C.POINTER(Params), C.c_int, C.c_double]
+        L.orc_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        for fn in (L.orc_format_blast6,):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_format_uc_hit.restype = C.c_int
+        L.orc_format_uc_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_format_uc_nohit.restype = C.c_int
+        L.orc_format_uc_nohit.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def params(is_nucleo=True, id=0.97, **kw):
+    p = Params()
+    lib().orc_params_init(C.byref(p), 1 if is_nucleo else 0, float(id))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+STATS_DTYPE = np.dtype([(n, "<u8") for n in ("postings", "query_letters", "target_letters", "pairs_aligned",
+                                             "dp_cells", "hits", "ungapped_calls", "dp_calls")])
+
+
+class OrcDB:
+    def __init__(self, p, seqs, offs):
+        self.p = p
+        self.seqs = as_u8(seqs)
+        self.offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        self.n = len(self.offs) - 1
+        h = C.c_void_p()
+        rc = lib().orc_db_create(C.byref(p), self.seqs.ctypes.data, self.offs.ctypes.data, self.n, C.byref(h))
+        assert rc == 0, rc
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().orc_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def masked(self):
+        n = int(self.offs[-1])
+        return np.ctypeslib.as_array(C.cast(lib().orc_db_masked(self.h), C.POINTER(C.c_uint8)), shape=(n,)).copy()
+
+    def index(self):
+        slots = int(lib().orc_db_slots(self.h))
+        ro = np.ctypeslib.as_array(C.cast(lib().orc_db_row_off(self.h), C.POINTER(C.c_uint64)), shape=(slots + 1,)).copy()
+        n = int(ro[-1])
+        po = np.ctypeslib.as_array(C.cast(lib().orc_db_postings(self.h), C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
+        return ro, po
+
+    def search(self, qseqs, qoffs, nthreads=1):
+        qseqs = as_u8(qseqs)
+        qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
+        nq = len(qoffs) - 1
+        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) + 1
+        hits = np.zeros(cap, dtype=HIT_DTYPE)
+        nh = np.zeros(nq + 1, dtype=np.uint32)
+        cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
+        pool = np.zeros(cig_cap, dtype=np.uint32)
+        used = C.c_uint64(0)
+        rc = lib().orc_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
+                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used), nthreads)
+        assert rc == 0, rc
+        nh = nh[:nq]
+        return hits[:int(nh.sum())], nh, pool[:used.value]
+
+    def stats(self):
+        st = np.zeros(1, dtype=STATS_DTYPE)
+        lib().orc_get_stats(self.h, st.ctypes.data)
+        return {k: int(st[0][k]) for k in STATS_DTYPE.names}
+
+    def rank(self, q, cap=64):
+        q = as_u8(q)
+        cand = np.zeros(cap, dtype=np.uint32)
+        cnt = np.zeros(cap, dtype=np.uint32)
+        n = lib().orc_rank(self.h, q.ctypes.data, len(q), cand.ctypes.data, cnt.ctypes.data, cap)
+        m = min(n, cap)
+        return n, cand[:m], cnt[:m]
+
+    def align_pair(self, q, t):
+        q, t = as_u8(q), as_u8(t)
+        buf = C.create_string_buffer(len(q) + len(t) + 8)
+        fid = C.c_float(0)
+        ok = lib().orc_align_pair(self.h, q.ctypes.data, len(q), t.ctypes.data, len(t), buf, len(buf), C.byref(fid))
+        return ok, buf.value.decode(), fid.value
+
+    def viterbi(self, a, b, band, pen):
+        a, b = as_u8(a), as_u8(b)
+        pen = np.ascontiguousarray(pen, dtype=np.float32)
+        buf = C.create_string_buffer(len(a) + len(b) + 8)
+        cells = C.c_uint64(0)
+        s = lib().orc_viterbi_band(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), band, pen.ctypes.data,
+                                   buf, len(buf), C.byref(cells))
+        return s, buf.value.decode(), cells.value
+
+
+def revcomp(seq):
+    s = as_u8(seq)
+    out = np.zeros(len(s), dtype=np.uint8)
+    lib().orc_revcomp(s.ctypes.data, len(s), out.ctypes.data)
+    return out
+
+
+def fastmask(seq):
+    s = as_u8(seq).copy()
+    lib().orc_fastmask(s.ctypes.data, len(s))
+    return s
+
+
+def format_outputs(fmt_lib, prefix, hits, nh, pool, qlabels, qlens, tlabels, is_nucleo):
+    """Render blast6 and uc text in query order with the writers of `fmt_lib`
+    (prefix 'orc' for the oracle, 'ugs' for the product)."""
+    b6, uc = [], []
+    buf = C.create_string_buffer(1 << 16)
+    f_b6 = getattr(fmt_lib, prefix + "_format_blast6")
+    f_uch = getattr(fmt_lib, prefix + "_format_uc_hit")
+    f_ucn = getattr(fmt_lib, prefix + "_format_uc_nohit")
+    pool = np.ascontiguousarray(pool, dtype=np.uint32)
+    k = 0
+    for qi, n in enumerate(nh):
+        ql = qlabels[qi].encode()
+        if n == 0:
+            f_ucn(int(qlens[qi]), ql, buf, len(buf))
+            uc.append(buf.value.decode())
+        for j in range(int(n)):
+            h = hits[k:k + 1]
+            tl = tlabels[int(h["target"][0])].encode()
+            f_b6(h.ctypes.data, ql, tl, buf, len(buf))
+            b6.append(buf.value.decode())
+            f_uch(h.ctypes.data, pool.ctypes.data, 1 if is_nucleo else 0, ql, tl, buf, len(buf))
+            uc.append(buf.value.decode())
+            k += 1
+    return "".join(b6), "".join(uc)
+
+
+def run_reference(qfa, dbfa, out_prefix, id=0.97, strand="plus", threads=1, extra=()):
+    """Run the compiled unmodified reference (oracle/_ref/usearch12) - only where it exists."""
+    cmd = [REF_BIN, "-usearch_global", qfa, "-db", dbfa, "-id", str(id), "-blast6out", out_prefix + ".b6",
+           "-uc", out_prefix + ".uc", "-threads", str(threads)]
+    if strand:
+        cmd += ["-strand", strand]
+    cmd += list(extra)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out_prefix + ".b6").read(), open(out_prefix + ".uc").read()

@@ -1,0 +1,80 @@
+"""ctypes mirror of include/ugs.h (structs + error codes), shared by the product
+binding (capi.py) and the test-only oracle binding (tests/orc.py)."""
+import ctypes as C
+import numpy as np
+
+UGS_OK = 0
+UGS_E_ARG, UGS_E_NODEVICE, UGS_E_HIP, UGS_E_NOMEM, UGS_E_CAPACITY, UGS_E_ENVELOPE = -1, -2, -3, -4, -5, -6
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("is_nucleo", C.c_int32), ("word_len", C.c_int32), ("id", C.c_float),
+        ("id_accept", C.c_double), ("id_set", C.c_int32), ("strand_both", C.c_int32),
+        ("max_accepts", C.c_int32), ("max_rejects", C.c_int32),
+        ("big", C.c_uint32), ("bump_pct", C.c_uint32), ("stepwords", C.c_uint32),
+        ("band", C.c_int32), ("minhsp", C.c_int32), ("xdrop_nw", C.c_float),
+        ("match", C.c_float), ("mismatch", C.c_float),
+        ("hsp_word_len", C.c_int32), ("dbmask", C.c_int32),
+    ]
+
+
+HIT_DTYPE = np.dtype({
+    "names": ["query", "target", "ids", "mism", "gaps_int", "aln_len", "opens",
+              "qlo", "qhi", "tlo", "thi", "ql", "tl", "strand", "cigar_off", "cigar_len", "cols"],
+    "formats": ["<u4"] * 14 + ["<u8", "<u4", "<u4"],
+    "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 64, 68],
+    "itemsize": 72,
+})
+
+
+class BatchStats(C.Structure):
+    _fields_ = [
+        ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_total", C.c_float),
+        ("postings", C.c_uint64), ("query_letters", C.c_uint64), ("target_letters", C.c_uint64),
+        ("pairs_aligned", C.c_uint64), ("dp_cells", C.c_uint64), ("hits", C.c_uint64),
+    ]
+
+
+def as_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else np.ascontiguousarray(buf, dtype=np.uint8)
+    return a
+
+
+def ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def cigar_text(pool, off, n):
+    """CompressPath text (comppath.cpp:7-48) from run-length pool entries."""
+    out = []
+    for r in pool[int(off):int(off) + int(n)]:
+        ln, op = int(r) >> 2, "MDI"[int(r) & 3]
+        out.append(op if ln == 1 else "%d%s" % (ln, op))
+    return "".join(out)
+
+
+def read_fasta(path):
+    """Minimal FASTA reader with the reference's filtering rules
+    (fastaseqsource.cpp:25-124): labels keep everything after '>', whitespace and
+    '-'/'.' are stripped from sequences, other non-alpha bytes dropped, empty records skipped."""
+    labels, seqs = [], []
+    cur = None
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if cur is not None and cur[1]:
+                    labels.append(cur[0]); seqs.append(b"".join(cur[1]))
+                cur = (line[1:].decode(), [])
+            elif cur is not None:
+                s = bytes(c for c in line if (65 <= c <= 90) or (97 <= c <= 122))
+                if s:
+                    cur[1].append(s)
+    if cur is not None and cur[1]:
+        labels.append(cur[0]); seqs.append(b"".join(cur[1]))
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
+    return labels, flat, offs
