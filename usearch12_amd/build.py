@@ -1,0 +1,37 @@
+"""Builds the product's HIP extension in-tree: usearch12_amd/libugs.so (gfx950 only)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libugs.so")
+SOURCES = ["ugs_host.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip"]
+DEPS = SOURCES + ["ugs_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
+
+
+def _mtime(path):
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def build(force=False, verbose=False):
+    newest = max(_mtime(os.path.join(CSRC, d)) for d in DEPS)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _mtime(obj) < newest:
+            cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

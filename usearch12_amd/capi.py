@@ -1,0 +1,190 @@
+"""ctypes binding of the product library usearch12_amd/libugs.so (the C-ABI in include/ugs.h).
+
+There is no CPU fallback: if the HIP extension is missing this module raises at load time,
+and every compute entry point fails with UGS_E_NODEVICE when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import Params, HIT_DTYPE, BatchStats, as_u8
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libugs.so")
+_lib = None
+
+EXPORTS = [
+    "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
+    "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates",
+    "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
+]
+
+
+class UgsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ugs error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("usearch12_amd/libugs.so is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.ugs_params_init.argtypes = [C.POINTER(Params), i32, C.c_double]
+        L.ugs_db_create.argtypes = [C.POINTER(Params), vp, vp, u32, i32, C.POINTER(vp)]
+        L.ugs_db_destroy.argtypes = [vp]
+        L.ugs_db_destroy.restype = None
+        L.ugs_db_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.ugs_db_debug_fetch.argtypes = [vp, vp, vp, vp]
+        L.ugs_search_batch.argtypes = [vp, vp, vp, u32, vp, u64, vp, vp, u64, C.POINTER(u64)]
+        L.ugs_batch_create.argtypes = [vp, u32, u64, C.POINTER(vp)]
+        L.ugs_batch_destroy.argtypes = [vp]
+        L.ugs_batch_destroy.restype = None
+        L.ugs_batch_upload.argtypes = [vp, vp, vp, u32]
+        L.ugs_batch_search.argtypes = [vp]
+        L.ugs_batch_sync.argtypes = [vp]
+        L.ugs_batch_fetch.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
+        L.ugs_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
+        L.ugs_batch_get_candidates.argtypes = [vp, vp, vp, vp, u32]
+        L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
+        L.ugs_format_uc_hit.argtypes = [vp, vp, i32, C.c_char_p, C.c_char_p, C.c_char_p, i32]
+        L.ugs_format_uc_nohit.argtypes = [u32, C.c_char_p, C.c_char_p, i32]
+        L.ugs_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise UgsError(rc, lib().ugs_last_error().decode())
+
+
+def params(is_nucleo=True, id=0.97, **kw):
+    p = Params()
+    lib().ugs_params_init(C.byref(p), 1 if is_nucleo else 0, float(id))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    return lib().ugs_device_count()
+
+
+class UgsDB:
+    """Masked DB + UDB word index resident in one GPU's HBM (ugs_db)."""
+
+    def __init__(self, p, seqs, offs, device=0):
+        self.p = p
+        seqs = as_u8(seqs)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        self.n = len(offs) - 1
+        self.nletters = int(offs[-1])
+        h = C.c_void_p()
+        _chk(lib().ugs_db_create(C.byref(p), seqs.ctypes.data, offs.ctypes.data, self.n, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ugs_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().ugs_db_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(postings=a.value, slots=b.value, hbm_bytes=c.value)
+
+    def debug_fetch(self):
+        st = self.stats()
+        masked = np.zeros(max(self.nletters, 1), dtype=np.uint8)
+        row_off = np.zeros(st["slots"] + 1, dtype=np.uint64)
+        postings = np.zeros(max(st["postings"], 1), dtype=np.uint32)
+        _chk(lib().ugs_db_debug_fetch(self.h, masked.ctypes.data, row_off.ctypes.data, postings.ctypes.data))
+        return masked[:self.nletters], row_off, postings[:st["postings"]]
+
+    def search(self, qseqs, qoffs):
+        """One-shot ugs_search_batch."""
+        qseqs = as_u8(qseqs)
+        qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
+        nq = len(qoffs) - 1
+        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) + 1
+        hits = np.zeros(cap, dtype=HIT_DTYPE)
+        nh = np.zeros(nq + 1, dtype=np.uint32)
+        cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
+        pool = np.zeros(cig_cap, dtype=np.uint32)
+        used = C.c_uint64(0)
+        _chk(lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
+                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
+        nh = nh[:nq]
+        return hits[:int(nh.sum())], nh, pool[:used.value]
+
+
+class UgsBatch:
+    """A query batch resident in HBM (ugs_batch): upload once, search many times."""
+
+    def __init__(self, db, max_queries, max_letters):
+        self.db = db
+        h = C.c_void_p()
+        _chk(lib().ugs_batch_create(db.h, max_queries, max_letters, C.byref(h)))
+        self.h = h
+        self.nq = 0
+        self.nletters = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ugs_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, qseqs, qoffs):
+        qseqs = as_u8(qseqs)
+        qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
+        self.nq = len(qoffs) - 1
+        self.nletters = int(qoffs[-1] - qoffs[0])
+        _chk(lib().ugs_batch_upload(self.h, qseqs.ctypes.data, qoffs.ctypes.data, self.nq))
+
+    def search(self):
+        _chk(lib().ugs_batch_search(self.h))
+
+    def sync(self):
+        _chk(lib().ugs_batch_sync(self.h))
+
+    def fetch(self):
+        p = self.db.p
+        cap = self.nq * max(1, p.max_accepts) * (2 if p.strand_both else 1) + 1
+        hits = np.zeros(cap, dtype=HIT_DTYPE)
+        nh = np.zeros(self.nq + 1, dtype=np.uint32)
+        cig_cap = self.nletters * 2 + 64 * self.nq + 1024
+        pool = np.zeros(cig_cap, dtype=np.uint32)
+        used = C.c_uint64(0)
+        _chk(lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
+        nh = nh[:self.nq]
+        return hits[:int(nh.sum())], nh, pool[:used.value]
+
+    def stats(self):
+        st = BatchStats()
+        _chk(lib().ugs_batch_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in BatchStats._fields_}
+
+    def candidates(self):
+        p = self.db.p
+        K = p.max_accepts + p.max_rejects - 1
+        units = self.nq * (2 if p.strand_both else 1)
+        cand = np.zeros((max(units, 1), K), dtype=np.uint32)
+        cnt = np.zeros((max(units, 1), K), dtype=np.uint32)
+        n = np.zeros(max(units, 1), dtype=np.uint32)
+        _chk(lib().ugs_batch_get_candidates(self.h, cand.ctypes.data, cnt.ctypes.data, n.ctypes.data, K))
+        return cand[:units], cnt[:units], n[:units]

@@ -1,0 +1,591 @@
+// ugs_align.hip - the global aligner + accept/terminate replay on gfx950.
+// One WAVE per (query, strand) walks that unit's ranked candidates serially with the
+// reference's early-termination rule; inside a pair the 64 lanes share the work.
+//
+// Replaces (reference, /root/reference/src):
+//   candidate loop + Terminator          udbusortedsearcherbig.cpp:113-134, terminator.cpp:64-100
+//   HSPFinder::SetA/SetB/SeqToWords      hspfinder.cpp:226-331
+//   HSPFinder::UngappedBlast             ungappedblast.cpp:8-211   (lanes = target seed positions;
+//                                         the serial "BPos = Bhi+1" skip is replayed by ballot)
+//   IsGlobalHSP / IsStaggered / Chain    hspfinder.cpp:594-636, hsp.h:102-126, chainer.cpp:352-500
+//   GetGlobalHSPs / gate                 getglobalhsps.cpp:9-61, globalalignmem.cpp:161-180
+//   GetHole / AlignHSPMem / AlnParams::Init   globalalignmem.cpp:25-112, alnparams.cpp:100-152
+//   ViterbiFastBandMem (+MainDiag)       viterbifastbandmem.cpp:12-253  (row sweep: lanes = band
+//                                         columns, M/D by shuffle from the previous row, the
+//                                         in-row I recurrence by a wavefront max-plus prefix scan)
+//   TraceBackBitMem                      tracebackbitmem.cpp:8-73
+//   AlignResult::FillLo / GetGapOpenCount     arscorer.cpp:201-296,554-569
+//   Accepter::IsAcceptLo (-id)           accepter.cpp:27-94
+// Scores are int32 in units of 0.5 (all reference scores are exact half-integers);
+// MINUS_INFINITY is a saturating sentinel so that -inf + x == -inf and -inf >= -inf hold as in fp32.
+#include "ugs_dev.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+
+#define NEG (-(1 << 29))
+#define NEGT (-(1 << 28))
+#define TB_DM 1
+#define TB_IM 2
+#define TB_MD 4
+#define TB_MI 8
+
+__device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : x + c; }
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+struct HSPd { uint32_t Loi, Loj, Len; int32_t Score2; };
+
+struct WaveState {            // per-wave LDS control block (written by lane 0, read by all after a wave fence)
+  uint32_t nhsp, nchain, nruns, cur_op, cur_len, rt_n, overflow, pad;
+};
+
+struct Pen { int OpenA, OpenB, ExtA, ExtB, LOpenA, LOpenB, LExtA, LExtB, ROpenA, ROpenB, RExtA, RExtB; };
+
+struct WaveCtx {
+  // LDS
+  uint8_t *A, *B;             // class codes of query / target letters
+  uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
+  int32_t *Mrow, *Drow;       // Mrow[-1] valid
+  HSPd *hsps;
+  uint32_t *chain;            // indexes into hsps in chain order
+  uint32_t *csc;              // chainer scratch
+  WaveState *ws;
+  const uint8_t *s_cls; const int8_t *s_sub2; const uint64_t *s_match; const uint8_t *s_hl;
+  // global scratch
+  uint8_t *tb; uint32_t *runs; uint32_t runs_cap;
+  uint32_t LA, LB, nwA, nA2, hsp_cap;
+  int lane;
+};
+
+__device__ __forceinline__ int score2(const WaveCtx &c, uint8_t a, uint8_t b) { return c.s_sub2[((a & 31) << 5) | (b & 31)]; }
+__device__ __forceinline__ bool ident(const WaveCtx &c, uint8_t a, uint8_t b) { return (c.s_match[a] >> b) & 1ull; }
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// hspfinder.cpp:594-636
+__device__ bool is_global_hsp(uint32_t ALo, uint32_t BLo, uint32_t LA, uint32_t LB)
+{
+  if (LA <= LB) {
+    uint32_t MaxGap = LA / 4 + 1;
+    if (ALo > BLo && ALo - BLo > MaxGap) return false;
+    uint32_t AR = LA - ALo, BR = LB - BLo;
+    if (AR > BR && AR - BR > MaxGap) return false;
+  } else {
+    uint32_t MaxGap = LB / 4 + 1;
+    if (BLo > ALo && BLo - ALo > MaxGap) return false;
+    uint32_t AR = LA - ALo, BR = LB - BLo;
+    if (BR > AR && BR - AR > MaxGap) return false;
+  }
+  return true;
+}
+
+// Query side of HSPFinder::SetA: words for every position (invalid letter -> 0), sorted by
+// (word, pos) so a word's first MaxReps positions are contiguous and ascending.
+__device__ void build_query_words(WaveCtx &c, int w, int alpha)
+{
+  const int lane = c.lane;
+  const uint32_t LA = c.LA;
+  c.nwA = LA >= (uint32_t)w ? LA - w + 1 : 0;
+  uint32_t n2 = 64; while (n2 < c.nwA) n2 <<= 1;
+  c.nA2 = n2;
+  for (uint32_t p = lane; p < n2; p += 64) {
+    uint32_t key = 0xffffffffu;
+    if (p < c.nwA) {
+      uint32_t word = 0;
+      for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31];
+      key = (word << 16) | p;
+    }
+    c.qsort[p] = key;
+  }
+  wave_sync();
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n2; i += 64) {
+        uint32_t l = i ^ j;
+        if (l > i) {
+          uint32_t x = c.qsort[i], y = c.qsort[l];
+          bool up = ((i & k) == 0);
+          if ((x > y) == up) { c.qsort[i] = y; c.qsort[l] = x; }
+        }
+      }
+      wave_sync();
+    }
+}
+
+// ungappedblast.cpp:8-211
+__device__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLength, unsigned long long *counters)
+{
+  const int lane = c.lane, w = db.hsp_w;
+  const uint32_t LA = c.LA, LB = c.LB;
+  uint32_t nh = 0;
+  if (LB >= 2u * w && c.nwA > 0) {
+    const uint32_t nwB = LB - w + 1;
+    uint32_t BPos = 0;
+    while (BPos < nwB) {
+      const uint32_t bpos = BPos + lane;
+      bool ok = false;
+      uint32_t rAlo = 0, rBlo = 0, rLen = 0; int rBest = 0;
+      if (bpos < nwB) {
+        uint32_t word = 0;
+        for (int k = 0; k < w; ++k) word = word * db.alpha + c.s_hl[c.B[bpos + k] & 31];
+        const uint32_t want = word << 16;
+        uint32_t lo = 0, hi = c.nwA;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c.qsort[mid] < want) lo = mid + 1; else hi = mid; }
+        for (uint32_t r = 0; r < UGS_MAXREPS && lo + r < c.nwA; ++r) {
+          const uint32_t ent = c.qsort[lo + r];
+          if ((ent >> 16) != word) break;
+          const uint32_t apos = ent & 0xffffu;
+          int score = 0;
+          for (int k = 0; k < w; ++k) score += score2(c, c.A[apos + k], c.B[bpos + k]);
+          int best = score;
+          uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
+          for (;;) {
+            ++b2; if (b2 >= LB) break;
+            ++a2; if (a2 >= LA) break;
+            score += score2(c, c.A[a2], c.B[b2]);
+            if (score > best) { best = score; bestb2 = b2; }
+            else if (best - score > db.xdrop2) break;
+          }
+          uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
+          score = best;
+          for (;;) {
+            if (b1 == 0 || a1 == 0) break;
+            --b1; --a1;
+            score += score2(c, c.A[a1], c.B[b1]);
+            if (score > best) { best = score; bestb1 = b1; }
+            else if (best - score > db.xdrop2) break;
+          }
+          const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
+          const uint32_t Alo = apos - (bpos - bestb1);
+          if (Len >= MinLength && best >= db.minscore2 && is_global_hsp(Alo, Blo, LA, LB)) {
+            ok = true; rAlo = Alo; rBlo = Blo; rLen = Len; rBest = best;
+            break;
+          }
+        }
+      }
+      const uint64_t m = __ballot(ok);
+      if (m) {
+        const int f = __ffsll((long long)m) - 1;
+        const uint32_t Alo = rl((int)rAlo, f), Blo = rl((int)rBlo, f), Len = rl((int)rLen, f);
+        const int Best = rl(rBest, f);
+        if (nh < c.hsp_cap) {
+          if (lane == 0) { c.hsps[nh].Loi = Alo; c.hsps[nh].Loj = Blo; c.hsps[nh].Len = Len; c.hsps[nh].Score2 = Best; }
+          ++nh;
+        } else if (lane == 0) atomicOr(&counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_HSPCAP);
+        BPos = Blo + Len;            // Bhi + 1
+      } else
+        BPos += 64;
+    }
+  }
+  if (lane == 0) c.ws->nhsp = nh;
+  wave_sync();
+}
+
+// chainer.cpp:352-500 on lane 0 (HSP counts are tiny); csc layout: [bp_pos 2n][bp_idxlo 2n][prev n][cscore n][list n]
+__device__ void chain_lane0(WaveCtx &c)
+{
+  const uint32_t n = c.ws->nhsp;
+  uint32_t nchain = 0;
+  if (n) {
+    uint32_t *bp_pos = c.csc, *bp_il = c.csc + 2 * c.hsp_cap, *prev = c.csc + 4 * c.hsp_cap;
+    int32_t *cs = (int32_t *)(c.csc + 5 * c.hsp_cap);
+    uint32_t *list = c.csc + 6 * c.hsp_cap;
+    for (uint32_t i = 0; i < n; ++i) {
+      bp_pos[2 * i] = c.hsps[i].Loi; bp_il[2 * i] = (i << 1) | 1u;
+      bp_pos[2 * i + 1] = c.hsps[i].Loi + c.hsps[i].Len - 1; bp_il[2 * i + 1] = (i << 1);
+    }
+    // stable sort: Pos ascending, Lo before Hi, ties keep input order (glibc qsort = merge sort)
+    for (uint32_t i = 1; i < 2 * n; ++i) {
+      const uint32_t p = bp_pos[i], il = bp_il[i];
+      uint32_t j = i;
+      while (j > 0) {
+        const uint32_t pp = bp_pos[j - 1], pil = bp_il[j - 1];
+        const bool less = (p != pp) ? (p < pp) : (((il & 1) != (pil & 1)) ? ((il & 1) && !(pil & 1)) : false);
+        if (!less) break;
+        bp_pos[j] = pp; bp_il[j] = pil; --j;
+      }
+      bp_pos[j] = p; bp_il[j] = il;
+    }
+    for (uint32_t i = 0; i < n; ++i) prev[i] = 0xffffffffu;
+    uint32_t nlist = 0;
+    for (uint32_t b = 0; b < 2 * n; ++b) {
+      if (!(bp_il[b] & 1)) continue;
+      const uint32_t hi = bp_il[b] >> 1;
+      const HSPd h = c.hsps[hi];
+      int best = 0; uint32_t bestc = 0xffffffffu;
+      for (uint32_t k = 0; k < nlist; ++k) {
+        const uint32_t ci = list[k];
+        const HSPd ch = c.hsps[ci];
+        if (ch.Loi + ch.Len - 1 < h.Loi && ch.Loj + ch.Len - 1 < h.Loj && (bestc == 0xffffffffu || cs[ci] > best)) { bestc = ci; best = cs[ci]; }
+      }
+      list[nlist++] = hi;
+      prev[hi] = bestc;
+      cs[hi] = bestc == 0xffffffffu ? h.Score2 : cs[bestc] + h.Score2;
+    }
+    uint32_t opt = 0; int optscore = cs[0];
+    for (uint32_t i = 1; i < n; ++i) if (cs[i] > optscore) { opt = i; optscore = cs[i]; }
+    uint32_t len = 0;
+    for (uint32_t i = opt; i != 0xffffffffu; i = prev[i]) ++len;
+    uint32_t k = 1;
+    for (uint32_t i = opt; i != 0xffffffffu; i = prev[i]) c.chain[len - k++] = i;
+    nchain = len;
+    // hspfinder.cpp:537-553 + hsp.h:102-126 IsStaggered
+    const int LA = (int)c.LA, LB = (int)c.LB;
+    for (uint32_t q = 0; q < nchain; ++q) {
+      const HSPd h = c.hsps[c.chain[q]];
+      const int Hii = (int)(h.Loi + h.Len - 1), Hij = (int)(h.Loj + h.Len - 1);
+      int gLA = (int)h.Loi - (int)h.Loj, gLB = (int)h.Loj - (int)h.Loi;
+      int gRA = LA - Hii - 1 - (LB - Hij - 1), gRB = LB - Hij - 1 - (LA - Hii - 1);
+      if (gLA < 0) gLA = 0;
+      if (gLB < 0) gLB = 0;
+      if (gRB < 0) gRB = 0;                     // TermGapRightA is not clamped in the reference
+      const int GapA = gLA + gRA, GapB = gLB + gRB;
+      if (GapA == 0 || GapB == 0) continue;
+      const double r = (LA < LB ? (double)GapA / LA : (double)GapB / LB);
+      if (r > 0.5) { nchain = 0; break; }
+    }
+  }
+  c.ws->nchain = nchain;
+}
+
+// ---- run-length path assembly (lane 0 only); PathInfo::AppendPath/AppendMs (pathinfo.h:7-87)
+__device__ void push_run(WaveCtx &c, uint32_t op, uint32_t len)
+{
+  if (!len) return;
+  WaveState *ws = c.ws;
+  if (ws->cur_len && ws->cur_op == op) { ws->cur_len += len; return; }
+  if (ws->cur_len) {
+    if (ws->nruns < c.runs_cap) c.runs[ws->nruns] = (ws->cur_len << 2) | ws->cur_op; else ws->overflow = 1;
+    ++ws->nruns;
+  }
+  ws->cur_op = op; ws->cur_len = len;
+}
+__device__ void flush_runs(WaveCtx &c)
+{
+  WaveState *ws = c.ws;
+  if (ws->cur_len) {
+    if (ws->nruns < c.runs_cap) c.runs[ws->nruns] = (ws->cur_len << 2) | ws->cur_op; else ws->overflow = 1;
+    ++ws->nruns; ws->cur_len = 0;
+  }
+}
+
+// diagbox.h:150-171
+__device__ __forceinline__ void get_range_j(uint32_t LA, uint32_t LB, uint32_t dlo, uint32_t dhi, uint32_t i,
+                                            uint32_t &Startj, uint32_t &Endj)
+{
+  uint32_t s = (dlo + i >= LA) ? dlo + i - LA : 0;
+  if (s >= LB) s = LB - 1;
+  uint32_t e = (dhi + i + 1 >= LA) ? dhi + i + 1 - LA : 0;
+  if (e > LB) e = LB;
+  Startj = s; Endj = e;
+}
+
+// ViterbiFastMainDiagMem + ViterbiFastBandMem + TraceBackBitMem on the hole A[a0..a0+LA) x B[b0..b0+LB);
+// appends the path to the run list.  All lanes participate; lane 0 does the traceback.
+__device__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t LA, uint32_t b0, uint32_t LB, uint32_t band,
+                             const Pen &P, unsigned long long *counters)
+{
+  const int lane = c.lane;
+  uint32_t dlo = LA < LB ? LA : LB, dhi = LA > LB ? LA : LB;
+  if (dlo > band) dlo -= band; else dlo = 1;
+  dhi += band;
+  if (dhi > LA + LB - 1) dhi = LA + LB - 1;
+  const uint32_t stride = (dhi - dlo + 1) + 3;
+  uint8_t *TB = c.tb;
+  int32_t *Mrow = c.Mrow, *Drow = c.Drow;
+  for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
+  wave_sync();
+  unsigned long long cells = 0;
+  for (uint32_t i = 0; i < LA; ++i) {
+    uint32_t Startj, Endj;
+    get_range_j(LA, LB, dlo, dhi, i, Startj, Endj);
+    if (Endj == 0) continue;
+    const uint8_t a = c.A[a0 + i];
+    const int OpenA = i == 0 ? P.LOpenA : P.OpenA, ExtA = i == 0 ? P.LExtA : P.ExtA;
+    int carryM = (i == 0) ? 0 : (Startj == 0 ? NEG : Mrow[(int)Startj - 1]);
+    int carryI = NEG;
+    uint8_t *TBrow = TB + (uint64_t)i * stride;
+    if (Startj > 0 && lane == 0) TBrow[0] = TB_IM;               // TBrow[Startj-1]
+    cells += Endj - Startj;
+    for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool act = j < Endj;
+      const int oldM = act ? Mrow[j] : NEG;
+      const int oldD = act ? Drow[j] : NEG;
+      int saved = __shfl_up(oldM, 1); if (lane == 0) saved = carryM;
+      const int mi = act ? sat_add(saved, OpenA) : NEG;
+      // in-row insert recurrence I[k] = max(mi[k], I[k-1]+ExtA) as a max-plus prefix scan
+      int v = mi <= NEGT ? NEG : mi - lane * ExtA;
+      for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (lane >= o && x > v) v = x; }
+      const int fromscan = v <= NEGT ? NEG : v + lane * ExtA;
+      const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * ExtA;
+      const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
+      int Iprev = __shfl_up(Iout, 1); if (lane == 0) Iprev = carryI;
+      uint8_t bits = 0;
+      int xM = saved;
+      if (oldD > xM) { xM = oldD; bits = TB_DM; }
+      if (Iprev > xM) { xM = Iprev; bits = TB_IM; }
+      const int sc = act ? score2(c, a, c.B[b0 + j]) : 0;
+      const int newM = sat_add(xM, sc);
+      const int ob = (j == 0) ? P.LOpenB : P.OpenB, eb = (j == 0) ? P.LExtB : P.ExtB;
+      const int md = sat_add(saved, ob);
+      int nd = sat_add(oldD, eb);
+      if (md >= nd) { nd = md; bits |= TB_MD; }
+      const int iext = sat_add(Iprev, ExtA);
+      if (mi >= iext) bits |= TB_MI;
+      if (act) { Mrow[j] = newM; Drow[j] = nd; TBrow[j - Startj + 1] = bits; }
+      const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
+      carryM = rl(oldM, lastl);
+      carryI = rl(Iout, lastl);
+      wave_sync();
+    }
+    if (lane == 0) {                                              // "Special case for end of Drow[]"
+      uint8_t tbe = 0;
+      const int md = sat_add(carryM, P.ROpenB);
+      int dl = sat_add(Drow[LB], P.RExtB);
+      if (md >= dl) { dl = md; tbe = TB_MD; }
+      Drow[LB] = dl; TBrow[stride - 1] = tbe;
+    }
+    wave_sync();
+  }
+  // last row of DPI (viterbifastbandmem.cpp:186-204), strict '>'
+  uint32_t Startj, Endj;
+  get_range_j(LA, LB, dlo, dhi, LA - 1, Startj, Endj);
+  uint8_t *TBlast = TB + (uint64_t)LA * stride;
+  if (lane == 0) Mrow[(int)Startj - 1] = NEG;
+  wave_sync();
+  cells += LB;
+  int carryI = NEG;
+  for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    const bool act = j < Endj;
+    const int mi = act ? sat_add(Mrow[(int)j - 1], P.ROpenA) : NEG;
+    int v = mi <= NEGT ? NEG : mi - lane * P.RExtA;
+    for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (lane >= o && x > v) v = x; }
+    const int fromscan = v <= NEGT ? NEG : v + lane * P.RExtA;
+    const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * P.RExtA;
+    const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
+    int Iprev = __shfl_up(Iout, 1); if (lane == 0) Iprev = carryI;
+    const int iext = sat_add(Iprev, P.RExtA);
+    if (act) TBlast[j - Startj + 1] = (mi > iext) ? TB_MI : 0;
+    const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
+    carryI = rl(Iout, lastl);
+  }
+  wave_sync();
+  if (lane == 0) {
+    atomicAdd(&counters[UGS_CTR_CELLS], cells);
+    const int FinalM = Mrow[LB - 1], FinalD = Drow[LB], FinalI = carryI;
+    int Score = FinalM; uint32_t State = 0;                       // 0=M 1=D 2=I
+    if (FinalD > Score) { Score = FinalD; State = 1; }
+    if (FinalI > Score) { Score = FinalI; State = 2; }
+    // traceback: reversed runs go to the upper half of the run buffer, then get pushed forward
+    uint32_t *rt = c.runs + c.runs_cap;
+    uint32_t nrt = 0, curop = 3, curlen = 0;
+    uint32_t i = LA, j = LB;
+    const uint32_t sLast = Startj;
+    auto tbget = [&](uint32_t ti, uint32_t tj) -> uint8_t {
+      if (tj == LB && ti < LA) return TB[(uint64_t)ti * stride + stride - 1];
+      uint32_t s, e;
+      if (ti >= LA) s = sLast; else get_range_j(LA, LB, dlo, dhi, ti, s, e);
+      const int idx = (int)tj - (int)s + 1;
+      if (idx < 0 || idx >= (int)stride - 1) return 0;
+      return TB[(uint64_t)ti * stride + idx];
+    };
+    while (i != 0 || j != 0) {
+      if (State == curop) ++curlen;
+      else { if (curlen) { if (nrt < c.runs_cap) rt[nrt] = (curlen << 2) | curop; else c.ws->overflow = 1; ++nrt; } curop = State; curlen = 1; }
+      uint8_t t;
+      if (State == 0) { t = tbget(i - 1, j - 1); State = (t & TB_DM) ? 1 : ((t & TB_IM) ? 2 : 0); --i; --j; }
+      else if (State == 1) { t = tbget(i - 1, j); State = (t & TB_MD) ? 0 : 1; --i; }
+      else { t = tbget(i, j - 1); State = (t & TB_MI) ? 0 : 2; --j; }
+    }
+    if (curlen) { if (nrt < c.runs_cap) rt[nrt] = (curlen << 2) | curop; else c.ws->overflow = 1; ++nrt; }
+    if (nrt > c.runs_cap) nrt = c.runs_cap;
+    for (int k = (int)nrt - 1; k >= 0; --k) push_run(c, rt[k] & 3, rt[k] >> 2);
+  }
+  wave_sync();
+}
+
+// globalalignmem.cpp:70-112 AlignHSPMem on a hole
+__device__ void align_hole(WaveCtx &c, const UgsDbView &db, uint32_t Loi, uint32_t Loj, uint32_t Leni, uint32_t Lenj,
+                           unsigned long long *counters)
+{
+  if (Leni == 0) { if (c.lane == 0) push_run(c, 2, Lenj); wave_sync(); return; }
+  if (Lenj == 0) { if (c.lane == 0) push_run(c, 1, Leni); wave_sync(); return; }
+  const bool LeftA = Loi == 0, LeftB = Loj == 0, RightA = Loi + Leni == c.LA, RightB = Loj + Lenj == c.LB;
+  Pen P;
+  P.OpenA = P.OpenB = db.open2; P.ExtA = P.ExtB = db.ext2;
+  P.LOpenA = LeftA ? db.topen2 : db.open2;  P.LExtA = LeftA ? db.text2 : db.ext2;
+  P.LOpenB = LeftB ? db.topen2 : db.open2;  P.LExtB = LeftB ? db.text2 : db.ext2;
+  P.ROpenA = RightA ? db.topen2 : db.open2; P.RExtA = RightA ? db.text2 : db.ext2;
+  P.ROpenB = RightB ? db.topen2 : db.open2; P.RExtB = RightB ? db.text2 : db.ext2;
+  viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
+}
+
+__global__ void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
+  // ---- workgroup-shared tables
+  uint8_t *s_cls = smem;                       // 256
+  uint8_t *s_hl = smem + 256;                  // 32
+  int8_t *s_sub2 = (int8_t *)(smem + 288);     // 1024
+  uint64_t *s_match = (uint64_t *)(smem + 1312);   // 64*8 = 512
+  uint8_t *s_comp = smem + 1824;               // 256  -> 2080
+  const UgsTables *tab = db.tab;
+  for (int k = tid; k < 256; k += blockDim.x) { s_cls[k] = tab->cls[k]; s_comp[k] = tab->comp[k]; }
+  for (int k = tid; k < 1024; k += blockDim.x) s_sub2[k] = tab->sub2[k];
+  for (int k = tid; k < 64; k += blockDim.x) s_match[k] = tab->match[k];
+  for (int k = tid; k < 32; k += blockDim.x) s_hl[k] = (k < 26) ? tab->hsp_letter['A' + k] : 0;
+  __syncthreads();
+
+  // ---- per-wave carve
+  const uint32_t maxq = (bv.max_qlen + 15u) & ~15u, maxt = (db.max_tlen + 15u) & ~15u;
+  uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
+  unsigned char *wb = smem + 2080 + (size_t)wave * wave_lds;
+  WaveCtx c;
+  size_t off = 0;
+  c.ws = (WaveState *)(wb + off); off += 32;
+  c.A = wb + off; off += maxq;
+  c.B = wb + off; off += maxt;
+  c.qsort = (uint32_t *)(wb + off); off += (size_t)q2 * 4;
+  c.Mrow = (int32_t *)(wb + off) + 4; off += ((size_t)maxt + 8) * 4;
+  c.Drow = (int32_t *)(wb + off); off += ((size_t)maxt + 8) * 4;
+  c.hsps = (HSPd *)(wb + off); off += (size_t)hsp_cap * sizeof(HSPd);
+  c.chain = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 4;
+  c.csc = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 7 * 4;
+  c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl;
+  c.lane = lane; c.hsp_cap = hsp_cap;
+  const uint32_t gw = blockIdx.x * wpb + wave, nw = gridDim.x * wpb;
+  c.tb = bv.tb + (uint64_t)gw * bv.tb_stride;
+  c.runs = bv.runs + (uint64_t)gw * bv.runs_stride;
+  c.runs_cap = bv.runs_stride / 2;
+
+  const uint32_t units = bv.nq * bv.nstrand, K = bv.K;
+  const uint32_t max_acc = (uint32_t)db.max_accepts, max_rej = (uint32_t)db.max_rejects;
+  unsigned long long *ctr = bv.counters;
+
+  for (uint32_t unit = gw; unit < units; unit += nw) {
+    const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
+    const uint64_t qo = bv.qoffs[qi];
+    const uint32_t LA = (uint32_t)(bv.qoffs[qi + 1] - qo);
+    c.LA = LA;
+    const uint32_t ncand = bv.cand_n[unit];
+    uint32_t nacc = 0, nrej = 0;
+    if (ncand) {
+      for (uint32_t p = lane; p < LA; p += 64) {
+        uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
+        c.A[p] = s_cls[ch];
+      }
+      wave_sync();
+      build_query_words(c, db.hsp_w, db.alpha);
+    }
+    for (uint32_t k = 0; k < ncand; ++k) {
+      const uint32_t t = bv.cand[(uint64_t)unit * K + k];
+      const uint64_t to = db.offs[t];
+      const uint32_t LB = (uint32_t)(db.offs[t + 1] - to);
+      c.LB = LB;
+      for (uint32_t p = lane; p < LB; p += 64) c.B[p] = s_cls[db.seqs[to + p]];
+      if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], (unsigned long long)LB); atomicAdd(&ctr[UGS_CTR_PAIRS], 1ull); }
+      wave_sync();
+      // ---- GlobalAlign_AllOpts (globalalignmem.cpp:129-236), FailIfNoHSPs = true
+      uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
+      if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
+      if (MinHSPLength < 16) MinHSPLength = 16;
+      ungapped_blast(c, db, MinHSPLength, ctr);
+      if (lane == 0) chain_lane0(c);
+      wave_sync();
+      const uint32_t nchain = c.ws->nchain;
+      bool accept = false;
+      if (nchain) {
+        uint32_t TotLen = 0, TotSame = 0;
+        for (uint32_t q = 0; q < nchain; ++q) {
+          const HSPd h = c.hsps[c.chain[q]];
+          TotLen += h.Len;
+          for (uint32_t x0 = 0; x0 < h.Len; x0 += 64) {
+            const uint32_t x = x0 + lane;
+            const bool idn = x < h.Len && ident(c, c.A[h.Loi + x], c.B[h.Loj + x]);
+            TotSame += __popcll(__ballot(idn));
+          }
+        }
+        const float HSPFractId = TotLen == 0 ? 0.0f : (float)TotSame / (float)TotLen;
+        if (!(HSPFractId < db.min_hsp_fract_id)) {
+          // ---- stitch holes and HSPs into the path
+          if (lane == 0) { c.ws->nruns = 0; c.ws->cur_len = 0; c.ws->cur_op = 0; c.ws->overflow = 0; }
+          wave_sync();
+          uint32_t pLoi = 0, pLoj = 0;                     // end (exclusive) of the previous HSP
+          for (uint32_t q = 0; q < nchain; ++q) {
+            const HSPd h = c.hsps[c.chain[q]];
+            align_hole(c, db, pLoi, pLoj, h.Loi - pLoi, h.Loj - pLoj, ctr);
+            if (lane == 0) push_run(c, 0, h.Len);
+            pLoi = h.Loi + h.Len; pLoj = h.Loj + h.Len;
+          }
+          align_hole(c, db, pLoi, pLoj, LA - pLoi, LB - pLoj, ctr);
+          if (lane == 0) { flush_runs(c); if (c.ws->overflow) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_RUNS); }
+          wave_sync();
+          const uint32_t nr = c.ws->nruns < c.runs_cap ? c.ws->nruns : c.runs_cap;
+          // ---- AlignResult::FillLo on the run list
+          int fm = -1, lm = -1; uint32_t cols = 0;
+          for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = c.runs[r]; cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
+          if (fm >= 0) {
+            uint32_t qpos = 0, tpos = 0, ids = 0, alen = 0, gaps = 0, opens = 0, mcols = 0, qlo = 0, tlo = 0, qhi = 0, thi = 0;
+            uint32_t lastop = 0;
+            for (uint32_t r = 0; r < nr; ++r) {
+              const uint32_t run = c.runs[r], op = run & 3, len = run >> 2;
+              const bool inside = (int)r >= fm && (int)r <= lm;
+              if ((int)r == fm) { qlo = qpos; tlo = tpos; }
+              if (op == 0) {
+                for (uint32_t x0 = 0; x0 < len; x0 += 64) {
+                  const uint32_t x = x0 + lane;
+                  const bool idn = x < len && ident(c, c.A[qpos + x], c.B[tpos + x]);
+                  ids += __popcll(__ballot(idn));
+                }
+                mcols += len; qpos += len; tpos += len;
+              } else if (op == 1) qpos += len; else tpos += len;
+              if (inside) {
+                alen += len;
+                if (op != 0) { gaps += len; if (lastop == 0) ++opens; }
+                lastop = op;
+              }
+              if ((int)r == lm) { qhi = qpos - 1; thi = tpos - 1; }
+            }
+            // Accepter::IsAcceptLo: FractId = double(ids)/double(alen) vs (double)(float)id
+            accept = true;
+            if (db.id_set) {
+              const double FractId = alen == 0 ? 0.0 : (double)ids / (double)alen;
+              if (FractId < db.id_accept) accept = false;
+            }
+            if (accept) {
+              unsigned long long coff = 0;
+              if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nr);
+              coff = ((unsigned long long)(uint32_t)rl((int)(coff >> 32), 0) << 32) | (uint32_t)rl((int)(uint32_t)coff, 0);
+              if (coff + nr <= bv.cigar_cap)
+                for (uint32_t r = lane; r < nr; r += 64) bv.cigar_pool[coff + r] = c.runs[r];
+              if (lane == 0) {
+                ugs_hit *h = &bv.hits[(uint64_t)unit * max_acc + nacc];
+                h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = alen;
+                h->opens = opens; h->qlo = qlo; h->qhi = qhi; h->tlo = tlo; h->thi = thi; h->ql = LA; h->tl = LB;
+                h->strand = strand; h->cigar_off = coff; h->cigar_len = nr; h->cols = cols;
+                atomicAdd(&ctr[UGS_CTR_HITS], 1ull);
+              }
+            }
+          }
+        }
+      }
+      // Terminator::Terminate (terminator.cpp:64-100)
+      if (accept) ++nacc; else ++nrej;
+      if (nacc == max_acc || nrej == max_rej) break;
+      wave_sync();
+    }
+    if (lane == 0) bv.hit_n[unit] = nacc;
+    wave_sync();
+  }
+}
+
+int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
+{
+  const uint32_t wave_lds = (uint32_t)((L.lds - 2080) / L.wpb);
+  HIPCHK(hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+  hipLaunchKernelGGL(k_align, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}

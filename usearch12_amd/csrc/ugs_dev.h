@@ -1,0 +1,101 @@
+// ugs_dev.h - internal device-side views shared by the HIP translation units.
+// Product code for gfx950 only (wave64, 160 KiB LDS/CU); see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ugs.h"
+
+#define UGS_WAVE 64
+#define UGS_MAXREPS 8          // hspfinder.h:10
+#define UGS_BAD_WORD 0xffffffffu
+#define UGS_KMAX 64            // max candidates walked per strand (max_accepts+max_rejects-1)
+
+// Per-DB constant tables (built on the host from the alphabet rules).
+struct UgsTables {
+  uint8_t udb_letter[256];   // UDB word letter, 0xff = voids the word (invalid or lower-case) udbparams.cpp:540-555
+  uint8_t hsp_letter[256];   // HSP-finder letter, invalid -> 0                               hspfinder.cpp:238-248
+  uint8_t cls[256];          // score/identity class: letter 0..25 | 32 if lower-case; 31 = non-alpha
+  uint8_t comp[256];         // reverse-complement byte map (seqinfo.cpp:292-323)
+  int8_t  sub2[32 * 32];     // 2 x substitution score by letter (setnucmx.cpp / blosum62.cpp)
+  uint64_t match[64];        // identity bitmask row per class (alpha2.cpp:220-300)
+};
+
+struct UgsDbView {
+  const uint8_t  *seqs;      // masked DB letters
+  const uint64_t *offs;      // [nseq+1]
+  uint32_t nseq;
+  uint32_t slots;
+  const uint64_t *row_off;   // [slots+1]
+  const uint32_t *postings;  // target indexes, ascending inside a row
+  const uint32_t *part;      // [slots*(np+1)] offset (relative to row start) of first posting with target >= p<<gshift
+  uint32_t np;               // number of target partitions
+  uint32_t gshift;           // partition size = 1<<gshift targets
+  const uint32_t *step_tab;  // [step_n] Big-path QueryStep for Nu unique words (wordparams.cpp:167-192)
+  uint32_t step_n;
+  const UgsTables *tab;
+  int32_t word_len;          // UDB word length
+  int32_t alpha;             // 4 / 20
+  int32_t big;               // Big ranking path (nseq > -big)
+  uint32_t bump_pct;
+  // aligner constants in half-score units
+  int32_t hsp_w;             // HSP finder word length
+  int32_t hsp_words;         // alpha^hsp_w
+  int32_t xdrop2;            // 2 * xdrop_nw
+  int32_t minscore2;         // smallest half-unit score >= MinGlobalHSPScore
+  float   min_hsp_fract_id;  // MinGlobalHSPFractId (float compare, getglobalhsps.cpp:57)
+  int32_t min_hsp_len_opt;   // -minhsp
+  int32_t band;
+  int32_t open2, ext2, topen2, text2;   // internal / terminal gap penalties x2 (alnparams.cpp:380-384)
+  double  id_accept;
+  int32_t id_set;
+  int32_t max_accepts, max_rejects;
+  int32_t is_nucleo;
+  uint32_t max_tlen;
+};
+
+struct UgsBatchView {
+  const uint8_t  *qseqs;
+  const uint64_t *qoffs;     // [nq+1]
+  uint32_t nq;
+  uint32_t nstrand;          // 1 or 2
+  uint32_t K;                // candidates kept per unit
+  uint32_t max_qlen;
+  // ranking outputs, per unit (= query*nstrand + strand)
+  uint32_t *cand;            // [units*K]
+  uint32_t *cand_cnt;        // [units*K]
+  uint32_t *cand_n;          // [units]
+  // ranking scratch: per resident workgroup
+  uint64_t *emit_buf;        // [rank_wgs * emit_cap]
+  uint64_t emit_cap;
+  // alignment outputs
+  ugs_hit  *hits;            // [units*max_accepts]
+  uint32_t *hit_n;           // [units]
+  uint32_t *cigar_pool;      // run pool
+  uint64_t cigar_cap;
+  unsigned long long *cigar_used;   // device counter (demand, may exceed cap => overflow)
+  // alignment scratch: per resident wave
+  uint8_t  *tb;              // [align_waves * tb_stride]
+  uint64_t tb_stride;
+  uint32_t *runs;            // [align_waves * runs_stride]
+  uint32_t runs_stride;
+  // counters: [0]=postings [1]=target letters [2]=pairs [3]=dp cells [4]=hits [5]=error flags
+  unsigned long long *counters;
+};
+
+enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR, UGS_CTR_N };
+enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8 };
+
+// launch descriptors computed on the host
+struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; };
+struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; };
+
+// kernels' host-callable launchers (defined in the .hip files)
+int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int dbmask, hipStream_t st);
+int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq,
+                    uint64_t nletters, int word_len, int alpha, uint32_t slots, uint64_t **d_row_off,
+                    uint32_t **d_postings, uint64_t *n_postings, uint32_t *max_row, hipStream_t st);
+int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
+                   uint32_t gshift, uint32_t *d_part, hipStream_t st);
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st);
+int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
+void ugs_set_error(const char *fmt, ...);

@@ -1,0 +1,696 @@
+// ugs_host.cpp - the C-ABI (include/ugs.h) over the HIP kernels: handles, launch geometry,
+// HBM residency, hit gathering, and the blast6/uc text writers.  No CPU compute fallback:
+// every search entry point needs a gfx950 device.
+#include "ugs_dev.h"
+
+#include <cctype>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+void ugs_set_error(const char *fmt, ...)
+{
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char *ugs_last_error(void) { return g_err; }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+#define RCCHK(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
+
+static const size_t LDS_MAX = 160 * 1024;
+
+struct ugs_db {
+  ugs_params p;
+  int device;
+  hipStream_t stream;
+  int num_cu;
+  UgsDbView v;
+  // owned device memory
+  uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
+  uint32_t *d_step; UgsTables *d_tab;
+  std::vector<uint32_t> step;       // host copy: step[Nu]
+  uint64_t n_postings, hbm_bytes;
+  uint32_t max_row, max_tlen;
+};
+
+struct ugs_batch {
+  ugs_db *db;
+  uint32_t max_queries; uint64_t max_letters;
+  uint32_t nq, max_qlen, K, nstrand;
+  UgsBatchView v;
+  uint8_t *d_qseqs; uint64_t *d_qoffs;
+  uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
+  ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
+  unsigned long long *d_cigar_used, *d_ctr;
+  uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
+  int rank_grid_alloc, align_waves_alloc;
+  UgsRankLaunch rl; UgsAlignLaunch al;
+  hipEvent_t ev0, ev1, ev2;
+  bool searched, synced;
+  unsigned long long ctr[UGS_CTR_N];
+  unsigned long long cigar_used_host;
+  uint64_t q_letters;
+};
+
+extern "C" int ugs_abi_version(void) { return UGS_ABI_VERSION; }
+
+extern "C" int ugs_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// o_defaults.inc, terminator.cpp:26-31, udbparams.cpp:235-261, alnheuristics.cpp:36,44;
+// option values are stored as float in the reference (opts.cpp:265)
+extern "C" int ugs_params_init(ugs_params *p, int is_nucleo, double id)
+{
+  if (!p) return UGS_E_ARG;
+  memset(p, 0, sizeof(*p));
+  p->is_nucleo = is_nucleo ? 1 : 0;
+  p->word_len = is_nucleo ? 8 : 5;
+  p->id = (float)id;
+  p->id_accept = (double)(float)id;
+  p->id_set = 1;
+  p->strand_both = 0;
+  p->max_accepts = 1; p->max_rejects = 32;
+  p->big = 100000; p->bump_pct = 50; p->stepwords = 8;
+  p->band = 16; p->minhsp = 16; p->xdrop_nw = 8.0f;
+  p->match = 1.0f; p->mismatch = -2.0f;
+  p->hsp_word_len = is_nucleo ? 5 : 3;
+  p->dbmask = 1;
+  return UGS_OK;
+}
+
+// ---------------------------------------------------------------- tables
+static const char B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX";
+static const signed char B62[23][23] = {   // BLOSUM62 (NCBI), the 23 alphabetic symbols
+  { 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0,-2,-1, 0},
+  {-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3,-1, 0,-1},
+  {-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3, 3, 0,-1},
+  {-2,-2, 1, 6,-3, 0, 2,-1,-1,-3,-4,-1,-3,-3,-1, 0,-1,-4,-3,-3, 4, 1,-1},
+  { 0,-3,-3,-3, 9,-3,-4,-3,-3,-1,-1,-3,-1,-2,-3,-1,-1,-2,-2,-1,-3,-3,-2},
+  {-1, 1, 0, 0,-3, 5, 2,-2, 0,-3,-2, 1, 0,-3,-1, 0,-1,-2,-1,-2, 0, 3,-1},
+  {-1, 0, 0, 2,-4, 2, 5,-2, 0,-3,-3, 1,-2,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1},
+  { 0,-2, 0,-1,-3,-2,-2, 6,-2,-4,-4,-2,-3,-3,-2, 0,-2,-2,-3,-3,-1,-2,-1},
+  {-2, 0, 1,-1,-3, 0, 0,-2, 8,-3,-3,-1,-2,-1,-2,-1,-2,-2, 2,-3, 0, 0,-1},
+  {-1,-3,-3,-3,-1,-3,-3,-4,-3, 4, 2,-3, 1, 0,-3,-2,-1,-3,-1, 3,-3,-3,-1},
+  {-1,-2,-3,-4,-1,-2,-3,-4,-3, 2, 4,-2, 2, 0,-3,-2,-1,-2,-1, 1,-4,-3,-1},
+  {-1, 2, 0,-1,-3, 1, 1,-2,-1,-3,-2, 5,-1,-3,-1, 0,-1,-3,-2,-2, 0, 1,-1},
+  {-1,-1,-2,-3,-1, 0,-2,-3,-2, 1, 2,-1, 5, 0,-2,-1,-1,-1,-1, 1,-3,-1,-1},
+  {-2,-3,-3,-3,-2,-3,-3,-3,-1, 0, 0,-3, 0, 6,-4,-2,-2, 1, 3,-1,-3,-3,-1},
+  {-1,-2,-2,-1,-3,-1,-1,-2,-2,-3,-3,-1,-2,-4, 7,-1,-1,-4,-3,-2,-2,-1,-2},
+  { 1,-1, 1, 0,-1, 0, 0, 0,-1,-2,-2, 0,-1,-2,-1, 4, 1,-3,-2,-2, 0, 0, 0},
+  { 0,-1, 0,-1,-1,-1,-1,-2,-2,-1,-1,-1,-1,-2,-1, 1, 5,-2,-2, 0,-1,-1, 0},
+  {-3,-3,-4,-4,-2,-2,-3,-2,-2,-3,-2,-3,-1, 1,-4,-3,-2,11, 2,-3,-4,-3,-2},
+  {-2,-2,-2,-3,-2,-1,-2,-3, 2,-1,-1,-2,-1, 3,-3,-2,-2, 2, 7,-1,-3,-2,-1},
+  { 0,-3,-3,-3,-1,-2,-2,-3,-3, 3, 1,-2, 1,-1,-2,-2, 0,-3,-1, 4,-3,-2,-1},
+  {-2,-1, 3, 4,-3, 0, 1,-1, 0,-3,-4, 0,-3,-3,-2, 0,-1,-4,-3,-3, 4, 1,-1},
+  {-1, 0, 0, 1,-3, 3, 4,-2, 0,-3,-3, 1,-1,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1},
+  { 0,-1,-1,-1,-2,-1,-1,-1,-1,-1,-1,-1,-1,-1,-2, 0, 0,-2,-1,-1,-1,-1,-1},
+};
+
+static int build_tables(const ugs_params &p, UgsTables &T)
+{
+  memset(&T, 0, sizeof(T));
+  const bool nt = p.is_nucleo != 0;
+  int let[26];                               // alphabet letter per 'A'+k, -1 = not in the word alphabet
+  for (int k = 0; k < 26; ++k) let[k] = -1;
+  if (nt) { let['A' - 'A'] = 0; let['C' - 'A'] = 1; let['G' - 'A'] = 2; let['T' - 'A'] = 3; let['U' - 'A'] = 3; }
+  else { const char *aa = "ACDEFGHIKLMNPQRSTVWY"; for (int i = 0; i < 20; ++i) let[aa[i] - 'A'] = i; }
+  for (int c = 0; c < 256; ++c) {
+    T.udb_letter[c] = 0xff; T.hsp_letter[c] = 0; T.cls[c] = 31; T.comp[c] = (uint8_t)c;
+    const bool up = c >= 'A' && c <= 'Z', lo = c >= 'a' && c <= 'z';
+    if (up || lo) {
+      const int k = up ? c - 'A' : c - 'a';
+      T.cls[c] = (uint8_t)(k | (lo ? 32 : 0));
+      if (let[k] >= 0) { T.hsp_letter[c] = (uint8_t)let[k]; if (up) T.udb_letter[c] = (uint8_t)let[k]; }
+    }
+  }
+  { // reverse complement map; lower-case 'u' is absent from the reference table (alpha.cpp:3005-3265)
+    const char *from = "ABCDGHKMNRSTUVWXY", *to = "TVGHCDMKNYSAABWXR";
+    for (int k = 0; from[k]; ++k) {
+      T.comp[(unsigned char)from[k]] = (uint8_t)to[k];
+      if (from[k] != 'U') T.comp[(unsigned char)(from[k] | 0x20)] = (uint8_t)(to[k] | 0x20);
+    }
+  }
+  // 2 x substitution score by letter
+  if (nt) {
+    const float m2 = p.match * 2.0f, mm2 = p.mismatch * 2.0f;
+    if (m2 != floorf(m2) || mm2 != floorf(mm2) || fabsf(m2) > 120 || fabsf(mm2) > 120) {
+      ugs_set_error("match/mismatch must be multiples of 0.5 within +-60 for the integer DP"); return UGS_E_ENVELOPE;
+    }
+    for (int i = 0; i < 26; ++i) for (int j = 0; j < 26; ++j)
+      if (let[i] >= 0 && let[j] >= 0) T.sub2[i * 32 + j] = (int8_t)(let[i] == let[j] ? m2 : mm2);
+  } else {
+    for (int i = 0; i < 23; ++i) for (int j = 0; j < 23; ++j)
+      T.sub2[(B62_ORDER[i] - 'A') * 32 + (B62_ORDER[j] - 'A')] = (int8_t)(2 * B62[i][j]);
+  }
+  // identity classes (alpha2.cpp:220-300): same letter; nt: IUPAC "base in wildcard set" either way;
+  // aa: X matches anything, and UPPER-CASE B/N, B/D, Z/Q, Z/E
+  int nucbit[26], iupac[26];
+  for (int k = 0; k < 26; ++k) nucbit[k] = iupac[k] = 0;
+  nucbit['A' - 'A'] = 1; nucbit['C' - 'A'] = 2; nucbit['G' - 'A'] = 4; nucbit['T' - 'A'] = 8; nucbit['U' - 'A'] = 8;
+  for (int k = 0; k < 26; ++k) iupac[k] = nucbit[k];
+  { const char *codes = "MRWSYKVHDBXN"; const char *sets[] = {"AC", "AG", "AT", "CG", "CT", "GT", "ACG", "ACT", "AGT", "CGT", "GATC", "GATC"};
+    for (int q = 0; codes[q]; ++q) { int b = 0; for (const char *s = sets[q]; *s; ++s) b |= nucbit[*s - 'A']; iupac[codes[q] - 'A'] = b; } }
+  for (int a = 0; a < 64; ++a) for (int b = 0; b < 64; ++b) {
+    const int ka = a & 31, kb = b & 31;
+    if (ka >= 26 || kb >= 26) continue;
+    bool m = (ka == kb);
+    if (!m) {
+      if (nt) m = (nucbit[ka] & iupac[kb]) || (nucbit[kb] & iupac[ka]);
+      else {
+        m = (ka == 'X' - 'A') || (kb == 'X' - 'A');
+        if (!m && a < 32 && b < 32) {
+          auto pr = [&](char x, char y) { return (ka == x - 'A' && kb == y - 'A') || (ka == y - 'A' && kb == x - 'A'); };
+          m = pr('B', 'N') || pr('B', 'D') || pr('Z', 'Q') || pr('Z', 'E');
+        }
+      }
+    }
+    if (m) T.match[a] |= (1ull << b);
+  }
+  return UGS_OK;
+}
+
+// wordparams.cpp:60-112 (table from CD-HIT as the reference holds it)
+static const double MinWordFractAmino[50] = {
+  0.00, 0.00, 0.00, 0.00, 0.01, 0.01, 0.01, 0.02, 0.02, 0.02, 0.03, 0.04, 0.04, 0.05, 0.06, 0.06, 0.08,
+  0.08, 0.10, 0.10, 0.11, 0.14, 0.14, 0.14, 0.17, 0.17, 0.18, 0.20, 0.21, 0.21, 0.27, 0.28, 0.31, 0.34,
+  0.36, 0.41, 0.43, 0.45, 0.48, 0.54, 0.55, 0.56, 0.64, 0.69, 0.73, 0.75, 0.80, 0.85, 0.90, 0.95};
+
+// wordparams.cpp:125-135,145-159,167-192: QueryStep for Nu unique query words.  Evaluated on the
+// host in fp64 exactly as the reference does (no FMA contraction) and uploaded as a table.
+static uint32_t query_step(const ugs_params &p, uint32_t Nu)
+{
+  volatile double FractId = (double)(p.id_set ? p.id : 0.5f);     // makedbsearcher.cpp:195
+  uint32_t Thresh;
+  if (p.is_nucleo) {
+    volatile double d = 1 - FractId;
+    volatile double e = d * p.word_len;
+    volatile double WordFract = 1 - e;
+    if (WordFract < 0.0) Thresh = 1;
+    else {
+      volatile double wf = WordFract * Nu;
+      Thresh = wf < 1.0 ? 1u : (uint32_t)wf;
+    }
+  } else {
+    if (FractId < 0.5) Thresh = 0;
+    else {
+      volatile double x = (FractId - 0.5) * 100;
+      uint32_t i = (uint32_t)x;
+      if (i >= 50) i = 49;
+      volatile double y = MinWordFractAmino[i] * Nu;
+      Thresh = (uint32_t)y;
+    }
+  }
+  if (p.stepwords == 0) return 1;
+  uint32_t Step = Thresh / p.stepwords;
+  return Step == 0 ? 1 : Step;
+}
+
+// ---------------------------------------------------------------- db
+extern "C" void ugs_db_destroy(ugs_db *db)
+{
+  if (!db) return;
+  hipSetDevice(db->device);
+  hipFree(db->d_seqs); hipFree(db->d_offs); hipFree(db->d_row_off); hipFree(db->d_postings); hipFree(db->d_part);
+  hipFree(db->d_step); hipFree(db->d_tab);
+  if (db->stream) hipStreamDestroy(db->stream);
+  delete db;
+}
+
+static int db_step_table(ugs_db *db, uint32_t n)
+{
+  if (db->step.size() >= n) return UGS_OK;
+  size_t old = db->step.size();
+  db->step.resize(n);
+  for (size_t i = old; i < n; ++i) db->step[i] = query_step(db->p, (uint32_t)i);
+  if (db->d_step) HIPCHK(hipFree(db->d_step));
+  HIPCHK(hipMalloc(&db->d_step, n * sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(db->d_step, db->step.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  db->v.step_tab = db->d_step; db->v.step_n = (uint32_t)n;
+  return UGS_OK;
+}
+
+extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                             int device, ugs_db **out)
+{
+  if (!p || !offs || !out || (nseq && !seqs)) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  int ndev = ugs_device_count();
+  if (device < 0 || device >= ndev) {
+    ugs_set_error("device %d not available (%d devices); there is no CPU fallback", device, ndev);
+    return UGS_E_NODEVICE;
+  }
+  if (p->max_accepts <= 0 || p->max_rejects <= 0 || p->max_accepts + p->max_rejects - 1 > UGS_KMAX) {
+    ugs_set_error("max_accepts/max_rejects must be > 0 and max_accepts+max_rejects-1 <= %d", UGS_KMAX);
+    return UGS_E_ENVELOPE;
+  }
+  const int alpha = p->is_nucleo ? 4 : 20;
+  uint64_t slots64 = 1;
+  for (int i = 0; i < p->word_len; ++i) { slots64 *= alpha; if (slots64 > (1ull << 28)) break; }
+  uint64_t hspw64 = 1;
+  for (int i = 0; i < p->hsp_word_len; ++i) { hspw64 *= alpha; if (hspw64 > 65536) break; }
+  if (p->word_len < 1 || slots64 > (1ull << 28) || p->hsp_word_len < 1 || hspw64 > 65536 || p->band < 1) {
+    ugs_set_error("unsupported word_len/hsp_word_len/band (band 0 = full DP is not implemented)"); return UGS_E_ENVELOPE;
+  }
+  if (p->strand_both && !p->is_nucleo) { ugs_set_error("strand_both needs a nucleotide search"); return UGS_E_ARG; }
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  ugs_db *db = new ugs_db();
+  memset(&db->v, 0, sizeof(db->v));
+  db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
+  db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
+  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr;
+  int rc = UGS_OK;
+  auto fail = [&](int code) { ugs_db_destroy(db); return code; };
+  if (hipStreamCreate(&db->stream) != hipSuccess) { ugs_set_error("hipStreamCreate failed"); return fail(UGS_E_HIP); }
+  const uint64_t nletters = offs[nseq];
+  uint32_t max_tlen = 0;
+  for (uint32_t t = 0; t < nseq; ++t) {
+    uint64_t L = offs[t + 1] - offs[t];
+    if (L > 65535) { ugs_set_error("target %u longer than 65535 letters", t); return fail(UGS_E_ENVELOPE); }
+    if (L > max_tlen) max_tlen = (uint32_t)L;
+  }
+  db->max_tlen = max_tlen;
+  UgsTables T;
+  if ((rc = build_tables(*p, T)) != UGS_OK) return fail(rc);
+#define DBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return fail(UGS_E_HIP); } } while (0)
+  DBCHK(hipMalloc(&db->d_tab, sizeof(UgsTables)));
+  DBCHK(hipMemcpy(db->d_tab, &T, sizeof(T), hipMemcpyHostToDevice));
+  DBCHK(hipMalloc(&db->d_seqs, nletters ? nletters : 16));
+  DBCHK(hipMalloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
+  if (nletters) DBCHK(hipMemcpy(db->d_seqs, seqs, nletters, hipMemcpyHostToDevice));
+  DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask, db->stream)) != UGS_OK) return fail(rc);
+  const uint32_t slots = (uint32_t)slots64;
+  if ((rc = ugs_build_index(db->d_tab, db->d_seqs, db->d_offs, nseq, nletters, p->word_len, alpha, slots,
+                            &db->d_row_off, &db->d_postings, &db->n_postings, &db->max_row, db->stream)) != UGS_OK)
+    return fail(rc);
+  // partition size: aim at ~96 postings per (row, partition) so a sub-row fills a wavefront
+  uint32_t gshift = 14;
+  {
+    double avg_row = db->n_postings ? (double)db->n_postings / (double)slots : 1.0;
+    double g = 96.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
+    gshift = 12;
+    while (gshift < 16 && (double)(1u << gshift) < g * 0.75) ++gshift;
+    const uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
+    while (gshift < 16 && (uint64_t)slots * (((uint64_t)nseq >> gshift) + 2) * 4 > budget) ++gshift;
+    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 5 && v <= 16) gshift = (uint32_t)v; }
+  }
+  const uint32_t np = nseq ? (uint32_t)((((uint64_t)nseq - 1) >> gshift) + 1) : 1;
+  DBCHK(hipMalloc(&db->d_part, (size_t)slots * (np + 1) * sizeof(uint32_t)));
+  if ((rc = ugs_build_part(db->d_row_off, db->d_postings, slots, np, gshift, db->d_part, db->stream)) != UGS_OK) return fail(rc);
+  DBCHK(hipStreamSynchronize(db->stream));
+#undef DBCHK
+  UgsDbView &v = db->v;
+  v.seqs = db->d_seqs; v.offs = db->d_offs; v.nseq = nseq; v.slots = slots; v.row_off = db->d_row_off;
+  v.postings = db->d_postings; v.part = db->d_part; v.np = np; v.gshift = gshift; v.tab = db->d_tab;
+  v.word_len = p->word_len; v.alpha = alpha; v.big = nseq > p->big ? 1 : 0; v.bump_pct = p->bump_pct;
+  v.hsp_w = p->hsp_word_len; v.hsp_words = (int)hspw64;
+  v.xdrop2 = (int)floor(2.0 * (double)p->xdrop_nw);
+  // alnheuristics.cpp:26-62 (float arithmetic as in the reference)
+  const float idf = p->id_set ? p->id : 0.5f;
+  float minfid, minscore;
+  if (p->is_nucleo) { minfid = idf > 0.75f ? idf : 0.75f; minscore = minfid * (float)p->minhsp * p->match; }
+  else {
+    float mind = 9e9f;
+    for (const char *a = "ACDEFGHIKLMNPQRSTVWY"; *a; ++a) { float s = (float)T.sub2[(*a - 'A') * 32 + (*a - 'A')] * 0.5f; if (s < mind) mind = s; }
+    minfid = idf > 0.5f ? idf : 0.5f; minscore = minfid * mind * (float)p->minhsp;
+  }
+  v.min_hsp_fract_id = minfid;
+  v.minscore2 = (int)ceil(2.0 * (double)minscore);
+  v.min_hsp_len_opt = p->minhsp; v.band = p->band;
+  v.open2 = p->is_nucleo ? -20 : -34; v.ext2 = -2; v.topen2 = -1; v.text2 = -1;   // alnparams.cpp:380-384
+  v.id_accept = p->id_accept; v.id_set = p->id_set;
+  v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
+  db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
+                  (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
+  if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
+  *out = db;
+  return UGS_OK;
+}
+
+extern "C" int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint64_t *hbm_bytes)
+{
+  if (!db) return UGS_E_ARG;
+  if (n_postings) *n_postings = db->n_postings;
+  if (n_slots) *n_slots = db->v.slots;
+  if (hbm_bytes) *hbm_bytes = db->hbm_bytes;
+  return UGS_OK;
+}
+
+// test/debug introspection (not in ugs.h): copy masked letters and the CSR index back to the host
+extern "C" int ugs_db_debug_fetch(const ugs_db *db, char *masked, uint64_t *row_off, uint32_t *postings)
+{
+  if (!db) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(db->device));
+  uint64_t nl = 0;
+  HIPCHK(hipMemcpy(&nl, db->d_offs + db->v.nseq, 8, hipMemcpyDeviceToHost));
+  if (masked && nl) HIPCHK(hipMemcpy(masked, db->d_seqs, nl, hipMemcpyDeviceToHost));
+  if (row_off) HIPCHK(hipMemcpy(row_off, db->d_row_off, ((size_t)db->v.slots + 1) * 8, hipMemcpyDeviceToHost));
+  if (postings && db->n_postings) HIPCHK(hipMemcpy(postings, db->d_postings, db->n_postings * 4, hipMemcpyDeviceToHost));
+  return UGS_OK;
+}
+
+// ---------------------------------------------------------------- batch
+extern "C" void ugs_batch_destroy(ugs_batch *b)
+{
+  if (!b) return;
+  hipSetDevice(b->db->device);
+  hipFree(b->d_qseqs); hipFree(b->d_qoffs); hipFree(b->d_cand); hipFree(b->d_cand_cnt); hipFree(b->d_cand_n);
+  hipFree(b->d_hit_n); hipFree(b->d_cigar); hipFree(b->d_runs); hipFree(b->d_hits); hipFree(b->d_emit); hipFree(b->d_tb);
+  hipFree(b->d_cigar_used); hipFree(b->d_ctr);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev2) hipEventDestroy(b->ev2);
+  delete b;
+}
+
+extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_letters, ugs_batch **out)
+{
+  if (!db || !out) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(db->device));
+  ugs_batch *b = new ugs_batch();
+  memset(b, 0, sizeof(*b));
+  b->db = db; b->max_queries = max_queries; b->max_letters = max_letters;
+  b->nstrand = db->p.strand_both ? 2 : 1;
+  b->K = (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
+  const uint64_t units = (uint64_t)max_queries * b->nstrand;
+  int rc = UGS_OK;
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); ugs_batch_destroy(b); return UGS_E_HIP; } } while (0)
+  BCHK(hipMalloc(&b->d_qseqs, max_letters ? max_letters : 16));
+  BCHK(hipMalloc(&b->d_qoffs, ((size_t)max_queries + 1) * 8));
+  BCHK(hipMalloc(&b->d_cand, std::max<uint64_t>(units * b->K, 1) * 4));
+  BCHK(hipMalloc(&b->d_cand_cnt, std::max<uint64_t>(units * b->K, 1) * 4));
+  BCHK(hipMalloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
+  BCHK(hipMalloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
+  BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * db->p.max_accepts, 1) * sizeof(ugs_hit)));
+  b->cigar_cap = units * db->p.max_accepts * 12 + 4096;
+  BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
+  BCHK(hipMalloc(&b->d_cigar_used, 8));
+  BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
+  BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
+#undef BCHK
+  (void)rc;
+  *out = b;
+  return UGS_OK;
+}
+
+static int plan_launch(ugs_batch *b)
+{
+  ugs_db *db = b->db;
+  const ugs_params &p = db->p;
+  const uint32_t maxq = (b->max_qlen + 15u) & ~15u;
+  const uint32_t maxt = (db->max_tlen + 15u) & ~15u;
+  // ---- ranking geometry
+  const uint32_t W = (uint32_t)p.word_len;
+  const uint32_t maxNu = b->max_qlen >= W ? b->max_qlen - W + 1 : 0;
+  RCCHK(db_step_table(db, maxNu + 2));
+  uint32_t ns_max = 1;
+  if (db->v.big) { for (uint32_t nu = 1; nu <= maxNu; ++nu) { uint32_t s = db->step[nu]; ns_max = std::max(ns_max, (nu + s - 1) / s); } }
+  else ns_max = std::max(1u, maxNu);
+  if (ns_max > 4095) { ugs_set_error("query needs %u sampled words > 4095 (device envelope)", ns_max); return UGS_E_ENVELOPE; }
+  const int bits = ns_max <= 15 ? 4 : (ns_max <= 255 ? 8 : 16);
+  const size_t tbl_bytes = (((size_t)1 << db->v.gshift) * bits) / 8;
+  const size_t fixed = 256 /*RankShared*/ + (((size_t)ns_max + 1) * 8 + 16) + (size_t)maxq * 4 + ((size_t)ns_max * 4 + 16) +
+                       2 * (size_t)maxq + 2 * (((size_t)ns_max + 1) * 4 + 16);
+  int wpb = 4;
+  while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
+  if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
+  const size_t rlds = fixed + wpb * tbl_bytes;
+  const uint64_t units = (uint64_t)b->nq * b->nstrand;
+  int per_cu = (int)std::min<size_t>(LDS_MAX / rlds, (size_t)(32 / wpb));
+  per_cu = std::max(1, std::min(per_cu, 8));
+  if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
+  b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max;
+  b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
+  // every target is emitted at most once per unit; bound by postings/2 as well
+  uint64_t ecap = std::min<uint64_t>(db->v.nseq, (uint64_t)ns_max * db->max_row / 2 + 1) + (uint64_t)db->v.np * b->K + 64;
+  if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
+    if (b->d_emit) HIPCHK(hipFree(b->d_emit));
+    HIPCHK(hipMalloc(&b->d_emit, ecap * (uint64_t)b->rl.grid * 8));
+    b->emit_cap_alloc = ecap * (uint64_t)b->rl.grid;
+  }
+  b->v.emit_cap = ecap;
+  // ---- alignment geometry
+  const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
+  uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
+  const size_t wave_lds = (32 + (size_t)maxq + maxt + (size_t)q2 * 4 + 2 * ((size_t)maxt + 8) * 4 + (size_t)hsp_cap * (16 + 4 + 28) + 15) & ~(size_t)15;
+  int awpb = 4;
+  while (awpb > 1 && 2080 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
+  if (2080 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2080 + wave_lds); return UGS_E_ENVELOPE; }
+  const size_t alds = 2080 + awpb * wave_lds;
+  int aper_cu = (int)std::min<size_t>(LDS_MAX / alds, (size_t)(32 / awpb));
+  aper_cu = std::max(1, std::min(aper_cu, 8));
+  b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap;
+  b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
+  const int waves = b->al.grid * awpb;
+  const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * p.band + 4) + 63) & ~63ull;
+  const uint32_t runs_stride = 2 * (b->max_qlen + db->max_tlen + 4);
+  if (!b->d_tb || tb_stride * waves > b->tb_alloc) {
+    if (b->d_tb) HIPCHK(hipFree(b->d_tb));
+    HIPCHK(hipMalloc(&b->d_tb, tb_stride * waves));
+    b->tb_alloc = tb_stride * waves;
+  }
+  if (!b->d_runs || (uint64_t)runs_stride * waves > b->runs_alloc) {
+    if (b->d_runs) HIPCHK(hipFree(b->d_runs));
+    HIPCHK(hipMalloc(&b->d_runs, (uint64_t)runs_stride * waves * 4));
+    b->runs_alloc = (uint64_t)runs_stride * waves;
+  }
+  b->v.tb_stride = tb_stride; b->v.runs_stride = runs_stride;
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t *qoffs, uint32_t nq)
+{
+  if (!b || !qoffs || (nq && !qseqs)) return UGS_E_ARG;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  if (nq > b->max_queries || qoffs[nq] - qoffs[0] > b->max_letters) { ugs_set_error("batch exceeds its capacity"); return UGS_E_CAPACITY; }
+  uint32_t maxl = 0;
+  for (uint32_t i = 0; i < nq; ++i) {
+    uint64_t L = qoffs[i + 1] - qoffs[i];
+    if (L > 65535) { ugs_set_error("query %u longer than 65535 letters", i); return UGS_E_ENVELOPE; }
+    if (L > maxl) maxl = (uint32_t)L;
+  }
+  b->nq = nq; b->max_qlen = maxl; b->q_letters = qoffs[nq] - qoffs[0];
+  std::vector<uint64_t> rel((size_t)nq + 1);
+  for (uint32_t i = 0; i <= nq; ++i) rel[i] = qoffs[i] - qoffs[0];
+  if (b->q_letters) HIPCHK(hipMemcpyAsync(b->d_qseqs, qseqs + qoffs[0], b->q_letters, hipMemcpyHostToDevice, db->stream));
+  HIPCHK(hipMemcpyAsync(b->d_qoffs, rel.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, db->stream));
+  HIPCHK(hipStreamSynchronize(db->stream));
+  RCCHK(plan_launch(b));
+  UgsBatchView &v = b->v;
+  v.qseqs = b->d_qseqs; v.qoffs = b->d_qoffs; v.nq = nq; v.nstrand = b->nstrand; v.K = b->K; v.max_qlen = maxl;
+  v.cand = b->d_cand; v.cand_cnt = b->d_cand_cnt; v.cand_n = b->d_cand_n; v.emit_buf = b->d_emit;
+  v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
+  v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
+  b->searched = false; b->synced = false;
+  return UGS_OK;
+}
+
+static int enqueue_align(ugs_batch *b)
+{
+  ugs_db *db = b->db;
+  HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
+  return ugs_launch_align(db->v, b->v, b->al, db->stream);
+}
+
+extern "C" int ugs_batch_search(ugs_batch *b)
+{
+  if (!b) return UGS_E_ARG;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
+  HIPCHK(hipEventRecord(b->ev0, db->stream));
+  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream));
+  HIPCHK(hipEventRecord(b->ev1, db->stream));
+  if (b->nq) RCCHK(enqueue_align(b));
+  HIPCHK(hipEventRecord(b->ev2, db->stream));
+  b->searched = true; b->synced = false;
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_sync(ugs_batch *b)
+{
+  if (!b || !b->searched) return UGS_E_ARG;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    HIPCHK(hipStreamSynchronize(db->stream));
+    HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
+    if (b->ctr[UGS_CTR_ERR]) {
+      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer)", b->ctr[UGS_CTR_ERR]);
+      return UGS_E_ENVELOPE;
+    }
+    if (b->cigar_used_host <= b->cigar_cap) { b->synced = true; return UGS_OK; }
+    // path pool too small: grow to the demanded size and re-run the alignment stage only
+    HIPCHK(hipFree(b->d_cigar));
+    b->cigar_cap = b->cigar_used_host + b->cigar_used_host / 4 + 4096;
+    HIPCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
+    b->v.cigar_pool = b->d_cigar; b->v.cigar_cap = b->cigar_cap;
+    unsigned long long keep = b->ctr[UGS_CTR_POSTINGS];
+    HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
+    HIPCHK(hipMemcpyAsync(b->d_ctr, &keep, 8, hipMemcpyHostToDevice, db->stream));
+    RCCHK(enqueue_align(b));
+    HIPCHK(hipEventRecord(b->ev2, db->stream));
+  }
+  ugs_set_error("path pool overflow persisted");
+  return UGS_E_CAPACITY;
+}
+
+// sort.h:85-117 QuickSortOrderRecurse<float, Desc=true> (HitMgr::Sort, hitmgr.cpp:477-483)
+static void qs_order_desc(const float *V, int left, int right, unsigned *Order)
+{
+  int i = left, j = right;
+  float pivot = V[Order[(left + right) / 2]];
+  while (i <= j) {
+    while (V[Order[i]] > pivot) i++;
+    while (V[Order[j]] < pivot) j--;
+    if (i <= j) { std::swap(Order[i], Order[j]); i++; j--; }
+  }
+  if (left < j) qs_order_desc(V, left, j, Order);
+  if (i < right) qs_order_desc(V, i, right, Order);
+}
+
+extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                               uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used)
+{
+  if (!b || !b->synced || !nhits_per_query) return UGS_E_ARG;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  const uint32_t nq = b->nq, ns = b->nstrand, ma = (uint32_t)db->p.max_accepts;
+  const uint64_t units = (uint64_t)nq * ns;
+  std::vector<uint32_t> hn(units ? units : 1);
+  std::vector<ugs_hit> hh(units * ma ? units * ma : 1);
+  std::vector<uint32_t> pool(b->cigar_used_host ? b->cigar_used_host : 1);
+  if (units) {
+    HIPCHK(hipMemcpy(hn.data(), b->d_hit_n, units * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hh.data(), b->d_hits, units * ma * sizeof(ugs_hit), hipMemcpyDeviceToHost));
+    if (b->cigar_used_host) HIPCHK(hipMemcpy(pool.data(), b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost));
+  }
+  uint64_t nh = 0, nc = 0;
+  std::vector<ugs_hit> tmp; std::vector<float> sc; std::vector<unsigned> ord;
+  for (uint32_t q = 0; q < nq; ++q) {
+    tmp.clear();
+    for (uint32_t s = 0; s < ns; ++s) {
+      const uint64_t u = (uint64_t)q * ns + s;
+      for (uint32_t k = 0; k < hn[u]; ++k) tmp.push_back(hh[u * ma + k]);
+    }
+    const uint32_t n = (uint32_t)tmp.size();
+    nhits_per_query[q] = n;
+    if (n > 1) {
+      sc.resize(n); ord.resize(n);
+      for (uint32_t i = 0; i < n; ++i) { sc[i] = (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
+      qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+      const ugs_hit &h = tmp[n > 1 ? ord[i] : i];
+      if (nh + 1 > hits_cap || nc + h.cigar_len > cigar_cap) { ugs_set_error("output buffers too small"); return UGS_E_CAPACITY; }
+      hits[nh] = h;
+      hits[nh].cigar_off = nc;
+      memcpy(cigar_pool + nc, pool.data() + h.cigar_off, (size_t)h.cigar_len * 4);
+      nc += h.cigar_len; ++nh;
+    }
+  }
+  if (cigar_used) *cigar_used = nc;
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
+{
+  if (!b || !st || !b->synced) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(b->db->device));
+  memset(st, 0, sizeof(*st));
+  HIPCHK(hipEventElapsedTime(&st->ms_rank, b->ev0, b->ev1));
+  HIPCHK(hipEventElapsedTime(&st->ms_align, b->ev1, b->ev2));
+  HIPCHK(hipEventElapsedTime(&st->ms_total, b->ev0, b->ev2));
+  st->postings = b->ctr[UGS_CTR_POSTINGS];
+  st->query_letters = b->q_letters * b->nstrand;
+  st->target_letters = b->ctr[UGS_CTR_TLETTERS];
+  st->pairs_aligned = b->ctr[UGS_CTR_PAIRS];
+  st->dp_cells = b->ctr[UGS_CTR_CELLS];
+  st->hits = b->ctr[UGS_CTR_HITS];
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap)
+{
+  if (!b || !b->synced || !cand || !cnt || !n) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(b->db->device));
+  const uint64_t units = (uint64_t)b->nq * b->nstrand;
+  const uint32_t K = b->K;
+  if (k_cap < K) { ugs_set_error("k_cap < %u", K); return UGS_E_CAPACITY; }
+  std::vector<uint32_t> c(units * K ? units * K : 1), cc(units * K ? units * K : 1);
+  if (units) {
+    HIPCHK(hipMemcpy(c.data(), b->d_cand, units * K * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cc.data(), b->d_cand_cnt, units * K * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n, b->d_cand_n, units * 4, hipMemcpyDeviceToHost));
+  }
+  for (uint64_t u = 0; u < units; ++u)
+    for (uint32_t k = 0; k < K; ++k) { cand[u * k_cap + k] = c[u * K + k]; cnt[u * k_cap + k] = cc[u * K + k]; }
+  return UGS_OK;
+}
+
+extern "C" int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
+                                ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
+                                uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used)
+{
+  if (!db || !qoffs) return UGS_E_ARG;
+  ugs_batch *b = nullptr;
+  RCCHK(ugs_batch_create(db, nq, qoffs[nq] - qoffs[0], &b));
+  int rc = ugs_batch_upload(b, qseqs, qoffs, nq);
+  if (rc == UGS_OK) rc = ugs_batch_search(b);
+  if (rc == UGS_OK) rc = ugs_batch_sync(b);
+  if (rc == UGS_OK) rc = ugs_batch_fetch(b, hits, hits_cap, nhits_per_query, cigar_pool, cigar_cap, cigar_used);
+  ugs_batch_destroy(b);
+  return rc;
+}
+
+// ---------------------------------------------------------------- text writers
+// blast6out.cpp:27-80: for global hits qstart/qend/sstart/send are 1..QL / 1..TL (the global HSP is
+// the whole of both sequences, alignresult.cpp:138-145); sstart/send swap for a rev-comp query
+// (arscorer.cpp:754-757); columns 11-12 are literally "*".
+extern "C" int ugs_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  const double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  const double PctId = 100.0 * FractId;
+  unsigned TLo = 1, THi = h->tl;
+  if (h->strand) { TLo = h->tl; THi = 1; }
+  return snprintf(buf, (size_t)cap, "%s\t%s\t%.1f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t*\t*\n", qlabel, tlabel, PctId,
+                  h->aln_len, h->mism, h->opens, 1u, h->ql, TLo, THi);
+}
+
+// outputuc.cpp:45-93 with CompressPath (comppath.cpp:7-48): run of n>1 prints "nC", n==1 prints "C"
+extern "C" int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
+                                 const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  const double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  const double PctId = 100.0 * FractId;
+  const char strand = !is_nucleo ? '.' : (h->strand ? '-' : '+');
+  int n = snprintf(buf, (size_t)cap, "H\t%u\t%u\t%.1f\t%c\t%u\t%u\t", h->target, h->ql, PctId, strand, 0u, 0u);
+  for (uint32_t k = 0; k < h->cigar_len; ++k) {
+    const uint32_t r = cigar_pool[h->cigar_off + k];
+    const char op = "MDI"[r & 3];
+    const uint32_t len = r >> 2;
+    char *dst = n < cap ? buf + n : nullptr;
+    const size_t room = n < cap ? (size_t)(cap - n) : 0;
+    if (len == 1) n += snprintf(dst, room, "%c", op); else n += snprintf(dst, room, "%u%c", len, op);
+  }
+  n += snprintf(n < cap ? buf + n : nullptr, n < cap ? (size_t)(cap - n) : 0, "\t%s\t%s\n", qlabel, tlabel);
+  return n;
+}
+
+// outputuc.cpp:10-23
+extern "C" int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap)
+{
+  return snprintf(buf, (size_t)cap, "N\t*\t%u\t*\t.\t*\t*\t*\t%s\t*\n", ql, qlabel);
+}

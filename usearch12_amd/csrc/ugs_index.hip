@@ -1,0 +1,209 @@
+// ugs_index.hip - DB soft-masking and UDB word-index construction on the GPU (gfx950).
+//
+// Replaces (reference, /root/reference/src):
+//   FastMaskSeq                      fastmask.cpp:88-158     (via MaskDB makeudb.cpp:11-25)
+//   UDBData::FromSeqDB               udbbuild.cpp:303-398    (+ AddSeqNoncoded :256-284,
+//   UDBParams::SeqToWordNoPattern    udbparams.cpp:540-555     SetTargetUniqueWords :680-711)
+//
+// Layout produced (all resident in HBM): CSR rows `postings[row_off[w] .. row_off[w+1])` =
+// ascending target indexes containing word w (each target once per distinct valid word), plus
+// a partition table part[w][p] = offset inside row w of the first target >= p * 2^gshift, which
+// lets the ranking kernel cut every row into LDS-sized target ranges without searching.
+//
+// Method: one 64-bit key (word << 32 | target) per sequence position, device radix sort,
+// adjacent-unique; sort order == (word asc, target asc) == the reference's sequential insert order.
+#include <cstring>
+#include "ugs_dev.h"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+
+// One thread per sequence: the reference's run detector is inherently sequential per sequence
+// (a few hundred letters), and the whole DB is masked once at load.
+__global__ void k_mask(uint8_t *seqs, const uint64_t *offs, uint32_t nseq, int dbmask)
+{
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseq) return;
+  uint8_t *S = seqs + offs[t];
+  const uint32_t L = (uint32_t)(offs[t + 1] - offs[t]);
+  for (uint32_t i = 0; i < L; ++i) { uint8_t c = S[i]; if (c >= 'a' && c <= 'z') S[i] = c - 32; }
+  if (!dbmask || L < 2) return;
+  // homopolymer runs: fastmask.cpp:106-130 (k1=5, j1=2); unsigned wrap of i-Start is intended
+  {
+    uint8_t last = '?';
+    uint32_t start = 0xffffffffu;
+    for (uint32_t i = 0; i < L; ++i) {
+      uint8_t c = S[i]; if (c >= 'a' && c <= 'z') c -= 32;
+      if (c != last || i + 1 == L) {
+        uint32_t n1 = i - start;
+        if (n1 >= 5) for (uint32_t j = start + 2; j < i; ++j) { uint8_t x = S[j]; if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
+        start = i;
+      }
+      last = c;
+    }
+  }
+  // same-phase dinucleotide repeats: fastmask.cpp:132-157 (k2=5, j2=1), both phases, no flush at end
+  for (uint32_t sp = 0; sp <= 1; ++sp) {
+    uint32_t lastpair = 0xffffffffu, start = 0xffffffffu;
+    for (uint32_t i = sp; i < L - 1; i += 2) {
+      uint8_t c1 = S[i], c2 = S[i + 1];
+      if (c1 >= 'a' && c1 <= 'z') c1 -= 32;
+      if (c2 >= 'a' && c2 <= 'z') c2 -= 32;
+      uint32_t pair = ((uint32_t)c1 << 8) + c2;
+      if (pair != lastpair) {
+        uint32_t n2 = i - start;
+        if (n2 >= 5) for (uint32_t j = start + 2; j < i; ++j) { uint8_t x = S[j]; if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
+        start = i;
+      }
+      lastpair = pair;
+    }
+  }
+}
+
+int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int dbmask, hipStream_t st)
+{
+  if (nseq == 0) return UGS_OK;
+  hipLaunchKernelGGL(k_mask, dim3((nseq + 255) / 256), dim3(256), 0, st, d_seqs, d_offs, nseq, dbmask);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
+
+// One wave per sequence; lane = position.  key = word<<32 | target, or slots<<32 (sorts last)
+// when the position has no valid word.
+__global__ void k_word_keys(const UgsTables *tab, const uint8_t *seqs, const uint64_t *offs, uint32_t nseq,
+                            int W, int alpha, uint32_t slots, uint64_t *keys)
+{
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (wave >= nseq) return;
+  const uint64_t o = offs[wave];
+  const uint32_t L = (uint32_t)(offs[wave + 1] - o);
+  const uint8_t *S = seqs + o;
+  const uint64_t bad = (uint64_t)slots << 32;
+  for (uint32_t pos = lane; pos < L; pos += 64) {
+    uint64_t key = bad;
+    if (pos + W <= L) {
+      uint32_t w = 0; bool ok = true;
+      for (int k = 0; k < W; ++k) {
+        uint32_t l = tab->udb_letter[S[pos + k]];
+        ok = ok && (l != 0xff);
+        w = w * alpha + l;
+      }
+      if (ok) key = ((uint64_t)w << 32) | wave;
+    }
+    keys[o + pos] = key;
+  }
+}
+
+__global__ void k_row_off(const uint64_t *ukeys, uint64_t n, uint32_t slots, uint64_t *row_off)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > slots) return;
+  const uint64_t want = (uint64_t)s << 32;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ukeys[mid] < want) lo = mid + 1; else hi = mid; }
+  row_off[s] = lo;
+}
+
+__global__ void k_postings(const uint64_t *ukeys, uint64_t n, uint32_t *postings)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) postings[k] = (uint32_t)ukeys[k];
+}
+
+__global__ void k_max_row(const uint64_t *row_off, uint32_t slots, uint32_t *max_row)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = 0;
+  if (s < slots) v = (uint32_t)(row_off[s + 1] - row_off[s]);
+  for (int o = 32; o > 0; o >>= 1) { uint32_t x = __shfl_down(v, o); v = x > v ? x : v; }
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(max_row, v);
+}
+
+int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq,
+                    uint64_t nletters, int word_len, int alpha, uint32_t slots, uint64_t **d_row_off_out,
+                    uint32_t **d_postings_out, uint64_t *n_postings, uint32_t *max_row, hipStream_t st)
+{
+  uint64_t *row_off = nullptr; uint32_t *postings = nullptr;
+  HIPCHK(hipMalloc(&row_off, ((size_t)slots + 1) * sizeof(uint64_t)));
+  *d_row_off_out = row_off; *d_postings_out = nullptr; *n_postings = 0; *max_row = 0;
+  if (nseq == 0 || nletters == 0) {
+    HIPCHK(hipMemsetAsync(row_off, 0, ((size_t)slots + 1) * sizeof(uint64_t), st));
+    HIPCHK(hipMalloc(&postings, 16));
+    *d_postings_out = postings;
+    return UGS_OK;
+  }
+  uint64_t *keys = nullptr, *keys2 = nullptr; unsigned long long *d_count = nullptr; void *tmp = nullptr; uint32_t *d_max = nullptr;
+  HIPCHK(hipMalloc(&keys, nletters * sizeof(uint64_t)));
+  HIPCHK(hipMalloc(&keys2, nletters * sizeof(uint64_t)));
+  HIPCHK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  HIPCHK(hipMalloc(&d_max, sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(d_max, 0, sizeof(uint32_t), st));
+  {
+    uint64_t threads = (uint64_t)nseq * 64;
+    hipLaunchKernelGGL(k_word_keys, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_tab, d_seqs, d_offs,
+                       nseq, word_len, alpha, slots, keys);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned wordbits = 1; while ((1ull << wordbits) <= slots) ++wordbits;   // values 0..slots
+  size_t tmp_bytes = 0;
+  HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
+  HIPCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
+  HIPCHK(hipFree(tmp)); tmp = nullptr;
+  size_t tmp2 = 0;
+  HIPCHK(rocprim::unique(nullptr, tmp2, keys2, keys, d_count, (size_t)nletters, rocprim::equal_to<uint64_t>(), st));
+  HIPCHK(hipMalloc(&tmp, tmp2 ? tmp2 : 16));
+  HIPCHK(rocprim::unique(tmp, tmp2, keys2, keys, d_count, (size_t)nletters, rocprim::equal_to<uint64_t>(), st));
+  unsigned long long nuniq = 0;
+  HIPCHK(hipMemcpyAsync(&nuniq, d_count, sizeof(nuniq), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(k_row_off, dim3((slots + 1 + 255) / 256), dim3(256), 0, st, keys, (uint64_t)nuniq, slots, row_off);
+  HIPCHK(hipGetLastError());
+  uint64_t np_host = 0;
+  HIPCHK(hipMemcpyAsync(&np_host, row_off + slots, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMalloc(&postings, (np_host ? np_host : 4) * sizeof(uint32_t)));
+  if (np_host) {
+    hipLaunchKernelGGL(k_postings, dim3((unsigned)((np_host + 255) / 256)), dim3(256), 0, st, keys, np_host, postings);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_max_row, dim3((slots + 255) / 256), dim3(256), 0, st, row_off, slots, d_max);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(max_row, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFree(tmp)); HIPCHK(hipFree(keys)); HIPCHK(hipFree(keys2)); HIPCHK(hipFree(d_count)); HIPCHK(hipFree(d_max));
+  *d_postings_out = postings;
+  *n_postings = np_host;
+  return UGS_OK;
+}
+
+// thread per (slot, p): lower_bound of p<<gshift inside the row; p == np -> row size
+__global__ void k_part(const uint64_t *row_off, const uint32_t *postings, uint32_t slots, uint32_t np,
+                       uint32_t gshift, uint32_t *part)
+{
+  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t total = (uint64_t)slots * (np + 1);
+  if (id >= total) return;
+  uint32_t s = (uint32_t)(id / (np + 1)), p = (uint32_t)(id % (np + 1));
+  const uint64_t b = row_off[s];
+  const uint32_t n = (uint32_t)(row_off[s + 1] - b);
+  uint32_t lo = 0, hi = n;
+  if (p == np) lo = n;
+  else {
+    const uint64_t want = (uint64_t)p << gshift;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint64_t)postings[b + mid] < want) lo = mid + 1; else hi = mid; }
+  }
+  part[id] = lo;
+}
+
+int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
+                   uint32_t gshift, uint32_t *d_part, hipStream_t st)
+{
+  uint64_t total = (uint64_t)slots * (np + 1);
+  hipLaunchKernelGGL(k_part, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_row_off, d_postings, slots, np,
+                     gshift, d_part);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
