@@ -1,0 +1,67 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/ugs.h
+declares, struct layouts match the ctypes mirror, and compute entry points fail loudly (no CPU
+fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from usearch12_amd import capi
+from usearch12_amd.abi import Params, HIT_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ugs.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ugs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(capi.EXPORTS) == names
+    assert L.ugs_abi_version() == 1
+
+
+def test_struct_layouts():
+    assert C.sizeof(Params) == 80
+    assert HIT_DTYPE.itemsize == 72
+    p = capi.params(is_nucleo=True, id=0.97)
+    assert (p.word_len, p.max_accepts, p.max_rejects, p.big, p.band, p.hsp_word_len) == (8, 1, 32, 100000, 16, 5)
+    assert p.id_accept == float(np.float32(0.97))     # options are stored as float (opts.cpp:265)
+    q = capi.params(is_nucleo=False, id=0.8)
+    assert (q.word_len, q.hsp_word_len) == (5, 3)
+
+
+def test_writers_text():
+    L = capi.lib()
+    h = np.zeros(1, dtype=HIT_DTYPE)
+    h["target"] = 408; h["ids"] = 244; h["mism"] = 5; h["aln_len"] = 250; h["opens"] = 1; h["ql"] = 249; h["tl"] = 250
+    h["cigar_off"] = 0; h["cigar_len"] = 3
+    pool = np.array([(206 << 2) | 0, (1 << 2) | 2, (43 << 2) | 0], dtype=np.uint32)
+    buf = C.create_string_buffer(512)
+    L.ugs_format_blast6(h.ctypes.data, b"q0;src=t408", b"t408", buf, 512)
+    assert buf.value == b"q0;src=t408\tt408\t97.6\t250\t5\t1\t1\t249\t1\t250\t*\t*\n"
+    L.ugs_format_uc_hit(h.ctypes.data, pool.ctypes.data, 1, b"q0;src=t408", b"t408", buf, 512)
+    assert buf.value == b"H\t408\t249\t97.6\t+\t0\t0\t206MI43M\tq0;src=t408\tt408\n"
+    L.ugs_format_uc_nohit(250, b"q9", buf, 512)
+    assert buf.value == b"N\t*\t250\t*\t.\t*\t*\t*\tq9\t*\n"
+
+
+def test_no_cpu_fallback():
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    seqs = np.frombuffer(b"ACGT" * 20, dtype=np.uint8)
+    offs = np.array([0, 80], dtype=np.uint64)
+    with pytest.raises(capi.UgsError) as e:
+        capi.UgsDB(capi.params(), seqs, offs, device=0)
+    assert e.value.code == -2          # UGS_E_NODEVICE
+    with pytest.raises(capi.UgsError):
+        capi.UgsDB(capi.params(), seqs, offs, device=-1)   # "-1 = CPU" does not exist here

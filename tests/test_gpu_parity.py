@@ -41,8 +41,12 @@ def test_gpu_hits_equal_oracle_records(name):
     odb = orc.OrcDB(op, db.seqs, db.offs)
     ohits, onh, opool = odb.search(qs.seqs, qs.offs, nthreads=4)
     assert np.array_equal(nh, onh)
-    assert hits.tobytes() == ohits.tobytes()
-    assert np.array_equal(pool, opool)
+    for f in hits.dtype.names:
+        if f != "cigar_off":          # pool layout is an implementation detail; runs compared below
+            assert np.array_equal(hits[f], ohits[f]), f
+    for h, o in zip(hits, ohits):
+        assert np.array_equal(pool[int(h["cigar_off"]):int(h["cigar_off"]) + int(h["cigar_len"])],
+                              opool[int(o["cigar_off"]):int(o["cigar_off"]) + int(o["cigar_len"])])
 
 
 @pytest.mark.parametrize("name", ["nt_big", "hard_big", "hard_id90", "hard_small", "nt_small", "hard_aa", "aa_small"])

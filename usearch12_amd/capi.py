@@ -18,6 +18,7 @@ EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
     "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates",
+    "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
 ]
 
@@ -52,6 +53,8 @@ def lib():
         L.ugs_batch_fetch.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
         L.ugs_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
         L.ugs_batch_get_candidates.argtypes = [vp, vp, vp, vp, u32]
+        L.ugs_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
+                                               C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_hit.argtypes = [vp, vp, i32, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_nohit.argtypes = [u32, C.c_char_p, C.c_char_p, i32]
@@ -178,6 +181,14 @@ class UgsBatch:
         st = BatchStats()
         _chk(lib().ugs_batch_get_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in BatchStats._fields_}
+
+    def device_results(self):
+        """(ptr, nbytes) triples of the device-resident hit table, hit counts and run pool."""
+        ph, pn, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        bh, bn, bc = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().ugs_batch_device_results(self.h, C.byref(ph), C.byref(bh), C.byref(pn), C.byref(bn),
+                                            C.byref(pc), C.byref(bc)))
+        return (ph.value, bh.value), (pn.value, bn.value), (pc.value, bc.value)
 
     def candidates(self):
         p = self.db.p

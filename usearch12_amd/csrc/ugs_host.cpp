@@ -218,10 +218,10 @@ static uint32_t query_step(const ugs_params &p, uint32_t Nu)
 extern "C" void ugs_db_destroy(ugs_db *db)
 {
   if (!db) return;
-  hipSetDevice(db->device);
-  hipFree(db->d_seqs); hipFree(db->d_offs); hipFree(db->d_row_off); hipFree(db->d_postings); hipFree(db->d_part);
-  hipFree(db->d_step); hipFree(db->d_tab);
-  if (db->stream) hipStreamDestroy(db->stream);
+  (void)hipSetDevice(db->device);
+  (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
+  (void)hipFree(db->d_step); (void)hipFree(db->d_tab);
+  if (db->stream) (void)hipStreamDestroy(db->stream);
   delete db;
 }
 
@@ -363,13 +363,13 @@ extern "C" int ugs_db_debug_fetch(const ugs_db *db, char *masked, uint64_t *row_
 extern "C" void ugs_batch_destroy(ugs_batch *b)
 {
   if (!b) return;
-  hipSetDevice(b->db->device);
-  hipFree(b->d_qseqs); hipFree(b->d_qoffs); hipFree(b->d_cand); hipFree(b->d_cand_cnt); hipFree(b->d_cand_n);
-  hipFree(b->d_hit_n); hipFree(b->d_cigar); hipFree(b->d_runs); hipFree(b->d_hits); hipFree(b->d_emit); hipFree(b->d_tb);
-  hipFree(b->d_cigar_used); hipFree(b->d_ctr);
-  if (b->ev0) hipEventDestroy(b->ev0);
-  if (b->ev1) hipEventDestroy(b->ev1);
-  if (b->ev2) hipEventDestroy(b->ev2);
+  (void)hipSetDevice(b->db->device);
+  (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
+  (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
+  (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev2) (void)hipEventDestroy(b->ev2);
   delete b;
 }
 
@@ -693,4 +693,21 @@ extern "C" int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, i
 extern "C" int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap)
 {
   return snprintf(buf, (size_t)cap, "N\t*\t%u\t*\t.\t*\t*\t*\t%s\t*\n", ql, qlabel);
+}
+
+// Device-resident result tables of the last search, for callers that move them GPU-to-GPU
+// (bench.py gathers them to rank 0 with RCCL over xGMI without touching the host):
+// hits[units*max_accepts] (ugs_hit), hit_n[units] (uint32), cigar pool (uint32 runs).
+extern "C" int ugs_batch_device_results(ugs_batch *b, void **d_hits, uint64_t *hits_bytes, void **d_hit_n,
+                                        uint64_t *hit_n_bytes, void **d_cigar, uint64_t *cigar_bytes)
+{
+  if (!b || !b->synced) return UGS_E_ARG;
+  const uint64_t units = (uint64_t)b->nq * b->nstrand;
+  if (d_hits) *d_hits = b->d_hits;
+  if (hits_bytes) *hits_bytes = units * (uint64_t)b->db->p.max_accepts * sizeof(ugs_hit);
+  if (d_hit_n) *d_hit_n = b->d_hit_n;
+  if (hit_n_bytes) *hit_n_bytes = units * 4;
+  if (d_cigar) *d_cigar = b->d_cigar;
+  if (cigar_bytes) *cigar_bytes = b->cigar_used_host * 4;
+  return UGS_OK;
 }
