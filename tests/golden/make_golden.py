@@ -43,6 +43,9 @@ CASES = {
     "hard_acc_s":  dict(gen="hard", seed=25, n_fam=300, fam=8, q_n=800, aa=False, id=0.95, strand="both", maxaccepts=4, maxrejects=16),
     "hard_aa":     dict(gen="hard", seed=26, n_fam=300, fam=8, q_n=1200, aa=True, id=0.8, big=100),
     "hard_aa_s":   dict(gen="hard", seed=27, n_fam=300, fam=8, q_n=1200, aa=True, id=0.9),
+    # mixed lengths 20..300: short queries need wider counters than the batch-typical ones
+    "hard_mixlen": dict(gen="hard", seed=28, n_fam=400, fam=6, q_n=1500, aa=False, id=0.97, strand="plus", big=100, lmin=20, lmax=300),
+    "hard_mixlen_s": dict(gen="hard", seed=29, n_fam=400, fam=6, q_n=1500, aa=False, id=0.95, strand="both", lmin=20, lmax=300),
 }
 
 
@@ -54,7 +57,8 @@ def make_inputs(c):
             kw = dict(p_sub=c["mut"][0], p_del=c["mut"][1], p_ins=c["mut"][2])
         qs = synth.make_queries(c["seed"], db, c["q_n"], c["length"], c["aa"], **kw)
     else:
-        db, qs = synth.make_hard(c["seed"], c["n_fam"], c["fam"], c["q_n"], aa=c["aa"])
+        db, qs = synth.make_hard(c["seed"], c["n_fam"], c["fam"], c["q_n"], lmin=c.get("lmin", 150), lmax=c.get("lmax", 400),
+                                 aa=c["aa"])
     if c.get("strand") == "both":
         qs = synth.revcomp_some(c["seed"], qs)
     return db, qs

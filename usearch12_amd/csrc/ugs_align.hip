@@ -62,7 +62,7 @@ __device__ __forceinline__ bool ident(const WaveCtx &c, uint8_t a, uint8_t b) { 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // hspfinder.cpp:594-636
-__device__ bool is_global_hsp(uint32_t ALo, uint32_t BLo, uint32_t LA, uint32_t LB)
+__device__ __forceinline__ bool is_global_hsp(uint32_t ALo, uint32_t BLo, uint32_t LA, uint32_t LB)
 {
   if (LA <= LB) {
     uint32_t MaxGap = LA / 4 + 1;
@@ -80,7 +80,7 @@ __device__ bool is_global_hsp(uint32_t ALo, uint32_t BLo, uint32_t LA, uint32_t 
 
 // Query side of HSPFinder::SetA: words for every position (invalid letter -> 0), sorted by
 // (word, pos) so a word's first MaxReps positions are contiguous and ascending.
-__device__ void build_query_words(WaveCtx &c, int w, int alpha)
+__device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
 {
   const int lane = c.lane;
   const uint32_t LA = c.LA;
@@ -112,7 +112,7 @@ __device__ void build_query_words(WaveCtx &c, int w, int alpha)
 }
 
 // ungappedblast.cpp:8-211
-__device__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLength, unsigned long long *counters)
+__device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLength, unsigned long long *counters)
 {
   const int lane = c.lane, w = db.hsp_w;
   const uint32_t LA = c.LA, LB = c.LB;
@@ -181,7 +181,7 @@ __device__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLeng
 }
 
 // chainer.cpp:352-500 on lane 0 (HSP counts are tiny); csc layout: [bp_pos 2n][bp_idxlo 2n][prev n][cscore n][list n]
-__device__ void chain_lane0(WaveCtx &c)
+__device__ __forceinline__ void chain_lane0(WaveCtx &c)
 {
   const uint32_t n = c.ws->nhsp;
   uint32_t nchain = 0;
@@ -248,7 +248,7 @@ __device__ void chain_lane0(WaveCtx &c)
 }
 
 // ---- run-length path assembly (lane 0 only); PathInfo::AppendPath/AppendMs (pathinfo.h:7-87)
-__device__ void push_run(WaveCtx &c, uint32_t op, uint32_t len)
+__device__ __forceinline__ void push_run(WaveCtx &c, uint32_t op, uint32_t len)
 {
   if (!len) return;
   WaveState *ws = c.ws;
@@ -259,7 +259,7 @@ __device__ void push_run(WaveCtx &c, uint32_t op, uint32_t len)
   }
   ws->cur_op = op; ws->cur_len = len;
 }
-__device__ void flush_runs(WaveCtx &c)
+__device__ __forceinline__ void flush_runs(WaveCtx &c)
 {
   WaveState *ws = c.ws;
   if (ws->cur_len) {
@@ -281,7 +281,7 @@ __device__ __forceinline__ void get_range_j(uint32_t LA, uint32_t LB, uint32_t d
 
 // ViterbiFastMainDiagMem + ViterbiFastBandMem + TraceBackBitMem on the hole A[a0..a0+LA) x B[b0..b0+LB);
 // appends the path to the run list.  All lanes participate; lane 0 does the traceback.
-__device__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t LA, uint32_t b0, uint32_t LB, uint32_t band,
+__device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t LA, uint32_t b0, uint32_t LB, uint32_t band,
                              const Pen &P, unsigned long long *counters)
 {
   const int lane = c.lane;
@@ -406,7 +406,7 @@ __device__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t LA, uint32_t b0, 
 }
 
 // globalalignmem.cpp:70-112 AlignHSPMem on a hole
-__device__ void align_hole(WaveCtx &c, const UgsDbView &db, uint32_t Loi, uint32_t Loj, uint32_t Leni, uint32_t Lenj,
+__device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint32_t Loi, uint32_t Loj, uint32_t Leni, uint32_t Lenj,
                            unsigned long long *counters)
 {
   if (Leni == 0) { if (c.lane == 0) push_run(c, 2, Lenj); wave_sync(); return; }
@@ -421,7 +421,7 @@ __device__ void align_hole(WaveCtx &c, const UgsDbView &db, uint32_t Loi, uint32
   viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
 }
 
-__global__ void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds)
+__global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;

@@ -293,12 +293,13 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   if ((rc = ugs_build_index(db->d_tab, db->d_seqs, db->d_offs, nseq, nletters, p->word_len, alpha, slots,
                             &db->d_row_off, &db->d_postings, &db->n_postings, &db->max_row, db->stream)) != UGS_OK)
     return fail(rc);
-  // partition size: aim at ~96 postings per (row, partition) so a sub-row fills a wavefront
+  // partition size: aim at ~32 postings per (row, partition): a sub-row then (almost) never exceeds
+  // one wavefront, which keeps the ranking kernel on its register-resident fast path
   uint32_t gshift = 14;
   {
     double avg_row = db->n_postings ? (double)db->n_postings / (double)slots : 1.0;
-    double g = 96.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
-    gshift = 12;
+    double g = 32.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
+    gshift = 10;
     while (gshift < 16 && (double)(1u << gshift) < g * 0.75) ++gshift;
     const uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
     while (gshift < 16 && (uint64_t)slots * (((uint64_t)nseq >> gshift) + 2) * 4 > budget) ++gshift;
@@ -417,9 +418,19 @@ static int plan_launch(ugs_batch *b)
   if (db->v.big) { for (uint32_t nu = 1; nu <= maxNu; ++nu) { uint32_t s = db->step[nu]; ns_max = std::max(ns_max, (nu + s - 1) / s); } }
   else ns_max = std::max(1u, maxNu);
   if (ns_max > 4095) { ugs_set_error("query needs %u sampled words > 4095 (device envelope)", ns_max); return UGS_E_ENVELOPE; }
-  const int bits = ns_max <= 15 ? 4 : (ns_max <= 255 ? 8 : 16);
+  // LDS counter width is sized for the TYPICAL query (the longest queries' sampled-row count);
+  // a query needing wider counters splits each partition into sub-ranges inside the kernel
+  uint32_t ns_typ = 1;
+  for (uint32_t k = 0; k <= 16 && k < maxNu; ++k) {
+    const uint32_t nu = maxNu - k;
+    ns_typ = std::max(ns_typ, db->v.big ? (nu + db->step[nu] - 1) / db->step[nu] : nu);
+  }
+  const int bits = ns_typ <= 15 ? 4 : (ns_typ <= 255 ? 8 : 16);
   const size_t tbl_bytes = (((size_t)1 << db->v.gshift) * bits) / 8;
-  const size_t fixed = 256 /*RankShared*/ + (((size_t)ns_max + 1) * 8 + 16) + (size_t)maxq * 4 + ((size_t)ns_max * 4 + 16) +
+  // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
+  uint32_t part_words = 0;
+  if (bits == 4 && (uint64_t)15 * (db->v.np + 1) * 4 <= 24 * 1024) part_words = (15 * (db->v.np + 1) + 3) & ~3u;
+  const size_t fixed = (size_t)part_words * 4 + 256 /*udb letters*/ + 512 /*RankShared*/ + (((size_t)ns_max + 1) * 8 + 16) + (size_t)maxq * 4 + ((size_t)ns_max * 4 + 16) +
                        2 * (size_t)maxq + 2 * (((size_t)ns_max + 1) * 4 + 16);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
@@ -429,10 +440,11 @@ static int plan_launch(ugs_batch *b)
   int per_cu = (int)std::min<size_t>(LDS_MAX / rlds, (size_t)(32 / wpb));
   per_cu = std::max(1, std::min(per_cu, 8));
   if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
-  b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max;
+  b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well
-  uint64_t ecap = std::min<uint64_t>(db->v.nseq, (uint64_t)ns_max * db->max_row / 2 + 1) + (uint64_t)db->v.np * b->K + 64;
+  // a target with count c is emitted c times (deduplicated at selection): bounded by the postings read
+  uint64_t ecap = std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20) + (uint64_t)db->v.np * 4 * b->K + 64;
   if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
     if (b->d_emit) HIPCHK(hipFree(b->d_emit));
     HIPCHK(hipMalloc(&b->d_emit, ecap * (uint64_t)b->rl.grid * 8));
@@ -619,6 +631,10 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
   st->pairs_aligned = b->ctr[UGS_CTR_PAIRS];
   st->dp_cells = b->ctr[UGS_CTR_CELLS];
   st->hits = b->ctr[UGS_CTR_HITS];
+  if (getenv("UGS_PHASE_CLOCKS"))
+    fprintf(stderr, "[ugs] rank phase clocks (sum over WGs, thread 0): setup %llu scan %llu scan-wait %llu select %llu | align: %llu %llu %llu %llu\n",
+            b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5],
+            b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]);
   return UGS_OK;
 }
 

@@ -10,14 +10,17 @@
 //
 // Design (DESIGN.md "K2/K3"): one workgroup per (query, strand).  The target space is cut into
 // partitions of 2^gshift targets; each WAVE owns a private LDS counter table (4/8/16-bit
-// counters) for one partition at a time and walks the sampled rows' sub-rows twice:
-//   pass 1  LDS atomic increment per posting                       (the reference's U[t]++)
-//   pass 2  same postings in row order: read the final count, clear the counter (so the table
-//           is clean for the next partition, no bulk zeroing), record the first-touch position
-//           per count value and emit every target with count >= 2 exactly once.
-// Row order inside a wave is program order, so no workgroup barrier is needed in the scan.
-// The reference fully sorts ~38 k touched targets per query; its candidate loop can consume at
-// most K = maxaccepts+maxrejects-1 of them, so only the K smallest keys
+// counters, width chosen per query) for one partition at a time and handles the sampled rows'
+// sub-rows (cut out by the index's partition table, no searching):
+//   pass 1  all sub-row loads of the partition are issued back-to-back (one register per row,
+//           one posting per lane), then one LDS atomic increment per posting (the reference's U[t]++)
+//   pass 2  read the final count of every posting, clear the counters (the table is clean for the
+//           next partition - no bulk zeroing), record the first-touch position per count value and
+//           emit every posting whose target has count >= 2
+// Nothing in the scan needs a workgroup barrier or a row order: a target with count c is emitted c
+// times and the duplicates are dropped during selection (the smallest key of a target is its
+// first touch).  The reference fully sorts ~38 k touched targets per query but its candidate loop
+// can consume at most K = maxaccepts+maxrejects-1 of them, so only the K smallest keys
 // (count desc, first-touch position asc) are selected, after applying the reference's
 // "MinValue = prevMax/2" (and, on the small path, -bump) cut-offs exactly.
 #include "ugs_dev.h"
@@ -28,6 +31,10 @@
 #define POS_MASK ((1ull << POS_BITS) - 1)
 #define CMAXV 4095u
 #define KEY_INF 0xffffffffffffffffull
+#define RB 16                  // rows per register batch
+#define SEL_REGS 8             // emitted entries held per thread during block-wide selection
+#define SELW 16                // entries per lane when one wave selects from registers
+#define TINV 0xffffffffu
 
 __device__ __forceinline__ uint64_t make_key(uint32_t c, uint64_t pos) { return ((uint64_t)(CMAXV - c) << POS_BITS) | pos; }
 __device__ __forceinline__ uint32_t key_count(uint64_t k) { return CMAXV - (uint32_t)(k >> POS_BITS); }
@@ -54,134 +61,320 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 }
 
 struct RankShared {
-  uint32_t Nu, ns, step, emit_n, M, next_value, min_value, n_kept, n_sel, nev, fill_limit_valid;
+  uint32_t emit_n, M, next_value, min_value, n_sel, nev, exhausted, pad1;
   uint64_t fill_limit;       // small path: count-1 targets kept only below this position
   uint64_t last_key;
   uint64_t red[8];
   uint32_t wsum[8];
-  uint32_t base;
+  uint32_t sel_t[UGS_KMAX];
 };
 
-// One pass over all partitions owned by this wave.  FILL=false: normal extraction.
-// FILL=true: emit count-1 targets in position order, at most `need` per partition.
-template <int BITS, bool FILL>
-__device__ void scan_partitions(const UgsDbView &db, const uint32_t *s_slots, uint32_t ns, uint32_t *tbl,
-                                unsigned long long *s_fp, RankShared *sh, uint64_t *ebuf, uint64_t ecap,
-                                int wave, int wpb, int lane, bool small_path, uint32_t need, uint64_t fill_limit)
+struct ScanCtx {
+  const uint64_t *row_off; const uint32_t *part; const uint32_t *postings;
+  const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
+  uint64_t *ebuf; uint64_t ecap;
+  uint32_t ns, np, gshift, tbl_words;
+  int wave, wpb, lane; bool small_path;
+};
+
+// emit the lanes with e==true (at most `take` of them, in lane order) into the WG's candidate buffer
+__device__ __forceinline__ void emit_lanes(const ScanCtx &s, bool e, uint32_t take_cap, uint64_t key)
 {
-  const uint32_t np = db.np, gshift = db.gshift;
-  const uint64_t *row_off = db.row_off;
-  const uint32_t *part = db.part;
-  const uint32_t *postings = db.postings;
-  for (uint32_t p = wave; p < np; p += wpb) {
-    const uint32_t base_t = p << gshift;
-    // ---- pass 1: count
-    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-      uint64_t a = 0, b = 0;
-      if (i0 + lane < ns) {
-        uint32_t slot = s_slots[i0 + lane];
-        uint64_t rb = row_off[slot];
-        const uint32_t *pp = part + (uint64_t)slot * (np + 1) + p;
-        a = rb + pp[0]; b = rb + pp[1];
-      }
-      const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
-      for (uint32_t r = 0; r < nrows; ++r) {
-        const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
-        for (uint64_t k = ra + lane; k < rbb; k += 64) Tbl<BITS>::inc(tbl, postings[k] - base_t);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    uint32_t quota_used = 0;
-    if (FILL && small_path) {
-      // small path scans U[] in ascending target order (udbusortedsearcher.cpp:230-267): walk the
-      // table itself, emit the first `need` count-1 targets of this partition, clear as we go
-      constexpr uint32_t EPW = 32 / BITS;
-      const uint32_t words = (1u << gshift) / EPW;
-      for (uint32_t w0 = 0; w0 < words; w0 += 64) {
-        const uint32_t wi = w0 + lane;
-        uint32_t word = 0;
-        if (wi < words) { word = tbl[wi]; if (word) tbl[wi] = 0; }
-        uint32_t mine = 0;
-        for (uint32_t e2 = 0; e2 < EPW; ++e2) {
-          const uint32_t c = (word >> (e2 * BITS)) & Tbl<BITS>::MASK;
-          const uint64_t t = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
-          if (c == 1 && t < fill_limit) ++mine;
-        }
-        uint32_t incl = mine;
-        for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
-        const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
-        if (total && quota_used < need) {
-          const uint32_t take = (need - quota_used) < total ? (need - quota_used) : total;
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&sh->emit_n, take);
-          base = __builtin_amdgcn_readfirstlane(base);
-          uint32_t r = incl - mine;
-          for (uint32_t e2 = 0; e2 < EPW; ++e2) {
-            const uint32_t c = (word >> (e2 * BITS)) & Tbl<BITS>::MASK;
-            const uint64_t t = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
-            if (c == 1 && t < fill_limit) {
-              if (r < take && (uint64_t)base + r < ecap) ebuf[base + r] = make_key(1, t);
-              ++r;
-            }
-          }
-        }
-        quota_used += total;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      continue;
-    }
-    // ---- pass 2: extract in row order
-    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-      uint64_t a = 0, b = 0;
-      if (i0 + lane < ns) {
-        uint32_t slot = s_slots[i0 + lane];
-        uint64_t rb = row_off[slot];
-        const uint32_t *pp = part + (uint64_t)slot * (np + 1) + p;
-        a = rb + pp[0]; b = rb + pp[1];
-      }
-      const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
-      for (uint32_t r = 0; r < nrows; ++r) {
-        const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
-        const uint32_t i = i0 + r;
-        for (uint64_t k0 = ra; k0 < rbb; k0 += 64) {
-          const uint64_t k = k0 + lane;
-          uint32_t t = 0, c = 0;
-          if (k < rbb) {
-            t = postings[k];
-            c = Tbl<BITS>::get(tbl, t - base_t);
-            if (c) Tbl<BITS>::clear(tbl, t - base_t);
-          }
-          const uint64_t pos = small_path ? (uint64_t)t : (((uint64_t)i << 32) | t);
-          bool e;
-          if (!FILL) {
-            if (c) { if (pos < s_fp[c]) atomicMin(&s_fp[c], (unsigned long long)pos); }
-            e = c >= 2;
-          } else {
-            e = (c == 1) && (pos < fill_limit);
-          }
-          const uint64_t m = __ballot(e);
-          if (m) {
-            const uint32_t n = __popcll(m);
-            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-            uint32_t take = n;
-            if (FILL) { take = (quota_used >= need) ? 0 : ((need - quota_used) < n ? (need - quota_used) : n); quota_used += n; }
-            if (take) {
-              uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(&sh->emit_n, take);
-              base = __builtin_amdgcn_readfirstlane(base);
-              if (e && rank < take && (uint64_t)base + rank < ecap) ebuf[base + rank] = make_key(c, pos);
-            }
-          }
-          // the clear must land before the next row reads the table (same wave, in-order LDS)
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint64_t m = __ballot(e);
+  if (!m) return;
+  const uint32_t n = __popcll(m);
+  const uint32_t take = n < take_cap ? n : take_cap;
+  if (!take) return;
+  const uint32_t rank = __popcll(m & ((1ull << s.lane) - 1ull));
+  uint32_t base = 0;
+  if (s.lane == 0) base = atomicAdd(&s.sh->emit_n, take);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (e && rank < take && (uint64_t)base + rank < s.ecap) s.ebuf[base + rank] = key;
+}
+
+// sub-row [a,b) of row `slot` restricted to targets [lo_t, hi_t); the partition table gives the
+// partition bounds, a binary search narrows them only when the LDS table is smaller than a partition
+__device__ __forceinline__ void row_bounds(const ScanCtx &s, uint32_t slot, uint32_t p, bool split,
+                                           uint32_t lo_t, uint32_t hi_t, uint64_t &a, uint64_t &b)
+{
+  const uint64_t rb = s.row_off[slot];
+  const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
+  a = rb + pp[0]; b = rb + pp[1];
+  if (split) {
+    uint64_t l = a, h = b;
+    while (l < h) { uint64_t m = (l + h) >> 1; if (s.postings[m] < lo_t) l = m + 1; else h = m; }
+    const uint64_t na = l;
+    h = b;
+    while (l < h) { uint64_t m = (l + h) >> 1; if (s.postings[m] < hi_t) l = m + 1; else h = m; }
+    a = na; b = l;
   }
 }
 
+// pass-2 work for one posting per lane (t valid iff `on`)
+template <int CB, bool FILL>
+__device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t t, uint32_t base_t, uint32_t i,
+                                            uint32_t c, uint32_t &quota_left, uint64_t fill_limit)
+{
+  const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)i << 32) | t);
+  if (!FILL) {
+    if (on && c) { if (pos < s.s_fp[c]) atomicMin(&s.s_fp[c], (unsigned long long)pos); }
+    emit_lanes(s, on && c >= 2, 0xffffffffu, make_key(c, pos));
+  } else {
+    const bool e = on && c == 1 && pos < fill_limit;
+    const uint32_t n = __popcll(__ballot(e));
+    emit_lanes(s, e, quota_left, make_key(1, pos));
+    quota_left = quota_left > n ? quota_left - n : 0;
+  }
+}
+
+// Generic handling of one table range [base_t, hi_t) of partition p: any number of rows, any
+// sub-row length; rows are walked in order and counters are cleared right after they are read, so
+// only the first touch of a target sees a non-zero count (no duplicates are emitted).
+// FILL=true: emit count-1 targets in scan order, at most `need` of them.
+template <int CB, bool FILL>
+__device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool split, uint32_t base_t, uint32_t hi_t,
+                                              uint32_t need, uint64_t fill_limit)
+{
+  constexpr uint32_t EPW = 32 / CB;
+  const int lane = s.lane;
+  const uint32_t ns = s.ns;
+  uint32_t *tbl = s.tbl;
+  const uint32_t *postings = s.postings;
+  uint32_t quota_left = need;
+  for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+    uint64_t a = 0, b = 0;
+    if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
+    const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
+    for (uint32_t r = 0; r < nrows; ++r) {
+      const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
+      for (uint64_t k = ra + lane; k < rbb; k += 64) Tbl<CB>::inc(tbl, postings[k] - base_t);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (FILL && s.small_path) {
+    // small path scans U[] in ascending target order (udbusortedsearcher.cpp:230-267): walk the
+    // table itself, emit the first `need` count-1 targets of this range, clear as we go
+    const uint32_t words = s.tbl_words;
+    for (uint32_t w0 = 0; w0 < words; w0 += 64) {
+      const uint32_t wi = w0 + lane;
+      uint32_t word = 0;
+      if (wi < words) { word = tbl[wi]; if (word) tbl[wi] = 0; }
+      uint32_t mine = 0;
+      for (uint32_t e2 = 0; e2 < EPW; ++e2) {
+        const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
+        const uint64_t tt = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
+        if (cc == 1 && tt < fill_limit) ++mine;
+      }
+      uint32_t incl = mine;
+      for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+      const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
+      if (total && quota_left) {
+        const uint32_t take = quota_left < total ? quota_left : total;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s.sh->emit_n, take);
+        base = __builtin_amdgcn_readfirstlane(base);
+        uint32_t rr = incl - mine;
+        for (uint32_t e2 = 0; e2 < EPW; ++e2) {
+          const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
+          const uint64_t tt = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
+          if (cc == 1 && tt < fill_limit) {
+            if (rr < take && (uint64_t)base + rr < s.ecap) s.ebuf[base + rr] = make_key(1, tt);
+            ++rr;
+          }
+        }
+      }
+      quota_left = quota_left > total ? quota_left - total : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return;
+  }
+  for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+    uint64_t a = 0, b = 0;
+    if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
+    const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
+    for (uint32_t r = 0; r < nrows; ++r) {
+      const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
+      for (uint64_t k0 = ra; k0 < rbb; k0 += 64) {
+        const uint64_t k = k0 + lane;
+        const bool o2 = k < rbb;
+        uint32_t t2 = 0, c2 = 0;
+        if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+        extract_one<CB, FILL>(s, o2, t2, base_t, i0 + r, c2, quota_left, fill_limit);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+template <int CB, bool FILL>
+__device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, uint64_t fill_limit)
+{
+  constexpr uint32_t EPW = 32 / CB;
+  const uint32_t G = 1u << s.gshift;
+  const uint32_t tbl_targets = s.tbl_words * EPW;
+  const bool split = tbl_targets < G;
+  const uint32_t nsub = split ? (G + tbl_targets - 1) / tbl_targets : 1;
+  for (uint32_t p = s.wave; p < s.np; p += s.wpb)
+    for (uint32_t sub = 0; sub < nsub; ++sub) {
+      const uint32_t base_t = (p << s.gshift) + sub * tbl_targets;
+      const uint32_t pend = (p + 1) << s.gshift;
+      const uint32_t hi_t = split ? (base_t + tbl_targets < pend ? base_t + tbl_targets : pend) : 0;
+      range_generic<CB, FILL>(s, p, split, base_t, hi_t, need, fill_limit);
+    }
+}
+
+// ---- the hot configuration: <= 15 sampled rows (4-bit counters), table covers a whole partition.
+// One register per row holds that row's sub-row (one posting per lane); the loads of the NEXT
+// partition are in flight while the current one is counted and extracted.
+template <int NR> struct Batch { uint32_t v[NR]; uint32_t len; bool tail; };
+
+// Issue the NR sub-row loads of partition p.  Exactly NR unconditional loads (rows beyond ns and
+// lanes beyond a sub-row read a clamped, valid address) so the compiler can count them and wait
+// for the OLDER batch only (s_waitcnt vmcnt(NR)) while these stay in flight.
+template <int NR>
+__device__ __forceinline__ void issue_batch(const ScanCtx &s, uint32_t p, uint32_t myslot, uint64_t myrb, Batch<NR> &B)
+{
+  const int lane = s.lane;
+  uint32_t pa = 0, pb = 0;
+  if ((uint32_t)lane < s.ns) {
+    if (s.s_part) { pa = s.s_part[lane * (s.np + 1) + p]; pb = s.s_part[lane * (s.np + 1) + p + 1]; }
+    else { const uint32_t *pp = s.part + (uint64_t)myslot * (s.np + 1) + p; pa = pp[0]; pb = pp[1]; }
+  }
+  const uint64_t a = myrb + pa;
+  B.len = pb - pa;
+  B.tail = __ballot(B.len > 64) != 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint64_t ra = shfl64(a, r);
+    const uint32_t rlen = __builtin_amdgcn_readlane((int)B.len, r);
+    const uint32_t o = (uint32_t)lane < rlen ? (uint32_t)lane : 0u;
+    B.v[r] = s.postings[ra + o];
+  }
+}
+
+template <int NR>
+__device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> &B, uint32_t p, unsigned long long &cache1)
+{
+  const int lane = s.lane;
+  uint32_t *tbl = s.tbl;
+  const uint32_t base_t = p << s.gshift;
+  if (B.tail) {
+    // a sub-row longer than a wavefront (rare at the chosen partition size): generic, row-ordered
+    range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
+    return;
+  }
+  uint32_t w[NR], sh[NR];    // LDS word index (TINV = lane has no posting in row r) and nibble shift
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint32_t rlen = __builtin_amdgcn_readlane((int)B.len, r);
+    const uint32_t x = B.v[r] - base_t;
+    w[r] = (uint32_t)lane < rlen ? (x >> 3) : TINV;
+    sh[r] = (x & 7u) << 2;
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) if (w[r] != TINV) atomicAdd(&tbl[w[r]], 1u << sh[r]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
+  // row that holds a target still sees its counter set and gets the target's final count back;
+  // later rows of the same target read 0.  One wait for the whole batch, no chain of waits.
+  uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    c[r] = 0;
+    if (w[r] != TINV) {
+      const uint32_t old = atomicAnd(&tbl[w[r]], ~(15u << sh[r]));
+      c[r] = (old >> sh[r]) & 15u;
+    }
+  }
+  const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint32_t t = B.v[r];
+    const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)r << 32) | t);
+    if (s.small_path || (uint32_t)r <= c1hi) {      // uniform: can this row still lower fp[1]?
+      const bool f1 = c[r] == 1 && pos < cache1;
+      if (__ballot(f1)) {
+        if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cache1 = s.s_fp[1];
+      }
+    }
+    const bool f2 = c[r] >= 2;
+    if (__ballot(f2)) {
+      if (f2 && pos < s.s_fp[c[r]]) atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);
+      emit_lanes(s, f2, 0xffffffffu, make_key(c[r], pos));
+    }
+  }
+}
+
+// ---- the hot configuration: <= 15 sampled rows (4-bit counters), table covers a whole partition.
+// One register per row holds that row's sub-row (one posting per lane); the loads of the NEXT
+// partition are in flight while the current one is counted and extracted (ping-pong batches).
+template <int NR>
+__device__ __forceinline__ void scan_fast4(const ScanCtx &s)
+{
+  const int lane = s.lane;
+  uint32_t myslot = 0; uint64_t myrb = 0;
+  if ((uint32_t)lane < s.ns) { myslot = s.s_slots[lane]; myrb = s.row_off[myslot]; }
+  unsigned long long cache1 = KEY_INF;          // register copy of fp[1] (a stale-high filter)
+  uint32_t p0 = s.wave;
+  if (p0 >= s.np) return;
+  const uint32_t last = s.np - 1;
+  Batch<NR> A, B;
+  issue_batch<NR>(s, p0, myslot, myrb, A);
+  for (;;) {
+    const uint32_t p1 = p0 + s.wpb;
+    issue_batch<NR>(s, p1 < last ? p1 : last, myslot, myrb, B);
+    process_batch<NR>(s, A, p0, cache1);
+    if (p1 >= s.np) break;
+    const uint32_t p2 = p1 + s.wpb;
+    issue_batch<NR>(s, p2 < last ? p2 : last, myslot, myrb, A);
+    process_batch<NR>(s, B, p1, cache1);
+    if (p2 >= s.np) break;
+    p0 = p2;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+template <bool FILL>
+__device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
+{
+  if (cb == 4) {
+    if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= (1u << s.gshift)) {
+      if (s.ns <= 8) scan_fast4<8>(s); else scan_fast4<12>(s);
+    }
+    else scan_generic<4, FILL>(s, need, fill_limit);
+  } else if (cb == 8) scan_generic<8, FILL>(s, need, fill_limit);
+  else scan_generic<16, FILL>(s, need, fill_limit);
+}
+
+// wave-uniform min of a u32 with DPP row shifts (no LDS crossbar): inclusive prefix-min inside each
+// row of 16 lanes, then the four row results are combined on the scalar unit
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+  uint32_t x;
+  x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); v = x < v ? x : v;   // row_shr:1
+  x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false); v = x < v ? x : v;   // row_shr:2
+  x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false); v = x < v ? x : v;   // row_shr:4
+  x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false); v = x < v ? x : v;   // row_shr:8
+  const uint32_t a = __builtin_amdgcn_readlane((int)v, 15), b = __builtin_amdgcn_readlane((int)v, 31);
+  const uint32_t c = __builtin_amdgcn_readlane((int)v, 47), d = __builtin_amdgcn_readlane((int)v, 63);
+  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+  const uint32_t hi = (uint32_t)(v >> 32);
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t lo = hi == mh ? (uint32_t)v : 0xffffffffu;
+  const uint32_t ml = wave_min_u32(lo);
+  return ((uint64_t)mh << 32) | ml;
+}
+
 // Block-wide min of a 64-bit key (all threads get the result)
-__device__ uint64_t block_min_u64(uint64_t v, RankShared *sh, int wave, int wpb, int lane)
+__device__ __forceinline__ uint64_t block_min_u64(uint64_t v, RankShared *sh, int wave, int wpb, int lane)
 {
   for (int o = 32; o > 0; o >>= 1) {
     uint32_t lo = __shfl_xor((int)(uint32_t)v, o), hi = __shfl_xor((int)(uint32_t)(v >> 32), o);
@@ -196,7 +389,7 @@ __device__ uint64_t block_min_u64(uint64_t v, RankShared *sh, int wave, int wpb,
   return r;
 }
 
-__device__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, int wave, int wpb, int lane)
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, int wave, int wpb, int lane)
 {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((int)v, o);
   __syncthreads();
@@ -207,8 +400,7 @@ __device__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, int wave, int wpb,
   return r;
 }
 
-template <int BITS>
-__global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words)
+__global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -224,6 +416,8 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
   uint8_t *s_first = (uint8_t *)(smem + off); off += maxq;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
+  uint8_t *s_udb = (uint8_t *)(smem + off); off += 256;                                 // UDB letter table
+  uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * tbl_words;
 
   const UgsTables *tab = db.tab;
@@ -234,14 +428,17 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
   uint64_t *ebuf = bv.emit_buf + (uint64_t)blockIdx.x * bv.emit_cap;
   const uint64_t ecap = bv.emit_cap;
 
+  for (int k = tid; k < 256; k += nthr) s_udb[k] = tab->udb_letter[k];
   // counter tables must start clean; pass 2 restores that invariant after every partition
   for (uint32_t k = lane; k < tbl_words; k += 64) tbl[k] = 0;
 
+  unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0;
   for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t L = (uint32_t)(bv.qoffs[qi + 1] - qo);
     __syncthreads();
+    const unsigned long long tk0 = clock64();
     // ---- query letters (reverse-complemented for strand 1: seqinfo.cpp:292-323)
     for (uint32_t p = tid; p < L; p += nthr) {
       uint8_t c;
@@ -257,7 +454,7 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
       uint32_t w = UGS_BAD_WORD;
       if (p + W <= L) {
         uint32_t acc = 0; bool ok = true;
-        for (int k = 0; k < W; ++k) { uint32_t l = tab->udb_letter[s_q[p + k]]; ok = ok && (l != 0xff); acc = acc * db.alpha + l; }
+        for (int k = 0; k < W; ++k) { uint32_t l = s_udb[s_q[p + k]]; ok = ok && (l != 0xff); acc = acc * db.alpha + l; }
         if (ok) w = acc;
       }
       s_words[p] = w;
@@ -268,7 +465,15 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
     for (uint32_t p = tid; p < L; p += nthr) {
       const uint32_t w = s_words[p];
       bool first = (w != UGS_BAD_WORD);
-      for (uint32_t q = 0; first && q < p; ++q) first = (s_words[q] != w);
+      if (first) {
+        // any earlier position with the same word?  128-bit LDS reads, no early exit
+        const uint4 *v4 = (const uint4 *)s_words;
+        const uint32_t nq4 = p >> 2;
+        bool dupf = false;
+        for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
+        for (uint32_t q = nq4 << 2; q < p; ++q) dupf = dupf | (s_words[q] == w);
+        first = !dupf;
+      }
       s_first[p] = first ? 1 : 0;
       my_first += first ? 1u : 0u;
     }
@@ -306,10 +511,29 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
       for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor((long long)psum, o);
       if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
     }
-    // ---- the scan
-    scan_partitions<BITS, false>(db, s_slots, ns, tbl, s_fp, sh, ebuf, ecap, wave, wpb, lane, small_path, 0, 0);
+    // ---- the scan; counter width by the largest possible count (= ns)
+    const int cb0 = ns <= 15 ? 4 : (ns <= 255 ? 8 : 16);
+    const bool use_part_cache = cb0 == 4 && (uint64_t)ns * (db.np + 1) <= part_words;
+    if (use_part_cache) {
+      const uint32_t npp = db.np + 1;
+      for (uint32_t r = wave; r < ns; r += wpb) {
+        const uint32_t *src = db.part + (uint64_t)s_slots[r] * npp;
+        for (uint32_t pp = lane; pp < npp; pp += 64) s_part[r * npp + pp] = src[pp];
+      }
+      __syncthreads();
+    }
+    ScanCtx sc;
+    sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
+    sc.s_part = use_part_cache ? s_part : nullptr;
+    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gshift = db.gshift;
+    sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
+    const int cb = cb0;
+    const unsigned long long tk1 = clock64();
+    scan_dispatch<false>(sc, cb, 0, 0);
+    const unsigned long long tk2w = clock64();
     __threadfence_block();
     __syncthreads();
+    const unsigned long long tk2 = clock64();
 
     // ---- cut-offs.  NextValue = running max just before the max last increased, in scan
     // (first-touch / ascending-target) order  == max{c < M : fp[c] < fp[M]}  (countsort.cpp:13-24,114-126)
@@ -335,16 +559,15 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
             const unsigned long long f = s_fp[c];
             if (f != KEY_INF && f < sufmin) { s_ev_c[nev++] = c; sufmin = f; }   // descending c
           }
-          // replay -bump over the events in scan order (ascending c); record (position, MinU after)
+          // replay -bump over the events in scan order (ascending c); record MinU after each
           const double Bump = db.bump_pct / 100.0;
           uint32_t MinU = 1, MaxCount = 0;
-          uint32_t *ev_minu = s_ev_minu;
           for (int e = (int)nev - 1; e >= 0; --e) {
             const uint32_t n = s_ev_c[e];
             const uint32_t NewMin = (uint32_t)(n * Bump);
             if (NewMin > MinU && NewMin < MaxCount) MinU = NewMin;
             MaxCount = n;
-            ev_minu[e] = MinU;
+            s_ev_minu[e] = MinU;
             if (MinU > 1 && sh->fill_limit == KEY_INF) sh->fill_limit = s_fp[n];
           }
           sh->nev = nev;
@@ -354,7 +577,6 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
     __syncthreads();
     const uint32_t min_value = sh->min_value;
     const uint32_t nev = sh->nev;
-    const uint32_t *ev_minu = s_ev_minu;
 
     // kept(entry): count >= MinValue and (small path) count >= MinU in force at its position
     auto kept = [&](uint64_t key) -> bool {
@@ -365,7 +587,7 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
         uint32_t minu = 1;
         // events are stored by descending count == descending position; MinU in force at pos
         // = MinU after the last event strictly before pos
-        for (uint32_t e = 0; e < nev; ++e) if (s_fp[s_ev_c[e]] < pos) { minu = ev_minu[e]; break; }
+        for (uint32_t e = 0; e < nev; ++e) if (s_fp[s_ev_c[e]] < pos) { minu = s_ev_minu[e]; break; }
         if (c < minu) return false;
       }
       return true;
@@ -373,27 +595,56 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
 
     for (int phase = 0; phase < 2; ++phase) {
       const uint32_t N = sh->emit_n < ecap ? sh->emit_n : (uint32_t)ecap;
-      // select the K smallest kept keys by repeated block-min above the previous one
+      // select the K smallest kept keys by repeated min above the previous one
       uint32_t nsel = sh->n_sel;
       uint64_t last = sh->last_key;
       bool exhausted = false;
-      while (nsel < K) {
-        uint64_t best = KEY_INF;
-        for (uint32_t k = tid; k < N; k += nthr) {
-          const uint64_t key = ebuf[k];
-          if ((nsel == 0 || key > last) && key < best && kept(key)) best = key;
+      if (N <= 64u * SELW) {
+        // one wave holds every emitted entry in registers; the others wait at the barrier
+        if (wave == 0) {
+          uint64_t ent[SELW];
+#pragma unroll
+          for (int e = 0; e < SELW; ++e) {
+            const uint32_t k = lane + e * 64;
+            uint64_t key = KEY_INF;
+            if (k < N) { key = ebuf[k]; if (!kept(key)) key = KEY_INF; }
+            ent[e] = key;
+          }
+          while (nsel < K) {
+            uint64_t best = KEY_INF;
+#pragma unroll
+            for (int e = 0; e < SELW; ++e) { const uint64_t key = ent[e]; if (((nsel == 0 && last == 0) || key > last) && key < best) best = key; }
+            best = wave_min_u64(best);
+            if (best == KEY_INF) { exhausted = true; break; }
+            if (lane == 0) {
+              bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
+              bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
+            }
+            last = best; ++nsel;
+          }
+          if (lane == 0) { sh->n_sel = nsel; sh->last_key = last; sh->exhausted = exhausted ? 1u : 0u; }
         }
-        best = block_min_u64(best, sh, wave, wpb, lane);
-        if (best == KEY_INF) { exhausted = true; break; }
-        if (tid == 0) {
-          bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
-          bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
+        __syncthreads();
+        nsel = sh->n_sel; last = sh->last_key; exhausted = sh->exhausted != 0;
+      } else {
+        while (nsel < K) {
+          uint64_t best = KEY_INF;
+          for (uint32_t k = tid; k < N; k += nthr) {
+            const uint64_t key = ebuf[k];
+            if (((nsel == 0 && last == 0) || key > last) && key < best && kept(key)) best = key;
+          }
+          best = block_min_u64(best, sh, wave, wpb, lane);
+          if (best == KEY_INF) { exhausted = true; break; }
+          if (tid == 0) {
+            bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
+            bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
+          }
+          last = best; ++nsel;
         }
-        last = best; ++nsel;
+        __syncthreads();
+        if (tid == 0) { sh->n_sel = nsel; sh->last_key = last; }
+        __syncthreads();
       }
-      __syncthreads();
-      if (tid == 0) { sh->n_sel = nsel; sh->last_key = last; }
-      __syncthreads();
       if (phase == 1 || !exhausted || nsel >= K) break;
       // fewer than K candidates with count >= 2: append count-1 targets in scan order if the
       // cut-offs keep them (MinValue <= 1; small path additionally position < first MinU bump)
@@ -401,14 +652,19 @@ __global__ void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t 
       const uint32_t need = K - nsel;
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
-      scan_partitions<BITS, true>(db, s_slots, ns, tbl, s_fp, sh, ebuf, ecap, wave, wpb, lane, small_path, need, fill_limit);
+      scan_dispatch<true>(sc, cb, need, fill_limit);
       __threadfence_block();
       __syncthreads();
     }
+    tacc0 += tk1 - tk0; tacc1 += tk2w - tk1; tacc2 += tk2 - tk2w; tacc3 += clock64() - tk2;
     if (tid == 0) {
       bv.cand_n[unit] = sh->n_sel;
       if (sh->emit_n > ecap) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
     }
+  }
+  if (tid == 0) {
+    atomicAdd(&bv.counters[UGS_CTR_T0], tacc0); atomicAdd(&bv.counters[UGS_CTR_T1], tacc1);
+    atomicAdd(&bv.counters[UGS_CTR_T2], tacc2); atomicAdd(&bv.counters[UGS_CTR_T3], tacc3);
   }
 }
 
@@ -416,17 +672,8 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
 {
   const uint32_t tbl_words = (uint32_t)((((uint64_t)1 << db.gshift) * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
-  switch (L.bits) {
-  case 4:
-    HIPCHK(hipFuncSetAttribute((const void *)k_rank<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_rank<4>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words); break;
-  case 8:
-    HIPCHK(hipFuncSetAttribute((const void *)k_rank<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_rank<8>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words); break;
-  default:
-    HIPCHK(hipFuncSetAttribute((const void *)k_rank<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_rank<16>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words); break;
-  }
+  HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+  hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }
