@@ -42,7 +42,10 @@ struct Pen { int OpenA, OpenB, ExtA, ExtB, LOpenA, LOpenB, LExtA, LExtB, ROpenA,
 
 struct WaveCtx {
   // LDS
-  uint8_t *A, *B;             // class codes of query / target letters
+  uint8_t *A, *B;             // class codes of query / target letters (identity tests)
+  uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
+  uint16_t *wstart;           // first index in qsort of each HSP word (0xffff = absent), or null
+  bool nt;
   uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
   int32_t *Mrow, *Drow;       // Mrow[-1] valid
   HSPd *hsps;
@@ -52,11 +55,19 @@ struct WaveCtx {
   const uint8_t *s_cls; const int8_t *s_sub2; const uint64_t *s_match; const uint8_t *s_hl;
   // global scratch
   uint8_t *tb; uint32_t *runs; uint32_t runs_cap;
-  uint32_t LA, LB, nwA, nA2, hsp_cap;
+  uint32_t LA, LB, nwA, nA2, hsp_cap, nwords;
   int lane;
 };
 
 __device__ __forceinline__ int score2(const WaveCtx &c, uint8_t a, uint8_t b) { return c.s_sub2[((a & 31) << 5) | (b & 31)]; }
+// score of two SCORE codes.  nt: pure arithmetic (setnucmx.cpp:11-99: ACGTU match/mismatch by letter,
+// anything else scores 0); aa: BLOSUM62 row lookup in LDS
+template <bool NT>
+__device__ __forceinline__ int sscore(const WaveCtx &c, int m2, int mm2, uint32_t a, uint32_t b)
+{
+  if (NT) return (a < 4 && b < 4) ? (a == b ? m2 : mm2) : 0;
+  return c.s_sub2[(a << 5) | b];
+}
 __device__ __forceinline__ bool ident(const WaveCtx &c, uint8_t a, uint8_t b) { return (c.s_match[a] >> b) & 1ull; }
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
@@ -109,12 +120,25 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       }
       wave_sync();
     }
+  if (c.wstart) {
+    // direct word -> first sorted index table (replaces a binary search per target position)
+    const uint32_t nwords = c.nwords;
+    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0xffffu;
+    wave_sync();
+    for (uint32_t i = lane; i < c.nwA; i += 64) {
+      const uint32_t wd = c.qsort[i] >> 16;
+      if (i == 0 || (c.qsort[i - 1] >> 16) != wd) c.wstart[wd] = (uint16_t)i;
+    }
+    wave_sync();
+  }
 }
 
 // ungappedblast.cpp:8-211
+template <bool NT>
 __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLength, unsigned long long *counters)
 {
   const int lane = c.lane, w = db.hsp_w;
+  const int m2 = c.s_sub2[0], mm2 = c.s_sub2[2];      // nt: 2*score(A,A), 2*score(A,C)
   const uint32_t LA = c.LA, LB = c.LB;
   uint32_t nh = 0;
   if (LB >= 2u * w && c.nwA > 0) {
@@ -127,32 +151,60 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       if (bpos < nwB) {
         uint32_t word = 0;
         for (int k = 0; k < w; ++k) word = word * db.alpha + c.s_hl[c.B[bpos + k] & 31];
-        const uint32_t want = word << 16;
-        uint32_t lo = 0, hi = c.nwA;
-        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c.qsort[mid] < want) lo = mid + 1; else hi = mid; }
+        uint32_t lo = 0;
+        if (c.wstart) { lo = c.wstart[word]; if (lo == 0xffffu) lo = c.nwA; }
+        else {
+          const uint32_t want = word << 16;
+          uint32_t hi = c.nwA;
+          while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c.qsort[mid] < want) lo = mid + 1; else hi = mid; }
+        }
         for (uint32_t r = 0; r < UGS_MAXREPS && lo + r < c.nwA; ++r) {
           const uint32_t ent = c.qsort[lo + r];
           if ((ent >> 16) != word) break;
           const uint32_t apos = ent & 0xffffu;
           int score = 0;
-          for (int k = 0; k < w; ++k) score += score2(c, c.A[apos + k], c.B[bpos + k]);
+          for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
           int best = score;
+          // x-drop extension, 8 letter pairs per LDS round trip (loads clamped inside the sequences;
+          // pairs are consumed strictly in order, so the result equals the one-by-one loop)
           uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
-          for (;;) {
-            ++b2; if (b2 >= LB) break;
-            ++a2; if (a2 >= LA) break;
-            score += score2(c, c.A[a2], c.B[b2]);
-            if (score > best) { best = score; bestb2 = b2; }
-            else if (best - score > db.xdrop2) break;
+          {
+            uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+            bool stop = false;
+            while (rem && !stop) {
+              uint32_t av[8], bv[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a2 + o]; bv[k] = c.Bs[b2 + o]; }
+              const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if ((uint32_t)k < n && !stop) {
+                  score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
+                  if (score > best) { best = score; bestb2 = b2 + k + 1; }
+                  else if (best - score > db.xdrop2) stop = true;
+                }
+              a2 += n; b2 += n; rem -= n;
+            }
           }
           uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
           score = best;
-          for (;;) {
-            if (b1 == 0 || a1 == 0) break;
-            --b1; --a1;
-            score += score2(c, c.A[a1], c.B[b1]);
-            if (score > best) { best = score; bestb1 = b1; }
-            else if (best - score > db.xdrop2) break;
+          {
+            uint32_t rem = b1 < a1 ? b1 : a1;
+            bool stop = false;
+            while (rem && !stop) {
+              uint32_t av[8], bv[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a1 - o]; bv[k] = c.Bs[b1 - o]; }
+              const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if ((uint32_t)k < n && !stop) {
+                  score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
+                  if (score > best) { best = score; bestb1 = b1 - k - 1; }
+                  else if (best - score > db.xdrop2) stop = true;
+                }
+              a1 -= n; b1 -= n; rem -= n;
+            }
           }
           const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
           const uint32_t Alo = apos - (bpos - bestb1);
@@ -431,22 +483,33 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
   int8_t *s_sub2 = (int8_t *)(smem + 288);     // 1024
   uint64_t *s_match = (uint64_t *)(smem + 1312);   // 64*8 = 512
   uint8_t *s_comp = smem + 1824;               // 256  -> 2080
+  uint8_t *s_sc = smem + 2080;                 // 32   -> 2112: letter -> score code
   const UgsTables *tab = db.tab;
   for (int k = tid; k < 256; k += blockDim.x) { s_cls[k] = tab->cls[k]; s_comp[k] = tab->comp[k]; }
   for (int k = tid; k < 1024; k += blockDim.x) s_sub2[k] = tab->sub2[k];
   for (int k = tid; k < 64; k += blockDim.x) s_match[k] = tab->match[k];
-  for (int k = tid; k < 32; k += blockDim.x) s_hl[k] = (k < 26) ? tab->hsp_letter['A' + k] : 0;
+  for (int k = tid; k < 32; k += blockDim.x) {
+    s_hl[k] = (k < 26) ? tab->hsp_letter['A' + k] : 0;
+    if (db.is_nucleo) s_sc[k] = (k < 26 && tab->udb_letter['A' + k] != 0xff) ? tab->hsp_letter['A' + k] : 4;
+    else s_sc[k] = (k < 26) ? (uint8_t)k : 31;
+  }
   __syncthreads();
 
   // ---- per-wave carve
   const uint32_t maxq = (bv.max_qlen + 15u) & ~15u, maxt = (db.max_tlen + 15u) & ~15u;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  unsigned char *wb = smem + 2080 + (size_t)wave * wave_lds;
+  unsigned char *wb = smem + 2112 + (size_t)wave * wave_lds;
   WaveCtx c;
   size_t off = 0;
   c.ws = (WaveState *)(wb + off); off += 32;
   c.A = wb + off; off += maxq;
   c.B = wb + off; off += maxt;
+  c.As = wb + off; off += maxq;
+  c.Bs = wb + off; off += maxt;
+  c.nwords = (uint32_t)db.hsp_words;
+  c.wstart = nullptr;
+  if (db.hsp_words <= 1024) { c.wstart = (uint16_t *)(wb + off); off += (((size_t)db.hsp_words * 2) + 15) & ~(size_t)15; }
+  c.nt = db.is_nucleo != 0;
   c.qsort = (uint32_t *)(wb + off); off += (size_t)q2 * 4;
   c.Mrow = (int32_t *)(wb + off) + 4; off += ((size_t)maxt + 8) * 4;
   c.Drow = (int32_t *)(wb + off); off += ((size_t)maxt + 8) * 4;
@@ -464,7 +527,9 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
   const uint32_t max_acc = (uint32_t)db.max_accepts, max_rej = (uint32_t)db.max_rejects;
   unsigned long long *ctr = bv.counters;
 
+  unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0, tq;
   for (uint32_t unit = gw; unit < units; unit += nw) {
+    tq = clock64();
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t LA = (uint32_t)(bv.qoffs[qi + 1] - qo);
@@ -474,24 +539,29 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
     if (ncand) {
       for (uint32_t p = lane; p < LA; p += 64) {
         uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
-        c.A[p] = s_cls[ch];
+        const uint8_t cl = s_cls[ch];
+        c.A[p] = cl; c.As[p] = s_sc[cl & 31];
       }
       wave_sync();
       build_query_words(c, db.hsp_w, db.alpha);
     }
+    ta0 += clock64() - tq;
     for (uint32_t k = 0; k < ncand; ++k) {
+      tq = clock64();
       const uint32_t t = bv.cand[(uint64_t)unit * K + k];
       const uint64_t to = db.offs[t];
       const uint32_t LB = (uint32_t)(db.offs[t + 1] - to);
       c.LB = LB;
-      for (uint32_t p = lane; p < LB; p += 64) c.B[p] = s_cls[db.seqs[to + p]];
+      for (uint32_t p = lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
       if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], (unsigned long long)LB); atomicAdd(&ctr[UGS_CTR_PAIRS], 1ull); }
       wave_sync();
       // ---- GlobalAlign_AllOpts (globalalignmem.cpp:129-236), FailIfNoHSPs = true
       uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
       if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
       if (MinHSPLength < 16) MinHSPLength = 16;
-      ungapped_blast(c, db, MinHSPLength, ctr);
+      ta1 += clock64() - tq; tq = clock64();
+      if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
+      ta2 += clock64() - tq; tq = clock64();
       if (lane == 0) chain_lane0(c);
       wave_sync();
       const uint32_t nchain = c.ws->nchain;
@@ -571,6 +641,7 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
           }
         }
       }
+      ta3 += clock64() - tq;
       // Terminator::Terminate (terminator.cpp:64-100)
       if (accept) ++nacc; else ++nrej;
       if (nacc == max_acc || nrej == max_rej) break;
@@ -579,11 +650,14 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
     if (lane == 0) bv.hit_n[unit] = nacc;
     wave_sync();
   }
+  if (tid == 0) {
+    atomicAdd(&ctr[UGS_CTR_T4], ta0); atomicAdd(&ctr[UGS_CTR_T5], ta1); atomicAdd(&ctr[UGS_CTR_T6], ta2); atomicAdd(&ctr[UGS_CTR_T7], ta3);
+  }
 }
 
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
-  const uint32_t wave_lds = (uint32_t)((L.lds - 2080) / L.wpb);
+  const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);
   HIPCHK(hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(k_align, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds);
   HIPCHK(hipGetLastError());

@@ -97,6 +97,7 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
                     uint32_t **d_postings, uint64_t *n_postings, uint32_t *max_row, hipStream_t st);
 int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
                    uint32_t gshift, uint32_t *d_part, hipStream_t st);
+size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words);
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);

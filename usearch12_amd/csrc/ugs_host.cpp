@@ -430,8 +430,7 @@ static int plan_launch(ugs_batch *b)
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
   if (bits == 4 && (uint64_t)15 * (db->v.np + 1) * 4 <= 24 * 1024) part_words = (15 * (db->v.np + 1) + 3) & ~3u;
-  const size_t fixed = (size_t)part_words * 4 + 256 /*udb letters*/ + 512 /*RankShared*/ + (((size_t)ns_max + 1) * 8 + 16) + (size_t)maxq * 4 + ((size_t)ns_max * 4 + 16) +
-                       2 * (size_t)maxq + 2 * (((size_t)ns_max + 1) * 4 + 16);
+  const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
   if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
@@ -454,11 +453,12 @@ static int plan_launch(ugs_batch *b)
   // ---- alignment geometry
   const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  const size_t wave_lds = (32 + (size_t)maxq + maxt + (size_t)q2 * 4 + 2 * ((size_t)maxt + 8) * 4 + (size_t)hsp_cap * (16 + 4 + 28) + 15) & ~(size_t)15;
+  const size_t wstart_b = db->v.hsp_words <= 1024 ? (((size_t)db->v.hsp_words * 2 + 15) & ~(size_t)15) : 0;
+  const size_t wave_lds = (32 + 2 * ((size_t)maxq + maxt) + wstart_b + (size_t)q2 * 4 + 2 * ((size_t)maxt + 8) * 4 + (size_t)hsp_cap * (16 + 4 + 28) + 15) & ~(size_t)15;
   int awpb = 4;
-  while (awpb > 1 && 2080 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
-  if (2080 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2080 + wave_lds); return UGS_E_ENVELOPE; }
-  const size_t alds = 2080 + awpb * wave_lds;
+  while (awpb > 1 && 2112 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
+  if (2112 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2112 + wave_lds); return UGS_E_ENVELOPE; }
+  const size_t alds = 2112 + awpb * wave_lds;
   int aper_cu = (int)std::min<size_t>(LDS_MAX / alds, (size_t)(32 / awpb));
   aper_cu = std::max(1, std::min(aper_cu, 8));
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap;

@@ -33,7 +33,7 @@
 #define KEY_INF 0xffffffffffffffffull
 #define RB 16                  // rows per register batch
 #define SEL_REGS 8             // emitted entries held per thread during block-wide selection
-#define SELW 16                // entries per lane when one wave selects from registers
+#define SELQ 4                 // entries per lane per wave in the register-resident selection
 #define TINV 0xffffffffu
 
 __device__ __forceinline__ uint64_t make_key(uint32_t c, uint64_t pos) { return ((uint64_t)(CMAXV - c) << POS_BITS) | pos; }
@@ -66,12 +66,14 @@ struct RankShared {
   uint64_t last_key;
   uint64_t red[8];
   uint32_t wsum[8];
-  uint32_t sel_t[UGS_KMAX];
+  uint32_t ncl, qcut, pad2, pad3;
+  uint32_t hist[256];        // emitted entries per (count, first row) class: hist[c*16 + i], 4-bit fast path only
 };
 
 struct ScanCtx {
   const uint64_t *row_off; const uint32_t *part; const uint32_t *postings;
   const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
+  uint32_t *hist;            // non-null: count emitted entries per (count,row) class
   uint64_t *ebuf; uint64_t ecap;
   uint32_t ns, np, gshift, tbl_words;
   int wave, wpb, lane; bool small_path;
@@ -118,6 +120,7 @@ __device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t 
   const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)i << 32) | t);
   if (!FILL) {
     if (on && c) { if (pos < s.s_fp[c]) atomicMin(&s.s_fp[c], (unsigned long long)pos); }
+    if (on && c >= 2 && s.hist) atomicAdd(&s.hist[c * 16 + i], 1u);
     emit_lanes(s, on && c >= 2, 0xffffffffu, make_key(c, pos));
   } else {
     const bool e = on && c == 1 && pos < fill_limit;
@@ -304,6 +307,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     const bool f2 = c[r] >= 2;
     if (__ballot(f2)) {
       if (f2 && pos < s.s_fp[c[r]]) atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);
+      if (f2 && s.hist) atomicAdd(&s.hist[c[r] * 16 + r], 1u);
       emit_lanes(s, f2, 0xffffffffu, make_key(c[r], pos));
     }
   }
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
   uint8_t *s_first = (uint8_t *)(smem + off); off += maxq;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
+  uint64_t *s_wsel = (uint64_t *)(smem + off); off += (size_t)4 * UGS_KMAX * 8;                 // per-wave selections
   uint8_t *s_udb = (uint8_t *)(smem + off); off += 256;                                 // UDB letter table
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * tbl_words;
@@ -446,7 +451,8 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
       else c = tab->comp[bv.qseqs[qo + (L - 1 - p)]];
       s_q[p] = c;
     }
-    if (tid == 0) { sh->emit_n = 0; sh->n_sel = 0; sh->last_key = 0; }
+    if (tid == 0) { sh->emit_n = 0; sh->n_sel = 0; sh->last_key = 0; sh->ncl = 0; }
+    for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
     for (uint32_t c = tid; c <= ns_max; c += nthr) s_fp[c] = KEY_INF;
     __syncthreads();
     // ---- UDB words per position (udbparams.cpp:540-555)
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
     ScanCtx sc;
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
     sc.s_part = use_part_cache ? s_part : nullptr;
+    sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
     sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gshift = db.gshift;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
@@ -599,28 +606,118 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
       uint32_t nsel = sh->n_sel;
       uint64_t last = sh->last_key;
       bool exhausted = false;
-      if (N <= 64u * SELW) {
-        // one wave holds every emitted entry in registers; the others wait at the barrier
+      bool done_fast = false;
+      if (phase == 0 && sc.hist && sh->M >= 2) {
+        // ---- class-histogram selection (4-bit Big path).  Classes in key order q = (M-c)*16 + i;
+        // a prefix sum over the class sizes gives the class that holds the K-th key, so only the
+        // few entries up to that class are ranked (all-pairs inside one wave) - no extraction rounds.
+        const uint32_t Mx = sh->M;
+        const uint32_t cmin = min_value > 2 ? min_value : 2;
         if (wave == 0) {
-          uint64_t ent[SELW];
+          uint32_t loc[4], sum = 0;
 #pragma unroll
-          for (int e = 0; e < SELW; ++e) {
-            const uint32_t k = lane + e * 64;
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t q = lane * 4 + e, cc = Mx - (q >> 4);
+            loc[e] = (q >> 4) < Mx && cc >= cmin ? sh->hist[cc * 16 + (q & 15)] : 0u;
+            sum += loc[e];
+          }
+          uint32_t incl = sum;
+          for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+          uint32_t run = incl - sum, qc = 0xffffffffu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { run += loc[e]; if (qc == 0xffffffffu && run >= K) qc = lane * 4 + e; }
+          const uint64_t mk = __ballot(qc != 0xffffffffu);
+          uint32_t qcut = 0xfffffffeu;                         // fewer than K entries: take them all
+          if (mk) qcut = __builtin_amdgcn_readlane((int)qc, __ffsll((long long)mk) - 1);
+          if (lane == 0) sh->qcut = qcut;
+        }
+        __syncthreads();
+        const uint32_t qcut = sh->qcut;
+        // gather every kept entry whose class is not after the cut class
+        for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
+          const uint32_t k = k0 + tid;
+          uint64_t key = 0; bool take = false;
+          if (k < N) {
+            key = ebuf[k];
+            const uint32_t cc = key_count(key), ii = (uint32_t)(key >> 32) & 0xfffu;
+            take = cc >= cmin && ((Mx - cc) * 16 + ii) <= qcut;
+          }
+          const uint64_t mk = __ballot(take);
+          if (mk) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh->ncl, (uint32_t)__popcll(mk));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+            if (take && slot < 4 * UGS_KMAX) s_wsel[slot] = key;
+          }
+        }
+        __syncthreads();
+        const uint32_t ncl = sh->ncl;
+        if (ncl <= 64u * (uint32_t)wpb && ncl <= 4 * UGS_KMAX) {
+          // all-pairs ranking: wave w ranks entries [64w, 64w+64) against the whole list (LDS broadcast reads)
+          const uint32_t me = wave * 64 + lane;
+          const uint64_t mykey = me < ncl ? s_wsel[me] : KEY_INF;
+          uint32_t rank = 0;
+          if (wave * 64u < ncl)
+            for (uint32_t j = 0; j < ncl; ++j) rank += s_wsel[j] < mykey ? 1u : 0u;
+          const uint32_t nout = ncl < K ? ncl : K;
+          if (me < ncl && rank < K) {
+            bv.cand[(uint64_t)unit * K + rank] = key_target(mykey);
+            bv.cand_cnt[(uint64_t)unit * K + rank] = key_count(mykey);
+            if (rank + 1 == nout) sh->last_key = mykey;
+          }
+          if (tid == 0) { sh->n_sel = nout; sh->exhausted = ncl < K ? 1u : 0u; }
+          __syncthreads();
+          nsel = sh->n_sel; last = sh->last_key; exhausted = sh->exhausted != 0;
+          done_fast = true;
+        }
+      }
+      if (done_fast) {
+      } else if (N <= 64u * SELQ * (uint32_t)wpb) {
+        // every wave selects the K smallest of its own interleaved share (entries in registers,
+        // DPP reductions, no barriers), then wave 0 merges the wpb*K survivors
+        {
+          uint64_t ent[SELQ];
+#pragma unroll
+          for (int e = 0; e < SELQ; ++e) {
+            const uint32_t k = (lane + e * 64) * wpb + wave;
             uint64_t key = KEY_INF;
-            if (k < N) { key = ebuf[k]; if (!kept(key)) key = KEY_INF; }
+            if (k < N) { key = ebuf[k]; if (!kept(key) || !((nsel == 0 && last == 0) || key > last)) key = KEY_INF; }
             ent[e] = key;
           }
+          uint64_t llast = 0; bool lfirst = true;
+          const uint32_t want = K - nsel;
+          for (uint32_t j = 0; j < want; ++j) {
+            uint64_t best = KEY_INF;
+#pragma unroll
+            for (int e = 0; e < SELQ; ++e) { const uint64_t key = ent[e]; if ((lfirst || key > llast) && key < best) best = key; }
+            best = wave_min_u64(best);
+            if (lane == 0) s_wsel[wave * UGS_KMAX + j] = best;
+            if (best == KEY_INF) { for (uint32_t j2 = j + 1 + lane; j2 < want; j2 += 64) s_wsel[wave * UGS_KMAX + j2] = KEY_INF; break; }
+            llast = best; lfirst = false;
+          }
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const uint32_t want = K - nsel;
+          uint64_t m[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t idx = lane + e * 64, w2 = idx / UGS_KMAX, j2 = idx % UGS_KMAX;
+            m[e] = (w2 < (uint32_t)wpb && j2 < want) ? s_wsel[w2 * UGS_KMAX + j2] : KEY_INF;
+          }
+          bool mfirst = true; uint64_t mlast = 0;
           while (nsel < K) {
             uint64_t best = KEY_INF;
 #pragma unroll
-            for (int e = 0; e < SELW; ++e) { const uint64_t key = ent[e]; if (((nsel == 0 && last == 0) || key > last) && key < best) best = key; }
+            for (int e = 0; e < 4; ++e) if ((mfirst || m[e] > mlast) && m[e] < best) best = m[e];
             best = wave_min_u64(best);
             if (best == KEY_INF) { exhausted = true; break; }
             if (lane == 0) {
               bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
               bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
             }
-            last = best; ++nsel;
+            mlast = best; mfirst = false; last = best; ++nsel;
           }
           if (lane == 0) { sh->n_sel = nsel; sh->last_key = last; sh->exhausted = exhausted ? 1u : 0u; }
         }
@@ -666,6 +763,23 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
     atomicAdd(&bv.counters[UGS_CTR_T0], tacc0); atomicAdd(&bv.counters[UGS_CTR_T1], tacc1);
     atomicAdd(&bv.counters[UGS_CTR_T2], tacc2); atomicAdd(&bv.counters[UGS_CTR_T3], tacc3);
   }
+}
+
+// LDS bytes of everything in k_rank's carve except the per-wave counter tables (must mirror the kernel)
+size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words)
+{
+  const size_t maxq = (max_qlen + 15u) & ~15u;
+  size_t off = 0;
+  off += (sizeof(RankShared) + 15) & ~(size_t)15;
+  off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;        // s_fp
+  off += maxq * 4;                                             // s_words
+  off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
+  off += maxq; off += maxq;                                    // s_q, s_first
+  off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
+  off += (size_t)4 * UGS_KMAX * 8;                             // s_wsel
+  off += 256;                                                  // s_udb
+  off += (size_t)part_words * 4;                               // s_part
+  return (off + 15) & ~(size_t)15;
 }
 
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st)
