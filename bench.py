@@ -101,7 +101,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from usearch12_amd import capi, synth
+    from usearch12_amd import capi, synth, multigpu
     from usearch12_amd.abi import HIT_DTYPE
 
     # ---- synthetic C2 workload (seed 2); rank r gets its own query shard against the replicated DB
@@ -133,24 +133,12 @@ def main():
         (ph, bh), (pn, bn), (pc, bc) = bat.device_results()
         t_h = torch.as_tensor(DevArray(ph, bh), device="cuda")
         t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
-        glist_h = [torch.empty_like(t_h) for _ in range(world)] if rank == 0 else None
-        glist_n = [torch.empty_like(t_n) for _ in range(world)] if rank == 0 else None
-        dist.gather(t_h, glist_h, dst=0)
-        dist.gather(t_n, glist_n, dst=0)
-        # alignment paths: variable size -> pad to the max over ranks
-        sz = torch.tensor([bc], device="cuda", dtype=torch.int64)
-        dist.all_reduce(sz, op=dist.ReduceOp.MAX)
-        mx = int(sz.item())
-        t_c = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        if bc:
-            t_c[:bc] = torch.as_tensor(DevArray(pc, bc), device="cuda")
-        glist_c = [torch.empty_like(t_c) for _ in range(world)] if rank == 0 else None
-        dist.gather(t_c, glist_c, dst=0)
+        t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
+        got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
         if rank == 0:
-            n_all = torch.stack(glist_n).cpu().numpy().view(np.uint32)
-            h_all = torch.stack(glist_h).cpu().numpy()
-            _ = torch.stack(glist_c).cpu()
-            return h_all, n_all, None
+            los = [k * qs.n for k in range(world)]        # weak scaling: rank k's shard = queries [k*nq, (k+1)*nq)
+            ghits, gpool = multigpu.merge_tables(got[0], got[1], got[2], los, p.max_accepts)
+            return ghits, None, gpool
         return None
 
     for _ in range(args.warmup):
@@ -184,12 +172,21 @@ def main():
             dom, b_dom, ms_dom = "k_rank", b_rank, ms_rank
         else:
             dom, b_dom, ms_dom = "k_align", b_align, ms_align
+        # HBM traffic per launch from the PMC passes of the same command (profiles/*_pmc.json, FETCH_SIZE
+        # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
+                traffic = pm["traffic_bytes_per_launch"][dom]
+        except (OSError, ValueError):
+            pass
         achieved = b_dom / (ms_dom * 1e-3) / 1e9
         if dist is None:
             hits, nh, pool = out
             n_hits = int(len(hits))
         else:
-            n_hits = int(out[1].sum())
+            n_hits = int(len(out[0]))
         threads = os.cpu_count() or 1
         sample_q = args.cpu_sample or max(2000, min(qs.n, 1500 * threads))
         cb = cpu_baseline(args.cpu_baseline, db, qs, args.id, sample_q, threads)
@@ -204,9 +201,15 @@ def main():
                        "queries_per_gpu": qs.n, "db_seqs": db.n, "seq_len": args.length,
                        "parallelism": "query shards, DB replicated per GPU" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_dom, "kernel_ms": ms_dom,
                          "bytes_per_query": b_dom / max(qs.n, 1)},
+            "roofline_per_kernel": {
+                "k_rank": {"bound": "hbm", "algorithmic_bytes_per_launch": b_rank, "kernel_ms": ms_rank,
+                           "achieved_GBps": b_rank / (ms_rank * 1e-3) / 1e9, "frac": b_rank / (ms_rank * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "k_align": {"bound": "integer ALU / LDS (not a bandwidth kernel)", "algorithmic_bytes_per_launch": b_align,
+                            "kernel_ms": ms_align, "achieved_GBps": b_align / (ms_align * 1e-3) / 1e9,
+                            "pair_alignments_per_s": st["pairs_aligned"] / (ms_align * 1e-3)}},
             "cpu_baseline": cb,
             "detail": {"ms_rank": ms_rank, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),

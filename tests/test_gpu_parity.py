@@ -97,3 +97,48 @@ def test_gpu_small_partitions(monkeypatch):
         gb6, guc = orc.format_outputs(capi.lib(), "ugs", hits, nh, pool, qs.labels(), qlens, db.labels(), True)
         assert gb6 == b6, name
         assert guc == uc, name
+
+
+def test_gpu_device_results_view_matches_fetch():
+    """The device-resident hit table exposed for the RCCL gather (ugs_batch_device_results) holds the
+    same records ugs_batch_fetch returns; it is wrapped zero-copy through __cuda_array_interface__."""
+    import torch
+    from usearch12_amd import multigpu
+    from usearch12_amd.abi import HIT_DTYPE
+    import bench
+    c, db, qs, b6, uc = G.load("hard_acc")
+    p = capi.params(is_nucleo=True, id=c["id"], **G.params_kw(c))
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    hits, nh, pool = bat.fetch()
+    (ph, bh), (pn, bn), (pc, bc) = bat.device_results()
+    t_h = torch.as_tensor(bench.DevArray(ph, bh), device="cuda").cpu().numpy()
+    t_n = torch.as_tensor(bench.DevArray(pn, bn), device="cuda").cpu().numpy()
+    t_c = torch.as_tensor(bench.DevArray(pc, bc), device="cuda").cpu().numpy()
+    ghits, gpool = multigpu.merge_tables([t_h], [t_n], [t_c], [0], p.max_accepts)
+    assert len(ghits) == len(hits)
+    # fetch() re-sorts the hits of a query by score; compare as per-query sets
+    key = lambda a: sorted(zip(a["query"].tolist(), a["target"].tolist(), a["ids"].tolist(), a["aln_len"].tolist()))
+    assert key(ghits) == key(hits)
+
+
+def test_cli_text_identical_to_reference(tmp_path):
+    """The C++ driver (usearch12_amd/ugs_cli, the reference's command line for this one command):
+    FASTA in, -blast6out / -uc out, byte-identical to the reference's files."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    for name in ("hard_both", "hard_aa"):
+        c, db, qs, b6, uc = G.load(name)
+        dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+        db.write_fasta(dbfa); qs.write_fasta(qfa)
+        cmd = [cli, "-usearch_global", qfa, "-db", dbfa, "-id", str(c["id"]), "-blast6out", str(tmp_path / "o.b6"),
+               "-uc", str(tmp_path / "o.uc"), "-batch", "500"]
+        if not c["aa"]:
+            cmd += ["-strand", c["strand"]]
+        for opt in ("big", "maxaccepts", "maxrejects"):
+            if opt in c:
+                cmd += ["-" + opt, str(c[opt])]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        assert open(tmp_path / "o.b6").read() == b6, name
+        assert open(tmp_path / "o.uc").read() == uc, name

@@ -5,6 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
+CLI = os.path.join(HERE, "ugs_cli")
 SOURCES = ["ugs_host.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip"]
 DEPS = SOURCES + ["ugs_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
@@ -27,6 +28,12 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
     if force or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(CSRC, "ugs_cli.cpp")
+    if force or _mtime(CLI) < max(_mtime(cli_src), _mtime(LIB)):
+        cmd = ["hipcc", "-O2", "-std=c++17", "-o", CLI, cli_src, "-L" + HERE, "-lugs", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,0 +1,156 @@
+// ugs_cli.cpp - host-side driver with the reference's command-line surface for the one command
+// this repository accelerates:
+//
+//   ugs_cli -usearch_global q.fa -db db.fa -id 0.97 -strand plus|both [-blast6out f] [-uc f]
+//           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
+//
+// It stands where cmd_usearch_global -> Search() -> Thread() stand in the reference
+// (searchcmd.cpp:6-9, search.cpp:51-141): load the DB, stream query batches through the C-ABI
+// (include/ugs.h), write hits in query input order (== the reference at -threads 1).
+// The mirror of the reference's object surface is deliberately thin: Searcher::Search(batch),
+// HitMgr (hit grouping, done inside ugs_batch_fetch) and OutputSink (the text writers).
+#include "../../include/ugs.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct SeqSet {                       // SeqDB (seqdb.h:29-52) flattened: labels + concatenated letters
+  std::vector<std::string> labels;
+  std::string letters;
+  std::vector<uint64_t> offs{0};
+  size_t size() const { return labels.size(); }
+};
+
+// FASTASeqSource::GetNextLo (fastaseqsource.cpp:25-124): label = everything after '>'; whitespace and
+// gap characters are stripped from sequences, other non-alpha bytes are dropped; empty records skipped.
+class FastaReader {
+ public:
+  explicit FastaReader(const char *path) : f_(fopen(path, "rb")) {
+    if (!f_) { fprintf(stderr, "cannot open %s\n", path); exit(1); }
+    have_ = next_line();
+  }
+  ~FastaReader() { if (f_) fclose(f_); }
+  // append up to max_seqs records to out; returns number appended
+  size_t read(SeqSet &out, size_t max_seqs) {
+    size_t n = 0;
+    while (n < max_seqs && have_) {
+      if (line_.empty()) { have_ = next_line(); continue; }
+      if (line_[0] != '>') { fprintf(stderr, "bad FASTA: expected '>'\n"); exit(1); }
+      std::string label = line_.substr(1);
+      const size_t start = out.letters.size();
+      while ((have_ = next_line()) && !(line_.size() && line_[0] == '>'))
+        for (unsigned char c : line_) if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) out.letters.push_back((char)c);
+      if (out.letters.size() == start) continue;                 // empty sequence: skipped (with a warning in the reference)
+      out.labels.push_back(label); out.offs.push_back(out.letters.size()); ++n;
+    }
+    return n;
+  }
+ private:
+  bool next_line() {
+    line_.clear();
+    int c;
+    bool any = false;
+    while ((c = fgetc(f_)) != EOF) { any = true; if (c == '\n') break; if (c != '\r') line_.push_back((char)c); }
+    return any;
+  }
+  FILE *f_; std::string line_; bool have_;
+};
+
+// Searcher (searcher.h:21-96) as a batch object over one ugs_db
+class Searcher {
+ public:
+  Searcher(const ugs_params &p, const SeqSet &db, int device) : p_(p) {
+    if (ugs_db_create(&p_, db.letters.data(), db.offs.data(), (uint32_t)db.size(), device, &db_) != UGS_OK) die("ugs_db_create");
+  }
+  ~Searcher() { ugs_db_destroy(db_); }
+  void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
+    const uint32_t nq = (uint32_t)q.size();
+    hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) + 1);
+    nhits.assign(nq + 1, 0);
+    pool.resize(q.letters.size() * 2 + 64 * (size_t)nq + 1024);
+    uint64_t used = 0;
+    if (ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(),
+                         pool.size(), &used) != UGS_OK) die("ugs_search_batch");
+  }
+ private:
+  [[noreturn]] static void die(const char *what) { fprintf(stderr, "%s: %s\n", what, ugs_last_error()); exit(1); }
+  ugs_params p_; ugs_db *db_ = nullptr;
+};
+
+// OutputSink::OnQueryDone (outputsink.cpp:358-384): hits of one query, or the uc no-hit record
+static void output_query(FILE *fb6, FILE *fuc, const ugs_params &p, const SeqSet &q, const SeqSet &db, uint32_t qi,
+                         const ugs_hit *h, uint32_t n, const uint32_t *pool)
+{
+  static char line[1 << 16];
+  const uint32_t ql = (uint32_t)(q.offs[qi + 1] - q.offs[qi]);
+  if (n == 0) { if (fuc) { ugs_format_uc_nohit(ql, q.labels[qi].c_str(), line, sizeof line); fputs(line, fuc); } return; }
+  for (uint32_t j = 0; j < n; ++j) {
+    const char *tl = db.labels[h[j].target].c_str();
+    if (fb6) { ugs_format_blast6(&h[j], q.labels[qi].c_str(), tl, line, sizeof line); fputs(line, fb6); }
+    if (fuc) { ugs_format_uc_hit(&h[j], pool, p.is_nucleo, q.labels[qi].c_str(), tl, line, sizeof line); fputs(line, fuc); }
+  }
+}
+
+static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100 letters (seqdb.cpp:268-320); here: the first 1000
+{
+  size_t n = 0, nt = 0;
+  for (char c : db.letters) {
+    if (n >= 1000) break;
+    ++n;
+    switch (c | 0x20) { case 'a': case 'c': case 'g': case 't': case 'u': case 'n': ++nt; }
+  }
+  return n > 0 && nt * 10 >= n * 9;
+}
+
+int main(int argc, char **argv)
+{
+  std::string qpath, dbpath, b6path, ucpath, strand;
+  double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
+    if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
+    else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
+    else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
+    else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
+    else if (a == "-dbtype") { std::string v = val(); dbtype = (v == "nt"); }
+    else if (a == "-threads" || a == "-quiet") { if (a == "-threads") val(); }   // accepted, meaningless here
+    else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+  }
+  if (qpath.empty() || dbpath.empty()) { fprintf(stderr, "usage: ugs_cli -usearch_global q.fa -db db.fa -id 0.97 -strand plus -blast6out o.b6 -uc o.uc\n"); return 1; }
+  SeqSet db;
+  { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
+  const bool nucleo = dbtype >= 0 ? dbtype != 0 : guess_nucleo(db);
+  if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
+  ugs_params p;
+  ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
+  p.id_set = id >= 0;
+  p.strand_both = nucleo && strand == "both";
+  if (maxacc >= 0) p.max_accepts = maxacc;
+  if (maxrej >= 0) p.max_rejects = maxrej;
+  if (big >= 0) p.big = (uint32_t)big;
+  FILE *fb6 = b6path.empty() ? nullptr : fopen(b6path.c_str(), "w");
+  FILE *fuc = ucpath.empty() ? nullptr : fopen(ucpath.c_str(), "w");
+  Searcher searcher(p, db, device);
+  FastaReader qr(qpath.c_str());
+  std::vector<ugs_hit> hits; std::vector<uint32_t> nhits, pool;
+  size_t total = 0, with_hit = 0;
+  for (;;) {
+    SeqSet q;
+    if (!qr.read(q, batch)) break;
+    searcher.Search(q, hits, nhits, pool);
+    size_t k = 0;
+    for (uint32_t qi = 0; qi < q.size(); ++qi) {
+      output_query(fb6, fuc, p, q, db, qi, hits.data() + k, nhits[qi], pool.data());
+      k += nhits[qi]; with_hit += nhits[qi] > 0;
+    }
+    total += q.size();
+  }
+  if (fb6) fclose(fb6);
+  if (fuc) fclose(fuc);
+  fprintf(stderr, "%zu queries, %zu with hits (%.1f%%)\n", total, with_hit, total ? 100.0 * with_hit / total : 0.0);
+  return 0;
+}
