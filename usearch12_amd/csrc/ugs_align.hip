@@ -28,6 +28,8 @@
 #define TB_IM 2
 #define TB_MD 4
 #define TB_MI 8
+#define LTB 2048               // per-wave LDS traceback bytes (holes up to ~80x36 cells)
+#define LRUNS 64               // runs kept in LDS per wave before spilling to HBM scratch
 
 __device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : x + c; }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -44,7 +46,8 @@ struct WaveCtx {
   // LDS
   uint8_t *A, *B;             // class codes of query / target letters (identity tests)
   uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
-  uint16_t *wstart;           // first index in qsort of each HSP word (0xffff = absent), or null
+  uint32_t *wstart;           // per HSP word: first index in qsort | min(count,8) << 16 (0 = absent), or null
+  uint32_t *seeds; uint32_t seed_cap;   // seed list of the current pair: bpos << 16 | apos, in reference order
   bool nt;
   uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
   int32_t *Mrow, *Drow;       // Mrow[-1] valid
@@ -55,6 +58,7 @@ struct WaveCtx {
   const uint8_t *s_cls; const int8_t *s_sub2; const uint64_t *s_match; const uint8_t *s_hl;
   // global scratch
   uint8_t *tb; uint32_t *runs; uint32_t runs_cap;
+  uint8_t *lds_tb; uint32_t *lds_runs; uint32_t *lds_rt;   // LDS fast copies: small traceback matrices, first LRUNS runs
   uint32_t LA, LB, nwA, nA2, hsp_cap, nwords;
   int lane;
 };
@@ -121,111 +125,216 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       wave_sync();
     }
   if (c.wstart) {
-    // direct word -> first sorted index table (replaces a binary search per target position)
+    // direct word -> (first sorted index | min(count, MaxReps) << 16) table: replaces a binary
+    // search per target position; count 0 = word absent from the query
     const uint32_t nwords = c.nwords;
-    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0xffffu;
+    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0;
     wave_sync();
     for (uint32_t i = lane; i < c.nwA; i += 64) {
       const uint32_t wd = c.qsort[i] >> 16;
-      if (i == 0 || (c.qsort[i - 1] >> 16) != wd) c.wstart[wd] = (uint16_t)i;
+      if (i == 0 || (c.qsort[i - 1] >> 16) != wd) {
+        uint32_t n = 1;
+        while (n < UGS_MAXREPS && i + n < c.nwA && (c.qsort[i + n] >> 16) == wd) ++n;
+        c.wstart[wd] = i | (n << 16);
+      }
     }
     wave_sync();
   }
 }
 
-// ungappedblast.cpp:8-211
+// 8 consecutive score codes starting at byte offset o of an LDS byte array (aligned dword reads +
+// v_alignbyte); the arrays carry 16 bytes of padding on both sides
+__device__ __forceinline__ uint64_t load8(const uint8_t *arr, int o)
+{
+  const uint32_t *w = (const uint32_t *)(arr + (o & ~3));
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+  const uint32_t sh = (uint32_t)o & 3u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+  return ((uint64_t)hi << 32) | lo;
+}
+// 0x80 in every byte of x that is non-zero
+__device__ __forceinline__ uint64_t nzbytes(uint64_t x)
+{
+  return (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;
+}
+
+// One seed of UngappedBlast (ungappedblast.cpp:62-180): seed score, x-drop extension right then
+// left, acceptance test.  nt: byte-SWAR - a run of matching letters is consumed per step (a match
+// always raises the score, so inside a run the best is the run's end and the x-drop test cannot
+// fire); aa: 8 letter pairs per LDS round trip, consumed strictly in order.
+template <bool NT>
+__device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &db, int m2, int mm2, uint32_t apos,
+                                            uint32_t bpos, uint32_t MinLength, uint32_t &oAlo, uint32_t &oBlo,
+                                            uint32_t &oLen, int &oBest)
+{
+  const int w = db.hsp_w;
+  const uint32_t LA = c.LA, LB = c.LB;
+  const int X = db.xdrop2;
+  int score = 0;
+  for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
+  int best = score;
+  uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
+  uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
+  if (NT) {
+    {
+      uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+      while (rem) {
+        const uint32_t n = rem < 8 ? rem : 8;
+        const uint64_t A8 = load8(c.As, (int)a2 + 1), B8 = load8(c.Bs, (int)b2 + 1);
+        uint64_t bad = nzbytes(A8 ^ B8) | nzbytes((A8 | B8) & 0x0404040404040404ull);
+        if (n < 8) bad |= 0x8080808080808080ull << (8 * n);
+        const uint32_t run = bad ? (uint32_t)(__ffsll((long long)bad) - 1) >> 3 : 8u;   // leading matches (<= n)
+        if (run) {
+          score += (int)run * m2; a2 += run; b2 += run; rem -= run;
+          if (score > best) { best = score; bestb2 = b2; }
+        }
+        if (run < n) {                                   // the next pair is a mismatch or a non-ACGT letter
+          const uint32_t a = (uint32_t)(A8 >> (8 * run)) & 0xffu, b = (uint32_t)(B8 >> (8 * run)) & 0xffu;
+          score += sscore<true>(c, m2, mm2, a, b);
+          ++a2; ++b2; --rem;
+          if (score > best) { best = score; bestb2 = b2; }
+          else if (best - score > X) break;
+        }
+      }
+    }
+    score = best;
+    {
+      uint32_t rem = b1 < a1 ? b1 : a1;
+      while (rem) {
+        const uint32_t n = rem < 8 ? rem : 8;
+        const uint64_t A8 = load8(c.As, (int)a1 - 8), B8 = load8(c.Bs, (int)b1 - 8);      // byte 7 = position -1
+        uint64_t bad = nzbytes(A8 ^ B8) | nzbytes((A8 | B8) & 0x0404040404040404ull);
+        if (n < 8) bad |= 0x8080808080808080ull >> (8 * n);
+        const uint32_t run = bad ? (uint32_t)__clzll((long long)bad) >> 3 : 8u;          // matches counted from the top byte
+        if (run) {
+          score += (int)run * m2; a1 -= run; b1 -= run; rem -= run;
+          if (score > best) { best = score; bestb1 = b1; }
+        }
+        if (run < n) {
+          const uint32_t sh = 8 * (7 - run);
+          const uint32_t a = (uint32_t)(A8 >> sh) & 0xffu, b = (uint32_t)(B8 >> sh) & 0xffu;
+          score += sscore<true>(c, m2, mm2, a, b);
+          --a1; --b1; --rem;
+          if (score > best) { best = score; bestb1 = b1; }
+          else if (best - score > X) break;
+        }
+      }
+    }
+  } else {
+    {
+      uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+      bool stop = false;
+      while (rem && !stop) {
+        uint32_t av[8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a2 + o]; bv[k] = c.Bs[b2 + o]; }
+        const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((uint32_t)k < n && !stop) {
+            score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
+            if (score > best) { best = score; bestb2 = b2 + k + 1; }
+            else if (best - score > X) stop = true;
+          }
+        a2 += n; b2 += n; rem -= n;
+      }
+    }
+    score = best;
+    {
+      uint32_t rem = b1 < a1 ? b1 : a1;
+      bool stop = false;
+      while (rem && !stop) {
+        uint32_t av[8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a1 - o]; bv[k] = c.Bs[b1 - o]; }
+        const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((uint32_t)k < n && !stop) {
+            score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
+            if (score > best) { best = score; bestb1 = b1 - k - 1; }
+            else if (best - score > X) stop = true;
+          }
+        a1 -= n; b1 -= n; rem -= n;
+      }
+    }
+  }
+  const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
+  const uint32_t Alo = apos - (bpos - bestb1);
+  oAlo = Alo; oBlo = Blo; oLen = Len; oBest = best;
+  return Len >= MinLength && best >= db.minscore2 && is_global_hsp(Alo, Blo, LA, LB);
+}
+
+// ungappedblast.cpp:8-211.  The reference walks target positions BPos upward, tries the (<= 8) query
+// positions of that word in order and, on the first accepted HSP, jumps to BPos = Bhi+1.  Here the
+// seeds (bpos, apos) are first listed in exactly that order into an LDS list (cheap: table lookups
+// only), then extended 64 at a time - one seed per lane, so lanes are evenly loaded whatever the
+// seed density - and the serial rule is replayed: the first accepting seed of a round wins, every
+// seed at a target position <= its Bhi is dropped.
 template <bool NT>
 __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, uint32_t MinLength, unsigned long long *counters)
 {
   const int lane = c.lane, w = db.hsp_w;
   const int m2 = c.s_sub2[0], mm2 = c.s_sub2[2];      // nt: 2*score(A,A), 2*score(A,C)
-  const uint32_t LA = c.LA, LB = c.LB;
+  const uint32_t LB = c.LB;
   uint32_t nh = 0;
   if (LB >= 2u * w && c.nwA > 0) {
     const uint32_t nwB = LB - w + 1;
-    uint32_t BPos = 0;
-    while (BPos < nwB) {
-      const uint32_t bpos = BPos + lane;
+    uint32_t scan = 0;          // next target position whose seeds are not listed yet
+    uint32_t count = 0, idx = 0;
+    for (;;) {
+      // ---- list seeds until the list is comfortably full or the target is exhausted
+      if (idx >= count) { idx = 0; count = 0; }
+      while (scan < nwB && count + 64 * UGS_MAXREPS <= c.seed_cap) {
+        const uint32_t bpos = scan + lane;
+        uint32_t lo = 0, cnt = 0;
+        if (bpos < nwB) {
+          uint32_t word = 0;
+          for (int k = 0; k < w; ++k) word = word * db.alpha + (NT ? (c.Bs[bpos + k] & 3u) * (c.Bs[bpos + k] < 4) : c.s_hl[c.B[bpos + k] & 31]);
+          if (c.wstart) { const uint32_t e = c.wstart[word]; lo = e & 0xffffu; cnt = e >> 16; }
+          else {
+            const uint32_t want = word << 16;
+            uint32_t hi = c.nwA;
+            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c.qsort[mid] < want) lo = mid + 1; else hi = mid; }
+            while (cnt < UGS_MAXREPS && lo + cnt < c.nwA && (c.qsort[lo + cnt] >> 16) == word) ++cnt;
+          }
+        }
+        uint32_t incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+        const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t off = count + incl - cnt;
+        for (uint32_t r = 0; r < cnt; ++r) c.seeds[off + r] = (bpos << 16) | (c.qsort[lo + r] & 0xffffu);
+        count += total;
+        scan += 64;
+      }
+      wave_sync();
+      if (idx >= count) { if (scan >= nwB) break; else continue; }
+      // ---- extend one round of (up to) 64 seeds
+      const uint32_t me = idx + lane;
       bool ok = false;
       uint32_t rAlo = 0, rBlo = 0, rLen = 0; int rBest = 0;
-      if (bpos < nwB) {
-        uint32_t word = 0;
-        for (int k = 0; k < w; ++k) word = word * db.alpha + c.s_hl[c.B[bpos + k] & 31];
-        uint32_t lo = 0;
-        if (c.wstart) { lo = c.wstart[word]; if (lo == 0xffffu) lo = c.nwA; }
-        else {
-          const uint32_t want = word << 16;
-          uint32_t hi = c.nwA;
-          while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c.qsort[mid] < want) lo = mid + 1; else hi = mid; }
-        }
-        for (uint32_t r = 0; r < UGS_MAXREPS && lo + r < c.nwA; ++r) {
-          const uint32_t ent = c.qsort[lo + r];
-          if ((ent >> 16) != word) break;
-          const uint32_t apos = ent & 0xffffu;
-          int score = 0;
-          for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
-          int best = score;
-          // x-drop extension, 8 letter pairs per LDS round trip (loads clamped inside the sequences;
-          // pairs are consumed strictly in order, so the result equals the one-by-one loop)
-          uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
-          {
-            uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
-            bool stop = false;
-            while (rem && !stop) {
-              uint32_t av[8], bv[8];
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a2 + o]; bv[k] = c.Bs[b2 + o]; }
-              const uint32_t n = rem < 8 ? rem : 8;
-#pragma unroll
-              for (int k = 0; k < 8; ++k)
-                if ((uint32_t)k < n && !stop) {
-                  score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
-                  if (score > best) { best = score; bestb2 = b2 + k + 1; }
-                  else if (best - score > db.xdrop2) stop = true;
-                }
-              a2 += n; b2 += n; rem -= n;
-            }
-          }
-          uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
-          score = best;
-          {
-            uint32_t rem = b1 < a1 ? b1 : a1;
-            bool stop = false;
-            while (rem && !stop) {
-              uint32_t av[8], bv[8];
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a1 - o]; bv[k] = c.Bs[b1 - o]; }
-              const uint32_t n = rem < 8 ? rem : 8;
-#pragma unroll
-              for (int k = 0; k < 8; ++k)
-                if ((uint32_t)k < n && !stop) {
-                  score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
-                  if (score > best) { best = score; bestb1 = b1 - k - 1; }
-                  else if (best - score > db.xdrop2) stop = true;
-                }
-              a1 -= n; b1 -= n; rem -= n;
-            }
-          }
-          const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
-          const uint32_t Alo = apos - (bpos - bestb1);
-          if (Len >= MinLength && best >= db.minscore2 && is_global_hsp(Alo, Blo, LA, LB)) {
-            ok = true; rAlo = Alo; rBlo = Blo; rLen = Len; rBest = best;
-            break;
-          }
-        }
+      if (me < count) {
+        const uint32_t sd = c.seeds[me];
+        ok = extend_seed<NT>(c, db, m2, mm2, sd & 0xffffu, sd >> 16, MinLength, rAlo, rBlo, rLen, rBest);
       }
       const uint64_t m = __ballot(ok);
-      if (m) {
-        const int f = __ffsll((long long)m) - 1;
-        const uint32_t Alo = rl((int)rAlo, f), Blo = rl((int)rBlo, f), Len = rl((int)rLen, f);
-        const int Best = rl(rBest, f);
-        if (nh < c.hsp_cap) {
-          if (lane == 0) { c.hsps[nh].Loi = Alo; c.hsps[nh].Loj = Blo; c.hsps[nh].Len = Len; c.hsps[nh].Score2 = Best; }
-          ++nh;
-        } else if (lane == 0) atomicOr(&counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_HSPCAP);
-        BPos = Blo + Len;            // Bhi + 1
-      } else
-        BPos += 64;
+      if (!m) { idx += 64; continue; }
+      const int f = __ffsll((long long)m) - 1;
+      const uint32_t Alo = rl((int)rAlo, f), Blo = rl((int)rBlo, f), Len = rl((int)rLen, f);
+      const int Best = rl(rBest, f);
+      if (nh < c.hsp_cap) {
+        if (lane == 0) { c.hsps[nh].Loi = Alo; c.hsps[nh].Loj = Blo; c.hsps[nh].Len = Len; c.hsps[nh].Score2 = Best; }
+        ++nh;
+      } else if (lane == 0) atomicOr(&counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_HSPCAP);
+      const uint32_t newB = Blo + Len;            // BPos = Bhi + 1
+      if (newB >= scan) { scan = newB; idx = count; }     // everything listed so far is skipped
+      else {
+        // first listed seed with bpos >= newB (the list is ordered by bpos)
+        uint32_t lo2 = idx + f + 1, hi2 = count;
+        while (lo2 < hi2) { uint32_t mid = (lo2 + hi2) >> 1; if ((c.seeds[mid] >> 16) < newB) lo2 = mid + 1; else hi2 = mid; }
+        idx = lo2;
+      }
     }
   }
   if (lane == 0) c.ws->nhsp = nh;
@@ -300,13 +409,27 @@ __device__ __forceinline__ void chain_lane0(WaveCtx &c)
 }
 
 // ---- run-length path assembly (lane 0 only); PathInfo::AppendPath/AppendMs (pathinfo.h:7-87)
+__device__ __forceinline__ void put_run(WaveCtx &c, uint32_t i, uint32_t run)
+{
+  if (i < LRUNS) c.lds_runs[i] = run;
+  else if (i < c.runs_cap) c.runs[i] = run;
+  else c.ws->overflow = 1;
+}
+__device__ __forceinline__ uint32_t get_run(const WaveCtx &c, uint32_t i) { return i < LRUNS ? c.lds_runs[i] : c.runs[i]; }
+__device__ __forceinline__ void put_rt(WaveCtx &c, uint32_t i, uint32_t run)
+{
+  if (i < LRUNS) c.lds_rt[i] = run;
+  else if (i < c.runs_cap) c.runs[c.runs_cap + i] = run;
+  else c.ws->overflow = 1;
+}
+__device__ __forceinline__ uint32_t get_rt(const WaveCtx &c, uint32_t i) { return i < LRUNS ? c.lds_rt[i] : c.runs[c.runs_cap + i]; }
 __device__ __forceinline__ void push_run(WaveCtx &c, uint32_t op, uint32_t len)
 {
   if (!len) return;
   WaveState *ws = c.ws;
   if (ws->cur_len && ws->cur_op == op) { ws->cur_len += len; return; }
   if (ws->cur_len) {
-    if (ws->nruns < c.runs_cap) c.runs[ws->nruns] = (ws->cur_len << 2) | ws->cur_op; else ws->overflow = 1;
+    put_run(c, ws->nruns, (ws->cur_len << 2) | ws->cur_op);
     ++ws->nruns;
   }
   ws->cur_op = op; ws->cur_len = len;
@@ -315,7 +438,7 @@ __device__ __forceinline__ void flush_runs(WaveCtx &c)
 {
   WaveState *ws = c.ws;
   if (ws->cur_len) {
-    if (ws->nruns < c.runs_cap) c.runs[ws->nruns] = (ws->cur_len << 2) | ws->cur_op; else ws->overflow = 1;
+    put_run(c, ws->nruns, (ws->cur_len << 2) | ws->cur_op);
     ++ws->nruns; ws->cur_len = 0;
   }
 }
@@ -342,7 +465,7 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
   dhi += band;
   if (dhi > LA + LB - 1) dhi = LA + LB - 1;
   const uint32_t stride = (dhi - dlo + 1) + 3;
-  uint8_t *TB = c.tb;
+  uint8_t *TB = ((uint64_t)(LA + 1) * stride <= LTB) ? c.lds_tb : c.tb;       // small holes trace back from LDS
   int32_t *Mrow = c.Mrow, *Drow = c.Drow;
   for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
   wave_sync();
@@ -430,7 +553,6 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     if (FinalD > Score) { Score = FinalD; State = 1; }
     if (FinalI > Score) { Score = FinalI; State = 2; }
     // traceback: reversed runs go to the upper half of the run buffer, then get pushed forward
-    uint32_t *rt = c.runs + c.runs_cap;
     uint32_t nrt = 0, curop = 3, curlen = 0;
     uint32_t i = LA, j = LB;
     const uint32_t sLast = Startj;
@@ -444,15 +566,15 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     };
     while (i != 0 || j != 0) {
       if (State == curop) ++curlen;
-      else { if (curlen) { if (nrt < c.runs_cap) rt[nrt] = (curlen << 2) | curop; else c.ws->overflow = 1; ++nrt; } curop = State; curlen = 1; }
+      else { if (curlen) { put_rt(c, nrt, (curlen << 2) | curop); ++nrt; } curop = State; curlen = 1; }
       uint8_t t;
       if (State == 0) { t = tbget(i - 1, j - 1); State = (t & TB_DM) ? 1 : ((t & TB_IM) ? 2 : 0); --i; --j; }
       else if (State == 1) { t = tbget(i - 1, j); State = (t & TB_MD) ? 0 : 1; --i; }
       else { t = tbget(i, j - 1); State = (t & TB_MI) ? 0 : 2; --j; }
     }
-    if (curlen) { if (nrt < c.runs_cap) rt[nrt] = (curlen << 2) | curop; else c.ws->overflow = 1; ++nrt; }
+    if (curlen) { put_rt(c, nrt, (curlen << 2) | curop); ++nrt; }
     if (nrt > c.runs_cap) nrt = c.runs_cap;
-    for (int k = (int)nrt - 1; k >= 0; --k) push_run(c, rt[k] & 3, rt[k] >> 2);
+    for (int k = (int)nrt - 1; k >= 0; --k) { const uint32_t r = get_rt(c, (uint32_t)k); push_run(c, r & 3, r >> 2); }
   }
   wave_sync();
 }
@@ -473,7 +595,7 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
   viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
 }
 
-__global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds)
+__global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
@@ -504,18 +626,29 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
   c.ws = (WaveState *)(wb + off); off += 32;
   c.A = wb + off; off += maxq;
   c.B = wb + off; off += maxt;
-  c.As = wb + off; off += maxq;
-  c.Bs = wb + off; off += maxt;
+  c.As = wb + off + 16; off += maxq + 32;
+  c.Bs = wb + off + 16; off += maxt + 32;
   c.nwords = (uint32_t)db.hsp_words;
   c.wstart = nullptr;
-  if (db.hsp_words <= 1024) { c.wstart = (uint16_t *)(wb + off); off += (((size_t)db.hsp_words * 2) + 15) & ~(size_t)15; }
+  if (db.hsp_words <= 1024) { c.wstart = (uint32_t *)(wb + off); off += (size_t)db.hsp_words * 4; }
+  c.lds_runs = (uint32_t *)(wb + off); off += LRUNS * 4;
+  c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
+  c.lds_tb = wb + off; off += LTB;
   c.nt = db.is_nucleo != 0;
   c.qsort = (uint32_t *)(wb + off); off += (size_t)q2 * 4;
-  c.Mrow = (int32_t *)(wb + off) + 4; off += ((size_t)maxt + 8) * 4;
-  c.Drow = (int32_t *)(wb + off); off += ((size_t)maxt + 8) * 4;
   c.hsps = (HSPd *)(wb + off); off += (size_t)hsp_cap * sizeof(HSPd);
   c.chain = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 4;
-  c.csc = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 7 * 4;
+  // union region: the seed list lives only inside UngappedBlast; the chainer scratch and the DP rows only after it
+  {
+    unsigned char *u = wb + off;
+    c.seeds = (uint32_t *)u; c.seed_cap = seed_cap;
+    size_t uo = 0;
+    c.Mrow = (int32_t *)(u + uo) + 4; uo += ((size_t)maxt + 8) * 4;
+    c.Drow = (int32_t *)(u + uo); uo += ((size_t)maxt + 8) * 4;
+    c.csc = (uint32_t *)(u + uo); uo += (size_t)hsp_cap * 7 * 4;
+    const size_t us = (size_t)seed_cap * 4 > uo ? (size_t)seed_cap * 4 : uo;
+    off += (us + 15) & ~(size_t)15;
+  }
   c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl;
   c.lane = lane; c.hsp_cap = hsp_cap;
   const uint32_t gw = blockIdx.x * wpb + wave, nw = gridDim.x * wpb;
@@ -528,6 +661,7 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
   unsigned long long *ctr = bv.counters;
 
   unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0, tq;
+  unsigned long long w_tletters = 0, w_pairs = 0;
   for (uint32_t unit = gw; unit < units; unit += nw) {
     tq = clock64();
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
@@ -546,14 +680,42 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
       build_query_words(c, db.hsp_w, db.alpha);
     }
     ta0 += clock64() - tq;
+    // one lane per candidate: id, offset and length fetched once for the whole unit
+    uint32_t ct = 0, clen = 0; uint64_t cto = 0;
+    if ((uint32_t)lane < ncand) {
+      ct = bv.cand[(uint64_t)unit * K + lane];
+      cto = db.offs[ct];
+      clen = (uint32_t)(db.offs[ct + 1] - cto);
+    }
+    // the NEXT candidate's letters travel while the current pair is aligned (4 x 4 letters per lane)
+    uint32_t pre[4] = {0, 0, 0, 0};
+    auto prefetch = [&](uint32_t k2) {
+      const uint64_t to2 = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k2) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k2);
+      const uint32_t L2 = (uint32_t)rl((int)clen, (int)k2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
+        uint32_t v = 0;
+        if (o < L2) __builtin_memcpy(&v, db.seqs + to2 + o, 4);     // unaligned dword load (the DB buffer is padded)
+        pre[e] = v;
+      }
+    };
+    if (ncand) prefetch(0);
     for (uint32_t k = 0; k < ncand; ++k) {
       tq = clock64();
-      const uint32_t t = bv.cand[(uint64_t)unit * K + k];
-      const uint64_t to = db.offs[t];
-      const uint32_t LB = (uint32_t)(db.offs[t + 1] - to);
+      const uint32_t t = (uint32_t)rl((int)ct, (int)k);
+      const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
+      const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
       c.LB = LB;
-      for (uint32_t p = lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
-      if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], (unsigned long long)LB); atomicAdd(&ctr[UGS_CTR_PAIRS], 1ull); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
+        if (o < LB)
+          for (uint32_t b = 0; b < 4 && o + b < LB; ++b) { const uint8_t cl = s_cls[(pre[e] >> (8 * b)) & 0xffu]; c.B[o + b] = cl; c.Bs[o + b] = s_sc[cl & 31]; }
+      }
+      for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
+      if (k + 1 < ncand) prefetch(k + 1);
+      w_tletters += LB; ++w_pairs;
       wave_sync();
       // ---- GlobalAlign_AllOpts (globalalignmem.cpp:129-236), FailIfNoHSPs = true
       uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
@@ -595,12 +757,12 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
           const uint32_t nr = c.ws->nruns < c.runs_cap ? c.ws->nruns : c.runs_cap;
           // ---- AlignResult::FillLo on the run list
           int fm = -1, lm = -1; uint32_t cols = 0;
-          for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = c.runs[r]; cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
+          for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = get_run(c, r); cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
           if (fm >= 0) {
             uint32_t qpos = 0, tpos = 0, ids = 0, alen = 0, gaps = 0, opens = 0, mcols = 0, qlo = 0, tlo = 0, qhi = 0, thi = 0;
             uint32_t lastop = 0;
             for (uint32_t r = 0; r < nr; ++r) {
-              const uint32_t run = c.runs[r], op = run & 3, len = run >> 2;
+              const uint32_t run = get_run(c, r), op = run & 3, len = run >> 2;
               const bool inside = (int)r >= fm && (int)r <= lm;
               if ((int)r == fm) { qlo = qpos; tlo = tpos; }
               if (op == 0) {
@@ -629,7 +791,7 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
               if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nr);
               coff = ((unsigned long long)(uint32_t)rl((int)(coff >> 32), 0) << 32) | (uint32_t)rl((int)(uint32_t)coff, 0);
               if (coff + nr <= bv.cigar_cap)
-                for (uint32_t r = lane; r < nr; r += 64) bv.cigar_pool[coff + r] = c.runs[r];
+                for (uint32_t r = lane; r < nr; r += 64) bv.cigar_pool[coff + r] = get_run(c, r);
               if (lane == 0) {
                 ugs_hit *h = &bv.hits[(uint64_t)unit * max_acc + nacc];
                 h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = alen;
@@ -650,6 +812,7 @@ __global__ __launch_bounds__(256) void k_align(UgsDbView db, UgsBatchView bv, ui
     if (lane == 0) bv.hit_n[unit] = nacc;
     wave_sync();
   }
+  if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs); }
   if (tid == 0) {
     atomicAdd(&ctr[UGS_CTR_T4], ta0); atomicAdd(&ctr[UGS_CTR_T5], ta1); atomicAdd(&ctr[UGS_CTR_T6], ta2); atomicAdd(&ctr[UGS_CTR_T7], ta3);
   }
@@ -659,7 +822,7 @@ int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignL
 {
   const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);
   HIPCHK(hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-  hipLaunchKernelGGL(k_align, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds);
+  hipLaunchKernelGGL(k_align, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

@@ -88,7 +88,7 @@ enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8 };
 
 // launch descriptors computed on the host
 struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; };
-struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; };
+struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; uint32_t seed_cap; };
 
 // kernels' host-callable launchers (defined in the .hip files)
 int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int dbmask, hipStream_t st);

@@ -284,7 +284,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
 #define DBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return fail(UGS_E_HIP); } } while (0)
   DBCHK(hipMalloc(&db->d_tab, sizeof(UgsTables)));
   DBCHK(hipMemcpy(db->d_tab, &T, sizeof(T), hipMemcpyHostToDevice));
-  DBCHK(hipMalloc(&db->d_seqs, nletters ? nletters : 16));
+  DBCHK(hipMalloc(&db->d_seqs, nletters + 64));          // padded: the aligner prefetches letters as unaligned dwords
   DBCHK(hipMalloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
   if (nletters) DBCHK(hipMemcpy(db->d_seqs, seqs, nletters, hipMemcpyHostToDevice));
   DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -453,15 +453,20 @@ static int plan_launch(ugs_batch *b)
   // ---- alignment geometry
   const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  const size_t wstart_b = db->v.hsp_words <= 1024 ? (((size_t)db->v.hsp_words * 2 + 15) & ~(size_t)15) : 0;
-  const size_t wave_lds = (32 + 2 * ((size_t)maxq + maxt) + wstart_b + (size_t)q2 * 4 + 2 * ((size_t)maxt + 8) * 4 + (size_t)hsp_cap * (16 + 4 + 28) + 15) & ~(size_t)15;
+  const size_t wstart_b = db->v.hsp_words <= 1024 ? (size_t)db->v.hsp_words * 4 : 0;
+  const uint32_t seed_cap = 64 * UGS_MAXREPS + 128;      // one listing round always fits; rounds of 64 seeds are extended at a time
+  // per-wave LDS (mirrors the carve in k_align): control block, class + score codes of both sequences, word table,
+  // sorted query words, run buffers, small-hole traceback, HSPs + chain, union{seed list | DP rows + chainer scratch}
+  const size_t u_region = std::max<size_t>((size_t)seed_cap * 4, 2 * ((size_t)maxt + 8) * 4 + (size_t)hsp_cap * 28);
+  const size_t wave_lds = (32 + ((size_t)maxq + maxt) + ((size_t)maxq + maxt + 64) + wstart_b + (size_t)q2 * 4 + 2 * 64 * 4 + 2048 +
+                           (size_t)hsp_cap * (16 + 4) + u_region + 15 + 16) & ~(size_t)15;
   int awpb = 4;
   while (awpb > 1 && 2112 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
   if (2112 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2112 + wave_lds); return UGS_E_ENVELOPE; }
   const size_t alds = 2112 + awpb * wave_lds;
   int aper_cu = (int)std::min<size_t>(LDS_MAX / alds, (size_t)(32 / awpb));
   aper_cu = std::max(1, std::min(aper_cu, 8));
-  b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap;
+  b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
   b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
   const int waves = b->al.grid * awpb;
   const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * p.band + 4) + 63) & ~63ull;
