@@ -818,6 +818,14 @@ __global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv,
   }
 }
 
+int ugs_align_blocks_per_cu(int threads, size_t lds)
+{
+  int n = 0;
+  if (hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_align, threads, lds) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
   const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);

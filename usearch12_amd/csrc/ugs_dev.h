@@ -27,9 +27,9 @@ struct UgsDbView {
   uint32_t slots;
   const uint64_t *row_off;   // [slots+1]
   const uint32_t *postings;  // target indexes, ascending inside a row
-  const uint32_t *part;      // [slots*(np+1)] offset (relative to row start) of first posting with target >= p<<gshift
+  const uint32_t *part;      // [slots*(np+1)] offset (relative to row start) of first posting with target >= p*gsize
   uint32_t np;               // number of target partitions
-  uint32_t gshift;           // partition size = 1<<gshift targets
+  uint32_t gsize;            // targets per partition (multiple of 64)
   const uint32_t *step_tab;  // [step_n] Big-path QueryStep for Nu unique words (wordparams.cpp:167-192)
   uint32_t step_n;
   const UgsTables *tab;
@@ -96,7 +96,9 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
                     uint64_t nletters, int word_len, int alpha, uint32_t slots, uint64_t **d_row_off,
                     uint32_t **d_postings, uint64_t *n_postings, uint32_t *max_row, hipStream_t st);
 int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
-                   uint32_t gshift, uint32_t *d_part, hipStream_t st);
+                   uint32_t gsize, uint32_t *d_part, hipStream_t st);
+int ugs_rank_blocks_per_cu(int threads, size_t lds);
+int ugs_align_blocks_per_cu(int threads, size_t lds);
 size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words);
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);

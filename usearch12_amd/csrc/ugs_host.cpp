@@ -295,24 +295,29 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     return fail(rc);
   // partition size: aim at ~32 postings per (row, partition): a sub-row then (almost) never exceeds
   // one wavefront, which keeps the ranking kernel on its register-resident fast path
-  uint32_t gshift = 14;
+  uint32_t gsize = 8192;
   {
+    // ~40 postings per (row, partition): a sub-row then (almost) never exceeds one wavefront
+    // (Poisson tail < 1e-3), while 60 % of the lanes of every row instruction carry a posting
     double avg_row = db->n_postings ? (double)db->n_postings / (double)slots : 1.0;
-    double g = 32.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
-    gshift = 10;
-    while (gshift < 16 && (double)(1u << gshift) < g * 0.75) ++gshift;
+    double g = 40.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
+    uint64_t gs = ((uint64_t)g + 511) / 1024 * 1024;
+    if (gs < 1024) gs = 1024;
+    if (gs > 65536) gs = 65536;
     const uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
-    while (gshift < 16 && (uint64_t)slots * (((uint64_t)nseq >> gshift) + 2) * 4 > budget) ++gshift;
-    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 5 && v <= 16) gshift = (uint32_t)v; }
+    while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
+    gsize = (uint32_t)gs;
+    if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
+    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 16) gsize = 1u << v; }
   }
-  const uint32_t np = nseq ? (uint32_t)((((uint64_t)nseq - 1) >> gshift) + 1) : 1;
+  const uint32_t np = nseq ? (uint32_t)(((uint64_t)nseq - 1) / gsize + 1) : 1;
   DBCHK(hipMalloc(&db->d_part, (size_t)slots * (np + 1) * sizeof(uint32_t)));
-  if ((rc = ugs_build_part(db->d_row_off, db->d_postings, slots, np, gshift, db->d_part, db->stream)) != UGS_OK) return fail(rc);
+  if ((rc = ugs_build_part(db->d_row_off, db->d_postings, slots, np, gsize, db->d_part, db->stream)) != UGS_OK) return fail(rc);
   DBCHK(hipStreamSynchronize(db->stream));
 #undef DBCHK
   UgsDbView &v = db->v;
   v.seqs = db->d_seqs; v.offs = db->d_offs; v.nseq = nseq; v.slots = slots; v.row_off = db->d_row_off;
-  v.postings = db->d_postings; v.part = db->d_part; v.np = np; v.gshift = gshift; v.tab = db->d_tab;
+  v.postings = db->d_postings; v.part = db->d_part; v.np = np; v.gsize = gsize; v.tab = db->d_tab;
   v.word_len = p->word_len; v.alpha = alpha; v.big = nseq > p->big ? 1 : 0; v.bump_pct = p->bump_pct;
   v.hsp_w = p->hsp_word_len; v.hsp_words = (int)hspw64;
   v.xdrop2 = (int)floor(2.0 * (double)p->xdrop_nw);
@@ -426,7 +431,7 @@ static int plan_launch(ugs_batch *b)
     ns_typ = std::max(ns_typ, db->v.big ? (nu + db->step[nu] - 1) / db->step[nu] : nu);
   }
   const int bits = ns_typ <= 15 ? 4 : (ns_typ <= 255 ? 8 : 16);
-  const size_t tbl_bytes = (((size_t)1 << db->v.gshift) * bits) / 8;
+  const size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;      // + 64 dummy words per wave
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
   if (bits == 4 && (uint64_t)15 * (db->v.np + 1) * 4 <= 24 * 1024) part_words = (15 * (db->v.np + 1) + 3) & ~3u;
@@ -436,7 +441,7 @@ static int plan_launch(ugs_batch *b)
   if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
   const size_t rlds = fixed + wpb * tbl_bytes;
   const uint64_t units = (uint64_t)b->nq * b->nstrand;
-  int per_cu = (int)std::min<size_t>(LDS_MAX / rlds, (size_t)(32 / wpb));
+  int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds);      // real residency (VGPRs, LDS, wave slots)
   per_cu = std::max(1, std::min(per_cu, 8));
   if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
@@ -464,8 +469,9 @@ static int plan_launch(ugs_batch *b)
   while (awpb > 1 && 2112 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
   if (2112 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2112 + wave_lds); return UGS_E_ENVELOPE; }
   const size_t alds = 2112 + awpb * wave_lds;
-  int aper_cu = (int)std::min<size_t>(LDS_MAX / alds, (size_t)(32 / awpb));
+  int aper_cu = ugs_align_blocks_per_cu(64 * awpb, alds);
   aper_cu = std::max(1, std::min(aper_cu, 8));
+  if (const char *e = getenv("UGS_ALIGN_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) aper_cu = std::min(aper_cu, v); }
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
   b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
   const int waves = b->al.grid * awpb;

@@ -7,7 +7,7 @@
 //
 // Layout produced (all resident in HBM): CSR rows `postings[row_off[w] .. row_off[w+1])` =
 // ascending target indexes containing word w (each target once per distinct valid word), plus
-// a partition table part[w][p] = offset inside row w of the first target >= p * 2^gshift, which
+// a partition table part[w][p] = offset inside row w of the first target >= p * gsize, which
 // lets the ranking kernel cut every row into LDS-sized target ranges without searching.
 //
 // Method: one 64-bit key (word << 32 | target) per sequence position, device radix sort,
@@ -179,9 +179,9 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   return UGS_OK;
 }
 
-// thread per (slot, p): lower_bound of p<<gshift inside the row; p == np -> row size
+// thread per (slot, p): lower_bound of p*gsize inside the row; p == np -> row size
 __global__ void k_part(const uint64_t *row_off, const uint32_t *postings, uint32_t slots, uint32_t np,
-                       uint32_t gshift, uint32_t *part)
+                       uint32_t gsize, uint32_t *part)
 {
   uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t total = (uint64_t)slots * (np + 1);
@@ -192,18 +192,18 @@ __global__ void k_part(const uint64_t *row_off, const uint32_t *postings, uint32
   uint32_t lo = 0, hi = n;
   if (p == np) lo = n;
   else {
-    const uint64_t want = (uint64_t)p << gshift;
+    const uint64_t want = (uint64_t)p * gsize;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint64_t)postings[b + mid] < want) lo = mid + 1; else hi = mid; }
   }
   part[id] = lo;
 }
 
 int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
-                   uint32_t gshift, uint32_t *d_part, hipStream_t st)
+                   uint32_t gsize, uint32_t *d_part, hipStream_t st)
 {
   uint64_t total = (uint64_t)slots * (np + 1);
   hipLaunchKernelGGL(k_part, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_row_off, d_postings, slots, np,
-                     gshift, d_part);
+                     gsize, d_part);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

@@ -9,7 +9,7 @@
 //   CountSortSubsetDesc / CountSortOrderDesc                           countsort.cpp:6-191
 //
 // Design (DESIGN.md "K2/K3"): one workgroup per (query, strand).  The target space is cut into
-// partitions of 2^gshift targets; each WAVE owns a private LDS counter table (4/8/16-bit
+// partitions of gsize targets; each WAVE owns a private LDS counter table (4/8/16-bit
 // counters, width chosen per query) for one partition at a time and handles the sampled rows'
 // sub-rows (cut out by the index's partition table, no searching):
 //   pass 1  all sub-row loads of the partition are issued back-to-back (one register per row,
@@ -75,7 +75,7 @@ struct ScanCtx {
   const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
   uint32_t *hist;            // non-null: count emitted entries per (count,row) class
   uint64_t *ebuf; uint64_t ecap;
-  uint32_t ns, np, gshift, tbl_words;
+  uint32_t ns, np, gsize, tbl_words;
   int wave, wpb, lane; bool small_path;
 };
 
@@ -215,14 +215,14 @@ template <int CB, bool FILL>
 __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, uint64_t fill_limit)
 {
   constexpr uint32_t EPW = 32 / CB;
-  const uint32_t G = 1u << s.gshift;
+  const uint32_t G = s.gsize;
   const uint32_t tbl_targets = s.tbl_words * EPW;
   const bool split = tbl_targets < G;
   const uint32_t nsub = split ? (G + tbl_targets - 1) / tbl_targets : 1;
   for (uint32_t p = s.wave; p < s.np; p += s.wpb)
     for (uint32_t sub = 0; sub < nsub; ++sub) {
-      const uint32_t base_t = (p << s.gshift) + sub * tbl_targets;
-      const uint32_t pend = (p + 1) << s.gshift;
+      const uint32_t base_t = p * s.gsize + sub * tbl_targets;
+      const uint32_t pend = (p + 1) * s.gsize;
       const uint32_t hi_t = split ? (base_t + tbl_targets < pend ? base_t + tbl_targets : pend) : 0;
       range_generic<CB, FILL>(s, p, split, base_t, hi_t, need, fill_limit);
     }
@@ -262,35 +262,37 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
 {
   const int lane = s.lane;
   uint32_t *tbl = s.tbl;
-  const uint32_t base_t = p << s.gshift;
+  const uint32_t base_t = p * s.gsize;
   if (B.tail) {
     // a sub-row longer than a wavefront (rare at the chosen partition size): generic, row-ordered
     range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
     return;
   }
-  uint32_t w[NR], sh[NR];    // LDS word index (TINV = lane has no posting in row r) and nibble shift
+  // Branch-free: lanes without a posting in row r aim at a private dummy word behind the table
+  // (add 0 / and ~0), so the 2*NR LDS atomics issue back-to-back and ONE wait covers the batch.
+  const uint32_t dummy = s.tbl_words + (uint32_t)lane;
+  uint32_t w[NR], sh[NR];    // LDS word index and nibble shift of this lane's posting in row r
+  bool on[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const uint32_t rlen = __builtin_amdgcn_readlane((int)B.len, r);
     const uint32_t x = B.v[r] - base_t;
-    w[r] = (uint32_t)lane < rlen ? (x >> 3) : TINV;
+    on[r] = (uint32_t)lane < rlen;
+    w[r] = on[r] ? (x >> 3) : dummy;
     sh[r] = (x & 7u) << 2;
   }
 #pragma unroll
-  for (int r = 0; r < NR; ++r) if (w[r] != TINV) atomicAdd(&tbl[w[r]], 1u << sh[r]);
+  for (int r = 0; r < NR; ++r) atomicAdd(&tbl[w[r]], on[r] ? (1u << sh[r]) : 0u);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
   // row that holds a target still sees its counter set and gets the target's final count back;
-  // later rows of the same target read 0.  One wait for the whole batch, no chain of waits.
+  // later rows of the same target read 0.
+  uint32_t old[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) old[r] = atomicAnd(&tbl[w[r]], on[r] ? ~(15u << sh[r]) : 0xffffffffu);
   uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    c[r] = 0;
-    if (w[r] != TINV) {
-      const uint32_t old = atomicAnd(&tbl[w[r]], ~(15u << sh[r]));
-      c[r] = (old >> sh[r]) & 15u;
-    }
-  }
+  for (int r = 0; r < NR; ++r) c[r] = on[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
   const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -346,7 +348,7 @@ template <bool FILL>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
   if (cb == 4) {
-    if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= (1u << s.gshift)) {
+    if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
       if (s.ns <= 8) scan_fast4<8>(s); else scan_fast4<12>(s);
     }
     else scan_generic<4, FILL>(s, need, fill_limit);
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
   uint64_t *s_wsel = (uint64_t *)(smem + off); off += (size_t)4 * UGS_KMAX * 8;                 // per-wave selections
   uint8_t *s_udb = (uint8_t *)(smem + off); off += 256;                                 // UDB letter table
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
-  uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * tbl_words;
+  uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * (tbl_words + 64);      // +64 dummy words per wave
 
   const UgsTables *tab = db.tab;
   const uint32_t units = bv.nq * bv.nstrand;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
 
   for (int k = tid; k < 256; k += nthr) s_udb[k] = tab->udb_letter[k];
   // counter tables must start clean; pass 2 restores that invariant after every partition
-  for (uint32_t k = lane; k < tbl_words; k += 64) tbl[k] = 0;
+  for (uint32_t k = lane; k < tbl_words + 64; k += 64) tbl[k] = 0;
 
   unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0;
   for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
     sc.s_part = use_part_cache ? s_part : nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
-    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gshift = db.gshift;
+    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
@@ -765,6 +767,16 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
   }
 }
 
+// resident workgroups per CU for a given block size / dynamic LDS (VGPR- and LDS-limited): the
+// persistent grid must not exceed it, or the surplus workgroups run as a second, unbalanced round
+int ugs_rank_blocks_per_cu(int threads, size_t lds)
+{
+  int n = 0;
+  if (hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank, threads, lds) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
 // LDS bytes of everything in k_rank's carve except the per-wave counter tables (must mirror the kernel)
 size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words)
 {
@@ -784,7 +796,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
 
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st)
 {
-  const uint32_t tbl_words = (uint32_t)((((uint64_t)1 << db.gshift) * L.bits) / 32);
+  const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
   HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
