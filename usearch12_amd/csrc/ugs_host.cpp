@@ -434,7 +434,7 @@ static int plan_launch(ugs_batch *b)
   const size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;      // + 64 dummy words per wave
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
-  if (bits == 4 && (uint64_t)15 * (db->v.np + 1) * 4 <= 24 * 1024) part_words = (15 * (db->v.np + 1) + 3) & ~3u;
+  (void)bits;   // (no LDS copy of the partition-table rows any more: the fast path uses scalar loads)
   const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;

@@ -130,7 +130,7 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   *d_row_off_out = row_off; *d_postings_out = nullptr; *n_postings = 0; *max_row = 0;
   if (nseq == 0 || nletters == 0) {
     HIPCHK(hipMemsetAsync(row_off, 0, ((size_t)slots + 1) * sizeof(uint64_t), st));
-    HIPCHK(hipMalloc(&postings, 16));
+    HIPCHK(hipMalloc(&postings, 256 * sizeof(uint32_t)));
     *d_postings_out = postings;
     return UGS_OK;
   }
@@ -164,7 +164,8 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   uint64_t np_host = 0;
   HIPCHK(hipMemcpyAsync(&np_host, row_off + slots, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipMalloc(&postings, (np_host ? np_host : 4) * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&postings, (np_host + 256) * sizeof(uint32_t)));        // padded: rows are read in whole-wave units
+  HIPCHK(hipMemsetAsync(postings + np_host, 0, 256 * sizeof(uint32_t), st));
   if (np_host) {
     hipLaunchKernelGGL(k_postings, dim3((unsigned)((np_host + 255) / 256)), dim3(256), 0, st, keys, np_host, postings);
     HIPCHK(hipGetLastError());

@@ -231,30 +231,37 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
 // ---- the hot configuration: <= 15 sampled rows (4-bit counters), table covers a whole partition.
 // One register per row holds that row's sub-row (one posting per lane); the loads of the NEXT
 // partition are in flight while the current one is counted and extracted.
-template <int NR> struct Batch { uint32_t v[NR]; uint32_t len; bool tail; };
+// ---- the hot configuration: <= 15 sampled rows (4-bit counters), table covers a whole partition.
+// Row descriptors (slot, row base pointer, sub-row bounds) are wave-uniform and live in SGPRs: the
+// partition table is read with scalar loads, a row's load is "scalar base + lane*4" (no per-row
+// address VALU), lanes beyond a sub-row simply read the following postings (the array is padded)
+// and are masked out later.  One register per row holds the sub-row; the loads of the NEXT
+// partition stay in flight while the current one is counted and extracted (ping-pong batches,
+// exactly NR loads per batch so the compiler can wait with s_waitcnt vmcnt(NR)).
+// read-only index arrays viewed through the constant address space: a wave-uniform address then
+// becomes a scalar load (s_load_*) instead of a 64-lane vector load
+typedef const uint32_t __attribute__((address_space(4))) *cptr32;
+typedef const uint64_t __attribute__((address_space(4))) *cptr64;
 
-// Issue the NR sub-row loads of partition p.  Exactly NR unconditional loads (rows beyond ns and
-// lanes beyond a sub-row read a clamped, valid address) so the compiler can count them and wait
-// for the OLDER batch only (s_waitcnt vmcnt(NR)) while these stay in flight.
+template <int NR> struct Batch { uint32_t v[NR]; uint32_t len[NR]; bool tail; };
+
+template <int NR> struct Rows { uint32_t slot[NR]; const uint32_t *base[NR]; };
+
 template <int NR>
-__device__ __forceinline__ void issue_batch(const ScanCtx &s, uint32_t p, uint32_t myslot, uint64_t myrb, Batch<NR> &B)
+__device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R, uint32_t p, Batch<NR> &B)
 {
   const int lane = s.lane;
-  uint32_t pa = 0, pb = 0;
-  if ((uint32_t)lane < s.ns) {
-    if (s.s_part) { pa = s.s_part[lane * (s.np + 1) + p]; pb = s.s_part[lane * (s.np + 1) + p + 1]; }
-    else { const uint32_t *pp = s.part + (uint64_t)myslot * (s.np + 1) + p; pa = pp[0]; pb = pp[1]; }
-  }
-  const uint64_t a = myrb + pa;
-  B.len = pb - pa;
-  B.tail = __ballot(B.len > 64) != 0;
+  uint32_t mx = 0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const uint64_t ra = shfl64(a, r);
-    const uint32_t rlen = __builtin_amdgcn_readlane((int)B.len, r);
-    const uint32_t o = (uint32_t)lane < rlen ? (uint32_t)lane : 0u;
-    B.v[r] = s.postings[ra + o];
+    cptr32 pp = (cptr32)(uintptr_t)s.part + (uint64_t)R.slot[r] * (s.np + 1) + p;     // uniform address -> scalar load
+    const uint32_t pa = pp[0], pb = pp[1];
+    const uint32_t len = (uint32_t)r < s.ns ? pb - pa : 0u;
+    B.len[r] = len;
+    mx = len > mx ? len : mx;
+    B.v[r] = R.base[r][pa + (uint32_t)lane];
   }
+  B.tail = mx > 64;
 }
 
 template <int NR>
@@ -269,74 +276,72 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     return;
   }
   // Branch-free: lanes without a posting in row r aim at a private dummy word behind the table
-  // (add 0 / and ~0), so the 2*NR LDS atomics issue back-to-back and ONE wait covers the batch.
-  const uint32_t dummy = s.tbl_words + (uint32_t)lane;
+  // (whatever they add / clear there is harmless), so the 2*NR LDS atomics issue back-to-back
+  // and ONE wait covers the batch.
+  const uint32_t dummy_x = (s.tbl_words + (uint32_t)lane) << 3;
   uint32_t w[NR], sh[NR];    // LDS word index and nibble shift of this lane's posting in row r
-  bool on[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const uint32_t rlen = __builtin_amdgcn_readlane((int)B.len, r);
-    const uint32_t x = B.v[r] - base_t;
-    on[r] = (uint32_t)lane < rlen;
-    w[r] = on[r] ? (x >> 3) : dummy;
+    const uint32_t x = (uint32_t)lane < B.len[r] ? B.v[r] - base_t : dummy_x;
+    w[r] = x >> 3;
     sh[r] = (x & 7u) << 2;
   }
 #pragma unroll
-  for (int r = 0; r < NR; ++r) atomicAdd(&tbl[w[r]], on[r] ? (1u << sh[r]) : 0u);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int r = 0; r < NR; ++r) atomicAdd(&tbl[w[r]], 1u << sh[r]);
+  asm volatile("" ::: "memory");       // order only: the LDS unit executes one wave's operations in program order
   // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
   // row that holds a target still sees its counter set and gets the target's final count back;
   // later rows of the same target read 0.
   uint32_t old[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) old[r] = atomicAnd(&tbl[w[r]], on[r] ? ~(15u << sh[r]) : 0xffffffffu);
-  uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
-#pragma unroll
-  for (int r = 0; r < NR; ++r) c[r] = on[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
+  for (int r = 0; r < NR; ++r) old[r] = atomicAnd(&tbl[w[r]], ~(15u << sh[r]));
   const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
+    // count if this lane's posting is the first touch of its target, else 0
+    const uint32_t c = (uint32_t)lane < B.len[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
     const uint32_t t = B.v[r];
     const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)r << 32) | t);
     if (s.small_path || (uint32_t)r <= c1hi) {      // uniform: can this row still lower fp[1]?
-      const bool f1 = c[r] == 1 && pos < cache1;
+      const bool f1 = c == 1 && pos < cache1;
       if (__ballot(f1)) {
         if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         cache1 = s.s_fp[1];
       }
     }
-    const bool f2 = c[r] >= 2;
+    const bool f2 = c >= 2;
     if (__ballot(f2)) {
-      if (f2 && pos < s.s_fp[c[r]]) atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);
-      if (f2 && s.hist) atomicAdd(&s.hist[c[r] * 16 + r], 1u);
-      emit_lanes(s, f2, 0xffffffffu, make_key(c[r], pos));
+      if (f2 && pos < s.s_fp[c]) atomicMin(&s.s_fp[c], (unsigned long long)pos);
+      if (f2 && s.hist) atomicAdd(&s.hist[c * 16 + r], 1u);
+      emit_lanes(s, f2, 0xffffffffu, make_key(c, pos));
     }
   }
 }
 
-// ---- the hot configuration: <= 15 sampled rows (4-bit counters), table covers a whole partition.
-// One register per row holds that row's sub-row (one posting per lane); the loads of the NEXT
-// partition are in flight while the current one is counted and extracted (ping-pong batches).
 template <int NR>
 __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
 {
-  const int lane = s.lane;
-  uint32_t myslot = 0; uint64_t myrb = 0;
-  if ((uint32_t)lane < s.ns) { myslot = s.s_slots[lane]; myrb = s.row_off[myslot]; }
+  Rows<NR> R;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(s.s_slots[(uint32_t)r < s.ns ? r : 0]);
+    R.slot[r] = slot;
+    R.base[r] = s.postings + ((cptr64)(uintptr_t)s.row_off)[slot];
+  }
   unsigned long long cache1 = KEY_INF;          // register copy of fp[1] (a stale-high filter)
   uint32_t p0 = s.wave;
   if (p0 >= s.np) return;
   const uint32_t last = s.np - 1;
   Batch<NR> A, B;
-  issue_batch<NR>(s, p0, myslot, myrb, A);
+  issue_batch<NR>(s, R, p0, A);
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
-    issue_batch<NR>(s, p1 < last ? p1 : last, myslot, myrb, B);
+    issue_batch<NR>(s, R, p1 < last ? p1 : last, B);
     process_batch<NR>(s, A, p0, cache1);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
-    issue_batch<NR>(s, p2 < last ? p2 : last, myslot, myrb, A);
+    issue_batch<NR>(s, R, p2 < last ? p2 : last, A);
     process_batch<NR>(s, B, p1, cache1);
     if (p2 >= s.np) break;
     p0 = p2;
@@ -349,7 +354,7 @@ __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t
 {
   if (cb == 4) {
     if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
-      if (s.ns <= 8) scan_fast4<8>(s); else scan_fast4<12>(s);
+      if (s.ns <= 8) scan_fast4<8>(s); else if (s.ns <= 11) scan_fast4<11>(s); else scan_fast4<12>(s);
     }
     else scan_generic<4, FILL>(s, need, fill_limit);
   } else if (cb == 8) scan_generic<8, FILL>(s, need, fill_limit);
@@ -406,11 +411,11 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, in
   return r;
 }
 
-__global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
+__global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, wpb = nthr >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave index in an SGPR
   const uint32_t maxq = (bv.max_qlen + 15u) & ~15u;
   // LDS carve (all offsets multiples of 16)
   size_t off = 0;
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
     uint32_t step = 1;
     if (!small_path) step = db.step_tab[Nu < db.step_n ? Nu : db.step_n - 1];
     const uint32_t ns_q = Nu == 0 ? 0 : (Nu + step - 1) / step;
-    const uint32_t ns = ns_q <= ns_max ? ns_q : ns_max;
+    const uint32_t ns = __builtin_amdgcn_readfirstlane(ns_q <= ns_max ? ns_q : ns_max);
     if (ns_q > ns_max && tid == 0) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_NS);
     // ---- ranks of unique words -> sampled slots (every step-th unique word)
     {
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256, 3) void k_rank(UgsDbView db, UgsBatchView bv, 
     }
     // ---- the scan; counter width by the largest possible count (= ns)
     const int cb0 = ns <= 15 ? 4 : (ns <= 255 ? 8 : 16);
-    const bool use_part_cache = cb0 == 4 && (uint64_t)ns * (db.np + 1) <= part_words;
+    const bool use_part_cache = false;      // (the fast path reads the partition table with scalar loads)
     if (use_part_cache) {
       const uint32_t npp = db.np + 1;
       for (uint32_t r = wave; r < ns; r += wpb) {
