@@ -124,11 +124,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_parts = {"search_sync": 0.0, "fetch": 0.0}
+
     def step():
+        ta = time.time()
         bat.search()
         bat.sync()
+        tb = time.time()
+        t_parts["search_sync"] += tb - ta
         if dist is None:
-            return bat.fetch()
+            out = bat.fetch()
+            t_parts["fetch"] += time.time() - tb
+            return out
         # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)
         (ph, bh), (pn, bn), (pc, bc) = bat.device_results()
         t_h = torch.as_tensor(DevArray(ph, bh), device="cuda")
@@ -215,6 +222,8 @@ def main():
                        "postings_per_query": st["postings"] / max(qs.n, 1),
                        "pairs_aligned_per_query": st["pairs_aligned"] / max(qs.n, 1),
                        "dp_gcells_per_s": st["dp_cells"] / max(ms_align * 1e-3, 1e-9) / 1e9,
+                       "host_ms_search_sync": 1000.0 * t_parts["search_sync"] / (args.steps + args.warmup),
+                       "host_ms_fetch": 1000.0 * t_parts["fetch"] / (args.steps + args.warmup),
                        "index_build_s": t_index, "upload_s": t_upload, "gen_s": t_gen,
                        "db_hbm_bytes": gdb.stats()["hbm_bytes"],
                        "gpu_over_cpu": (value / world / cb["value"]) if cb else None},

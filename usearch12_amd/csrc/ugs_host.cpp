@@ -44,6 +44,7 @@ struct ugs_batch {
   uint32_t nq, max_qlen, K, nstrand;
   UgsBatchView v;
   uint8_t *d_qseqs; uint64_t *d_qoffs;
+  uint32_t *d_qn, *d_qoff; ugs_hit *d_compact; void *d_scan_tmp; size_t scan_tmp_bytes;
   uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
   ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
   unsigned long long *d_cigar_used, *d_ctr;
@@ -400,6 +401,11 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * db->p.max_accepts, 1) * sizeof(ugs_hit)));
   b->cigar_cap = units * db->p.max_accepts * 12 + 4096;
   BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
+  BCHK(hipMalloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
+  BCHK(hipMalloc(&b->d_qoff, ((uint64_t)max_queries + 1) * 4));
+  BCHK(hipMalloc(&b->d_compact, std::max<uint64_t>(units * db->p.max_accepts, 1) * sizeof(ugs_hit)));
+  b->scan_tmp_bytes = ugs_compact_tmp_bytes(max_queries);
+  BCHK(hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes));
   BCHK(hipMalloc(&b->d_cigar_used, 8));
   BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
@@ -591,40 +597,37 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
   const uint32_t nq = b->nq, ns = b->nstrand, ma = (uint32_t)db->p.max_accepts;
-  const uint64_t units = (uint64_t)nq * ns;
-  std::vector<uint32_t> hn(units ? units : 1);
-  std::vector<ugs_hit> hh(units * ma ? units * ma : 1);
-  std::vector<uint32_t> pool(b->cigar_used_host ? b->cigar_used_host : 1);
-  if (units) {
-    HIPCHK(hipMemcpy(hn.data(), b->d_hit_n, units * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hh.data(), b->d_hits, units * ma * sizeof(ugs_hit), hipMemcpyDeviceToHost));
-    if (b->cigar_used_host) HIPCHK(hipMemcpy(pool.data(), b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost));
-  }
-  uint64_t nh = 0, nc = 0;
-  std::vector<ugs_hit> tmp; std::vector<float> sc; std::vector<unsigned> ord;
-  for (uint32_t q = 0; q < nq; ++q) {
-    tmp.clear();
-    for (uint32_t s = 0; s < ns; ++s) {
-      const uint64_t u = (uint64_t)q * ns + s;
-      for (uint32_t k = 0; k < hn[u]; ++k) tmp.push_back(hh[u * ma + k]);
-    }
-    const uint32_t n = (uint32_t)tmp.size();
-    nhits_per_query[q] = n;
-    if (n > 1) {
-      sc.resize(n); ord.resize(n);
-      for (uint32_t i = 0; i < n; ++i) { sc[i] = (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
-      qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-      const ugs_hit &h = tmp[n > 1 ? ord[i] : i];
-      if (nh + 1 > hits_cap || nc + h.cigar_len > cigar_cap) { ugs_set_error("output buffers too small"); return UGS_E_CAPACITY; }
-      hits[nh] = h;
-      hits[nh].cigar_off = nc;
-      memcpy(cigar_pool + nc, pool.data() + h.cigar_off, (size_t)h.cigar_len * 4);
-      nc += h.cigar_len; ++nh;
+  if (cigar_used) *cigar_used = 0;
+  if (nq == 0) return UGS_OK;
+  // group by query on the device (count, exclusive scan, gather), then three plain D2H copies
+  RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
+                         b->scan_tmp_bytes, db->stream));
+  uint32_t last_off = 0, last_n = 0;
+  HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
+  HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
+  HIPCHK(hipMemcpyAsync(nhits_per_query, b->d_qn, (size_t)nq * 4, hipMemcpyDeviceToHost, db->stream));
+  HIPCHK(hipStreamSynchronize(db->stream));
+  const uint64_t total = (uint64_t)last_off + last_n;
+  if (total > hits_cap || b->cigar_used_host > cigar_cap) { ugs_set_error("output buffers too small"); return UGS_E_CAPACITY; }
+  if (total) HIPCHK(hipMemcpyAsync(hits, b->d_compact, total * sizeof(ugs_hit), hipMemcpyDeviceToHost, db->stream));
+  if (b->cigar_used_host) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost, db->stream));
+  HIPCHK(hipStreamSynchronize(db->stream));
+  if (cigar_used) *cigar_used = b->cigar_used_host;
+  // HitMgr::Sort for the (rare) queries with several hits; cigar_off keeps pointing into the pool as copied
+  if (ma > 1 || ns > 1) {
+    std::vector<ugs_hit> tmp; std::vector<float> sc; std::vector<unsigned> ord;
+    uint64_t k = 0;
+    for (uint32_t q = 0; q < nq; ++q) {
+      const uint32_t n = nhits_per_query[q];
+      if (n > 1) {
+        tmp.assign(hits + k, hits + k + n); sc.resize(n); ord.resize(n);
+        for (uint32_t i = 0; i < n; ++i) { sc[i] = (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
+        qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
+        for (uint32_t i = 0; i < n; ++i) hits[k + i] = tmp[ord[i]];
+      }
+      k += n;
     }
   }
-  if (cigar_used) *cigar_used = nc;
   return UGS_OK;
 }
 

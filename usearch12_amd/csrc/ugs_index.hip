@@ -16,6 +16,7 @@
 #include "ugs_dev.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
@@ -207,4 +208,52 @@ int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32
                      gsize, d_part);
   HIPCHK(hipGetLastError());
   return UGS_OK;
+}
+
+
+// ---- hit-table compaction (the device side of HitMgr bookkeeping, hitmgr.cpp:120-183): the
+// alignment kernel leaves a fixed-size table hits[unit*max_accepts + k] + hit_n[unit]; the host only
+// wants the hits, grouped by query in query order (strand 0 before strand 1).
+__global__ void k_hits_per_query(const uint32_t *hit_n, uint32_t nq, uint32_t ns, uint32_t *qn)
+{
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t n = 0;
+  for (uint32_t s = 0; s < ns; ++s) n += hit_n[q * ns + s];
+  qn[q] = n;
+}
+
+__global__ void k_hits_compact(const uint32_t *hit_n, const ugs_hit *table, const uint32_t *qoff, uint32_t nq, uint32_t ns,
+                               uint32_t ma, ugs_hit *out)
+{
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t o = qoff[q];
+  for (uint32_t s = 0; s < ns; ++s) {
+    const uint32_t u = q * ns + s, n = hit_n[u];
+    for (uint32_t k = 0; k < n; ++k) out[o++] = table[(uint64_t)u * ma + k];
+  }
+}
+
+int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma,
+                     uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, hipStream_t st)
+{
+  if (nq == 0) return UGS_OK;
+  hipLaunchKernelGGL(k_hits_per_query, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, nq, ns, d_qn);
+  HIPCHK(hipGetLastError());
+  size_t need = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+  if (need > tmp_bytes) { ugs_set_error("scan scratch too small"); return UGS_E_NOMEM; }
+  HIPCHK(rocprim::exclusive_scan(d_tmp, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_hits_compact, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, d_table, d_qoff, nq, ns, ma, d_out);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
+
+size_t ugs_compact_tmp_bytes(uint32_t nq)
+{
+  size_t need = 0;
+  uint32_t *p = nullptr;
+  if (rocprim::exclusive_scan(nullptr, need, p, p, 0u, (size_t)(nq ? nq : 1), rocprim::plus<uint32_t>(), (hipStream_t)0) != hipSuccess) return 1 << 20;
+  return need + 256;
 }
