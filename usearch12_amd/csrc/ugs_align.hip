@@ -47,7 +47,7 @@ struct WaveCtx {
   uint8_t *A, *B;             // class codes of query / target letters (identity tests)
   uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
   uint32_t *wstart;           // per HSP word: first index in qsort | min(count,8) << 16 (0 = absent), or null
-  uint32_t *seeds; uint32_t seed_cap;   // seed list of the current pair: bpos << 16 | apos, in reference order
+  uint32_t *seeds; uint32_t seed_cap; uint32_t union_words;   // seed list of the current pair: bpos << 16 | apos, in reference order
   bool nt;
   uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
   int32_t *Mrow, *Drow;       // Mrow[-1] valid
@@ -102,6 +102,50 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
   c.nwA = LA >= (uint32_t)w ? LA - w + 1 : 0;
   uint32_t n2 = 64; while (n2 < c.nwA) n2 <<= 1;
   c.nA2 = n2;
+  if (c.wstart && (uint64_t)c.nwA * 3 / 2 + 16 <= c.union_words) {
+    // ---- counting sort by word (<= 1024 words), stable in position: O(L^2/64) equal-word ranks with
+    // 128-bit LDS reads instead of a 36-stage bitonic network
+    uint32_t *tw = c.seeds;                               // word per position (union region, free here)
+    uint16_t *tr = (uint16_t *)(c.seeds + ((c.nwA + 3) & ~3u));       // rank among earlier equal words
+    const uint32_t nwords = c.nwords, nwA = c.nwA;
+    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0;
+    for (uint32_t p = lane; p < ((nwA + 3) & ~3u); p += 64) {
+      uint32_t word = 0xffffffffu;
+      if (p < nwA) { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; }
+      tw[p] = word;
+    }
+    wave_sync();
+    for (uint32_t p = lane; p < nwA; p += 64) {
+      const uint32_t wd = tw[p];
+      const uint4 *v4 = (const uint4 *)tw;
+      uint32_t rank = 0;
+      const uint32_t nq4 = p >> 2;
+      for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += (x.x == wd) + (x.y == wd) + (x.z == wd) + (x.w == wd); }
+      for (uint32_t q = nq4 << 2; q < p; ++q) rank += tw[q] == wd;
+      tr[p] = (uint16_t)rank;
+      atomicAdd(&c.wstart[wd], 1u);
+    }
+    wave_sync();
+    {   // exclusive prefix sum of the counts: each lane owns a contiguous block of words
+      const uint32_t per = (nwords + 63) / 64;
+      uint32_t sum = 0;
+      for (uint32_t k = 0; k < per; ++k) { const uint32_t wi = lane * per + k; if (wi < nwords) sum += c.wstart[wi]; }
+      uint32_t incl = sum;
+      for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+      uint32_t run = incl - sum;
+      for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t wi = lane * per + k;
+        if (wi < nwords) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = n ? (run | ((n < UGS_MAXREPS ? n : UGS_MAXREPS) << 16)) : 0u; run += n; }
+      }
+    }
+    wave_sync();
+    for (uint32_t p = lane; p < nwA; p += 64) {
+      const uint32_t wd = tw[p];
+      c.qsort[(c.wstart[wd] & 0xffffu) + tr[p]] = (wd << 16) | p;
+    }
+    wave_sync();
+    return;
+  }
   for (uint32_t p = lane; p < n2; p += 64) {
     uint32_t key = 0xffffffffu;
     if (p < c.nwA) {
@@ -647,6 +691,7 @@ __global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv,
     c.Drow = (int32_t *)(u + uo); uo += ((size_t)maxt + 8) * 4;
     c.csc = (uint32_t *)(u + uo); uo += (size_t)hsp_cap * 7 * 4;
     const size_t us = (size_t)seed_cap * 4 > uo ? (size_t)seed_cap * 4 : uo;
+    c.union_words = (uint32_t)(us / 4);
     off += (us + 15) & ~(size_t)15;
   }
   c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl;
