@@ -60,6 +60,19 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
   return ((uint64_t)hi << 32) | lo;
 }
 
+// wave-wide inclusive prefix sum with DPP row shifts (no LDS crossbar round trips)
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  // add the totals of the preceding 16-lane rows
+  const uint32_t t0 = __builtin_amdgcn_readlane((int)v, 15), t1 = __builtin_amdgcn_readlane((int)v, 31), t2 = __builtin_amdgcn_readlane((int)v, 47);
+  const uint32_t row = (uint32_t)(threadIdx.x & 63) >> 4;
+  return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
+}
+
 struct RankShared {
   uint32_t emit_n, M, next_value, min_value, n_sel, nev, exhausted, pad1;
   uint64_t fill_limit;       // small path: count-1 targets kept only below this position
@@ -296,26 +309,40 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
 #pragma unroll
   for (int r = 0; r < NR; ++r) old[r] = atomicAnd(&tbl[w[r]], ~(15u << sh[r]));
   const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
+  uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
+  uint32_t m2 = 0;           // bit r: this lane holds a first touch with count >= 2 in row r
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    // count if this lane's posting is the first touch of its target, else 0
-    const uint32_t c = (uint32_t)lane < B.len[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
-    const uint32_t t = B.v[r];
-    const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)r << 32) | t);
+    c[r] = (uint32_t)lane < B.len[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
+    m2 |= (c[r] >= 2u ? 1u : 0u) << r;
     if (s.small_path || (uint32_t)r <= c1hi) {      // uniform: can this row still lower fp[1]?
-      const bool f1 = c == 1 && pos < cache1;
+      const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
+      const bool f1 = c[r] == 1 && pos < cache1;
       if (__ballot(f1)) {
         if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         cache1 = s.s_fp[1];
       }
     }
-    const bool f2 = c >= 2;
-    if (__ballot(f2)) {
-      if (f2 && pos < s.s_fp[c]) atomicMin(&s.s_fp[c], (unsigned long long)pos);
-      if (f2 && s.hist) atomicAdd(&s.hist[c * 16 + r], 1u);
-      emit_lanes(s, f2, 0xffffffffu, make_key(c, pos));
-    }
+  }
+  // every (lane,row) with count >= 2 of the whole partition is emitted with ONE slot allocation
+  if (__ballot(m2 != 0)) {
+    const uint32_t cnt = __popc(m2);
+    const uint32_t incl = wave_incl_sum_u32(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&s.sh->emit_n, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t o = base + incl - cnt;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if ((m2 >> r) & 1u) {
+        const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
+        atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);          // fire-and-forget LDS atomics
+        if (s.hist) atomicAdd(&s.hist[c[r] * 16 + r], 1u);
+        if ((uint64_t)o < s.ecap) s.ebuf[o] = make_key(c[r], pos);
+        ++o;
+      }
   }
 }
 
