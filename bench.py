@@ -137,15 +137,13 @@ def main():
             t_parts["fetch"] += time.time() - tb
             return out
         # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)
-        (ph, bh), (pn, bn), (pc, bc) = bat.device_results()
-        t_h = torch.as_tensor(DevArray(ph, bh), device="cuda")
+        (ph, bh), (pn, bn), (pc, bc) = bat.device_results(query_base=rank * qs.n)   # compacted + global query ids on device
+        t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
         t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
         t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
         got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
         if rank == 0:
-            los = [k * qs.n for k in range(world)]        # weak scaling: rank k's shard = queries [k*nq, (k+1)*nq)
-            ghits, gpool = multigpu.merge_tables(got[0], got[1], got[2], los, p.max_accepts)
-            return ghits, None, gpool
+            return multigpu.merge_tables(got[0], got[1], got[2])
         return None
 
     for _ in range(args.warmup):

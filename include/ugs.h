@@ -173,13 +173,14 @@ int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st);
 int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap);
 
 /*
- * Device-resident result tables of the last synced search (valid until the next search or
- * destroy): hits[units*max_accepts] ugs_hit records, hit_n[units] counts and the run pool.
- * For callers that move results GPU-to-GPU (the multi-GPU driver gathers them to rank 0 with
- * RCCL over xGMI) instead of fetching to the host.
+ * Device-resident, query-grouped results of the last synced search (valid until the next search
+ * or destroy): compact hits[n] (ugs_hit records with `query` offset by query_base; hits of one
+ * query adjacent, strand 0 first, discovery order), nhits_per_query[nq] (uint32) and the run pool.
+ * For callers that move results GPU-to-GPU (the multi-GPU driver gathers them to rank 0 with RCCL
+ * over xGMI) instead of fetching to the host.
  */
-int ugs_batch_device_results(ugs_batch *b, void **d_hits, uint64_t *hits_bytes, void **d_hit_n,
-                             uint64_t *hit_n_bytes, void **d_cigar, uint64_t *cigar_bytes);
+int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void **d_hits, uint64_t *hits_bytes,
+                             void **d_nhits, uint64_t *nhits_bytes, void **d_cigar, uint64_t *cigar_bytes);
 
 /*
  * Text writers replacing OutputSink::OutputBlast6 / OutputUC / OutputUCNoHits

@@ -112,12 +112,13 @@ def test_gpu_device_results_view_matches_fetch():
     bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
     bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
     hits, nh, pool = bat.fetch()
-    (ph, bh), (pn, bn), (pc, bc) = bat.device_results()
+    (ph, bh), (pn, bn), (pc, bc) = bat.device_results(query_base=1000)
     t_h = torch.as_tensor(bench.DevArray(ph, bh), device="cuda").cpu().numpy()
     t_n = torch.as_tensor(bench.DevArray(pn, bn), device="cuda").cpu().numpy()
     t_c = torch.as_tensor(bench.DevArray(pc, bc), device="cuda").cpu().numpy()
-    ghits, gpool = multigpu.merge_tables([t_h], [t_n], [t_c], [0], p.max_accepts)
-    assert len(ghits) == len(hits)
+    ghits, gcnt, gpool = multigpu.merge_tables([t_h], [t_n], [t_c])
+    assert len(ghits) == len(hits) and np.array_equal(gcnt, nh)
+    ghits["query"] -= 1000
     # fetch() re-sorts the hits of a query by score; compare as per-query sets
     key = lambda a: sorted(zip(a["query"].tolist(), a["target"].tolist(), a["ids"].tolist(), a["aln_len"].tolist()))
     assert key(ghits) == key(hits)

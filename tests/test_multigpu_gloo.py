@@ -19,19 +19,6 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _table_from_hits(hits, nh, max_acc):
-    """Lay compact per-query hits out like the device table [units*max_accepts] + counts."""
-    units = len(nh)
-    tab = np.zeros(units * max_acc, dtype=HIT_DTYPE)
-    k = 0
-    for u, n in enumerate(nh):
-        for j in range(int(n)):
-            tab[u * max_acc + j] = hits[k]
-            tab[u * max_acc + j]["query"] = u
-            k += 1
-    return tab
-
-
 def _worker(rank, world, port, case, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,14 +29,15 @@ def _worker(rank, world, port, case, out_path):
     shard = qs.slice(lo, hi)
     odb = orc.OrcDB(p, db.seqs, db.offs)            # replica of the index on every rank
     hits, nh, pool = odb.search(shard.seqs, shard.offs)
-    tab = _table_from_hits(hits, nh, p.max_accepts)
-    t_h = torch.from_numpy(tab.view(np.uint8).copy())
+    hits = hits.copy()
+    hits["query"] += np.uint32(lo)                  # what the device compaction does with query_base
+    t_h = torch.from_numpy(hits.view(np.uint8).reshape(-1).copy())
     t_n = torch.from_numpy(nh.astype(np.uint32).view(np.uint8).copy())
     t_p = torch.from_numpy(pool.astype(np.uint32).view(np.uint8).copy())
     got = multigpu.gather_tables(dist, torch, t_h, t_n, t_p, rank, world, dst=0)
     if rank == 0:
-        los = [multigpu.shard_range(qs.n, world, r)[0] for r in range(world)]
-        ghits, gpool = multigpu.merge_tables(got[0], got[1], got[2], los, p.max_accepts)
+        ghits, gcnt, gpool = multigpu.merge_tables(got[0], got[1], got[2])
+        assert int(gcnt.sum()) == len(ghits) and len(gcnt) == qs.n
         np.save(out_path + ".hits.npy", ghits)
         np.save(out_path + ".pool.npy", gpool)
     dist.barrier()

@@ -53,7 +53,7 @@ def lib():
         L.ugs_batch_fetch.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
         L.ugs_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
         L.ugs_batch_get_candidates.argtypes = [vp, vp, vp, vp, u32]
-        L.ugs_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
+        L.ugs_batch_device_results.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_hit.argtypes = [vp, vp, i32, C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -182,11 +182,12 @@ class UgsBatch:
         _chk(lib().ugs_batch_get_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in BatchStats._fields_}
 
-    def device_results(self):
-        """(ptr, nbytes) triples of the device-resident hit table, hit counts and run pool."""
+    def device_results(self, query_base=0):
+        """(ptr, nbytes) of the device-resident compact hits (query ids offset by query_base),
+        per-query hit counts and run pool."""
         ph, pn, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
         bh, bn, bc = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        _chk(lib().ugs_batch_device_results(self.h, C.byref(ph), C.byref(bh), C.byref(pn), C.byref(bn),
+        _chk(lib().ugs_batch_device_results(self.h, query_base, C.byref(ph), C.byref(bh), C.byref(pn), C.byref(bn),
                                             C.byref(pc), C.byref(bc)))
         return (ph.value, bh.value), (pn.value, bn.value), (pc.value, bc.value)
 

@@ -601,7 +601,7 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   if (nq == 0) return UGS_OK;
   // group by query on the device (count, exclusive scan, gather), then three plain D2H copies
   RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                         b->scan_tmp_bytes, db->stream));
+                         b->scan_tmp_bytes, 0, db->stream));
   uint32_t last_off = 0, last_n = 0;
   HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
   HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
@@ -725,18 +725,32 @@ extern "C" int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, i
   return snprintf(buf, (size_t)cap, "N\t*\t%u\t*\t.\t*\t*\t*\t%s\t*\n", ql, qlabel);
 }
 
-// Device-resident result tables of the last search, for callers that move them GPU-to-GPU
-// (bench.py gathers them to rank 0 with RCCL over xGMI without touching the host):
-// hits[units*max_accepts] (ugs_hit), hit_n[units] (uint32), cigar pool (uint32 runs).
-extern "C" int ugs_batch_device_results(ugs_batch *b, void **d_hits, uint64_t *hits_bytes, void **d_hit_n,
-                                        uint64_t *hit_n_bytes, void **d_cigar, uint64_t *cigar_bytes)
+// Device-resident, query-grouped results of the last search, for callers that move them GPU-to-GPU
+// (the multi-GPU driver gathers them to rank 0 with RCCL over xGMI without touching the host):
+// compact hits[n_hits] (ugs_hit, `query` offset by query_base), nhits_per_query[nq] (uint32) and the
+// run pool (uint32).  Hits of a query are in discovery order (strand 0 first); ugs_batch_fetch
+// additionally applies HitMgr::Sort to queries with several hits.
+extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void **d_hits, uint64_t *hits_bytes,
+                                        void **d_nhits, uint64_t *nhits_bytes, void **d_cigar, uint64_t *cigar_bytes)
 {
   if (!b || !b->synced) return UGS_E_ARG;
-  const uint64_t units = (uint64_t)b->nq * b->nstrand;
-  if (d_hits) *d_hits = b->d_hits;
-  if (hits_bytes) *hits_bytes = units * (uint64_t)b->db->p.max_accepts * sizeof(ugs_hit);
-  if (d_hit_n) *d_hit_n = b->d_hit_n;
-  if (hit_n_bytes) *hit_n_bytes = units * 4;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  const uint32_t nq = b->nq, ns = b->nstrand, ma = (uint32_t)db->p.max_accepts;
+  uint64_t total = 0;
+  if (nq) {
+    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
+                           b->scan_tmp_bytes, query_base, db->stream));
+    uint32_t last_off = 0, last_n = 0;
+    HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
+    HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
+    HIPCHK(hipStreamSynchronize(db->stream));
+    total = (uint64_t)last_off + last_n;
+  }
+  if (d_hits) *d_hits = b->d_compact;
+  if (hits_bytes) *hits_bytes = total * sizeof(ugs_hit);
+  if (d_nhits) *d_nhits = b->d_qn;
+  if (nhits_bytes) *nhits_bytes = (uint64_t)nq * 4;
   if (d_cigar) *d_cigar = b->d_cigar;
   if (cigar_bytes) *cigar_bytes = b->cigar_used_host * 4;
   return UGS_OK;

@@ -224,19 +224,20 @@ __global__ void k_hits_per_query(const uint32_t *hit_n, uint32_t nq, uint32_t ns
 }
 
 __global__ void k_hits_compact(const uint32_t *hit_n, const ugs_hit *table, const uint32_t *qoff, uint32_t nq, uint32_t ns,
-                               uint32_t ma, ugs_hit *out)
+                               uint32_t ma, ugs_hit *out, uint32_t query_base)
 {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   uint32_t o = qoff[q];
   for (uint32_t s = 0; s < ns; ++s) {
     const uint32_t u = q * ns + s, n = hit_n[u];
-    for (uint32_t k = 0; k < n; ++k) out[o++] = table[(uint64_t)u * ma + k];
+    for (uint32_t k = 0; k < n; ++k) { ugs_hit h = table[(uint64_t)u * ma + k]; h.query += query_base; out[o++] = h; }
   }
 }
 
 int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma,
-                     uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, hipStream_t st)
+                     uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, uint32_t query_base,
+                     hipStream_t st)
 {
   if (nq == 0) return UGS_OK;
   hipLaunchKernelGGL(k_hits_per_query, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, nq, ns, d_qn);
@@ -245,7 +246,7 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
   HIPCHK(rocprim::exclusive_scan(nullptr, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
   if (need > tmp_bytes) { ugs_set_error("scan scratch too small"); return UGS_E_NOMEM; }
   HIPCHK(rocprim::exclusive_scan(d_tmp, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
-  hipLaunchKernelGGL(k_hits_compact, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, d_table, d_qoff, nq, ns, ma, d_out);
+  hipLaunchKernelGGL(k_hits_compact, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, d_table, d_qoff, nq, ns, ma, d_out, query_base);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

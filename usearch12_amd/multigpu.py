@@ -46,26 +46,22 @@ def gather_tables(dist, torch, t_hits, t_n, t_pool, rank, world, dst=0):
     return hits, counts, pools
 
 
-def merge_tables(hit_bytes, count_bytes, pool_bytes, shard_lo, max_accepts):
-    """Rank-0 merge of gathered device tables into one compact hit array with GLOBAL query indexes and
-    pool offsets.  hit_bytes[r] is the raw [units*max_accepts] ugs_hit table of rank r (uint8),
-    count_bytes[r] its uint32 per-unit hit counts, pool_bytes[r] its uint32 run pool (as uint8)."""
-    out_hits, out_pool = [], []
+def merge_tables(hit_bytes, count_bytes, pool_bytes):
+    """Rank-0 merge of the gathered per-rank results: hit_bytes[r] = compact ugs_hit records of rank r
+    (uint8, global query ids already applied on the device), count_bytes[r] = uint32 hits per query,
+    pool_bytes[r] = uint32 run pool.  Only the pool offsets need rebasing."""
+    out_hits, out_cnt, out_pool = [], [], []
     pool_base = 0
     for r in range(len(hit_bytes)):
-        cnt = np.frombuffer(np.ascontiguousarray(count_bytes[r]).tobytes(), dtype=np.uint32)
-        tab = np.frombuffer(np.ascontiguousarray(hit_bytes[r]).tobytes(), dtype=HIT_DTYPE)
+        h = np.frombuffer(np.ascontiguousarray(hit_bytes[r]).tobytes(), dtype=HIT_DTYPE).copy()
         pool = np.frombuffer(np.ascontiguousarray(pool_bytes[r]).tobytes(), dtype=np.uint32)
-        units = len(cnt)
-        if units:
-            tab = tab[:units * max_accepts].reshape(units, max_accepts)
-            mask = np.arange(max_accepts)[None, :] < cnt[:, None]
-            h = tab[mask].copy()
-            h["query"] += np.uint32(shard_lo[r])
+        if pool_base:
             h["cigar_off"] += np.uint64(pool_base)
-            out_hits.append(h)
+        out_hits.append(h)
+        out_cnt.append(np.frombuffer(np.ascontiguousarray(count_bytes[r]).tobytes(), dtype=np.uint32))
         out_pool.append(pool)
         pool_base += len(pool)
     hits = np.concatenate(out_hits) if out_hits else np.zeros(0, dtype=HIT_DTYPE)
+    counts = np.concatenate(out_cnt) if out_cnt else np.zeros(0, dtype=np.uint32)
     pool = np.concatenate(out_pool) if out_pool else np.zeros(0, dtype=np.uint32)
-    return hits, pool
+    return hits, counts, pool
