@@ -143,3 +143,95 @@ def test_cli_text_identical_to_reference(tmp_path):
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         assert open(tmp_path / "o.b6").read() == b6, name
         assert open(tmp_path / "o.uc").read() == uc, name
+
+
+@pytest.mark.parametrize("shape", ["aa_60k", "nt_both_120k", "nt_long_1500", "nt_small_60k"])
+def test_gpu_medium_shapes_equal_oracle(shape):
+    """Shapes beyond the golden cases (real Big path on >100k targets, both strands, 1500-letter
+    sequences, protein, small path at tens of thousands of targets): every hit record and path
+    equals the oracle's."""
+    from usearch12_amd import synth
+    kw, aa, ident = {}, False, 0.97
+    if shape == "aa_60k":
+        aa, ident = True, 0.8
+        db = synth.make_db(5, 60_000, 300, aa=True); qs = synth.make_queries(5, db, 8_000, 300, aa=True)
+        kw = dict(big=1000)
+    elif shape == "nt_both_120k":
+        db = synth.make_db(31, 120_000, 250); qs = synth.revcomp_some(31, synth.make_queries(31, db, 8_000, 250))
+        kw = dict(strand_both=1)
+    elif shape == "nt_long_1500":
+        db, qs = synth.make_hard(32, 600, 10, 800, lmin=1200, lmax=1600)
+        kw = dict(big=100)
+    else:
+        db = synth.make_db(34, 60_000, 250); qs = synth.make_queries(34, db, 4_000, 250)
+    p = capi.params(is_nucleo=not aa, id=ident, **kw)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    hits, nh, pool = gdb.search(qs.seqs, qs.offs)
+    odb = orc.OrcDB(orc.params(is_nucleo=not aa, id=ident, **kw), db.seqs, db.offs)
+    oh, onh, opool = odb.search(qs.seqs, qs.offs, nthreads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(nh, onh)
+    assert len(hits) > 0.5 * qs.n
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(hits[f], oh[f]), f
+    for a, b in zip(hits[::53], oh[::53]):
+        assert np.array_equal(pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])],
+                              opool[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])])
+
+
+def test_gpu_full_size_properties():
+    """BASELINE.json configs[1] at FULL size (1M x 250 nt vs 1M-seq DB) through size-independent
+    properties: per-hit invariants of the reference semantics, path/length consistency, ranking
+    order, determinism (two runs bit-identical) and agreement with the oracle on a sample."""
+    from usearch12_amd import synth
+    db = synth.make_db(2, 1_000_000, 250)
+    qs = synth.make_queries(2, db, 1_000_000, 250)
+    p = capi.params(is_nucleo=True, id=0.97)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs)
+    bat.search(); bat.sync()
+    hits, nh, pool = bat.fetch()
+    cand, cnt, n = bat.candidates()
+    # accept rule and bookkeeping (accepter.cpp:35-39, terminator.cpp:64-100, arscorer.cpp:201-296)
+    assert nh.max() <= 1 and len(hits) == int(nh.sum())
+    assert np.all(hits["ids"].astype(np.float64) / hits["aln_len"] >= float(np.float32(0.97)))
+    assert np.all(hits["ids"] + hits["mism"] + hits["gaps_int"] == hits["aln_len"])
+    assert np.array_equal(hits["query"], np.flatnonzero(nh))
+    qlen = np.diff(qs.offs.astype(np.int64))
+    assert np.array_equal(hits["ql"], qlen[hits["query"]]) and np.all(hits["tl"] == 250)
+    # path consistency: M+D columns == query length, M+I columns == target length, cols == sum of runs
+    starts = hits["cigar_off"].astype(np.int64); lens = hits["cigar_len"].astype(np.int64)
+    order = np.argsort(starts, kind="stable")       # pool order is allocation order on the device
+    run_hit = np.repeat(np.arange(len(hits))[order], lens[order])
+    assert int(lens.sum()) == len(pool)
+    runs = pool[np.concatenate([np.arange(s, s + l) for s, l in zip(starts[order][:2000], lens[order][:2000])])]
+    rh = run_hit[:len(runs)]
+    op, ln = runs & 3, (runs >> 2).astype(np.int64)
+    for h in np.unique(rh)[:2000]:
+        m = rh == h
+        assert ln[m][op[m] != 2].sum() == hits["ql"][h] and ln[m][op[m] != 1].sum() == hits["tl"][h]
+        assert ln[m].sum() == hits["cols"][h]
+    # true source recovered for the overwhelming majority of mutated queries
+    src = qs.src[hits["query"]]
+    assert np.mean(src == hits["target"].astype(np.int64)) > 0.999
+    assert 0.80 < len(hits) / qs.n < 0.83
+    # ranking order: counts never increase along a candidate list (count sort, countsort.cpp:110-191)
+    c = cnt.astype(np.int64)
+    valid = np.arange(c.shape[1])[None, :] < n[:, None]
+    assert np.all((np.diff(c, axis=1) <= 0) | ~valid[:, 1:])
+    # determinism
+    bat.search(); bat.sync()
+    hits2, nh2, pool2 = bat.fetch()
+    assert np.array_equal(nh, nh2)
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(hits[f], hits2[f]), f
+    # oracle agreement on a 3000-query sample of the same batch (full DB)
+    sample = qs.slice(500_000, 503_000)
+    odb = orc.OrcDB(orc.params(is_nucleo=True, id=0.97), db.seqs, db.offs)
+    oh, onh, opool = odb.search(sample.seqs, sample.offs, nthreads=min(32, os.cpu_count() or 1))
+    sel = (hits["query"] >= 500_000) & (hits["query"] < 503_000)
+    assert np.array_equal(nh[500_000:503_000], onh)
+    for f in ("target", "ids", "mism", "gaps_int", "aln_len", "opens", "qlo", "qhi", "tlo", "thi", "cigar_len", "cols"):
+        assert np.array_equal(hits[f][sel], oh[f]), f
