@@ -74,6 +74,21 @@ __device__ __forceinline__ int sscore(const WaveCtx &c, int m2, int mm2, uint32_
 }
 __device__ __forceinline__ bool ident(const WaveCtx &c, uint8_t a, uint8_t b) { return (c.s_match[a] >> b) & 1ull; }
 
+// wave-wide inclusive prefix sum with DPP row shifts (no LDS crossbar round trips)
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  const uint32_t t0 = __builtin_amdgcn_readlane((int)v, 15), t1 = __builtin_amdgcn_readlane((int)v, 31), t2 = __builtin_amdgcn_readlane((int)v, 47);
+  const uint32_t row = (uint32_t)(threadIdx.x & 63) >> 4;
+  return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
+}
+// LDS-only hand-off inside one wave: the LDS unit executes a wave's operations in program order,
+// so only the compiler must be kept from reordering
+__device__ __forceinline__ void lds_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // hspfinder.cpp:594-636
@@ -114,7 +129,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       if (p < nwA) { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; }
       tw[p] = word;
     }
-    wave_sync();
+    lds_sync();
     for (uint32_t p = lane; p < nwA; p += 64) {
       const uint32_t wd = tw[p];
       const uint4 *v4 = (const uint4 *)tw;
@@ -125,25 +140,24 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       tr[p] = (uint16_t)rank;
       atomicAdd(&c.wstart[wd], 1u);
     }
-    wave_sync();
+    lds_sync();
     {   // exclusive prefix sum of the counts: each lane owns a contiguous block of words
       const uint32_t per = (nwords + 63) / 64;
       uint32_t sum = 0;
       for (uint32_t k = 0; k < per; ++k) { const uint32_t wi = lane * per + k; if (wi < nwords) sum += c.wstart[wi]; }
-      uint32_t incl = sum;
-      for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+      const uint32_t incl = wave_incl_sum_u32(sum);
       uint32_t run = incl - sum;
       for (uint32_t k = 0; k < per; ++k) {
         const uint32_t wi = lane * per + k;
         if (wi < nwords) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = n ? (run | ((n < UGS_MAXREPS ? n : UGS_MAXREPS) << 16)) : 0u; run += n; }
       }
     }
-    wave_sync();
+    lds_sync();
     for (uint32_t p = lane; p < nwA; p += 64) {
       const uint32_t wd = tw[p];
       c.qsort[(c.wstart[wd] & 0xffffu) + tr[p]] = (wd << 16) | p;
     }
-    wave_sync();
+    lds_sync();
     return;
   }
   for (uint32_t p = lane; p < n2; p += 64) {
@@ -155,7 +169,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     }
     c.qsort[p] = key;
   }
-  wave_sync();
+  lds_sync();
   for (uint32_t k = 2; k <= n2; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       for (uint32_t i = lane; i < n2; i += 64) {
@@ -166,14 +180,14 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
           if ((x > y) == up) { c.qsort[i] = y; c.qsort[l] = x; }
         }
       }
-      wave_sync();
+      lds_sync();
     }
   if (c.wstart) {
     // direct word -> (first sorted index | min(count, MaxReps) << 16) table: replaces a binary
     // search per target position; count 0 = word absent from the query
     const uint32_t nwords = c.nwords;
     for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0;
-    wave_sync();
+    lds_sync();
     for (uint32_t i = lane; i < c.nwA; i += 64) {
       const uint32_t wd = c.qsort[i] >> 16;
       if (i == 0 || (c.qsort[i - 1] >> 16) != wd) {
@@ -182,7 +196,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
         c.wstart[wd] = i | (n << 16);
       }
     }
-    wave_sync();
+    lds_sync();
   }
 }
 
@@ -344,15 +358,14 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
             while (cnt < UGS_MAXREPS && lo + cnt < c.nwA && (c.qsort[lo + cnt] >> 16) == word) ++cnt;
           }
         }
-        uint32_t incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+        const uint32_t incl = wave_incl_sum_u32(cnt);
         const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t off = count + incl - cnt;
         for (uint32_t r = 0; r < cnt; ++r) c.seeds[off + r] = (bpos << 16) | (c.qsort[lo + r] & 0xffffu);
         count += total;
         scan += 64;
       }
-      wave_sync();
+      lds_sync();
       if (idx >= count) { if (scan >= nwB) break; else continue; }
       // ---- extend one round of (up to) 64 seeds
       const uint32_t me = idx + lane;
@@ -382,7 +395,7 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
     }
   }
   if (lane == 0) c.ws->nhsp = nh;
-  wave_sync();
+  lds_sync();
 }
 
 // chainer.cpp:352-500 on lane 0 (HSP counts are tiny); csc layout: [bp_pos 2n][bp_idxlo 2n][prev n][cscore n][list n]
