@@ -192,6 +192,53 @@ int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucle
                       const char *qlabel, const char *tlabel, char *buf, int cap);
 int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
 
+/* ------------------------------------------------------------------------------------------
+ * Gapped x-drop extension: the kernel the reference's local aligner
+ * calls per anchor (localaligner.cpp:190, :330).  Batched: every job is one call of
+ *   mode UGS_XDROP_ALIGN : XDropAlignMem   xdropalignmem.cpp:217-244 (-> :26-214; sides longer than
+ *                          g_MaxL = 4096 go through XDropFwdSplit / XDropBwdSplit
+ *                          xdropfwdsplit.cpp:24-91, xdropbwdsplit.cpp:15-79)
+ *   mode UGS_XDROP_FWD   : XDropFwdFastMem xdropfwdmem.cpp:344-749 on (A,B) from their first letters
+ *   mode UGS_XDROP_BWD   : XDropBwdFastMem xdropbwdmem.cpp:23-70   on (A,B) from their last letters
+ * (FWD/BWD require LA,LB <= 4096 as the reference's callers guarantee.)
+ * Scores are exact small integers held in float by the reference (alnparams.cpp:362-369:
+ * LocalOpen/LocalExt = -lopen/-lext = -10/-1 for both alphabets - the option defaults count as
+ * "filled", opts.cpp:187-192, so the aa -5 branch at :373-376 never runs; substitution matrix as
+ * for the global path).
+ */
+enum { UGS_XDROP_ALIGN = 0, UGS_XDROP_FWD = 1, UGS_XDROP_BWD = 2 };
+
+typedef struct ugs_xdrop_params {
+  int32_t is_nucleo;
+  float   match, mismatch;      /* nt matrix (setnucmx.cpp:11-99); aa: BLOSUM62 implied            */
+  float   local_open, local_ext;/* negative penalties, AlnParams::GetLocalOpen/Ext                  */
+  float   xdrop;                /* X: -xdrop_g, default 32 (o_defaults.inc:20)                      */
+} ugs_xdrop_params;
+
+typedef struct ugs_xdrop_job {
+  uint32_t a, b;                /* sequence indices into the A set / B set                          */
+  uint32_t anc_loi, anc_loj, anc_len;   /* anchor (ALIGN mode only)                                 */
+  uint32_t mode;
+} ugs_xdrop_job;
+
+typedef struct ugs_xdrop_hsp {  /* HSPData (hsp.h:4-11) + where the path went                        */
+  float    score;               /* 0 => no alignment (path empty)                                    */
+  uint32_t loi, loj, leni, lenj;
+  uint32_t path_len;            /* runs in the pool: len<<2 | op, op 0=M 1=D 2=I                     */
+  uint64_t path_off;
+} ugs_xdrop_hsp;
+
+void ugs_xdrop_params_init(ugs_xdrop_params *p, int is_nucleo);
+/* host buffers in, host buffers out; results in job order; path_pool filled in job order.
+ * UGS_E_CAPACITY if path_cap is too small (path_used then holds the needed size). */
+int ugs_xdrop_batch(int device, const ugs_xdrop_params *p,
+                    const char *a_seqs, const uint64_t *a_offs, uint32_t na,
+                    const char *b_seqs, const uint64_t *b_offs, uint32_t nb,
+                    const ugs_xdrop_job *jobs, uint32_t njobs,
+                    ugs_xdrop_hsp *hsps, uint32_t *path_pool, uint64_t path_cap, uint64_t *path_used);
+/* device time of the last ugs_xdrop_batch on this thread (kernel only, HIP events) and its DP cells */
+int ugs_xdrop_last_stats(float *ms_kernel, uint64_t *dp_cells);
+
 const char *ugs_last_error(void);
 
 #ifdef __cplusplus

@@ -32,3 +32,7 @@ export -f build_one; export OUT REF CXXFLAGS CFLAGS
 ls "$REF"/*.cpp "$REF"/*.c | xargs -P "$JOBS" -I{} bash -c 'build_one {}'
 g++ -O3 -pthread -static -o "$OUT/usearch12" "$OUT"/o/*.o -lpthread
 echo "build_ref: built $OUT/usearch12"
+# x-drop known-answer driver: our own main() (oracle/ref_xdrop_main.cpp) over the reference's objects
+g++ $CXXFLAGS -I"$REF" -c "$HERE/ref_xdrop_main.cpp" -o "$OUT/ref_xdrop_main.o"
+g++ -O3 -pthread -static -o "$OUT/ref_xdrop" "$OUT/ref_xdrop_main.o" $(ls "$OUT"/o/*.o | grep -v '/usearch_main\.o$') -lpthread
+echo "build_ref: built $OUT/ref_xdrop"

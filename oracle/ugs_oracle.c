@@ -1377,3 +1377,319 @@ int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap)
 {
   return snprintf(buf, (size_t)cap, "N\t*\t%u\t*\t.\t*\t*\t*\t%s\t*\n", ql, qlabel);
 }
+
+/* ================================================================== gapped x-drop (8a X1-X3)
+ * Restatement of the local aligner's extension kernel.  Same float arithmetic, same
+ * tie rules, same window bookkeeping as the reference; arrays are explicit instead of XDPMem. */
+
+#define XD_MAXL 4096u                 /* xdpmem.h:6 g_MaxL */
+#define XD_NEG  (-9e9f)               /* mx.h:12 MINUS_INFINITY */
+#define XD_DM 0x01                    /* tracebit.h:4-7 */
+#define XD_IM 0x02
+#define XD_MD 0x04
+#define XD_MI 0x08
+
+typedef struct XdMem {
+  float *mrow_base, *drow;            /* mrow = mrow_base + 1 so mrow[-1] exists (xdropfwdmem.cpp:393) */
+  byte *tb;                           /* (LA+1) x (LB+1) */
+  size_t tb_cap; unsigned row_cap;
+  byte *reva, *revb; unsigned rev_cap;
+  uint64_t cells;
+} XdMem;
+
+static void xd_alloc(XdMem *m, unsigned LA, unsigned LB)
+{
+  size_t need = (size_t)(LA + 1) * (LB + 1);
+  if (need > m->tb_cap) { m->tb = (byte *)xrealloc(m->tb, need); m->tb_cap = need; }
+  if (LB + 4 > m->row_cap) {
+    m->row_cap = LB + 4;
+    m->mrow_base = (float *)xrealloc(m->mrow_base, sizeof(float) * (m->row_cap + 1));
+    m->drow = (float *)xrealloc(m->drow, sizeof(float) * (m->row_cap + 1));
+  }
+  unsigned L = LA > LB ? LA : LB;
+  if (L > m->rev_cap) {
+    m->rev_cap = L;
+    m->reva = (byte *)xrealloc(m->reva, L);
+    m->revb = (byte *)xrealloc(m->revb, L);
+  }
+}
+
+static void xd_free(XdMem *m)
+{
+  free(m->mrow_base); free(m->drow); free(m->tb); free(m->reva); free(m->revb);
+  memset(m, 0, sizeof *m);
+}
+
+static unsigned xd_min(unsigned a, unsigned b) { return a < b ? a : b; }
+static unsigned xd_max(unsigned a, unsigned b) { return a > b ? a : b; }
+
+/* XDropFwdFastMem xdropfwdmem.cpp:344-749 (+ traceback :271-342).  path receives the
+ * forward M/D/I string, NUL-terminated (needs LA+LB+2 bytes). */
+static float xd_fwd(XdMem *mem, const float (*Sub)[256], float Open, float Ext,
+                    const byte *A, unsigned LA, const byte *B, unsigned LB, float X,
+                    unsigned *Leni, unsigned *Lenj, char *path)
+{
+  if (LA == 1 || LB == 1) {                               /* :360-368 */
+    *Leni = 1; *Lenj = 1; path[0] = 'M'; path[1] = 0;
+    return Sub[A[0]][B[0]];
+  }
+  xd_alloc(mem, LA, LB);
+  const float AbsOpen = -Open, AbsExt = -Ext;
+  const size_t W = (size_t)LB + 1;
+  byte *TB = mem->tb;
+  float *Mrow = mem->mrow_base + 1, *Drow = mem->drow;
+  Mrow[-1] = XD_NEG;
+  Drow[0] = XD_NEG; Drow[1] = XD_NEG;
+
+  float Best = Sub[A[0]][B[0]];                            /* :404 */
+  unsigned Besti = 0, Bestj = 0, prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
+  float M0 = Best;
+  for (unsigned i = 1; i < LA; ++i) {
+    if (jlo == prev_jlo) { Mrow[jlo - 1] = XD_NEG; Drow[jlo] = XD_NEG; }            /* :421-430 */
+    unsigned endj = xd_min(prev_jhi + 1, LB);
+    for (unsigned j = endj + 1; j <= xd_min(jhi + 1, LB); ++j) { Mrow[j - 1] = XD_NEG; Drow[j] = XD_NEG; }
+    unsigned next_jlo = UINT32_MAX, next_jhi = UINT32_MAX;
+    const float *MxRow = Sub[A[i]];
+    float I0 = XD_NEG;
+    byte *TBrow = TB + (size_t)i * W;
+    for (unsigned j = jlo; j <= jhi; ++j) {
+      ++mem->cells;
+      byte bits = 0;
+      const float SavedM0 = M0;
+      /* match :478-560 */
+      float xM = M0;
+      if (Drow[j] > xM) { xM = Drow[j]; bits = XD_DM; }
+      if (I0 > xM) { xM = I0; bits = XD_IM; }
+      M0 = Mrow[j];
+      float s = xM + MxRow[B[j]];
+      Mrow[j] = s;
+      float h = s - Best + X;
+      if (h > 0) { next_jlo = xd_min(next_jlo, j + 1); next_jhi = j + 1; }
+      if (h > AbsOpen) next_jlo = xd_min(next_jlo, j);
+      if (h > AbsExt && j == jhi && jhi + 1 < LB) {
+        ++jhi;
+        unsigned new_endj = xd_max(xd_min(jhi + 1, LB), endj);
+        for (unsigned j2 = endj + 1; j2 <= new_endj; ++j2) {
+          if (j2 - 1 > j) Mrow[j2 - 1] = XD_NEG;            /* :538-546: Mrow[j] already holds row i+1 */
+          Drow[j2] = XD_NEG;
+        }
+        endj = new_endj;
+      }
+      if (s >= Best) { Best = s; Besti = i; Bestj = j; }  /* :555 ties prefer later cells */
+      /* delete :563-589 */
+      if (j != jlo) {
+        float md = SavedM0 + Open;
+        Drow[j] += Ext;
+        if (md >= Drow[j]) { Drow[j] = md; bits |= XD_MD; }
+        float hd = Drow[j] - Best + X;
+        if (hd > 0) { next_jlo = xd_min(next_jlo, j - 1); next_jhi = xd_max(next_jhi, j - 1); }
+      }
+      /* insert :592-640 */
+      {
+        float mi = SavedM0 + Open;
+        I0 += Ext;
+        if (mi >= I0) { I0 = mi; bits |= XD_MI; }
+        float hi = I0 - Best + X;
+        if (hi > 0) { next_jlo = xd_min(next_jlo, j + 1); next_jhi = j + 1; }
+        if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
+          ++jhi;
+          unsigned new_endj = xd_max(xd_min(jhi + 1, LB), endj);
+          for (unsigned j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = XD_NEG; Drow[j2] = XD_NEG; }
+          endj = new_endj;
+        }
+      }
+      TBrow[j] = bits;
+    }
+    if (jhi < LB) {                                         /* end of Drow :645-666 */
+      const unsigned j1 = jhi + 1;
+      TBrow[j1] = 0;
+      float md = M0 + Open;
+      Drow[j1] += Ext;
+      if (md >= Drow[j1]) { Drow[j1] = md; TBrow[j1] = XD_MD; }
+    }
+    if (next_jlo == UINT32_MAX) break;
+    prev_jlo = jlo; prev_jhi = jhi;
+    jlo = next_jlo; jhi = next_jhi;
+    if (jlo >= LB) jlo = LB - 1;
+    if (jhi >= LB) jhi = LB - 1;
+    if (jlo == prev_jlo) { M0 = XD_NEG; Drow[jlo] = XD_NEG; }
+    else M0 = Mrow[jlo - 1];
+  }
+  if (Best <= 0.0f) { *Leni = 0; *Lenj = 0; path[0] = 0; return 0.0f; }   /* :712-718 */
+
+  /* XDropFwdTraceBackBitMem :271-342 */
+  unsigned i = Besti, j = Bestj, n = 0;
+  char State = 'M';
+  for (;;) {
+    path[n++] = State;
+    if (i == 0 && j == 0) break;
+    char Next;
+    if (State == 'M') {
+      byte c = TB[(size_t)i * W + j];
+      Next = (c & XD_DM) ? 'D' : (c & XD_IM) ? 'I' : 'M';
+      --i; --j;
+    } else if (State == 'D') {
+      byte c = TB[(size_t)i * W + j + 1];
+      Next = (c & XD_MD) ? 'M' : 'D';
+      --i;
+    } else {
+      byte c = TB[(size_t)(i + 1) * W + j];
+      Next = (c & XD_MI) ? 'M' : 'I';
+      --j;
+    }
+    State = Next;
+  }
+  for (unsigned k = 0; k < n / 2; ++k) { char t = path[k]; path[k] = path[n - 1 - k]; path[n - 1 - k] = t; }
+  path[n] = 0;
+  *Leni = Besti + 1; *Lenj = Bestj + 1;
+  return Best;
+}
+
+/* XDropBwdFastMem xdropbwdmem.cpp:23-70: reverse both, extend forward, reverse the path */
+static float xd_bwd(XdMem *mem, const float (*Sub)[256], float Open, float Ext,
+                    const byte *A, unsigned LA, const byte *B, unsigned LB, float X,
+                    unsigned *Leni, unsigned *Lenj, char *path)
+{
+  xd_alloc(mem, LA, LB);
+  for (unsigned i = 0; i < LA; ++i) mem->reva[i] = A[LA - 1 - i];
+  for (unsigned i = 0; i < LB; ++i) mem->revb[i] = B[LB - 1 - i];
+  /* the reversed copies live in mem; xd_fwd's xd_alloc cannot move them (same sizes) */
+  float Score = xd_fwd(mem, Sub, Open, Ext, mem->reva, LA, mem->revb, LB, X, Leni, Lenj, path);
+  if (Score <= 0.0f) return Score;
+  size_t n = strlen(path);
+  for (size_t k = 0; k < n / 2; ++k) { char t = path[k]; path[k] = path[n - 1 - k]; path[n - 1 - k] = t; }
+  return Score;
+}
+
+static unsigned xd_subl(unsigned L)                        /* GetSubL xdropfwdsplit.cpp:15-22 */
+{
+  if (L <= XD_MAXL) return L;
+  if (L < 2 * XD_MAXL) return L / 2;
+  return XD_MAXL;
+}
+
+/* XDropFwdSplit xdropfwdsplit.cpp:24-91 */
+static float xd_fwd_split(XdMem *mem, const float (*Sub)[256], float Open, float Ext,
+                          const byte *A, unsigned LA, const byte *B, unsigned LB, float X,
+                          unsigned *Leni, unsigned *Lenj, char *path, char *tmp)
+{
+  *Leni = 0; *Lenj = 0; path[0] = 0;
+  size_t n = 0;
+  float Sum = 0.0f;
+  for (;;) {
+    if (*Leni == LA || *Lenj == LB) break;
+    unsigned SubLA = xd_subl(LA - *Leni), SubLB = xd_subl(LB - *Lenj), si, sj;
+    float Score = xd_fwd(mem, Sub, Open, Ext, A + *Leni, SubLA, B + *Lenj, SubLB, X, &si, &sj, tmp);
+    if (Score == 0.0f) break;
+    Sum += Score; *Leni += si; *Lenj += sj;
+    size_t k = strlen(tmp);
+    memcpy(path + n, tmp, k + 1); n += k;
+    if (si < SubLA && sj < SubLB) break;
+  }
+  return Sum;
+}
+
+/* XDropBwdSplit xdropbwdsplit.cpp:15-79 */
+static float xd_bwd_split(XdMem *mem, const float (*Sub)[256], float Open, float Ext,
+                          const byte *A, unsigned LA, const byte *B, unsigned LB, float X,
+                          unsigned *Leni, unsigned *Lenj, char *path, char *tmp)
+{
+  *Leni = 0; *Lenj = 0; path[0] = 0;
+  size_t n = 0;
+  float Sum = 0.0f;
+  unsigned DoneA = 0, DoneB = 0;
+  for (;;) {
+    if (DoneA == LA || DoneB == LB) break;
+    unsigned SubLA = xd_subl(LA - DoneA), SubLB = xd_subl(LB - DoneB), si, sj;
+    const byte *SubA = A + LA - DoneA - SubLA, *SubB = B + LB - DoneB - SubLB;
+    float Score = xd_bwd(mem, Sub, Open, Ext, SubA, SubLA, SubB, SubLB, X, &si, &sj, tmp);
+    if (Score == 0.0f) break;
+    Sum += Score; *Leni += si; *Lenj += sj;
+    size_t k = strlen(tmp);                                 /* PrependPath */
+    memmove(path + k, path, n + 1); memcpy(path, tmp, k); n += k;
+    if (si < SubLA && sj < SubLB) break;
+    DoneA += si; DoneB += sj;
+  }
+  return Sum;
+}
+
+static const float (*xd_subst(const ugs_xdrop_params *p, float (*custom)[256]))[256]
+{
+  init_tables();
+  if (!p->is_nucleo) return g_subst_aa;
+  if (p->match == 1.0f && p->mismatch == -2.0f) return g_subst_nt_default;
+  fill_subst_nt(custom, p->match, p->mismatch);
+  return custom;
+}
+
+void orc_xdrop_params_init(ugs_xdrop_params *p, int is_nucleo)
+{
+  memset(p, 0, sizeof *p);
+  p->is_nucleo = is_nucleo;
+  p->match = 1.0f; p->mismatch = -2.0f;                     /* o_defaults.inc -match/-mismatch */
+  /* alnparams.cpp:362-369: -lopen/-lext defaults (o_defaults.inc:3-4: 10, 1) count as 'filled'
+   * (opts.cpp:187-192), so the -5 aa branch at :373-376 is dead: -10/-1 for both alphabets */
+  p->local_open = -10.0f;
+  p->local_ext = -1.0f;
+  p->xdrop = 32.0f;                                         /* o_defaults.inc:20 xdrop_g */
+}
+
+/* One job of the batched ABI.  path: NUL-terminated M/D/I, needs la+lb+2 bytes. */
+int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const char *b, uint32_t lb,
+                  const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells)
+{
+  float (*custom)[256] = NULL;
+  if (p->is_nucleo && !(p->match == 1.0f && p->mismatch == -2.0f)) custom = (float (*)[256])malloc(sizeof(float) * 65536);
+  const float (*Sub)[256] = xd_subst(p, custom);
+  const float Open = p->local_open, Ext = p->local_ext, X = p->xdrop;
+  const byte *A = (const byte *)a, *B = (const byte *)b;
+  XdMem mem; memset(&mem, 0, sizeof mem);
+  memset(hsp, 0, sizeof *hsp);
+  path[0] = 0;
+  int rc = 0;
+  if (job->mode == UGS_XDROP_FWD || job->mode == UGS_XDROP_BWD) {
+    if (la == 0 || lb == 0 || la > XD_MAXL || lb > XD_MAXL) { rc = -1; goto done; }
+    unsigned li, lj;
+    float sc = job->mode == UGS_XDROP_FWD ? xd_fwd(&mem, Sub, Open, Ext, A, la, B, lb, X, &li, &lj, path)
+                                          : xd_bwd(&mem, Sub, Open, Ext, A, la, B, lb, X, &li, &lj, path);
+    hsp->score = sc; hsp->leni = li; hsp->lenj = lj;
+    if (job->mode == UGS_XDROP_BWD) { hsp->loi = la - li; hsp->loj = lb - lj; }
+    goto done;
+  }
+  /* XDropAlignMemMaxL2 xdropalignmem.cpp:26-214 */
+  {
+    const unsigned AncLoi = job->anc_loi, AncLoj = job->anc_loj, AncLen = job->anc_len;
+    if (AncLen <= 1) goto done;                             /* :44-49 score 0, empty path */
+    if (!(AncLoi < la && AncLoj < lb && AncLoi + AncLen <= la && AncLoj + AncLen <= lb)) { rc = -1; goto done; }
+    const unsigned AncHii = AncLoi + AncLen - 1, AncHij = AncLoj + AncLen - 1;
+    const unsigned FwdLA = la - AncHii, FwdLB = lb - AncHij;
+    char *bp = (char *)malloc((size_t)la + lb + 4), *fp = (char *)malloc((size_t)la + lb + 4),
+         *tmp = (char *)malloc((size_t)la + lb + 4);
+    unsigned bi, bj, fi, fj;
+    float BwdScore, FwdScore;
+    if (AncLoi > XD_MAXL || AncLoj > XD_MAXL)
+      BwdScore = xd_bwd_split(&mem, Sub, Open, Ext, A, AncLoi + 1, B, AncLoj + 1, X, &bi, &bj, bp, tmp);
+    else
+      BwdScore = xd_bwd(&mem, Sub, Open, Ext, A, AncLoi + 1, B, AncLoj + 1, X, &bi, &bj, bp);
+    if (FwdLA > XD_MAXL || FwdLB > XD_MAXL)
+      FwdScore = xd_fwd_split(&mem, Sub, Open, Ext, A + AncHii, FwdLA, B + AncHij, FwdLB, X, &fi, &fj, fp, tmp);
+    else
+      FwdScore = xd_fwd(&mem, Sub, Open, Ext, A + AncHii, FwdLA, B + AncHij, FwdLB, X, &fi, &fj, fp);
+    size_t n = strlen(bp);
+    memcpy(path, bp, n);
+    memset(path + n, 'M', AncLen - 2); n += AncLen - 2;     /* :150 first & last anchor columns are in the x-drop paths */
+    strcpy(path + n, fp);
+    float AncScore = 0.0f;
+    for (unsigned k = 0; k < AncLen; ++k) AncScore += Sub[A[AncLoi + k]][B[AncLoj + k]];
+    float Dupe = Sub[A[AncLoi]][B[AncLoj]] + Sub[A[AncHii]][B[AncHij]];
+    hsp->score = BwdScore + FwdScore + AncScore - Dupe;     /* :176 */
+    hsp->loi = AncLoi + 1 - bi; hsp->loj = AncLoj + 1 - bj;
+    hsp->leni = bi + fi + AncLen - 2; hsp->lenj = bj + fj + AncLen - 2;
+    free(bp); free(fp); free(tmp);
+  }
+done:
+  if (cells) *cells = mem.cells;
+  xd_free(&mem);
+  free(custom);
+  return rc;
+}

@@ -72,6 +72,14 @@ int orc_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucle
                       const char *qlabel, const char *tlabel, char *buf, int cap);
 int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
 
+/* gapped x-drop extension, SURVEY.md 8a X1-X3 (xdropfwdmem.cpp, xdropbwdmem.cpp, xdropfwdsplit.cpp,
+ * xdropbwdsplit.cpp, xdropalignmem.cpp).  One job of the batched ABI (include/ugs.h ugs_xdrop_batch);
+ * path receives the NUL-terminated M/D/I text (needs la+lb+2 bytes); hsp->path_* are left 0.
+ * Returns 0, or -1 when the job violates the reference's asserts. */
+void orc_xdrop_params_init(ugs_xdrop_params *p, int is_nucleo);
+int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const char *b, uint32_t lb,
+                  const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells);
+
 void orc_params_init(ugs_params *p, int is_nucleo, double id);
 
 #ifdef __cplusplus

@@ -45,3 +45,22 @@ def params_kw(c):
     if "maxrejects" in c:
         kw["max_rejects"] = c["maxrejects"]
     return kw
+
+
+def load_xdrop(name):
+    """tests/golden/xdrop_{nt,aa}.txt -> list of dict(mode, x, a, b, anc, want) where want is the
+    reference's answer: (score, loi, loj, leni, lenj, path) with loi/loj None for F/B lines."""
+    out = []
+    lines = open(os.path.join(GOLD, "xdrop_%s.txt" % name)).read().splitlines()
+    for k in range(0, len(lines), 2):
+        c = lines[k].split()
+        r = lines[k + 1].split()
+        assert r[0] == "="
+        mode, x, a, b = c[0], float(c[1]), c[2], c[3]
+        anc = tuple(int(v) for v in c[4:7]) if mode == "A" else (0, 0, 0)
+        if mode == "A":
+            want = (float(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), "" if r[6] == "-" else r[6])
+        else:
+            want = (float(r[1]), None, None, int(r[2]), int(r[3]), "" if r[4] == "-" else r[4])
+        out.append(dict(mode=mode, x=x, a=a, b=b, anc=anc, want=want))
+    return out

@@ -4,7 +4,7 @@ import os
 import subprocess
 import numpy as np
 
-from usearch12_amd.abi import Params, HIT_DTYPE, ptr, as_u8, cigar_text
+from usearch12_amd.abi import Params, HIT_DTYPE, ptr, as_u8, cigar_text, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
@@ -53,8 +53,36 @@ def lib():
         L.orc_format_uc_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.orc_format_uc_nohit.restype = C.c_int
         L.orc_format_uc_nohit.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_xdrop_params_init.argtypes = [C.POINTER(XdropParams), C.c_int]
+        L.orc_xdrop_job.restype = C.c_int
+        L.orc_xdrop_job.argtypes = [C.POINTER(XdropParams), C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
+
+
+def xdrop_params(is_nucleo=True, xdrop=32.0):
+    p = XdropParams()
+    lib().orc_xdrop_params_init(C.byref(p), int(is_nucleo))
+    p.xdrop = xdrop
+    return p
+
+
+def xdrop_job(p, a, b, mode, anc=(0, 0, 0)):
+    """one x-drop job through the oracle -> (score, loi, loj, leni, lenj, path text, cells) or None if rc<0"""
+    a = a if isinstance(a, bytes) else a.encode()
+    b = b if isinstance(b, bytes) else b.encode()
+    job = np.zeros(1, XDROP_JOB_DTYPE)
+    job["anc_loi"], job["anc_loj"], job["anc_len"] = anc
+    job["mode"] = mode
+    hsp = np.zeros(1, XDROP_HSP_DTYPE)
+    path = C.create_string_buffer(len(a) + len(b) + 8)
+    cells = C.c_uint64(0)
+    rc = lib().orc_xdrop_job(C.byref(p), a, len(a), b, len(b), job.ctypes.data, hsp.ctypes.data, path, C.byref(cells))
+    if rc < 0:
+        return None
+    h = hsp[0]
+    return float(h["score"]), int(h["loi"]), int(h["loj"]), int(h["leni"]), int(h["lenj"]), path.value.decode(), cells.value
 
 
 def params(is_nucleo=True, id=0.97, **kw):

@@ -36,6 +36,26 @@ class BatchStats(C.Structure):
     ]
 
 
+class XdropParams(C.Structure):
+    """mirror of ugs_xdrop_params (include/ugs.h)"""
+    _fields_ = [("is_nucleo", C.c_int32), ("match", C.c_float), ("mismatch", C.c_float),
+                ("local_open", C.c_float), ("local_ext", C.c_float), ("xdrop", C.c_float)]
+
+
+XDROP_ALIGN, XDROP_FWD, XDROP_BWD = 0, 1, 2
+XDROP_JOB_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("anc_loi", "<u4"), ("anc_loj", "<u4"), ("anc_len", "<u4"),
+                            ("mode", "<u4")])
+XDROP_HSP_DTYPE = np.dtype([("score", "<f4"), ("loi", "<u4"), ("loj", "<u4"), ("leni", "<u4"), ("lenj", "<u4"),
+                            ("path_len", "<u4"), ("path_off", "<u8")])
+assert XDROP_JOB_DTYPE.itemsize == 24 and XDROP_HSP_DTYPE.itemsize == 32
+
+
+def path_text(pool, off, n):
+    """run-length pool (len<<2|op) -> M/D/I text"""
+    runs = pool[int(off):int(off) + int(n)]
+    return "".join("MDI"[int(r) & 3] * (int(r) >> 2) for r in runs)
+
+
 def as_u8(buf):
     a = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else np.ascontiguousarray(buf, dtype=np.uint8)
     return a
