@@ -1420,6 +1420,9 @@ static void xd_free(XdMem *m)
   memset(m, 0, sizeof *m);
 }
 
+static unsigned long g_xd_wipes = 0;       /* how often the insert-branch re-initialisation hit a live cell */
+unsigned long orc_xdrop_wipes(void) { return g_xd_wipes; }
+
 static unsigned xd_min(unsigned a, unsigned b) { return a < b ? a : b; }
 static unsigned xd_max(unsigned a, unsigned b) { return a > b ? a : b; }
 
@@ -1494,6 +1497,9 @@ static float xd_fwd(XdMem *mem, const float (*Sub)[256], float Open, float Ext,
         if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
           ++jhi;
           unsigned new_endj = xd_max(xd_min(jhi + 1, LB), endj);
+          /* no guard here (the match branch has one): when endj == j this wipes the DPM[i+1][j+1]
+           * just stored in Mrow[j] - reproduced, results depend on it; counted for the tests */
+          if (endj + 1 <= new_endj && endj == j) ++g_xd_wipes;
           for (unsigned j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = XD_NEG; Drow[j2] = XD_NEG; }
           endj = new_endj;
         }

@@ -77,6 +77,9 @@ int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
  * path receives the NUL-terminated M/D/I text (needs la+lb+2 bytes); hsp->path_* are left 0.
  * Returns 0, or -1 when the job violates the reference's asserts. */
 void orc_xdrop_params_init(ugs_xdrop_params *p, int is_nucleo);
+/* test statistic: times the reference's unguarded insert-branch re-initialisation (xdropfwdmem.cpp:625-631)
+ * overwrote a freshly stored cell (not thread-safe; tests only) */
+unsigned long orc_xdrop_wipes(void);
 int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const char *b, uint32_t lb,
                   const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells);
 

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .abi import Params, HIT_DTYPE, BatchStats, as_u8
+from .abi import Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libugs.so")
@@ -20,6 +20,7 @@ EXPORTS = [
     "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
+    "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
 ]
 
 
@@ -59,6 +60,10 @@ def lib():
         L.ugs_format_uc_hit.argtypes = [vp, vp, i32, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_nohit.argtypes = [u32, C.c_char_p, C.c_char_p, i32]
         L.ugs_last_error.restype = C.c_char_p
+        L.ugs_xdrop_params_init.argtypes = [C.POINTER(XdropParams), i32]
+        L.ugs_xdrop_params_init.restype = None
+        L.ugs_xdrop_batch.argtypes = [i32, C.POINTER(XdropParams), vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, u64, C.POINTER(u64)]
+        L.ugs_xdrop_last_stats.argtypes = [C.POINTER(C.c_float), C.POINTER(u64)]
         _lib = L
     return _lib
 
@@ -200,3 +205,45 @@ class UgsBatch:
         n = np.zeros(max(units, 1), dtype=np.uint32)
         _chk(lib().ugs_batch_get_candidates(self.h, cand.ctypes.data, cnt.ctypes.data, n.ctypes.data, K))
         return cand[:units], cnt[:units], n[:units]
+
+
+def xdrop_params(is_nucleo=True, **kw):
+    p = XdropParams()
+    lib().ugs_xdrop_params_init(C.byref(p), 1 if is_nucleo else 0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def xdrop_batch(p, a_set, b_set, jobs, device=0):
+    """Gapped x-drop extension of every job (include/ugs.h ugs_xdrop_batch; reference XDropAlignMem /
+    XDropFwdFastMem / XDropBwdFastMem).  a_set, b_set: (uint8 letters, uint64 offsets) pairs; jobs: XDROP_JOB_DTYPE
+    array.  Returns (hsps[XDROP_HSP_DTYPE], path pool uint32)."""
+    a_seqs, a_offs = a_set
+    b_seqs, b_offs = b_set
+    a_seqs, b_seqs = as_u8(a_seqs), as_u8(b_seqs)
+    a_offs = np.ascontiguousarray(a_offs, dtype=np.uint64)
+    b_offs = np.ascontiguousarray(b_offs, dtype=np.uint64)
+    jobs = np.ascontiguousarray(jobs, dtype=XDROP_JOB_DTYPE)
+    n = len(jobs)
+    hsps = np.zeros(n, XDROP_HSP_DTYPE)
+    cap = 1 << 16
+    while True:
+        pool = np.zeros(cap, np.uint32)
+        used = C.c_uint64(0)
+        rc = lib().ugs_xdrop_batch(device, C.byref(p), a_seqs.ctypes.data, a_offs.ctypes.data, len(a_offs) - 1,
+                                   b_seqs.ctypes.data, b_offs.ctypes.data, len(b_offs) - 1, jobs.ctypes.data, n,
+                                   hsps.ctypes.data, pool.ctypes.data, cap, C.byref(used))
+        if rc == -5 and used.value > cap:          # UGS_E_CAPACITY: path_used holds the needed size
+            cap = int(used.value)
+            continue
+        _chk(rc)
+        return hsps, pool[:used.value]
+
+
+def xdrop_last_stats():
+    ms, cells = C.c_float(0), C.c_uint64(0)
+    lib().ugs_xdrop_last_stats(C.byref(ms), C.byref(cells))
+    return ms.value, cells.value

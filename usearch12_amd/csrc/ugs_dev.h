@@ -107,3 +107,5 @@ size_t ugs_compact_tmp_bytes(uint32_t nq);
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);
+extern const char UGS_B62_ORDER[];          // the 23 alphabetic BLOSUM62 symbols
+extern const signed char UGS_B62[23][23];

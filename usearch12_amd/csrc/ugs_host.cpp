@@ -89,8 +89,9 @@ extern "C" int ugs_params_init(ugs_params *p, int is_nucleo, double id)
 }
 
 // ---------------------------------------------------------------- tables
-static const char B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX";
-static const signed char B62[23][23] = {   // BLOSUM62 (NCBI), the 23 alphabetic symbols
+extern const char UGS_B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX";
+#define B62_ORDER UGS_B62_ORDER
+extern const signed char UGS_B62[23][23] = {   // BLOSUM62 (NCBI), the 23 alphabetic symbols
   { 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0,-2,-1, 0},
   {-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3,-1, 0,-1},
   {-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3, 3, 0,-1},
@@ -150,7 +151,7 @@ static int build_tables(const ugs_params &p, UgsTables &T)
       if (let[i] >= 0 && let[j] >= 0) T.sub2[i * 32 + j] = (int8_t)(let[i] == let[j] ? m2 : mm2);
   } else {
     for (int i = 0; i < 23; ++i) for (int j = 0; j < 23; ++j)
-      T.sub2[(B62_ORDER[i] - 'A') * 32 + (B62_ORDER[j] - 'A')] = (int8_t)(2 * B62[i][j]);
+      T.sub2[(B62_ORDER[i] - 'A') * 32 + (B62_ORDER[j] - 'A')] = (int8_t)(2 * UGS_B62[i][j]);
   }
   // identity classes (alpha2.cpp:220-300): same letter; nt: IUPAC "base in wildcard set" either way;
   // aa: X matches anything, and UPPER-CASE B/N, B/D, Z/Q, Z/E
