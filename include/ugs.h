@@ -239,6 +239,30 @@ int ugs_xdrop_batch(int device, const ugs_xdrop_params *p,
 /* device time of the last ugs_xdrop_batch on this thread (kernel only, HIP events) and its DP cells */
 int ugs_xdrop_last_stats(float *ms_kernel, uint64_t *dp_cells);
 
+/* ------------------------------------------------------------------------------------------
+ * .udb files: the reference's on-disk database, written by -makeudb_usearch
+ * (UDBData::ToUDBFile udbio.cpp:280-352 + SeqDB::ToFile seqdbio.cpp:17-113) and read by LoadUDB
+ * (loaddb.cpp:100-125 -> UDBData::FromUDBFile udbio.cpp:242-278 + SeqDB::FromFile seqdbio.cpp:160-235).
+ * Layout: packed UDBFileHdr (udbfile.h:18-49, 200 bytes) | uint32 row sizes[slots] | 'UDB3' | rows
+ * (uint32 target indexes, ascending) | 'UDB4' | SeqDBFileHdr (32 bytes) | label offsets | labels |
+ * lengths | letters (as masked at makeudb time).
+ * Only the default index flavour is supported (unhashed, unspaced, uncoded, dbstep 1, dbaccel 100);
+ * anything else returns UGS_E_ENVELOPE.
+ */
+typedef struct ugs_udb_info {
+  int32_t  is_nucleo;
+  uint32_t word_len;
+  uint64_t nseq, nletters, label_bytes;   /* labels: NUL-terminated, concatenated in target order */
+  uint64_t slots, n_postings;
+} ugs_udb_info;
+int ugs_udb_stat(const char *path, ugs_udb_info *info);
+/* Any of the output pointers may be NULL.  seqs[nletters], offs[nseq+1], labels[label_bytes],
+ * row_sizes[slots], postings[n_postings] (rows concatenated in slot order). */
+int ugs_udb_read(const char *path, char *seqs, uint64_t *offs, char *labels, uint32_t *row_sizes, uint32_t *postings);
+/* Writes the database held by `db` (masked letters + the index built on the GPU) in the reference's format;
+ * byte-identical to the reference's -makeudb_usearch output for the same FASTA.  labels: nseq NUL-terminated strings. */
+int ugs_udb_write(const char *path, const ugs_db *db, const char *labels, uint64_t label_bytes);
+
 const char *ugs_last_error(void);
 
 #ifdef __cplusplus

@@ -36,6 +36,12 @@ class BatchStats(C.Structure):
     ]
 
 
+class UdbInfo(C.Structure):
+    """mirror of ugs_udb_info (include/ugs.h)"""
+    _fields_ = [("is_nucleo", C.c_int32), ("word_len", C.c_uint32), ("nseq", C.c_uint64), ("nletters", C.c_uint64),
+                ("label_bytes", C.c_uint64), ("slots", C.c_uint64), ("n_postings", C.c_uint64)]
+
+
 class XdropParams(C.Structure):
     """mirror of ugs_xdrop_params (include/ugs.h)"""
     _fields_ = [("is_nucleo", C.c_int32), ("match", C.c_float), ("mismatch", C.c_float),

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .abi import Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from .abi import UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libugs.so")
@@ -21,6 +21,7 @@ EXPORTS = [
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
+    "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
 ]
 
 
@@ -64,6 +65,9 @@ def lib():
         L.ugs_xdrop_params_init.restype = None
         L.ugs_xdrop_batch.argtypes = [i32, C.POINTER(XdropParams), vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, u64, C.POINTER(u64)]
         L.ugs_xdrop_last_stats.argtypes = [C.POINTER(C.c_float), C.POINTER(u64)]
+        L.ugs_udb_stat.argtypes = [C.c_char_p, C.POINTER(UdbInfo)]
+        L.ugs_udb_read.argtypes = [C.c_char_p, vp, vp, vp, vp, vp]
+        L.ugs_udb_write.argtypes = [C.c_char_p, vp, vp, u64]
         _lib = L
     return _lib
 
@@ -247,3 +251,27 @@ def xdrop_last_stats():
     ms, cells = C.c_float(0), C.c_uint64(0)
     lib().ugs_xdrop_last_stats(C.byref(ms), C.byref(cells))
     return ms.value, cells.value
+
+
+def udb_read(path, index=False):
+    """Reference-format .udb (include/ugs.h ugs_udb_read) -> dict(is_nucleo, word_len, seqs, offs, labels[, row_sizes, postings])"""
+    info = UdbInfo()
+    _chk(lib().ugs_udb_stat(path.encode(), C.byref(info)))
+    seqs = np.zeros(info.nletters, np.uint8)
+    offs = np.zeros(info.nseq + 1, np.uint64)
+    labels = np.zeros(max(info.label_bytes, 1), np.uint8)
+    sizes = np.zeros(info.slots if index else 1, np.uint32)
+    post = np.zeros(max(info.n_postings, 1) if index else 1, np.uint32)
+    _chk(lib().ugs_udb_read(path.encode(), seqs.ctypes.data, offs.ctypes.data, labels.ctypes.data,
+                            sizes.ctypes.data if index else None, post.ctypes.data if index else None))
+    out = dict(is_nucleo=bool(info.is_nucleo), word_len=int(info.word_len), seqs=seqs, offs=offs,
+               labels=bytes(labels[:info.label_bytes]).decode().split("\0")[:-1])
+    if index:
+        out.update(row_sizes=sizes, postings=post[:info.n_postings])
+    return out
+
+
+def udb_write(path, db, labels):
+    """Write db (a UgsDB) with the given labels as a reference-format .udb (index as built on the GPU)."""
+    blob = b"".join(l.encode() + b"\0" for l in labels)
+    _chk(lib().ugs_udb_write(path.encode(), db.h, blob, len(blob)))

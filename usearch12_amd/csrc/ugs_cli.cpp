@@ -1,8 +1,9 @@
 // ugs_cli.cpp - host-side driver with the reference's command-line surface for the one command
 // this repository accelerates:
 //
-//   ugs_cli -usearch_global q.fa -db db.fa -id 0.97 -strand plus|both [-blast6out f] [-uc f]
+//   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
+//   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
 //
 // It stands where cmd_usearch_global -> Search() -> Thread() stand in the reference
 // (searchcmd.cpp:6-9, search.cpp:51-141): load the DB, stream query batches through the C-ABI
@@ -66,6 +67,7 @@ class Searcher {
     if (ugs_db_create(&p_, db.letters.data(), db.offs.data(), (uint32_t)db.size(), device, &db_) != UGS_OK) die("ugs_db_create");
   }
   ~Searcher() { ugs_db_destroy(db_); }
+  const ugs_db *handle() const { return db_; }
   void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
     const uint32_t nq = (uint32_t)q.size();
     hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) + 1);
@@ -94,6 +96,31 @@ static void output_query(FILE *fb6, FILE *fuc, const ugs_params &p, const SeqSet
   }
 }
 
+// LoadUDB (loaddb.cpp:100-125): a .udb is recognised by its magic; its letters are used as stored (already masked)
+static bool is_udb_file(const char *path)
+{
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  unsigned char m[4] = {0, 0, 0, 0};
+  const size_t n = fread(m, 1, 4, f);
+  fclose(f);
+  return n == 4 && m[0] == 'F' && m[1] == 'B' && m[2] == 'D' && m[3] == 'U';
+}
+
+static bool load_udb(const char *path, SeqSet &db, bool &nucleo, uint32_t &word_len)
+{
+  ugs_udb_info info;
+  if (ugs_udb_stat(path, &info) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return false; }
+  db.letters.resize(info.nletters);
+  db.offs.assign(info.nseq + 1, 0);
+  std::string labels(info.label_bytes, '\0');
+  if (ugs_udb_read(path, &db.letters[0], db.offs.data(), &labels[0], nullptr, nullptr) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return false; }
+  db.labels.clear();
+  for (size_t o = 0; o < labels.size(); o += strlen(labels.c_str() + o) + 1) db.labels.emplace_back(labels.c_str() + o);
+  nucleo = info.is_nucleo != 0; word_len = info.word_len;
+  return db.labels.size() == info.nseq;
+}
+
 static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100 letters (seqdb.cpp:268-320); here: the first 1000
 {
   size_t n = 0, nt = 0;
@@ -107,12 +134,13 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 
 int main(int argc, char **argv)
 {
-  std::string qpath, dbpath, b6path, ucpath, strand;
+  std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
-    if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
+    if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
+    else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
     else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
@@ -120,10 +148,28 @@ int main(int argc, char **argv)
     else if (a == "-threads" || a == "-quiet") { if (a == "-threads") val(); }   // accepted, meaningless here
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
   }
+  if (!makeudb.empty()) {                                   // cmd_makeudb_usearch makeudb.cpp:27-66
+    if (outpath.empty()) { fprintf(stderr, "-makeudb_usearch needs -output\n"); return 1; }
+    SeqSet db;
+    { FastaReader r(makeudb.c_str()); while (r.read(db, 1u << 20)) {} }
+    if (db.size() == 0) { fprintf(stderr, "Empty database\n"); return 1; }
+    const bool nucleo = dbtype >= 0 ? dbtype != 0 : guess_nucleo(db);
+    ugs_params p;
+    ugs_params_init(&p, nucleo, 0.5);
+    Searcher s(p, db, device);
+    std::string labels;
+    for (const std::string &l : db.labels) { labels += l; labels.push_back('\0'); }
+    if (ugs_udb_write(outpath.c_str(), s.handle(), labels.data(), labels.size()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    return 0;
+  }
   if (qpath.empty() || dbpath.empty()) { fprintf(stderr, "usage: ugs_cli -usearch_global q.fa -db db.fa -id 0.97 -strand plus -blast6out o.b6 -uc o.uc\n"); return 1; }
   SeqSet db;
-  { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
-  const bool nucleo = dbtype >= 0 ? dbtype != 0 : guess_nucleo(db);
+  bool from_udb = false, udb_nucleo = true; uint32_t udb_word = 0;
+  if (is_udb_file(dbpath.c_str())) {
+    if (!load_udb(dbpath.c_str(), db, udb_nucleo, udb_word)) return 1;
+    from_udb = true;
+  } else { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
+  const bool nucleo = from_udb ? udb_nucleo : (dbtype >= 0 ? dbtype != 0 : guess_nucleo(db));
   if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
@@ -132,6 +178,7 @@ int main(int argc, char **argv)
   if (maxacc >= 0) p.max_accepts = maxacc;
   if (maxrej >= 0) p.max_rejects = maxrej;
   if (big >= 0) p.big = (uint32_t)big;
+  if (from_udb) { p.dbmask = 0; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   FILE *fb6 = b6path.empty() ? nullptr : fopen(b6path.c_str(), "w");
   FILE *fuc = ucpath.empty() ? nullptr : fopen(ucpath.c_str(), "w");
   Searcher searcher(p, db, device);

@@ -756,3 +756,148 @@ extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void 
   if (cigar_bytes) *cigar_bytes = b->cigar_used_host * 4;
   return UGS_OK;
 }
+
+// ---------------------------------------------------------------- .udb files
+namespace {
+#pragma pack(push, 1)
+struct UdbHdr {                       // udbfile.h:18-49
+  uint32_t magic1, hashed, seq_index_bits, seq_pos_bits, word_width, db_step, db_accel_pct, rfu1, rfu2, utax, end_of_row;
+  uint64_t slot_count, seq_count;
+  uint8_t step_prefix[8];
+  char alpha[64], pattern[64];
+  uint32_t magic2;
+};
+#pragma pack(pop)
+struct SeqDbHdr { uint32_t magic1, seq_count; uint64_t seq_bytes; uint32_t label_bytes, split_count, magic2, pad; };   // seqdb.h:19-27
+static_assert(sizeof(UdbHdr) == 200 && sizeof(SeqDbHdr) == 32, "file header layout");
+constexpr uint32_t fourcc(char a, char b, char c, char d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
+const uint32_t UDB_MAGIC1 = fourcc('F', 'B', 'D', 'U'), UDB_MAGIC2 = fourcc('f', 'B', 'D', 'U');   // MAGIC('U','D','B','F') as stored
+const uint32_t UDB_MAGIC3 = fourcc('3', 'B', 'D', 'U'), UDB_MAGIC4 = fourcc('4', 'B', 'D', 'U');
+const uint32_t SEQDB_MAGIC1 = 0x5E0DB3, SEQDB_MAGIC2 = 0x5E0DB4;
+
+struct File {
+  FILE *f = nullptr;
+  ~File() { if (f) fclose(f); }
+};
+bool rd(FILE *f, void *p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+bool wr(FILE *f, const void *p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+
+// parse both headers; leaves the file positioned at the label offsets
+int udb_open(const char *path, File &F, UdbHdr &h, SeqDbHdr &sh, ugs_udb_info &info, std::vector<uint32_t> *sizes_out)
+{
+  if (!path) { ugs_set_error("null path"); return UGS_E_ARG; }
+  F.f = fopen(path, "rb");
+  if (!F.f) { ugs_set_error("cannot open %s", path); return UGS_E_ARG; }
+  if (!rd(F.f, &h, sizeof h) || h.magic1 != UDB_MAGIC1 || h.magic2 != UDB_MAGIC2) { ugs_set_error("%s: not a .udb file", path); return UGS_E_ARG; }
+  const bool nt = strcmp(h.alpha, "nt") == 0, aa = strcmp(h.alpha, "aa") == 0;
+  if ((!nt && !aa) || h.hashed || h.pattern[0] || h.seq_pos_bits != 0 || h.seq_index_bits != 32 || h.db_step != 1 ||
+      h.db_accel_pct != 100 || h.end_of_row || h.utax || h.word_width == 0 || h.word_width > 12) {
+    ugs_set_error("%s: unsupported .udb flavour (alpha '%s', hashed %u, spaced %d, coded %u/%u, dbstep %u, dbaccel %u)", path, h.alpha,
+                  h.hashed, h.pattern[0] != 0, h.seq_index_bits, h.seq_pos_bits, h.db_step, h.db_accel_pct);
+    return UGS_E_ENVELOPE;
+  }
+  uint64_t slots = 1;
+  for (uint32_t k = 0; k < h.word_width; ++k) slots *= nt ? 4 : 20;       // udbparams.cpp:235-261 unhashed dictionary
+  if (slots > (1ull << 32)) { ugs_set_error("%s: word width %u too large", path, h.word_width); return UGS_E_ENVELOPE; }
+  std::vector<uint32_t> sizes(slots);
+  if (!rd(F.f, sizes.data(), slots * 4)) { ugs_set_error("%s: truncated (row sizes)", path); return UGS_E_ARG; }
+  uint32_t m = 0;
+  if (!rd(F.f, &m, 4) || m != UDB_MAGIC3) { ugs_set_error("%s: bad magic3", path); return UGS_E_ARG; }
+  uint64_t np = 0;
+  for (uint32_t v : sizes) np += v;
+  info.is_nucleo = nt; info.word_len = h.word_width; info.slots = slots; info.n_postings = np; info.nseq = h.seq_count;
+  const long rows_pos = ftell(F.f);
+  if (fseek(F.f, (long)(rows_pos + np * 4), SEEK_SET) != 0 || !rd(F.f, &m, 4) || m != UDB_MAGIC4) { ugs_set_error("%s: bad magic4", path); return UGS_E_ARG; }
+  if (!rd(F.f, &sh, 28) ) { ugs_set_error("%s: truncated (seqdb header)", path); return UGS_E_ARG; }
+  uint32_t pad = 0;
+  if (!rd(F.f, &pad, 4) || sh.magic1 != SEQDB_MAGIC1 || sh.magic2 != SEQDB_MAGIC2 || sh.seq_count != h.seq_count) { ugs_set_error("%s: bad seqdb header", path); return UGS_E_ARG; }
+  info.nletters = sh.seq_bytes; info.label_bytes = sh.label_bytes;
+  if (sizes_out) sizes_out->swap(sizes);
+  // remember where the rows start for the caller
+  info.slots = slots;
+  (void)rows_pos;
+  return UGS_OK;
+}
+}  // namespace
+
+extern "C" int ugs_udb_stat(const char *path, ugs_udb_info *info)
+{
+  if (!info) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  memset(info, 0, sizeof *info);
+  File F; UdbHdr h; SeqDbHdr sh;
+  return udb_open(path, F, h, sh, *info, nullptr);
+}
+
+extern "C" int ugs_udb_read(const char *path, char *seqs, uint64_t *offs, char *labels, uint32_t *row_sizes, uint32_t *postings)
+{
+  File F; UdbHdr h; SeqDbHdr sh; ugs_udb_info info;
+  memset(&info, 0, sizeof info);
+  std::vector<uint32_t> sizes;
+  int rc = udb_open(path, F, h, sh, info, &sizes);
+  if (rc != UGS_OK) return rc;
+  const uint64_t n = info.nseq;
+  // positioned behind the seqdb header: label offsets, labels, lengths, letters
+  std::vector<uint32_t> loffs(n), lens(n);
+  std::vector<char> lbuf(info.label_bytes);
+  if (!rd(F.f, loffs.data(), n * 4) || !rd(F.f, lbuf.data(), info.label_bytes) || !rd(F.f, lens.data(), n * 4)) { ugs_set_error("%s: truncated (labels/lengths)", path); return UGS_E_ARG; }
+  if (labels) {                       // re-pack in target order (the file keeps them in order already; offsets are honoured anyway)
+    uint64_t o = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      if (loffs[k] >= info.label_bytes) { ugs_set_error("%s: bad label offset", path); return UGS_E_ARG; }
+      const size_t l = strnlen(lbuf.data() + loffs[k], info.label_bytes - loffs[k]) + 1;
+      if (o + l > info.label_bytes) { ugs_set_error("%s: labels overlap", path); return UGS_E_ARG; }
+      memcpy(labels + o, lbuf.data() + loffs[k], l - 1); labels[o + l - 1] = 0; o += l;
+    }
+  }
+  uint64_t tot = 0;
+  for (uint64_t k = 0; k < n; ++k) { if (offs) offs[k] = tot; tot += lens[k]; }
+  if (offs) offs[n] = tot;
+  if (tot != info.nletters) { ugs_set_error("%s: sequence lengths do not add up", path); return UGS_E_ARG; }
+  if (seqs && !rd(F.f, seqs, tot)) { ugs_set_error("%s: truncated (letters)", path); return UGS_E_ARG; }
+  if (row_sizes) memcpy(row_sizes, sizes.data(), sizes.size() * 4);
+  if (postings) {
+    if (fseek(F.f, (long)(sizeof(UdbHdr) + info.slots * 4 + 4), SEEK_SET) != 0 || !rd(F.f, postings, info.n_postings * 4)) { ugs_set_error("%s: truncated (rows)", path); return UGS_E_ARG; }
+  }
+  return UGS_OK;
+}
+
+extern "C" int ugs_udb_write(const char *path, const ugs_db *db, const char *labels, uint64_t label_bytes)
+{
+  if (!path || !db || (!labels && db->v.nseq)) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  const uint64_t n = db->v.nseq, slots = db->v.slots;
+  if (label_bytes > 0xfffffbffull) { ugs_set_error("label data too big"); return UGS_E_ENVELOPE; }
+  std::vector<uint32_t> loffs(n);
+  {
+    uint64_t o = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      if (o >= label_bytes) { ugs_set_error("fewer than %llu labels", (unsigned long long)n); return UGS_E_ARG; }
+      loffs[k] = (uint32_t)o;
+      o += strnlen(labels + o, label_bytes - o) + 1;
+    }
+    if (o != label_bytes) { ugs_set_error("label_bytes does not match %llu NUL-terminated labels", (unsigned long long)n); return UGS_E_ARG; }
+  }
+  std::vector<uint64_t> row_off(slots + 1), offs(n + 1);
+  std::vector<uint32_t> postings(db->n_postings);
+  HIPCHK(hipSetDevice(db->device));
+  HIPCHK(hipMemcpy(offs.data(), db->d_offs, (n + 1) * 8, hipMemcpyDeviceToHost));
+  std::vector<char> seqs(offs[n]);
+  int rc = ugs_db_debug_fetch(db, seqs.data(), row_off.data(), postings.data());
+  if (rc != UGS_OK) return rc;
+  UdbHdr h; memset(&h, 0, sizeof h);                          // UDBFileHdr::FromParams udbio.cpp:13-52
+  h.magic1 = UDB_MAGIC1; h.seq_index_bits = 32; h.word_width = (uint32_t)db->p.word_len; h.db_step = 1; h.db_accel_pct = 100;
+  h.seq_count = n; strcpy(h.alpha, db->p.is_nucleo ? "nt" : "aa"); h.magic2 = UDB_MAGIC2;
+  std::vector<uint32_t> sizes(slots), lens(n);
+  for (uint64_t s = 0; s < slots; ++s) sizes[s] = (uint32_t)(row_off[s + 1] - row_off[s]);
+  for (uint64_t k = 0; k < n; ++k) lens[k] = (uint32_t)(offs[k + 1] - offs[k]);
+  SeqDbHdr sh; memset(&sh, 0, sizeof sh);
+  sh.magic1 = SEQDB_MAGIC1; sh.seq_count = (uint32_t)n; sh.seq_bytes = offs[n]; sh.label_bytes = (uint32_t)label_bytes; sh.magic2 = SEQDB_MAGIC2;
+  File F;
+  F.f = fopen(path, "wb");
+  if (!F.f) { ugs_set_error("cannot create %s", path); return UGS_E_ARG; }
+  const uint32_t m3 = UDB_MAGIC3, m4 = UDB_MAGIC4;
+  const bool ok = wr(F.f, &h, sizeof h) && wr(F.f, sizes.data(), slots * 4) && wr(F.f, &m3, 4) && wr(F.f, postings.data(), postings.size() * 4) &&
+                  wr(F.f, &m4, 4) && wr(F.f, &sh, sizeof sh) && wr(F.f, loffs.data(), n * 4) && wr(F.f, labels, label_bytes) &&
+                  wr(F.f, lens.data(), n * 4) && wr(F.f, seqs.data(), seqs.size());
+  if (!ok) { ugs_set_error("write error on %s", path); return UGS_E_ARG; }
+  return UGS_OK;
+}
