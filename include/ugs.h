@@ -263,6 +263,35 @@ int ugs_udb_read(const char *path, char *seqs, uint64_t *offs, char *labels, uin
  * byte-identical to the reference's -makeudb_usearch output for the same FASTA.  labels: nseq NUL-terminated strings. */
 int ugs_udb_write(const char *path, const ugs_db *db, const char *labels, uint64_t label_bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Output fidelity beyond blast6/uc; host-side formatting of device results.
+ *
+ * ugs_format_userout: OutputSink::OutputUser (h != NULL) / OutputUserNoHits (h == NULL), userout.cpp:47-352.
+ * fields = the -userfields string ("query+target+id+..."); supported names: query target clusternr evalue id
+ * fractid dist mid pctpv pctgaps pairs gaps allgaps qlo qhi tlo thi qlor qhir tlor thir qlot qhit qunt tlot thit
+ * tunt pv ql tl qs ts alnlen opens exts raw bits aln caln qseq tseq qseg tseg qstrand tstrand qrow trow qrowdots
+ * trowdots qframe tframe orflo orfhi orfframe mism ids qcov tcov diffs diffsa editdiffs (global-alignment
+ * semantics, AlignResult getters arscorer.cpp / alignresult.h:97-240); anything else -> UGS_E_ARG.
+ * qseq is the query as read (it is reverse-complemented here for a minus-strand hit); tseq the target as the
+ * reference holds it (i.e. the masked DB letters for -db x.fa / x.udb).
+ * Like the other writers: returns the line length (excluding NUL), or a negative error code.
+ */
+int ugs_userfields_check(const char *fields);
+int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
+                       const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                       const char *tseq, uint32_t tl, char *buf, int cap);
+/* OutputBlast6NoHits blast6out.cpp:82-103 (-output_no_hits) */
+int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap);
+/* SeqToFasta seqdb.cpp:62-90 (-matched / -notmatched / -dbmatched / -dbnotmatched records) */
+int ugs_format_fasta(const char *label, const char *seq, uint32_t len, char *buf, int cap);
+/* HitMgr::GetHitCount / GetHit hitmgr.cpp:366-393,464-475: how many of one query's (sorted) hits are reported under
+ * -maxhits (0 = unset) / -top_hit_only / -top_hits_only, starting at hits[*first] (0 unless -top_hit_only, where
+ * the single reported hit is GetTopHit: best score, ties to the smallest target index) */
+uint32_t ugs_hits_to_report(const ugs_hit *hits, uint32_t n, uint32_t maxhits, int top_hit_only, int top_hits_only,
+                            uint32_t *first);
+/* the DB letters as the reference holds them after MaskDB (makeudb.cpp:11-25): out[nletters] */
+int ugs_db_masked_letters(const ugs_db *db, char *out);
+
 const char *ugs_last_error(void);
 
 #ifdef __cplusplus

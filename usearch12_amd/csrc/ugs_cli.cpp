@@ -82,18 +82,50 @@ class Searcher {
   ugs_params p_; ugs_db *db_ = nullptr;
 };
 
-// OutputSink::OnQueryDone (outputsink.cpp:358-384): hits of one query, or the uc no-hit record
-static void output_query(FILE *fb6, FILE *fuc, const ugs_params &p, const SeqSet &q, const SeqSet &db, uint32_t qi,
-                         const ugs_hit *h, uint32_t n, const uint32_t *pool)
+// the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
+struct Outputs {
+  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr;
+  std::string userfields;
+  bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
+  uint32_t maxhits = 0;
+  std::vector<uint32_t> db_hit_counts;      // DBHitSink::m_HitCounts
+  const char *db_masked = nullptr;          // DB letters as the reference holds them (masked)
+};
+
+// OutputSink::OnQueryDone (outputsink.cpp:358-384): hits of one query, or the no-hit records
+static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const SeqSet &db, uint32_t qi,
+                         const ugs_hit *h, uint32_t n_all, const uint32_t *pool)
 {
-  static char line[1 << 16];
+  static std::vector<char> line(1 << 20);
   const uint32_t ql = (uint32_t)(q.offs[qi + 1] - q.offs[qi]);
-  if (n == 0) { if (fuc) { ugs_format_uc_nohit(ql, q.labels[qi].c_str(), line, sizeof line); fputs(line, fuc); } return; }
-  for (uint32_t j = 0; j < n; ++j) {
-    const char *tl = db.labels[h[j].target].c_str();
-    if (fb6) { ugs_format_blast6(&h[j], q.labels[qi].c_str(), tl, line, sizeof line); fputs(line, fb6); }
-    if (fuc) { ugs_format_uc_hit(&h[j], pool, p.is_nucleo, q.labels[qi].c_str(), tl, line, sizeof line); fputs(line, fuc); }
+  const char *qs = q.letters.data() + q.offs[qi], *qlab = q.labels[qi].c_str();
+  auto put = [&](FILE *f, int len) {
+    if (len < 0) { fprintf(stderr, "%s\n", ugs_last_error()); exit(1); }
+    if ((size_t)len >= line.size()) { fprintf(stderr, "output line too long\n"); exit(1); }
+    fputs(line.data(), f);
+  };
+  uint32_t first = 0;
+  const uint32_t n = ugs_hits_to_report(h, n_all, O.maxhits, O.top_hit_only, O.top_hits_only, &first);   // HitMgr::GetHitCount
+  h += first;
+  if (n == 0) {                                                       // OutputMatchedFalse outputsink.cpp:392-403
+    if (O.uc) put(O.uc, ugs_format_uc_nohit(ql, qlab, line.data(), (int)line.size()));
+    if (O.output_no_hits) {
+      if (O.b6) put(O.b6, ugs_format_blast6_nohit(qlab, line.data(), (int)line.size()));
+      if (O.user) put(O.user, ugs_format_userout(nullptr, nullptr, p.is_nucleo, O.userfields.c_str(), qlab, nullptr, qs, ql, nullptr, 0, line.data(), (int)line.size()));
+    }
+    if (O.notmatched) put(O.notmatched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
+    return;
   }
+  for (uint32_t j = 0; j < n; ++j) {
+    const uint32_t t = h[j].target;
+    const char *tl = db.labels[t].c_str();
+    if (O.b6) put(O.b6, ugs_format_blast6(&h[j], qlab, tl, line.data(), (int)line.size()));
+    if (O.uc) put(O.uc, ugs_format_uc_hit(&h[j], pool, p.is_nucleo, qlab, tl, line.data(), (int)line.size()));
+    if (O.user) put(O.user, ugs_format_userout(&h[j], pool, p.is_nucleo, O.userfields.c_str(), qlab, tl, qs, ql,
+                                                O.db_masked + db.offs[t], (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
+    if (!O.db_hit_counts.empty()) ++O.db_hit_counts[t];               // DBHitSink::OnQueryDone dbhitsink.cpp:117-140
+  }
+  if (O.matched) put(O.matched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
 }
 
 // LoadUDB (loaddb.cpp:100-125): a .udb is recognised by its magic; its letters are used as stored (already masked)
@@ -134,7 +166,8 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 
 int main(int argc, char **argv)
 {
-  std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath;
+  std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
+  Outputs O;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -144,6 +177,11 @@ int main(int argc, char **argv)
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
     else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
+    else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
+    else if (a == "-matched") matchedpath = val(); else if (a == "-notmatched") notmatchedpath = val();
+    else if (a == "-dbmatched") dbmatchedpath = val(); else if (a == "-dbnotmatched") dbnotmatchedpath = val();
+    else if (a == "-output_no_hits") O.output_no_hits = true; else if (a == "-top_hit_only") O.top_hit_only = true;
+    else if (a == "-top_hits_only") O.top_hits_only = true; else if (a == "-maxhits") O.maxhits = (uint32_t)atol(val());
     else if (a == "-dbtype") { std::string v = val(); dbtype = (v == "nt"); }
     else if (a == "-threads" || a == "-quiet") { if (a == "-threads") val(); }   // accepted, meaningless here
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
@@ -179,9 +217,26 @@ int main(int argc, char **argv)
   if (maxrej >= 0) p.max_rejects = maxrej;
   if (big >= 0) p.big = (uint32_t)big;
   if (from_udb) { p.dbmask = 0; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
-  FILE *fb6 = b6path.empty() ? nullptr : fopen(b6path.c_str(), "w");
-  FILE *fuc = ucpath.empty() ? nullptr : fopen(ucpath.c_str(), "w");
+  auto open_out = [](const std::string &path) -> FILE * {
+    if (path.empty()) return nullptr;
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) { fprintf(stderr, "cannot create %s\n", path.c_str()); exit(1); }
+    return f;
+  };
+  if (!userpath.empty()) {                                            // outputsink.cpp:96-103
+    if (O.userfields.empty()) { fprintf(stderr, "--userout requires --userfields\n"); return 1; }
+    if (ugs_userfields_check(O.userfields.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+  }
+  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath);
+  O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
   Searcher searcher(p, db, device);
+  std::string masked;
+  if (O.user || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
+    masked.resize(db.letters.size());
+    if (ugs_db_masked_letters(searcher.handle(), &masked[0]) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    O.db_masked = masked.data();
+    O.db_hit_counts.assign(db.size(), 0);
+  }
   FastaReader qr(qpath.c_str());
   std::vector<ugs_hit> hits; std::vector<uint32_t> nhits, pool;
   size_t total = 0, with_hit = 0;
@@ -191,13 +246,26 @@ int main(int argc, char **argv)
     searcher.Search(q, hits, nhits, pool);
     size_t k = 0;
     for (uint32_t qi = 0; qi < q.size(); ++qi) {
-      output_query(fb6, fuc, p, q, db, qi, hits.data() + k, nhits[qi], pool.data());
+      output_query(O, p, q, db, qi, hits.data() + k, nhits[qi], pool.data());
       k += nhits[qi]; with_hit += nhits[qi] > 0;
     }
     total += q.size();
   }
-  if (fb6) fclose(fb6);
-  if (fuc) fclose(fuc);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched}) if (f) fclose(f);
+  for (int m = 0; m < 2; ++m) {                                       // DBHitSink::ToFASTA dbhitsink.cpp:89-115
+    const std::string &path = m ? dbmatchedpath : dbnotmatchedpath;
+    if (path.empty()) continue;
+    FILE *f = open_out(path);
+    std::vector<char> rec;
+    for (size_t t = 0; t < db.size(); ++t) {
+      if ((O.db_hit_counts[t] > 0) != (m == 1)) continue;
+      const uint32_t L = (uint32_t)(db.offs[t + 1] - db.offs[t]);
+      rec.resize((size_t)L + L / 80 + db.labels[t].size() + 8);
+      ugs_format_fasta(db.labels[t].c_str(), O.db_masked + db.offs[t], L, rec.data(), (int)rec.size());
+      fputs(rec.data(), f);
+    }
+    fclose(f);
+  }
   fprintf(stderr, "%zu queries, %zu with hits (%.1f%%)\n", total, with_hit, total ? 100.0 * with_hit / total : 0.0);
   return 0;
 }

@@ -367,6 +367,12 @@ extern "C" int ugs_db_debug_fetch(const ugs_db *db, char *masked, uint64_t *row_
   return UGS_OK;
 }
 
+extern "C" int ugs_db_masked_letters(const ugs_db *db, char *out)
+{
+  if (!db || !out) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  return ugs_db_debug_fetch(db, out, nullptr, nullptr);
+}
+
 // ---------------------------------------------------------------- batch
 extern "C" void ugs_batch_destroy(ugs_batch *b)
 {

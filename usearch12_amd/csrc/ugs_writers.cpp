@@ -1,0 +1,298 @@
+// ugs_writers.cpp - host-side text writers beyond blast6/uc: -userout with
+// -userfields, the -output_no_hits records, FASTA records, and HitMgr's hit-count rules.
+// Pure formatting of device results (ugs_hit + run-length path + the two sequences); no search logic.
+//
+// Reference: OutputSink::OutputUser / OutputUserNoHits userout.cpp:47-352 (field list userfields.h:5-77),
+// AlignResult getters arscorer.cpp / alignresult.h:97-240, OutputBlast6NoHits blast6out.cpp:82-103,
+// SeqToFasta seqdb.cpp:62-90, HitMgr::GetHitCount hitmgr.cpp:366-393.
+#include "ugs_dev.h"
+
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// alpha2.cpp:220-300 identity classes, on upper- or lower-case letters
+struct MatchTables {
+  bool nt[256][256], aa[256][256];
+  bool pos_nt[256][256], pos_aa[256][256];      // substitution score > 0 (setnucmx.cpp:11-99, blosum62.cpp)
+  unsigned char comp[256];                      // alpha.cpp:3005-3265 g_CharToCompChar
+  MatchTables()
+  {
+    int nucbit[256], iupac[256];
+    memset(nucbit, 0, sizeof nucbit); memset(iupac, 0, sizeof iupac);
+    nucbit['A'] = nucbit['a'] = 1; nucbit['C'] = nucbit['c'] = 2; nucbit['G'] = nucbit['g'] = 4;
+    nucbit['T'] = nucbit['t'] = 8; nucbit['U'] = nucbit['u'] = 8;
+    for (int c = 0; c < 256; ++c) iupac[c] = nucbit[c];
+    const char *codes = "MRWSYKVHDBXN";
+    const char *sets[] = {"AC", "AG", "AT", "CG", "CT", "GT", "ACG", "ACT", "AGT", "CGT", "GATC", "GATC"};
+    for (int q = 0; codes[q]; ++q) {
+      int b = 0;
+      for (const char *s = sets[q]; *s; ++s) b |= nucbit[(unsigned char)*s];
+      iupac[(unsigned char)codes[q]] = b; iupac[(unsigned char)tolower(codes[q])] = b;
+    }
+    for (int i = 0; i < 256; ++i) for (int j = 0; j < 256; ++j) {
+      const bool ai = isalpha(i) != 0, aj = isalpha(j) != 0;
+      if (!ai || !aj) { const bool g = (i == '-' || i == '.') && (j == '-' || j == '.'); nt[i][j] = aa[i][j] = g; continue; }
+      if (toupper(i) == toupper(j)) { nt[i][j] = aa[i][j] = true; continue; }
+      aa[i][j] = toupper(i) == 'X' || toupper(j) == 'X';
+      nt[i][j] = (nucbit[i] & iupac[j]) || (nucbit[j] & iupac[i]);
+    }
+    aa['B']['N'] = aa['N']['B'] = aa['B']['D'] = aa['D']['B'] = true;
+    aa['Z']['Q'] = aa['Q']['Z'] = aa['Z']['E'] = aa['E']['Z'] = true;
+    memset(pos_nt, 0, sizeof pos_nt); memset(pos_aa, 0, sizeof pos_aa);
+    for (int i = 0; i < 256; ++i) for (int j = 0; j < 256; ++j) {
+      if (nucbit[i] && nucbit[j] && nucbit[i] == nucbit[j]) pos_nt[i][j] = true;      // default -match 1 > 0
+      const char *pi = isalpha(i) ? strchr(UGS_B62_ORDER, toupper(i)) : nullptr, *pj = isalpha(j) ? strchr(UGS_B62_ORDER, toupper(j)) : nullptr;
+      if (pi && pj && *pi && *pj) pos_aa[i][j] = UGS_B62[pi - UGS_B62_ORDER][pj - UGS_B62_ORDER] > 0;
+    }
+    pos_aa['*']['*'] = true;
+    memset(comp, '?', sizeof comp);
+    const char *from = "ABCDGHKMNRSTUVWXY", *to = "TVGHCDMKNYSAABWXR";
+    for (int k = 0; from[k]; ++k) {
+      comp[(unsigned char)from[k]] = (unsigned char)to[k];
+      if (from[k] != 'U') comp[(unsigned char)tolower(from[k])] = (unsigned char)tolower(to[k]);
+    }
+  }
+};
+const MatchTables &tables() { static const MatchTables T; return T; }
+
+enum Field {
+  F_query, F_target, F_clusternr, F_evalue, F_id, F_fractid, F_dist, F_mid, F_pctpv, F_pctgaps, F_pairs, F_gaps, F_allgaps,
+  F_qlo, F_qhi, F_tlo, F_thi, F_qlot, F_qhit, F_qunt, F_tlot, F_thit, F_tunt, F_pv, F_ql, F_tl, F_qs, F_ts, F_alnlen,
+  F_opens, F_exts, F_raw, F_bits, F_aln, F_caln, F_qseq, F_tseq, F_qseg, F_tseg, F_qstrand, F_tstrand, F_qrow, F_trow,
+  F_qrowdots, F_trowdots, F_qframe, F_tframe, F_mism, F_ids, F_qcov, F_tcov, F_diffs, F_diffsa, F_editdiffs,
+  F_qlor, F_qhir, F_tlor, F_thir, F_orflo, F_orfhi, F_orfframe, F_COUNT
+};
+const char *const FIELD_NAMES[F_COUNT] = {
+  "query", "target", "clusternr", "evalue", "id", "fractid", "dist", "mid", "pctpv", "pctgaps", "pairs", "gaps", "allgaps",
+  "qlo", "qhi", "tlo", "thi", "qlot", "qhit", "qunt", "tlot", "thit", "tunt", "pv", "ql", "tl", "qs", "ts", "alnlen",
+  "opens", "exts", "raw", "bits", "aln", "caln", "qseq", "tseq", "qseg", "tseg", "qstrand", "tstrand", "qrow", "trow",
+  "qrowdots", "trowdots", "qframe", "tframe", "mism", "ids", "qcov", "tcov", "diffs", "diffsa", "editdiffs",
+  "qlor", "qhir", "tlor", "thir", "orflo", "orfhi", "orfframe"};
+
+// SetUserFieldIndexes userout.cpp:36-52
+int parse_fields(const char *fields, std::vector<int> &out)
+{
+  out.clear();
+  if (!fields || !*fields) { ugs_set_error("Invalid user fields ''"); return UGS_E_ARG; }
+  std::string s(fields);
+  size_t pos = 0;
+  for (;;) {
+    const size_t e = s.find('+', pos);
+    const std::string name = s.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+    int f = -1;
+    for (int k = 0; k < F_COUNT; ++k) if (name == FIELD_NAMES[k]) f = k;
+    if (f < 0) { ugs_set_error("Invalid or unsupported user field name '%s'", name.c_str()); return UGS_E_ARG; }
+    out.push_back(f);
+    if (e == std::string::npos) break;
+    pos = e + 1;
+  }
+  return UGS_OK;
+}
+
+void app(std::string &o, const char *fmt, ...)
+{
+  char tmp[128];
+  va_list ap; va_start(ap, fmt);
+  const int n = vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  if (n > 0) o.append(tmp, (size_t)(n < (int)sizeof tmp ? n : (int)sizeof tmp - 1));
+}
+
+double ratio(double x, double y) { return y == 0 ? 0.0 : x / y; }      // GetRatio myutils.h:234
+
+int finish(const std::string &o, char *buf, int cap)
+{
+  if (buf && cap > 0) {
+    const size_t n = o.size() < (size_t)cap - 1 ? o.size() : (size_t)cap - 1;
+    memcpy(buf, o.data(), n); buf[n] = 0;
+  }
+  return (int)o.size();
+}
+
+}  // namespace
+
+extern "C" int ugs_userfields_check(const char *fields)
+{
+  std::vector<int> f;
+  return parse_fields(fields, f);
+}
+
+extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
+                                  const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                                  const char *tseq, uint32_t tl, char *buf, int cap)
+{
+  std::vector<int> fs;
+  const int rc = parse_fields(fields, fs);
+  if (rc != UGS_OK) return rc;
+  if (!qlabel || !qseq) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  std::string o;
+  if (!h) {                                                  // OutputUserNoHits userout.cpp:47-105
+    for (size_t i = 0; i < fs.size(); ++i) {
+      if (i) o.push_back('\t');
+      switch (fs[i]) {
+        case F_query: o += qlabel; break;
+        case F_ql: app(o, "%u", ql); break;
+        case F_clusternr: app(o, "%u", 0xffffffffu); break;   // HM->m_QueryClusterIndex is UINT_MAX outside clustering
+        case F_qseq: o.append(qseq, ql); break;
+        case F_dist: case F_allgaps: case F_qlot: case F_qhit: case F_qunt: case F_tlot: case F_thit: case F_tunt: case F_qseg: case F_tseg:
+        case F_qrowdots: case F_trowdots: case F_editdiffs: case F_orflo: case F_orfhi: case F_orfframe:
+          ugs_set_error("Invalid user field index %s (-output_no_hits)", FIELD_NAMES[fs[i]]); return UGS_E_ARG;   // the reference dies on these
+        default: o.push_back('*');
+      }
+    }
+    o.push_back('\n');
+    return finish(o, buf, cap);
+  }
+  if (!tlabel || !tseq || !cigar_pool) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (ql != h->ql || tl != h->tl) { ugs_set_error("sequence lengths do not match the hit record"); return UGS_E_ARG; }
+  const MatchTables &T = tables();
+  // the query as it was aligned (reverse-complemented for a minus-strand hit, seqinfo.cpp:292-323)
+  std::string Q(qseq, ql);
+  if (h->strand) for (uint32_t k = 0; k < ql; ++k) { const unsigned char c = (unsigned char)qseq[ql - 1 - k]; const unsigned char cc = T.comp[c]; Q[k] = (char)(cc == '?' ? c : cc); }
+  std::string path;
+  for (uint32_t k = 0; k < h->cigar_len; ++k) { const uint32_t r = cigar_pool[h->cigar_off + k]; path.append(r >> 2, "MDI"[r & 3]); }
+  // AlignResult::FillLo arscorer.cpp:201-296 (only what the record does not already hold)
+  const size_t cols = path.size();
+  size_t firstM = path.find('M'), lastM = path.rfind('M');
+  if (firstM == std::string::npos) { ugs_set_error("path has no match column"); return UGS_E_ARG; }
+  const uint32_t qlo = h->qlo, tlo = h->tlo;                  // m_FirstMQPos / m_FirstMTPos
+  const uint32_t aln = (uint32_t)(lastM - firstM + 1), term = (uint32_t)cols - aln;
+  uint32_t diffsa = 0, pv = 0, opens = 0, exts = 0;
+  std::string qrow, trow, qdots, tdots;
+  {
+    const bool (*Mx)[256] = is_nucleo ? T.nt : T.aa;
+    const bool (*Pos)[256] = is_nucleo ? T.pos_nt : T.pos_aa;
+    uint32_t qp = qlo, tp = tlo;
+    char last = 'M';
+    for (size_t c = firstM; c <= lastM; ++c) {
+      const char op = path[c];
+      const unsigned char qc = (op == 'M' || op == 'D') ? (unsigned char)Q[qp] : 0, tc = (op == 'M' || op == 'I') ? (unsigned char)tseq[tp] : 0;
+      const char qu = qc ? (char)toupper(qc) : '-', tu = tc ? (char)toupper(tc) : '-';
+      if (op == 'M') { if (qu != tu) ++diffsa; if (Pos[qc][tc]) ++pv; }
+      if (op != 'M') { if (last == 'M') ++opens; else ++exts; }
+      last = op;
+      qrow.push_back(qu); trow.push_back(tu);
+      qdots.push_back(qc ? (Mx[(unsigned char)qu][(unsigned char)tu] ? '.' : qu) : '-');
+      tdots.push_back(tc ? (Mx[(unsigned char)qu][(unsigned char)tu] ? '.' : tu) : '-');
+      if (qc) ++qp;
+      if (tc) ++tp;
+    }
+  }
+  const double fract = aln == 0 ? 0.0 : (double)h->ids / (double)aln;
+  const uint32_t pairs = h->ids + h->mism;
+  for (size_t i = 0; i < fs.size(); ++i) {
+    if (i) o.push_back('\t');
+    switch (fs[i]) {
+      case F_query: o += qlabel; break;
+      case F_target: o += tlabel; break;
+      case F_clusternr: app(o, "%u", h->target); break;
+      case F_evalue: app(o, "%.3g", -1.0); break;              // global: GetEvalue() = -1 (arscorer.cpp:69-73)
+      case F_id: app(o, "%.1f", 100.0 * fract); break;
+      case F_fractid: app(o, "%.4f", fract); break;
+      case F_dist: app(o, "%.4f", 1.0 - fract); break;
+      case F_mid: app(o, "%.1f", 100.0 * (h->ids == 0 ? 0.0 : (double)h->ids / (double)pairs)); break;
+      case F_pctpv: app(o, "%.1f", 100.0 * ratio(pv, aln)); break;
+      case F_pctgaps: app(o, "%.1f", 100.0 * ratio(h->gaps_int, aln)); break;
+      case F_pairs: app(o, "%u", pairs); break;
+      case F_gaps: app(o, "%u", h->gaps_int); break;
+      case F_allgaps: app(o, "%u", h->gaps_int + term); break;
+      case F_qlo: app(o, "%u", 1u); break;                     // global HSP = whole sequences (alignresult.cpp:206-211)
+      case F_qhi: app(o, "%u", ql); break;
+      case F_tlo: app(o, "%u", 1u); break;
+      case F_thi: app(o, "%u", tl); break;
+      case F_qlor: case F_tlor: app(o, "%u", 0u); break;
+      case F_qhir: app(o, "%u", ql - 1); break;
+      case F_thir: app(o, "%u", tl - 1); break;
+      case F_qlot: app(o, "%u", h->qlo); break;
+      case F_qhit: app(o, "%u", h->qhi); break;
+      case F_qunt: app(o, "%u", ql - h->qhi - 1); break;
+      case F_tlot: app(o, "%u", h->tlo); break;
+      case F_thit: app(o, "%u", h->thi); break;
+      case F_tunt: app(o, "%u", tl - h->thi - 1); break;
+      case F_pv: app(o, "%u", pv); break;
+      case F_ql: case F_qs: app(o, "%u", ql); break;
+      case F_tl: case F_ts: app(o, "%u", tl); break;
+      case F_alnlen: app(o, "%u", aln); break;
+      case F_opens: app(o, "%u", opens); break;
+      case F_exts: app(o, "%u", exts); break;
+      case F_raw: case F_bits: app(o, "%.0f", 0.0); break;    // global: 0 (arscorer.cpp:87-91,105-109)
+      case F_aln: o += path; break;
+      case F_caln:
+        for (uint32_t k = 0; k < h->cigar_len; ++k) { const uint32_t r = cigar_pool[h->cigar_off + k]; if ((r >> 2) == 1) o.push_back("MDI"[r & 3]); else app(o, "%u%c", r >> 2, "MDI"[r & 3]); }
+        break;
+      case F_qseq: o += Q; break;
+      case F_tseq: o.append(tseq, tl); break;
+      // the reference prints segment-LENGTH (= whole sequence for a global hit) letters starting at the first
+      // aligned position, i.e. it reads past the end when the alignment has a leading gap; here: up to the end
+      case F_qseg: o.append(Q, h->qlo, std::string::npos); break;
+      case F_tseg: o.append(tseq + h->tlo, tl - h->tlo); break;
+      case F_qstrand: o.push_back(!is_nucleo ? '.' : (h->strand ? '-' : '+')); break;
+      case F_tstrand: o.push_back(!is_nucleo ? '.' : '+'); break;
+      case F_qrow: o += qrow; break;
+      case F_trow: o += trow; break;
+      case F_qrowdots: o += qdots; break;
+      case F_trowdots: o += tdots; break;
+      case F_qframe: case F_tframe: case F_orfframe: app(o, "%+d", 0); break;
+      case F_orflo: case F_orfhi: app(o, "%u", 0u); break;
+      case F_mism: app(o, "%u", h->mism); break;
+      case F_ids: app(o, "%u", h->ids); break;
+      case F_qcov: app(o, "%.0f", 100.0 * ((double)(h->qhi - h->qlo + 1) / ql)); break;
+      case F_tcov: app(o, "%.0f", 100.0 * ((double)pairs / (double)tl)); break;
+      case F_diffs: app(o, "%u", h->mism + h->gaps_int); break;
+      case F_diffsa: app(o, "%u", diffsa); break;
+      case F_editdiffs: app(o, "%u", h->mism + h->gaps_int + term); break;
+    }
+  }
+  o.push_back('\n');
+  return finish(o, buf, cap);
+}
+
+// OutputBlast6NoHits blast6out.cpp:82-103 (written only under -output_no_hits)
+extern "C" int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap)
+{
+  return snprintf(buf, (size_t)cap, "%s\t*\t0\t0\t0\t0\t0\t0\t0\t0\t*\t0\n", qlabel);
+}
+
+// SeqToFasta seqdb.cpp:62-90: ">label", then rows of fasta_cols (80) letters; nothing for an empty sequence
+extern "C" int ugs_format_fasta(const char *label, const char *seq, uint32_t len, char *buf, int cap)
+{
+  if (len == 0) { if (buf && cap > 0) buf[0] = 0; return 0; }
+  std::string o;
+  if (label) { o.push_back('>'); o += label; o.push_back('\n'); }
+  for (uint32_t p = 0; p < len; p += 80) { o.append(seq + p, len - p < 80 ? len - p : 80); o.push_back('\n'); }
+  return finish(o, buf, cap);
+}
+
+// HitMgr::GetHitCount hitmgr.cpp:366-393 on the (already HitMgr::Sort-ed) hits of one query:
+// -maxhits caps, -top_hits_only keeps the leading hits whose score (float fractional identity) equals the top
+// score, -top_hit_only reports exactly one hit and that one is HitMgr::GetTopHit (hitmgr.cpp:395-415,464-467):
+// the best score, ties to the smallest target index - not the sort order's first.  *first receives the index
+// of the first hit to report (0 unless -top_hit_only).
+extern "C" uint32_t ugs_hits_to_report(const ugs_hit *hits, uint32_t n, uint32_t maxhits, int top_hit_only, int top_hits_only,
+                                       uint32_t *first)
+{
+  if (first) *first = 0;
+  if (n == 0) return 0;
+  auto score = [](const ugs_hit &h) { return h.aln_len == 0 ? 0.0f : (float)((double)h.ids / (double)h.aln_len); };
+  uint32_t count = n;
+  if (maxhits && count > maxhits) count = maxhits;
+  if (top_hit_only) {
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < n; ++i)
+      if (score(hits[i]) > score(hits[best]) || (score(hits[i]) == score(hits[best]) && hits[i].target < hits[best].target)) best = i;
+    if (first) *first = best;
+    return 1;
+  }
+  if (top_hits_only) {
+    float top = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) if (score(hits[i]) > top) top = score(hits[i]);
+    for (uint32_t i = 1; i < count; ++i) if (score(hits[i]) < top) return i;
+  }
+  return count;
+}
