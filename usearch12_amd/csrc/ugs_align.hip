@@ -46,7 +46,7 @@ struct WaveCtx {
   // LDS
   uint8_t *A, *B;             // class codes of query / target letters (identity tests)
   uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
-  uint32_t *wstart;           // per HSP word: first index in qsort | min(count,8) << 16 (0 = absent), or null
+  uint16_t *wstart;           // per HSP word: first index in qsort (12 bits) | min(count,8) << 12 (0 = absent), or null
   uint32_t *seeds; uint32_t seed_cap; uint32_t union_words;   // seed list of the current pair: bpos << 16 | apos, in reference order
   bool nt;
   uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
@@ -123,7 +123,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     uint32_t *tw = c.seeds;                               // word per position (union region, free here)
     uint16_t *tr = (uint16_t *)(c.seeds + ((c.nwA + 3) & ~3u));       // rank among earlier equal words
     const uint32_t nwords = c.nwords, nwA = c.nwA;
-    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0;
+    for (uint32_t k = lane; k < (nwords + 1) / 2; k += 64) ((uint32_t *)c.wstart)[k] = 0;
     for (uint32_t p = lane; p < ((nwA + 3) & ~3u); p += 64) {
       uint32_t word = 0xffffffffu;
       if (p < nwA) { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; }
@@ -138,7 +138,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += (x.x == wd) + (x.y == wd) + (x.z == wd) + (x.w == wd); }
       for (uint32_t q = nq4 << 2; q < p; ++q) rank += tw[q] == wd;
       tr[p] = (uint16_t)rank;
-      atomicAdd(&c.wstart[wd], 1u);
+      atomicAdd(&((uint32_t *)c.wstart)[wd >> 1], 1u << ((wd & 1u) * 16));     // 16-bit counters, two per LDS word
     }
     lds_sync();
     {   // exclusive prefix sum of the counts: each lane owns a contiguous block of words
@@ -149,13 +149,13 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       uint32_t run = incl - sum;
       for (uint32_t k = 0; k < per; ++k) {
         const uint32_t wi = lane * per + k;
-        if (wi < nwords) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = n ? (run | ((n < UGS_MAXREPS ? n : UGS_MAXREPS) << 16)) : 0u; run += n; }
+        if (wi < nwords) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = (uint16_t)(n ? (run | ((n < UGS_MAXREPS ? n : UGS_MAXREPS) << 12)) : 0u); run += n; }
       }
     }
     lds_sync();
     for (uint32_t p = lane; p < nwA; p += 64) {
       const uint32_t wd = tw[p];
-      c.qsort[(c.wstart[wd] & 0xffffu) + tr[p]] = (wd << 16) | p;
+      c.qsort[(c.wstart[wd] & 0xfffu) + tr[p]] = (wd << 16) | p;
     }
     lds_sync();
     return;
@@ -186,14 +186,14 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     // direct word -> (first sorted index | min(count, MaxReps) << 16) table: replaces a binary
     // search per target position; count 0 = word absent from the query
     const uint32_t nwords = c.nwords;
-    for (uint32_t k = lane; k < nwords; k += 64) c.wstart[k] = 0;
+    for (uint32_t k = lane; k < (nwords + 1) / 2; k += 64) ((uint32_t *)c.wstart)[k] = 0;
     lds_sync();
     for (uint32_t i = lane; i < c.nwA; i += 64) {
       const uint32_t wd = c.qsort[i] >> 16;
       if (i == 0 || (c.qsort[i - 1] >> 16) != wd) {
         uint32_t n = 1;
         while (n < UGS_MAXREPS && i + n < c.nwA && (c.qsort[i + n] >> 16) == wd) ++n;
-        c.wstart[wd] = i | (n << 16);
+        c.wstart[wd] = (uint16_t)(i | (n << 12));
       }
     }
     lds_sync();
@@ -350,7 +350,7 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
         if (bpos < nwB) {
           uint32_t word = 0;
           for (int k = 0; k < w; ++k) word = word * db.alpha + (NT ? (c.Bs[bpos + k] & 3u) * (c.Bs[bpos + k] < 4) : c.s_hl[c.B[bpos + k] & 31]);
-          if (c.wstart) { const uint32_t e = c.wstart[word]; lo = e & 0xffffu; cnt = e >> 16; }
+          if (c.wstart) { const uint32_t e = c.wstart[word]; lo = e & 0xfffu; cnt = e >> 12; }
           else {
             const uint32_t want = word << 16;
             uint32_t hi = c.nwA;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv,
   c.Bs = wb + off + 16; off += maxt + 32;
   c.nwords = (uint32_t)db.hsp_words;
   c.wstart = nullptr;
-  if (db.hsp_words <= 1024) { c.wstart = (uint32_t *)(wb + off); off += (size_t)db.hsp_words * 4; }
+  if (db.hsp_words <= 1024 && bv.max_qlen < 4096) { c.wstart = (uint16_t *)(wb + off); off += ((size_t)db.hsp_words * 2 + 15) & ~(size_t)15; }
   c.lds_runs = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_tb = wb + off; off += LTB;

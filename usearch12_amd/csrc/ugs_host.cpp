@@ -471,7 +471,7 @@ static int plan_launch(ugs_batch *b)
   // ---- alignment geometry
   const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  const size_t wstart_b = db->v.hsp_words <= 1024 ? (size_t)db->v.hsp_words * 4 : 0;
+  const size_t wstart_b = (db->v.hsp_words <= 1024 && b->max_qlen < 4096) ? (((size_t)db->v.hsp_words * 2 + 15) & ~(size_t)15) : 0;
   const uint32_t seed_cap = 64 * UGS_MAXREPS + 128;      // one listing round always fits; rounds of 64 seeds are extended at a time
   // per-wave LDS (mirrors the carve in k_align): control block, class + score codes of both sequences, word table,
   // sorted query words, run buffers, small-hole traceback, HSPs + chain, union{seed list | DP rows + chainer scratch}
@@ -655,7 +655,9 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
   if (getenv("UGS_PHASE_CLOCKS"))
     fprintf(stderr, "[ugs] rank phase clocks (sum over WGs, thread 0): setup %llu scan %llu scan-wait %llu select %llu | align: %llu %llu %llu %llu\n",
             b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5],
-            b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]);
+            b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]),
+    fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
+            b->al.grid, b->al.wpb, b->al.lds);
   return UGS_OK;
 }
 
