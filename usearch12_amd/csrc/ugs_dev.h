@@ -64,6 +64,9 @@ struct UgsBatchView {
   uint32_t *cand;            // [units*K]
   uint32_t *cand_cnt;        // [units*K]
   uint32_t *cand_n;          // [units]
+  // sampled index rows per unit, written by k_rank_setup and read by k_rank
+  uint32_t *unit_ns;         // [units]
+  uint32_t *unit_slots;      // [units * ns_max]
   // ranking scratch: per resident workgroup
   uint64_t *emit_buf;        // [rank_wgs * emit_cap]
   uint64_t emit_cap;

@@ -47,6 +47,7 @@ struct ugs_batch {
   uint32_t *d_qn, *d_qoff; ugs_hit *d_compact; void *d_scan_tmp; size_t scan_tmp_bytes;
   uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
   ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
+  uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
   unsigned long long *d_cigar_used, *d_ctr;
   uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
   int rank_grid_alloc, align_waves_alloc;
@@ -380,6 +381,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipSetDevice(b->db->device);
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
+  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -501,6 +503,15 @@ static int plan_launch(ugs_batch *b)
     b->runs_alloc = (uint64_t)runs_stride * waves;
   }
   b->v.tb_stride = tb_stride; b->v.runs_stride = runs_stride;
+  {   // sampled rows per unit (k_rank_setup -> k_rank)
+    const uint64_t need = (uint64_t)units * b->rl.ns_max;
+    if (!b->d_unit_ns) HIPCHK(hipMalloc(&b->d_unit_ns, (size_t)b->max_queries * 2 * 4));
+    if (!b->d_unit_slots || need > b->unit_slots_alloc) {
+      if (b->d_unit_slots) HIPCHK(hipFree(b->d_unit_slots));
+      HIPCHK(hipMalloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
+      b->unit_slots_alloc = need;
+    }
+  }
   return UGS_OK;
 }
 
@@ -526,6 +537,7 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   UgsBatchView &v = b->v;
   v.qseqs = b->d_qseqs; v.qoffs = b->d_qoffs; v.nq = nq; v.nstrand = b->nstrand; v.K = b->K; v.max_qlen = maxl;
   v.cand = b->d_cand; v.cand_cnt = b->d_cand_cnt; v.cand_n = b->d_cand_n; v.emit_buf = b->d_emit;
+  v.unit_ns = b->d_unit_ns; v.unit_slots = b->d_unit_slots;
   v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
   v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
   b->searched = false; b->synced = false;

@@ -24,6 +24,7 @@
 // (count desc, first-touch position asc) are selected, after applying the reference's
 // "MinValue = prevMax/2" (and, on the small path, -bump) cut-offs exactly.
 #include "ugs_dev.h"
+#include <algorithm>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
@@ -438,6 +439,94 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, in
   return r;
 }
 
+// Chooses the sampled index rows of every unit (= query x strand) ahead of the scan: query letters -> UDB words
+// (udbparams.cpp:540-555) -> unique words in first-occurrence order (udbsearcher.cpp:161-194) -> every step-th of them
+// (GetWordCountingParams wordparams.cpp:179-191 via the host's step table).  One wavefront per unit, no block barriers:
+// this stage is a chain of dependent loads with little arithmetic, so it runs at full occupancy in its own launch
+// instead of stalling a 128-VGPR scan workgroup.
+__global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView bv, uint32_t ns_max)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
+  const uint32_t maxq = (bv.max_qlen + 15u) & ~15u;
+  uint8_t *s_udb = smem;
+  unsigned char *wb = smem + 256 + (size_t)wave * ((size_t)maxq * 6);
+  uint32_t *s_words = (uint32_t *)wb;
+  uint8_t *s_q = wb + (size_t)maxq * 4, *s_first = s_q + maxq;
+  const UgsTables *tab = db.tab;
+  for (int k = tid; k < 256; k += blockDim.x) s_udb[k] = tab->udb_letter[k];
+  __syncthreads();
+  const uint32_t units = bv.nq * bv.nstrand;
+  const int W = db.word_len;
+  const bool small_path = !db.big;
+  unsigned long long psum = 0;
+  for (uint32_t unit = blockIdx.x * wpb + wave; unit < units; unit += gridDim.x * wpb) {
+    const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
+    const uint64_t qo = bv.qoffs[qi];
+    const uint32_t L = (uint32_t)(bv.qoffs[qi + 1] - qo);
+    // ---- query letters (reverse-complemented for strand 1: seqinfo.cpp:292-323)
+    for (uint32_t p = lane; p < L; p += 64) s_q[p] = strand == 0 ? bv.qseqs[qo + p] : tab->comp[bv.qseqs[qo + (L - 1 - p)]];
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    for (uint32_t p = lane; p < ((L + 3) & ~3u); p += 64) {
+      uint32_t w = UGS_BAD_WORD;
+      if (p + W <= L) {
+        uint32_t acc = 0; bool ok = true;
+        for (int k = 0; k < W; ++k) { uint32_t l = s_udb[s_q[p + k]]; ok = ok && (l != 0xff); acc = acc * db.alpha + l; }
+        if (ok) w = acc;
+      }
+      s_words[p] = w;
+    }
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    // ---- first occurrences: any earlier position with the same word?  (128-bit LDS reads, no early exit)
+    uint32_t Nu = 0;
+    for (uint32_t p0 = 0; p0 < L; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      bool first = false;
+      if (p < L) {
+        const uint32_t w = s_words[p];
+        first = (w != UGS_BAD_WORD);
+        if (first) {
+          const uint4 *v4 = (const uint4 *)s_words;
+          const uint32_t nq4 = p >> 2;
+          bool dupf = false;
+          for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
+          for (uint32_t q = nq4 << 2; q < p; ++q) dupf = dupf | (s_words[q] == w);
+          first = !dupf;
+        }
+        s_first[p] = first ? 1 : 0;
+      }
+      Nu += (uint32_t)__popcll(__ballot(first));
+    }
+    uint32_t step = 1;
+    if (!small_path) step = db.step_tab[Nu < db.step_n ? Nu : db.step_n - 1];
+    const uint32_t ns_q = Nu == 0 ? 0 : (Nu + step - 1) / step;
+    const uint32_t ns = ns_q <= ns_max ? ns_q : ns_max;
+    if (ns_q > ns_max && lane == 0) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_NS);
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    // ---- ranks of unique words -> sampled slots (every step-th unique word)
+    uint32_t run = 0;
+    uint32_t *out = bv.unit_slots + (uint64_t)unit * ns_max;
+    for (uint32_t p0 = 0; p0 < L; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      const bool f = p < L && s_first[p];
+      const uint64_t m = __ballot(f);
+      if (f) {
+        const uint32_t rank = run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (rank % step == 0 && rank / step < ns) {
+          const uint32_t slot = s_words[p];
+          out[rank / step] = slot;
+          psum += db.row_off[slot + 1] - db.row_off[slot];          // algorithmic postings P(q)
+        }
+      }
+      run += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) bv.unit_ns[unit] = ns;
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+  }
+  for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor((long long)psum, o);
+  if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
+}
+
 __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -478,79 +567,13 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     const uint32_t L = (uint32_t)(bv.qoffs[qi + 1] - qo);
     __syncthreads();
     const unsigned long long tk0 = clock64();
-    // ---- query letters (reverse-complemented for strand 1: seqinfo.cpp:292-323)
-    for (uint32_t p = tid; p < L; p += nthr) {
-      uint8_t c;
-      if (strand == 0) c = bv.qseqs[qo + p];
-      else c = tab->comp[bv.qseqs[qo + (L - 1 - p)]];
-      s_q[p] = c;
-    }
+    // ---- the sampled index rows of this unit were chosen by k_rank_setup
     if (tid == 0) { sh->emit_n = 0; sh->n_sel = 0; sh->last_key = 0; sh->ncl = 0; }
     for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
     for (uint32_t c = tid; c <= ns_max; c += nthr) s_fp[c] = KEY_INF;
+    const uint32_t ns = __builtin_amdgcn_readfirstlane(bv.unit_ns[unit]);
+    for (uint32_t i = tid; i < ns; i += nthr) s_slots[i] = bv.unit_slots[(uint64_t)unit * ns_max + i];
     __syncthreads();
-    // ---- UDB words per position (udbparams.cpp:540-555)
-    for (uint32_t p = tid; p < L; p += nthr) {
-      uint32_t w = UGS_BAD_WORD;
-      if (p + W <= L) {
-        uint32_t acc = 0; bool ok = true;
-        for (int k = 0; k < W; ++k) { uint32_t l = s_udb[s_q[p + k]]; ok = ok && (l != 0xff); acc = acc * db.alpha + l; }
-        if (ok) w = acc;
-      }
-      s_words[p] = w;
-    }
-    __syncthreads();
-    // ---- first occurrences (udbsearcher.cpp:161-194 keeps first-occurrence order)
-    uint32_t my_first = 0;
-    for (uint32_t p = tid; p < L; p += nthr) {
-      const uint32_t w = s_words[p];
-      bool first = (w != UGS_BAD_WORD);
-      if (first) {
-        // any earlier position with the same word?  128-bit LDS reads, no early exit
-        const uint4 *v4 = (const uint4 *)s_words;
-        const uint32_t nq4 = p >> 2;
-        bool dupf = false;
-        for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
-        for (uint32_t q = nq4 << 2; q < p; ++q) dupf = dupf | (s_words[q] == w);
-        first = !dupf;
-      }
-      s_first[p] = first ? 1 : 0;
-      my_first += first ? 1u : 0u;
-    }
-    const uint32_t Nu = block_sum_u32(my_first, sh, wave, wpb, lane);
-    uint32_t step = 1;
-    if (!small_path) step = db.step_tab[Nu < db.step_n ? Nu : db.step_n - 1];
-    const uint32_t ns_q = Nu == 0 ? 0 : (Nu + step - 1) / step;
-    const uint32_t ns = __builtin_amdgcn_readfirstlane(ns_q <= ns_max ? ns_q : ns_max);
-    if (ns_q > ns_max && tid == 0) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_NS);
-    // ---- ranks of unique words -> sampled slots (every step-th unique word)
-    {
-      uint32_t run = 0;   // running count of firsts before the current tile
-      for (uint32_t p0 = 0; p0 < L; p0 += nthr) {
-        const uint32_t p = p0 + tid;
-        const bool f = p < L && s_first[p];
-        const uint64_t m = __ballot(f);
-        const uint32_t inw = __popcll(m & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) sh->wsum[wave] = __popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (int w2 = 0; w2 < wpb; ++w2) { if (w2 < wave) before += sh->wsum[w2]; total += sh->wsum[w2]; }
-        if (f) {
-          const uint32_t rank = run + before + inw;
-          if (rank % step == 0 && rank / step < ns) s_slots[rank / step] = s_words[p];
-        }
-        run += total;
-      }
-    }
-    __syncthreads();
-    // algorithmic postings P(q)
-    {
-      unsigned long long psum = 0;
-      for (uint32_t i = tid; i < ns; i += nthr) { uint32_t s = s_slots[i]; psum += db.row_off[s + 1] - db.row_off[s]; }
-      for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor((long long)psum, o);
-      if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
-    }
     // ---- the scan; counter width by the largest possible count (= ns)
     const int cb0 = ns <= 15 ? 4 : (ns <= 255 ? 8 : 16);
     const bool use_part_cache = false;      // (the fast path reads the partition table with scalar loads)
@@ -830,6 +853,18 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
 {
   const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
+  {   // stage 1: sampled rows of every unit (one wavefront per unit, as many workgroups as fit)
+    const uint32_t units = b.nq * b.nstrand, maxq = (b.max_qlen + 15u) & ~15u;
+    const size_t slds = 256 + 4 * (size_t)maxq * 6;
+    if (slds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_rank_setup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+    int per_cu = 0, ncu = 0, dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_rank_setup, 256, slds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint32_t sgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)ncu * per_cu));
+    if (units) hipLaunchKernelGGL(k_rank_setup, dim3(sgrid), dim3(256), slds, st, db, b, L.ns_max);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
   HIPCHK(hipGetLastError());
