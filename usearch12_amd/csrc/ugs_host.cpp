@@ -668,8 +668,8 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
     fprintf(stderr, "[ugs] rank phase clocks (sum over WGs, thread 0): setup %llu scan %llu scan-wait %llu select %llu | align: %llu %llu %llu %llu\n",
             b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5],
             b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]),
-    fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
-            b->al.grid, b->al.wpb, b->al.lds);
+    fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu, bits %d ns_max %u gsize %u np %u | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
+            b->rl.bits, b->rl.ns_max, b->db->v.gsize, b->db->v.np, b->al.grid, b->al.wpb, b->al.lds);
   return UGS_OK;
 }
 

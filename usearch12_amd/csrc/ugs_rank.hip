@@ -150,7 +150,8 @@ __device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t 
 // FILL=true: emit count-1 targets in scan order, at most `need` of them.
 template <int CB, bool FILL>
 __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool split, uint32_t base_t, uint32_t hi_t,
-                                              uint32_t need, uint64_t fill_limit)
+                                              uint32_t need, uint64_t fill_limit, bool have_ab = false, uint64_t a_in = 0,
+                                              uint64_t b_in = 0)
 {
   constexpr uint32_t EPW = 32 / CB;
   const int lane = s.lane;
@@ -160,9 +161,12 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
   uint32_t quota_left = need;
   for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
     uint64_t a = 0, b = 0;
-    if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
-    const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
-    for (uint32_t r = 0; r < nrows; ++r) {
+    if (have_ab) { a = a_in; b = b_in; }                       // (ns <= 64: the caller tracks each row's cursor)
+    else if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
+    uint64_t rows = __ballot(b > a);                           // only rows with postings in this range, in row order
+    while (rows) {
+      const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+      rows &= rows - 1;
       const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
       for (uint64_t k = ra + lane; k < rbb; k += 64) Tbl<CB>::inc(tbl, postings[k] - base_t);
     }
@@ -207,9 +211,12 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
   }
   for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
     uint64_t a = 0, b = 0;
-    if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
-    const uint32_t nrows = (ns - i0) < 64 ? (ns - i0) : 64;
-    for (uint32_t r = 0; r < nrows; ++r) {
+    if (have_ab) { a = a_in; b = b_in; }
+    else if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
+    uint64_t rows = __ballot(b > a);
+    while (rows) {
+      const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+      rows &= rows - 1;
       const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
       for (uint64_t k0 = ra; k0 < rbb; k0 += 64) {
         const uint64_t k = k0 + lane;
@@ -233,6 +240,32 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
   const uint32_t tbl_targets = s.tbl_words * EPW;
   const bool split = tbl_targets < G;
   const uint32_t nsub = split ? (G + tbl_targets - 1) / tbl_targets : 1;
+  if (split && s.ns <= 64) {
+    // Sparse rows (protein indexes: a row holds far fewer postings than there are table ranges): lane r walks
+    // row r with a cursor through the consecutive ranges of a partition, so a range's sub-row bounds cost the
+    // postings actually crossed instead of two binary searches per (row, range) and pass.
+    for (uint32_t p = s.wave; p < s.np; p += s.wpb) {
+      uint64_t cur = 0, end = 0;
+      uint32_t vcur = 0xffffffffu;
+      if ((uint32_t)s.lane < s.ns) {
+        const uint32_t slot = s.s_slots[s.lane];
+        const uint64_t rb = s.row_off[slot];
+        const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
+        cur = rb + pp[0]; end = rb + pp[1];
+        if (cur < end) vcur = s.postings[cur];
+      }
+      for (uint32_t sub = 0; sub < nsub; ++sub) {
+        const uint32_t base_t = p * s.gsize + sub * tbl_targets;
+        const uint32_t pend = (p + 1) * s.gsize;
+        const uint32_t hi_t = base_t + tbl_targets < pend ? base_t + tbl_targets : pend;
+        const uint64_t a = cur;
+        while (cur < end && vcur < hi_t) { ++cur; vcur = cur < end ? s.postings[cur] : 0xffffffffu; }
+        if (!__ballot(cur > a)) continue;                        // no sampled row has a posting in this range
+        range_generic<CB, FILL>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
+      }
+    }
+    return;
+  }
   for (uint32_t p = s.wave; p < s.np; p += s.wpb)
     for (uint32_t sub = 0; sub < nsub; ++sub) {
       const uint32_t base_t = p * s.gsize + sub * tbl_targets;
