@@ -170,6 +170,7 @@ def main():
         st = stats[-1]
         ms_rank = float(np.mean([s["ms_rank"] for s in stats]))
         ms_align = float(np.mean([s["ms_align"] for s in stats]))
+        ms_setup = float(np.mean([s["ms_rank_setup"] for s in stats]))
         # algorithmic bytes per launch: B(q) = 4*P(q) + L_q + sum L_candidates
         b_rank = 4 * st["postings"] + st["query_letters"]
         b_align = st["query_letters"] + st["target_letters"]
@@ -180,12 +181,14 @@ def main():
         # HBM traffic per launch from the PMC passes of the same command (profiles/*_pmc.json, FETCH_SIZE
         # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
         traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
-                traffic = pm["traffic_bytes_per_launch"][dom]
-        except (OSError, ValueError):
-            pass
+        for pmc_name in ("r01f_pmc.json", "r01_pmc.json"):       # newest PMC pass first
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+                if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
+                    traffic = pm["traffic_bytes_per_launch"][dom]
+                    break
+            except (OSError, ValueError):
+                pass
         achieved = b_dom / (ms_dom * 1e-3) / 1e9
         if dist is None:
             hits, nh, pool = out
@@ -212,11 +215,12 @@ def main():
             "roofline_per_kernel": {
                 "k_rank": {"bound": "hbm", "algorithmic_bytes_per_launch": b_rank, "kernel_ms": ms_rank,
                            "achieved_GBps": b_rank / (ms_rank * 1e-3) / 1e9, "frac": b_rank / (ms_rank * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "k_rank_setup": {"bound": "latency (dependent loads, one wavefront per query)", "kernel_ms": ms_setup},
                 "k_align": {"bound": "integer ALU / LDS (not a bandwidth kernel)", "algorithmic_bytes_per_launch": b_align,
                             "kernel_ms": ms_align, "achieved_GBps": b_align / (ms_align * 1e-3) / 1e9,
                             "pair_alignments_per_s": st["pairs_aligned"] / (ms_align * 1e-3)}},
             "cpu_baseline": cb,
-            "detail": {"ms_rank": ms_rank, "ms_align": ms_align, "hits_per_step": n_hits,
+            "detail": {"ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),
                        "pairs_aligned_per_query": st["pairs_aligned"] / max(qs.n, 1),
                        "dp_gcells_per_s": st["dp_cells"] / max(ms_align * 1e-3, 1e-9) / 1e9,

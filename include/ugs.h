@@ -151,7 +151,7 @@ int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, uint32_t *nh
  * semantics requires reading, letters of query + aligned candidates, DP cells.
  */
 typedef struct ugs_batch_stats {
-  float    ms_rank;          /* ranking kernel(s)                         */
+  float    ms_rank;          /* ranking kernel (k_rank) alone             */
   float    ms_align;         /* alignment kernel                          */
   float    ms_total;
   uint64_t postings;         /* sum over queries of P(q)                  */
@@ -160,6 +160,8 @@ typedef struct ugs_batch_stats {
   uint64_t pairs_aligned;
   uint64_t dp_cells;
   uint64_t hits;
+  float    ms_rank_setup;    /* sampled-row selection kernel (k_rank_setup), runs before k_rank */
+  float    reserved_;
 } ugs_batch_stats;
 int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st);
 

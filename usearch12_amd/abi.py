@@ -33,6 +33,7 @@ class BatchStats(C.Structure):
         ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_total", C.c_float),
         ("postings", C.c_uint64), ("query_letters", C.c_uint64), ("target_letters", C.c_uint64),
         ("pairs_aligned", C.c_uint64), ("dp_cells", C.c_uint64), ("hits", C.c_uint64),
+        ("ms_rank_setup", C.c_float), ("reserved_", C.c_float),
     ]
 
 

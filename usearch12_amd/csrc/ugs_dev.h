@@ -107,7 +107,7 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
                      uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, uint32_t query_base,
                      hipStream_t st);
 size_t ugs_compact_tmp_bytes(uint32_t nq);
-int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st);
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);
 extern const char UGS_B62_ORDER[];          // the 23 alphabetic BLOSUM62 symbols

@@ -306,7 +306,8 @@ __device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R,
     const uint32_t len = (uint32_t)r < s.ns ? pb - pa : 0u;
     B.len[r] = len;
     mx = len > mx ? len : mx;
-    B.v[r] = R.base[r][pa + (uint32_t)lane];
+    const uint32_t *rowp = R.base[r] + pa;          // wave-uniform pointer (SALU); the load is "scalar base + lane*4"
+    B.v[r] = rowp[(uint32_t)lane];
   }
   B.tail = mx > 64;
 }
@@ -882,7 +883,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   return (off + 15) & ~(size_t)15;
 }
 
-int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st)
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done)
 {
   const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
@@ -897,6 +898,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     const uint32_t sgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)ncu * per_cu));
     if (units) hipLaunchKernelGGL(k_rank_setup, dim3(sgrid), dim3(256), slds, st, db, b, L.ns_max);
     HIPCHK(hipGetLastError());
+    if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
   }
   HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
