@@ -326,23 +326,28 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   // Branch-free: lanes without a posting in row r aim at a private dummy word behind the table
   // (whatever they add / clear there is harmless), so the 2*NR LDS atomics issue back-to-back
   // and ONE wait covers the batch.
-  const uint32_t dummy_x = (s.tbl_words + (uint32_t)lane) << 3;
-  uint32_t w[NR], sh[NR];    // LDS word index and nibble shift of this lane's posting in row r
+  // LDS byte address of a target's counter word = table base + (x >> 3) * 4 with x = target - base_t.  The base is
+  // folded into x once per batch (x' = x + 2 * base, base a multiple of 4): address = (x' >> 1) & ~3, nibble = x' & 7.
+  typedef uint32_t __attribute__((address_space(3))) *lds32;
+  const uint32_t tb2 = 2u * (uint32_t)(uintptr_t)tbl;
+  const uint32_t sub = base_t - tb2;                           // x' = posting - sub  (mod 2^32)
+  const uint32_t dummy_x = ((s.tbl_words + (uint32_t)lane) << 3) + tb2;
+  uint32_t ad[NR], sh[NR];   // LDS byte address and nibble shift of this lane's posting in row r
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const uint32_t x = (uint32_t)lane < B.len[r] ? B.v[r] - base_t : dummy_x;
-    w[r] = x >> 3;
+    const uint32_t x = (uint32_t)lane < B.len[r] ? B.v[r] - sub : dummy_x;
+    ad[r] = (x >> 1) & ~3u;
     sh[r] = (x & 7u) << 2;
   }
 #pragma unroll
-  for (int r = 0; r < NR; ++r) atomicAdd(&tbl[w[r]], 1u << sh[r]);
+  for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[r], 1u << sh[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");       // order only: the LDS unit executes one wave's operations in program order
   // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
   // row that holds a target still sees its counter set and gets the target's final count back;
   // later rows of the same target read 0.
   uint32_t old[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) old[r] = atomicAnd(&tbl[w[r]], ~(15u << sh[r]));
+  for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[r], ~(15u << sh[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
   uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
   uint32_t m2 = 0;           // bit r: this lane holds a first touch with count >= 2 in row r
