@@ -337,24 +337,25 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   for (int r = 0; r < NR; ++r) {
     const uint32_t x = (uint32_t)lane < B.len[r] ? B.v[r] - sub : dummy_x;
     ad[r] = (x >> 1) & ~3u;
-    sh[r] = (x & 7u) << 2;
+    sh[r] = x << 2;                    // only bits [4:0] are ever used (shift amounts, bit-field offset)
   }
 #pragma unroll
-  for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[r], 1u << sh[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[r], 1u << (sh[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");       // order only: the LDS unit executes one wave's operations in program order
   // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
   // row that holds a target still sees its counter set and gets the target's final count back;
   // later rows of the same target read 0.
   uint32_t old[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[r], ~(15u << sh[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[r], ~(15u << (sh[r] & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
   uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
-  uint32_t m2 = 0;           // bit r: this lane holds a first touch with count >= 2 in row r
+  uint32_t cnt = 0;          // rows in which this lane holds a first touch with count >= 2
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    c[r] = (uint32_t)lane < B.len[r] ? ((old[r] >> sh[r]) & 15u) : 0u;
-    m2 |= (c[r] >= 2u ? 1u : 0u) << r;
+    // v_bfe_u32 takes the offset mod 32, so the unmasked shift (x << 2) serves directly
+    c[r] = (uint32_t)lane < B.len[r] ? __builtin_amdgcn_ubfe(old[r], sh[r], 4u) : 0u;
+    cnt += c[r] >= 2u ? 1u : 0u;
     if (s.small_path || (uint32_t)r <= c1hi) {      // uniform: can this row still lower fp[1]?
       const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
       const bool f1 = c[r] == 1 && pos < cache1;
@@ -366,8 +367,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     }
   }
   // every (lane,row) with count >= 2 of the whole partition is emitted with ONE slot allocation
-  if (__ballot(m2 != 0)) {
-    const uint32_t cnt = __popc(m2);
+  if (__ballot(cnt != 0)) {
     const uint32_t incl = wave_incl_sum_u32(cnt);
     const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
     uint32_t base = 0;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     uint32_t o = base + incl - cnt;
 #pragma unroll
     for (int r = 0; r < NR; ++r)
-      if ((m2 >> r) & 1u) {
+      if (c[r] >= 2u) {
         const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
         atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);          // fire-and-forget LDS atomics
         if (s.hist) atomicAdd(&s.hist[c[r] * 16 + r], 1u);
