@@ -366,7 +366,10 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
       }
     }
   }
-  // every (lane,row) with count >= 2 of the whole partition is emitted with ONE slot allocation
+  // every (lane,row) with count >= 2 of the whole partition is emitted with ONE slot allocation.  A lane almost
+  // never holds more than one such row, so instead of walking the rows (NR predicated emit blocks per batch) each
+  // lane first selects its lowest qualifying row with a chain of conditional moves and emits once; a second
+  // item per lane takes another trip through the loop.
   if (__ballot(cnt != 0)) {
     const uint32_t incl = wave_incl_sum_u32(cnt);
     const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
@@ -374,15 +377,27 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     if (lane == 0) base = atomicAdd(&s.sh->emit_n, total);
     base = __builtin_amdgcn_readfirstlane(base);
     uint32_t o = base + incl - cnt;
+    auto emit = [&](uint32_t csel, uint32_t vsel, uint32_t rsel) {
+      const uint64_t pos = s.small_path ? (uint64_t)vsel : (((uint64_t)rsel << 32) | vsel);
+      atomicMin(&s.s_fp[csel], (unsigned long long)pos);          // fire-and-forget LDS atomics
+      if (s.hist) atomicAdd(&s.hist[csel * 16 + rsel], 1u);
+      if ((uint64_t)o < s.ecap) s.ebuf[o] = make_key(csel, pos);
+      ++o;
+    };
+    {
+      uint32_t csel = 0, vsel = 0, rsel = 0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
-      if (c[r] >= 2u) {
-        const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
-        atomicMin(&s.s_fp[c[r]], (unsigned long long)pos);          // fire-and-forget LDS atomics
-        if (s.hist) atomicAdd(&s.hist[c[r] * 16 + r], 1u);
-        if ((uint64_t)o < s.ecap) s.ebuf[o] = make_key(c[r], pos);
-        ++o;
+      for (int r = NR - 1; r >= 0; --r) {
+        const bool take = c[r] >= 2u;
+        csel = take ? c[r] : csel; vsel = take ? B.v[r] : vsel; rsel = take ? (uint32_t)r : rsel;
       }
+      if (cnt) emit(csel, vsel, rsel);
+      if (__ballot(cnt >= 2u)) {                       // rare: further items of a lane, rows above the one just emitted
+#pragma unroll
+        for (int r = 1; r < NR; ++r)
+          if (c[r] >= 2u && (uint32_t)r > rsel) emit(c[r], B.v[r], (uint32_t)r);
+      }
+    }
   }
 }
 
