@@ -144,6 +144,34 @@ __device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t 
   }
 }
 
+// Row-major flattening of up to 64 sub-rows [a_r, b_r) held one per lane: posting f of the concatenation belongs to
+// the row r with excl_r <= f < incl_r (binary search over the lanes' inclusive prefix sums with ds_bpermute, no memory).
+// Used when the sub-rows are short (protein indexes: 1-6 postings per row and range), where a loop over rows would
+// spend an instruction stream per row to move a handful of postings.
+struct FlatRows { uint32_t incl, excl, T; uint64_t a; };
+__device__ __forceinline__ bool flat_rows_setup(FlatRows &fr, uint64_t a, uint64_t b, uint64_t rows)
+{
+  const uint32_t len = (uint32_t)(b - a);
+  fr.incl = wave_incl_sum_u32(len); fr.excl = fr.incl - len; fr.a = a;
+  fr.T = (uint32_t)__builtin_amdgcn_readlane((int)fr.incl, 63);
+  return rows != 0 && fr.T < 32u * (uint32_t)__popcll(rows);      // average sub-row below half a wavefront
+}
+__device__ __forceinline__ bool flat_rows_at(const FlatRows &fr, uint32_t f, uint32_t &row, uint64_t &k)
+{
+  uint32_t lo = 0, hi = 63;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const uint32_t v = (uint32_t)__shfl((int)fr.incl, (int)mid);
+    if (v > f) hi = mid; else lo = mid + 1;
+  }
+  row = lo;
+  const uint32_t ex = (uint32_t)__shfl((int)fr.excl, (int)lo);
+  const uint32_t alo = (uint32_t)__shfl((int)(uint32_t)fr.a, (int)lo), ahi = (uint32_t)__shfl((int)(uint32_t)(fr.a >> 32), (int)lo);
+  k = (((uint64_t)ahi << 32) | alo) + (f - ex);
+  return f < fr.T;
+}
+
 // Generic handling of one table range [base_t, hi_t) of partition p: any number of rows, any
 // sub-row length; rows are walked in order and counters are cleared right after they are read, so
 // only the first touch of a target sees a non-zero count (no duplicates are emitted).
@@ -164,6 +192,16 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
     if (have_ab) { a = a_in; b = b_in; }                       // (ns <= 64: the caller tracks each row's cursor)
     else if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
     uint64_t rows = __ballot(b > a);                           // only rows with postings in this range, in row order
+    FlatRows fr;
+    if (flat_rows_setup(fr, a, b, rows)) {
+      // sparse sub-rows: lanes = postings of ALL rows of this range in row-major order
+      for (uint32_t f0 = 0; f0 < fr.T; f0 += 64) {
+        uint32_t row; uint64_t k;
+        const bool on = flat_rows_at(fr, f0 + (uint32_t)lane, row, k);
+        if (on) Tbl<CB>::inc(tbl, postings[k] - base_t);
+      }
+      continue;
+    }
     while (rows) {
       const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
       rows &= rows - 1;
@@ -214,6 +252,30 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
     if (have_ab) { a = a_in; b = b_in; }
     else if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, split, base_t, hi_t, a, b);
     uint64_t rows = __ballot(b > a);
+    FlatRows fr;
+    if (flat_rows_setup(fr, a, b, rows)) {
+      for (uint32_t f0 = 0; f0 < fr.T; f0 += 64) {
+        uint32_t row; uint64_t k;
+        const bool o2 = flat_rows_at(fr, f0 + (uint32_t)lane, row, k);
+        uint32_t t2 = 0, c2 = 0;
+        if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+        // one instruction now spans several rows: a target held by two of its lanes (count >= 2) is reported by the
+        // lower lane = the earlier row only, as the row-by-row walk would
+        bool dup = false;
+        uint64_t m = __ballot(o2 && c2 >= 2);
+        while (m) {
+          const int L = __ffsll((long long)m) - 1;
+          const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t2, L);
+          const bool same = o2 && lane > L && t2 == tL;
+          dup = dup || same;
+          m &= ~(__ballot(same) | (1ull << L));
+        }
+        extract_one<CB, FILL>(s, o2 && !dup, t2, base_t, i0 + row, c2, quota_left, fill_limit);
+      }
+      continue;
+    }
     while (rows) {
       const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
       rows &= rows - 1;
