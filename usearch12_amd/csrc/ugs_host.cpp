@@ -306,8 +306,15 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     double g = 40.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
     uint64_t gs = ((uint64_t)g + 511) / 1024 * 1024;
     if (gs < 1024) gs = 1024;
-    if (gs > 65536) gs = 65536;
-    const uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
+    uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
+    if (gs > 65536) {
+      // sparse rows (protein dictionaries: a few hundred postings per row): no partition size gives 40 postings per
+      // sub-row; the scan then flattens all sub-rows of a range into one instruction stream and what matters is the
+      // number of resident waves, i.e. a small counter table (16 Ki targets x 8 bits = 16 KiB of LDS per wave).
+      // The partition table may grow up to the size of the postings themselves for it.
+      gs = 16384;
+      budget = std::max<uint64_t>(256ull << 20, db->n_postings * 4);
+    }
     while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
     gsize = (uint32_t)gs;
     if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
