@@ -294,6 +294,20 @@ uint32_t ugs_hits_to_report(const ugs_hit *hits, uint32_t n, uint32_t maxhits, i
 /* the DB letters as the reference holds them after MaskDB (makeudb.cpp:11-25): out[nletters] */
 int ugs_db_masked_letters(const ugs_db *db, char *out);
 
+/* ------------------------------------------------------------------------------------------
+ * otutab sink (cmd_otutab searchcmd.cpp:20-40: usearch_global with -id 0.97 -maxaccepts 3 -maxrejects 32
+ * -stepwords 0 -strand both, hits consumed by OTUTableSink otutabsink.cpp:31-58).  Feed every query in input order
+ * with the label of its top hit (ugs_hits_to_report(..., top_hit_only=1, ...) = HitMgr::GetTopHit) or NULL;
+ * map_line receives the -mapout line ("query<TAB>otu\n", empty when unassigned).  ugs_otutab_write = -otutabout
+ * (OTUTable::ToTabbedFile otutab.cpp:247-313: rows / columns in order of first appearance).
+ */
+typedef struct ugs_otutab ugs_otutab;
+ugs_otutab *ugs_otutab_create(void);
+void ugs_otutab_destroy(ugs_otutab *t);
+int ugs_otutab_add(ugs_otutab *t, const char *qlabel, const char *top_hit_tlabel, char *map_line, int cap);
+int ugs_otutab_write(const ugs_otutab *t, const char *path);
+int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64_t *total);
+
 const char *ugs_last_error(void);
 
 #ifdef __cplusplus

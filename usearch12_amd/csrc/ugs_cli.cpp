@@ -4,6 +4,8 @@
 //   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
+//   ugs_cli -otutab reads.fa -otus otus.fa|-zotus ..|-db .. [-otutabout f] [-mapout f] [+ the usearch_global outputs]
+//           (cmd_otutab searchcmd.cpp:20-40: defaults -id 0.97 -maxaccepts 3 -maxrejects 32 -stepwords 0 -strand both)
 //
 // It stands where cmd_usearch_global -> Search() -> Thread() stand in the reference
 // (searchcmd.cpp:6-9, search.cpp:51-141): load the DB, stream query batches through the C-ABI
@@ -88,6 +90,7 @@ struct Outputs {
   std::string userfields;
   bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
   uint32_t maxhits = 0;
+  ugs_otutab *otutab = nullptr; FILE *map = nullptr;   // OTUTableSink
   std::vector<uint32_t> db_hit_counts;      // DBHitSink::m_HitCounts
   const char *db_masked = nullptr;          // DB letters as the reference holds them (masked)
 };
@@ -99,6 +102,10 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   static std::vector<char> line(1 << 20);
   const uint32_t ql = (uint32_t)(q.offs[qi + 1] - q.offs[qi]);
   const char *qs = q.letters.data() + q.offs[qi], *qlab = q.labels[qi].c_str();
+  auto put_to = [&](FILE *f, int len) {
+    if (len < 0) { fprintf(stderr, "%s\n", ugs_last_error()); exit(1); }
+    if (f && len > 0) fputs(line.data(), f);
+  };
   auto put = [&](FILE *f, int len) {
     if (len < 0) { fprintf(stderr, "%s\n", ugs_last_error()); exit(1); }
     if ((size_t)len >= line.size()) { fprintf(stderr, "output line too long\n"); exit(1); }
@@ -106,6 +113,11 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   };
   uint32_t first = 0;
   const uint32_t n = ugs_hits_to_report(h, n_all, O.maxhits, O.top_hit_only, O.top_hits_only, &first);   // HitMgr::GetHitCount
+  if (O.otutab) {                                                     // OTUTableSink::OnQueryDone otutabsink.cpp:31-58
+    uint32_t top = 0;
+    if (n) ugs_hits_to_report(h, n_all, 0, 1, 0, &top);               // HitMgr::GetTopHit
+    put_to(O.map, ugs_otutab_add(O.otutab, qlab, n ? db.labels[h[top].target].c_str() : nullptr, line.data(), (int)line.size()));
+  }
   h += first;
   if (n == 0) {                                                       // OutputMatchedFalse outputsink.cpp:392-403
     if (O.uc) put(O.uc, ugs_format_uc_nohit(ql, qlab, line.data(), (int)line.size()));
@@ -123,7 +135,7 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
     if (O.uc) put(O.uc, ugs_format_uc_hit(&h[j], pool, p.is_nucleo, qlab, tl, line.data(), (int)line.size()));
     if (O.user) put(O.user, ugs_format_userout(&h[j], pool, p.is_nucleo, O.userfields.c_str(), qlab, tl, qs, ql,
                                                 O.db_masked + db.offs[t], (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
-    if (!O.db_hit_counts.empty()) ++O.db_hit_counts[t];               // DBHitSink::OnQueryDone dbhitsink.cpp:117-140
+    if (!O.db_hit_counts.empty() && !(O.otutab && j > 0)) ++O.db_hit_counts[t];   // DBHitSink::OnQueryDone dbhitsink.cpp:117-140 (otutab: first hit only, :137)
   }
   if (O.matched) put(O.matched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
 }
@@ -167,12 +179,15 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
+  std::string otutabout, mapout; bool otutab_cmd = false; long stepwords = -1;
   Outputs O;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
+    else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
+    else if (a == "-otutabout") otutabout = val(); else if (a == "-mapout") mapout = val(); else if (a == "-stepwords") stepwords = atol(val());
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
@@ -208,6 +223,13 @@ int main(int argc, char **argv)
     from_udb = true;
   } else { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
   const bool nucleo = from_udb ? udb_nucleo : (dbtype >= 0 ? dbtype != 0 : guess_nucleo(db));
+  if (otutab_cmd) {                                                   // cmd_otutab searchcmd.cpp:20-40 (oset_*d: only if not given)
+    if (id < 0) id = 0.97;
+    if (maxacc < 0) maxacc = 3;
+    if (maxrej < 0) maxrej = 32;
+    if (stepwords < 0) stepwords = 0;
+    if (strand.empty()) strand = "both";
+  }
   if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
@@ -216,6 +238,7 @@ int main(int argc, char **argv)
   if (maxacc >= 0) p.max_accepts = maxacc;
   if (maxrej >= 0) p.max_rejects = maxrej;
   if (big >= 0) p.big = (uint32_t)big;
+  if (stepwords >= 0) p.stepwords = (uint32_t)stepwords;
   if (from_udb) { p.dbmask = 0; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
     if (path.empty()) return nullptr;
@@ -229,6 +252,7 @@ int main(int argc, char **argv)
   }
   O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath);
   O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
+  if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   Searcher searcher(p, db, device);
   std::string masked;
   if (O.user || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
@@ -251,7 +275,14 @@ int main(int argc, char **argv)
     }
     total += q.size();
   }
-  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched}) if (f) fclose(f);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map}) if (f) fclose(f);
+  if (O.otutab) {                                                     // OTUTableSink::OnAllDone otutabsink.cpp:60-76
+    uint64_t assigned = 0, tot = 0;
+    ugs_otutab_totals(O.otutab, &assigned, &tot);
+    fprintf(stderr, "%llu / %llu mapped to OTUs (%.1f%%)\n", (unsigned long long)assigned, (unsigned long long)tot, tot ? 100.0 * assigned / tot : 0.0);
+    if (!otutabout.empty() && ugs_otutab_write(O.otutab, otutabout.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    ugs_otutab_destroy(O.otutab);
+  }
   for (int m = 0; m < 2; ++m) {                                       // DBHitSink::ToFASTA dbhitsink.cpp:89-115
     const std::string &path = m ? dbmatchedpath : dbnotmatchedpath;
     if (path.empty()) continue;

@@ -296,3 +296,116 @@ extern "C" uint32_t ugs_hits_to_report(const ugs_hit *hits, uint32_t n, uint32_t
   }
   return count;
 }
+
+// ---------------------------------------------------------------- OTU table (otutab sink)
+// OTUTableSink::OnQueryDone otutabsink.cpp:31-58 (top hit -> OTU name from the target label, sample name from
+// the query label, count += size= annotation), OTUTable::IncCount / ToTabbedFile otutab.cpp:548-557,247-313
+// (rows and columns in order of first appearance), label rules label.cpp:27-44,152-226.
+#include <map>
+
+namespace {
+
+void split_fields(const std::string &s, char sep, std::vector<std::string> &out)      // Split() myutils.cpp: empty fields dropped
+{
+  out.clear();
+  std::string cur;
+  for (char c : s) { if (c == sep) { if (!cur.empty()) out.push_back(cur); cur.clear(); } else cur.push_back(c); }
+  if (!cur.empty()) out.push_back(cur);
+}
+
+std::string str_field(const std::string &label, const char *name_eq)                  // GetStrField label.cpp:27-44
+{
+  std::vector<std::string> f;
+  split_fields(label, ';', f);
+  const size_t n = strlen(name_eq);
+  for (const std::string &x : f) if (x.compare(0, n, name_eq) == 0) return x.substr(n);
+  return std::string();
+}
+
+unsigned size_from_label(const std::string &label, unsigned dflt)                     // GetSizeFromLabel label.cpp:152-161
+{
+  const char *p = strstr(label.c_str(), ";size=");
+  return p ? (unsigned)atoi(p + 6) : dflt;
+}
+
+std::string acc_from_label(const std::string &label)                                  // GetAccFromLabel label.cpp:168-182
+{
+  std::string acc;
+  for (char c : label) {
+    if (c == ' ' || c == '|' || c == ';') { if (acc != "gi") return acc; }
+    acc.push_back(c);
+  }
+  return acc;
+}
+
+std::string sample_from_label(const std::string &label)                               // GetSampleNameFromLabel label.cpp:204-226
+{
+  std::string s = str_field(label, "sample=");
+  if (!s.empty()) return s;
+  s = str_field(label, "barcodelabel=");
+  if (!s.empty()) return s;
+  for (char c : label) { if (!isalpha((unsigned char)c) && !isdigit((unsigned char)c) && c != '_') break; s.push_back(c); }
+  return s;
+}
+
+}  // namespace
+
+struct ugs_otutab {
+  std::vector<std::string> otus, samples;
+  std::map<std::string, unsigned> otu_ix, sample_ix;
+  std::vector<std::vector<unsigned>> counts;          // [otu][sample]
+  unsigned long long assigned = 0, total = 0;
+};
+
+extern "C" ugs_otutab *ugs_otutab_create(void) { return new ugs_otutab(); }
+extern "C" void ugs_otutab_destroy(ugs_otutab *t) { delete t; }
+
+extern "C" int ugs_otutab_add(ugs_otutab *t, const char *qlabel, const char *top_hit_tlabel, char *map_line, int cap)
+{
+  if (!t || !qlabel) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  const std::string ql(qlabel);
+  const unsigned size = size_from_label(ql, 1);
+  t->total += size;
+  if (map_line && cap > 0) map_line[0] = 0;
+  if (!top_hit_tlabel) return 0;
+  const std::string tl(top_hit_tlabel);
+  std::string otu = str_field(tl, "otu=");                                            // GetOTUNameFromLabel label.cpp:193-202
+  if (otu.empty()) otu = acc_from_label(tl);
+  if (otu.empty()) { ugs_set_error("Empty OTU name in label >%s", top_hit_tlabel); return UGS_E_ARG; }
+  const std::string sample = sample_from_label(ql);
+  t->assigned += size;
+  unsigned oi, si;
+  auto io = t->otu_ix.find(otu);
+  if (io == t->otu_ix.end()) { oi = (unsigned)t->otus.size(); t->otus.push_back(otu); t->otu_ix[otu] = oi; t->counts.emplace_back(t->samples.size(), 0u); }
+  else oi = io->second;
+  auto is = t->sample_ix.find(sample);
+  if (is == t->sample_ix.end()) { si = (unsigned)t->samples.size(); t->samples.push_back(sample); t->sample_ix[sample] = si; for (auto &row : t->counts) row.push_back(0u); }
+  else si = is->second;
+  t->counts[oi][si] += size;
+  return snprintf(map_line, map_line ? (size_t)cap : 0, "%s\t%s\n", qlabel, otu.c_str());
+}
+
+extern "C" int ugs_otutab_write(const ugs_otutab *t, const char *path)
+{
+  if (!t || !path) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  FILE *f = fopen(path, "w");
+  if (!f) { ugs_set_error("cannot create %s", path); return UGS_E_ARG; }
+  fputs("#OTU ID", f);
+  for (const std::string &s : t->samples) { fputc('\t', f); fputs(s.c_str(), f); }
+  fputc('\n', f);
+  for (size_t o = 0; o < t->otus.size(); ++o) {
+    fputs(t->otus[o].c_str(), f);
+    for (size_t s = 0; s < t->samples.size(); ++s) fprintf(f, "\t%u", t->counts[o][s]);
+    fputc('\n', f);
+  }
+  fclose(f);
+  return UGS_OK;
+}
+
+extern "C" int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64_t *total)
+{
+  if (!t) return UGS_E_ARG;
+  if (assigned) *assigned = t->assigned;
+  if (total) *total = t->total;
+  return UGS_OK;
+}
