@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UGS_ABI_VERSION 1
+#define UGS_ABI_VERSION 2   /* 2: ugs_params gained the accept/pair filters, ugs_batch_stats the setup-kernel time */
 
 /* error codes */
 #define UGS_OK            0
@@ -51,7 +51,17 @@ extern "C" {
  *   band, minhsp, xdrop_nw, hsp_word_len                              (alnheuristics.cpp:26-62)
  *   match, mismatch (nt) ; aa uses BLOSUM62                           (alnparams.cpp:333,380-384)
  *   dbmask        0 = upper-case only, 1 = fastnucleo/fastamino       (makeudb.cpp:11-25)
+ *   filter_mask + values: the optional accept filters of Accepter::IsAcceptLo (accepter.cpp:41-91): -maxid (only
+ *                 tested when -id is set), -mincols, -maxgaps, -query_cov, -max_query_cov, -target_cov,
+ *                 -max_target_cov, -maxdiffs, -mindiffs.  A filter is active when its UGS_F_* bit is set; float
+ *                 values are compared as (double)(float)value like every option (opts.cpp:265).  A hit that fails
+ *                 one is a reject for the terminator, exactly like a failed -id.  (The pair filters of
+ *                 Accepter::RejectPair - -self, -selfid, -minqt ... - are not implemented.)
  */
+enum {
+  UGS_F_MAXID = 1, UGS_F_MINCOLS = 2, UGS_F_MAXGAPS = 4, UGS_F_QUERY_COV = 8, UGS_F_MAX_QUERY_COV = 16,
+  UGS_F_TARGET_COV = 32, UGS_F_MAX_TARGET_COV = 64, UGS_F_MAXDIFFS = 128, UGS_F_MINDIFFS = 256
+};
 typedef struct ugs_params {
   int32_t  is_nucleo;
   int32_t  word_len;       /* UDB word length: 8 nt / 5 aa            */
@@ -71,6 +81,10 @@ typedef struct ugs_params {
   float    mismatch;
   int32_t  hsp_word_len;   /* 5 nt / 3 aa                              */
   int32_t  dbmask;
+  uint32_t filter_mask;    /* UGS_F_* bits                             */
+  float    maxid, query_cov, max_query_cov, target_cov, max_target_cov;
+  uint32_t mincols, maxgaps, maxdiffs, mindiffs;
+  uint32_t reserved_[2];
 } ugs_params;
 
 /*

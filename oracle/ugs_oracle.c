@@ -1182,6 +1182,34 @@ static void hb_push(HitBuf *hb, const ugs_hit *h, const char *path)
  * candidate loop (udbusortedsearcher.cpp:138-151 / udbusortedsearcherbig.cpp:113-134), OnAR
  * (searcher.cpp:52-61), Accepter::IsAcceptLo (accepter.cpp:27-94, default filters), Terminator
  * (terminator.cpp:64-100) */
+/* Accepter::IsAcceptLo accepter.cpp:24-91 on the FillLo statistics of a global hit (coverages: arscorer.cpp:122-154) */
+static int is_accept_lo(const ugs_params *p, const ugs_hit *h)
+{
+  const unsigned m = p->filter_mask;
+  if (p->id_set) {
+    double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+    if (FractId < p->id_accept) return 0;
+    if ((m & UGS_F_MAXID) && FractId > (double)p->maxid) return 0;
+  }
+  if ((m & UGS_F_MINCOLS) && h->aln_len < p->mincols) return 0;
+  if ((m & UGS_F_MAXGAPS) && h->gaps_int > p->maxgaps) return 0;
+  if (m & (UGS_F_QUERY_COV | UGS_F_MAX_QUERY_COV)) {
+    unsigned n = h->qhi - h->qlo + 1;
+    double Cov = (double)n / h->ql;
+    if ((m & UGS_F_QUERY_COV) && Cov < (double)p->query_cov) return 0;
+    if ((m & UGS_F_MAX_QUERY_COV) && Cov > (double)p->max_query_cov) return 0;
+  }
+  if (m & (UGS_F_TARGET_COV | UGS_F_MAX_TARGET_COV)) {
+    unsigned MCount = h->ids + h->mism;
+    double Cov = (double)MCount / (double)h->tl;
+    if ((m & UGS_F_TARGET_COV) && Cov < (double)p->target_cov) return 0;
+    if ((m & UGS_F_MAX_TARGET_COV) && Cov > (double)p->max_target_cov) return 0;
+  }
+  if ((m & UGS_F_MAXDIFFS) && h->mism + h->gaps_int > p->maxdiffs) return 0;
+  if ((m & UGS_F_MINDIFFS) && h->mism + h->gaps_int < p->mindiffs) return 0;
+  return 1;
+}
+
 static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb)
 {
   orc_db *db = w->db;
@@ -1200,11 +1228,7 @@ static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, 
     if (aligned) {
       ugs_hit h; memset(&h, 0, sizeof(h));
       fill_hit(db, w->path, q, QL, T, TL, &h);
-      Accept = 1;
-      if (db->p.id_set) {
-        double FractId = h.aln_len == 0 ? 0.0 : (double)h.ids / (double)h.aln_len;
-        if (FractId < db->p.id_accept) Accept = 0;
-      }
+      Accept = is_accept_lo(&db->p, &h);
       if (Accept) { h.query = qindex; h.target = t; h.strand = (uint32_t)strand; hb_push(hb, &h, w->path); ++w->st.hits; }
     }
     if (Accept) ++AcceptCount; else ++RejectCount;

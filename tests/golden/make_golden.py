@@ -46,7 +46,15 @@ CASES = {
     # mixed lengths 20..300: short queries need wider counters than the batch-typical ones
     "hard_mixlen": dict(gen="hard", seed=28, n_fam=400, fam=6, q_n=1500, aa=False, id=0.97, strand="plus", big=100, lmin=20, lmax=300),
     "hard_mixlen_s": dict(gen="hard", seed=29, n_fam=400, fam=6, q_n=1500, aa=False, id=0.95, strand="both", lmin=20, lmax=300),
+    # optional accept filters of Accepter::IsAcceptLo (a failed filter is a reject for the terminator)
+    "hard_filt":   dict(gen="hard", seed=30, n_fam=300, fam=8, q_n=1200, aa=False, id=0.90, strand="plus", big=100, maxaccepts=4, maxrejects=16,
+                        query_cov=0.9, target_cov=0.85, maxgaps=3, maxdiffs=25, mindiffs=1, maxid=0.995, mincols=150),
+    "hard_filt_s": dict(gen="hard", seed=31, n_fam=300, fam=8, q_n=1200, aa=False, id=0.92, strand="both", maxaccepts=3, maxrejects=12,
+                        max_query_cov=0.999, max_target_cov=0.995, maxgaps=6, maxdiffs=30, lmin=100, lmax=400),
+    "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
+                         query_cov=0.95, maxgaps=4, mindiffs=3),
 }
+FILTER_OPTS = ("maxid", "mincols", "maxgaps", "query_cov", "max_query_cov", "target_cov", "max_target_cov", "maxdiffs", "mindiffs")
 
 
 def make_inputs(c):
@@ -76,7 +84,7 @@ def ref_cmd(c, qfa, dbfa, prefix):
            "-uc", prefix + ".uc", "-threads", "1"]
     if not c["aa"]:
         cmd += ["-strand", c["strand"]]
-    for opt in ("big", "maxaccepts", "maxrejects"):
+    for opt in ("big", "maxaccepts", "maxrejects") + FILTER_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
     return cmd

@@ -44,6 +44,9 @@ def params_kw(c):
         kw["max_accepts"] = c["maxaccepts"]
     if "maxrejects" in c:
         kw["max_rejects"] = c["maxrejects"]
+    for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
+        if opt in c:
+            kw[opt] = c[opt]
     return kw
 
 

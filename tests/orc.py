@@ -4,7 +4,7 @@ import os
 import subprocess
 import numpy as np
 
-from usearch12_amd.abi import Params, HIT_DTYPE, ptr, as_u8, cigar_text, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from usearch12_amd.abi import FILTER_BITS, Params, HIT_DTYPE, ptr, as_u8, cigar_text, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
@@ -92,6 +92,8 @@ def params(is_nucleo=True, id=0.97, **kw):
         if not hasattr(p, k):
             raise AttributeError(k)
         setattr(p, k, v)
+        if k in FILTER_BITS:            # an optional accept filter is active when its bit is set (include/ugs.h)
+            p.filter_mask |= FILTER_BITS[k]
     return p
 
 

@@ -129,7 +129,7 @@ def test_cli_text_identical_to_reference(tmp_path):
     FASTA in, -blast6out / -uc out, byte-identical to the reference's files."""
     import subprocess
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
-    for name in ("hard_both", "hard_aa"):
+    for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s"):
         c, db, qs, b6, uc = G.load(name)
         dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
@@ -137,7 +137,7 @@ def test_cli_text_identical_to_reference(tmp_path):
                "-uc", str(tmp_path / "o.uc"), "-batch", "500"]
         if not c["aa"]:
             cmd += ["-strand", c["strand"]]
-        for opt in ("big", "maxaccepts", "maxrejects"):
+        for opt in ("big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:
             if opt in c:
                 cmd += ["-" + opt, str(c[opt])]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)

@@ -16,7 +16,19 @@ class Params(C.Structure):
         ("band", C.c_int32), ("minhsp", C.c_int32), ("xdrop_nw", C.c_float),
         ("match", C.c_float), ("mismatch", C.c_float),
         ("hsp_word_len", C.c_int32), ("dbmask", C.c_int32),
+        ("filter_mask", C.c_uint32),
+        ("maxid", C.c_float), ("query_cov", C.c_float), ("max_query_cov", C.c_float), ("target_cov", C.c_float),
+        ("max_target_cov", C.c_float),
+        ("mincols", C.c_uint32), ("maxgaps", C.c_uint32), ("maxdiffs", C.c_uint32), ("mindiffs", C.c_uint32),
+        ("reserved_", C.c_uint32 * 2),
     ]
+
+
+# UGS_F_* bits of Params.filter_mask (include/ugs.h)
+F_MAXID, F_MINCOLS, F_MAXGAPS, F_QUERY_COV, F_MAX_QUERY_COV, F_TARGET_COV, F_MAX_TARGET_COV, F_MAXDIFFS, F_MINDIFFS = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256)
+FILTER_BITS = dict(maxid=F_MAXID, mincols=F_MINCOLS, maxgaps=F_MAXGAPS, query_cov=F_QUERY_COV, max_query_cov=F_MAX_QUERY_COV,
+                   target_cov=F_TARGET_COV, max_target_cov=F_MAX_TARGET_COV, maxdiffs=F_MAXDIFFS, mindiffs=F_MINDIFFS)
 
 
 HIT_DTYPE = np.dtype({

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .abi import UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from .abi import FILTER_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libugs.so")
@@ -87,6 +87,8 @@ def params(is_nucleo=True, id=0.97, **kw):
         if not hasattr(p, k):
             raise AttributeError(k)
         setattr(p, k, v)
+        if k in FILTER_BITS:            # an optional accept filter is active when its bit is set (include/ugs.h)
+            p.filter_mask |= FILTER_BITS[k]
     return p
 
 

@@ -843,6 +843,24 @@ __global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv,
             if (db.id_set) {
               const double FractId = alen == 0 ? 0.0 : (double)ids / (double)alen;
               if (FractId < db.id_accept) accept = false;
+              if ((db.filter_mask & UGS_F_MAXID) && FractId > (double)db.maxid) accept = false;
+            }
+            if (db.filter_mask) {                          // the other optional filters of IsAcceptLo (accepter.cpp:41-91)
+              const uint32_t fm = db.filter_mask, diffs = (mcols - ids) + gaps;
+              if ((fm & UGS_F_MINCOLS) && alen < db.mincols) accept = false;
+              if ((fm & UGS_F_MAXGAPS) && gaps > db.maxgaps) accept = false;
+              if (fm & (UGS_F_QUERY_COV | UGS_F_MAX_QUERY_COV)) {
+                const double Cov = (double)(qhi - qlo + 1) / (double)LA;           // arscorer.cpp:122-137
+                if ((fm & UGS_F_QUERY_COV) && Cov < (double)db.query_cov) accept = false;
+                if ((fm & UGS_F_MAX_QUERY_COV) && Cov > (double)db.max_query_cov) accept = false;
+              }
+              if (fm & (UGS_F_TARGET_COV | UGS_F_MAX_TARGET_COV)) {
+                const double Cov = (double)mcols / (double)LB;                      // arscorer.cpp:139-154
+                if ((fm & UGS_F_TARGET_COV) && Cov < (double)db.target_cov) accept = false;
+                if ((fm & UGS_F_MAX_TARGET_COV) && Cov > (double)db.max_target_cov) accept = false;
+              }
+              if ((fm & UGS_F_MAXDIFFS) && diffs > db.maxdiffs) accept = false;
+              if ((fm & UGS_F_MINDIFFS) && diffs < db.mindiffs) accept = false;
             }
             if (accept) {
               unsigned long long coff = 0;

@@ -180,6 +180,7 @@ int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
   std::string otutabout, mapout; bool otutab_cmd = false; long stepwords = -1;
+  ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
@@ -192,6 +193,15 @@ int main(int argc, char **argv)
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
     else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
+    else if (a == "-maxid") { filt.maxid = (float)atof(val()); filt.filter_mask |= UGS_F_MAXID; }
+    else if (a == "-mincols") { filt.mincols = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINCOLS; }
+    else if (a == "-maxgaps") { filt.maxgaps = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXGAPS; }
+    else if (a == "-query_cov") { filt.query_cov = (float)atof(val()); filt.filter_mask |= UGS_F_QUERY_COV; }
+    else if (a == "-max_query_cov") { filt.max_query_cov = (float)atof(val()); filt.filter_mask |= UGS_F_MAX_QUERY_COV; }
+    else if (a == "-target_cov") { filt.target_cov = (float)atof(val()); filt.filter_mask |= UGS_F_TARGET_COV; }
+    else if (a == "-max_target_cov") { filt.max_target_cov = (float)atof(val()); filt.filter_mask |= UGS_F_MAX_TARGET_COV; }
+    else if (a == "-maxdiffs") { filt.maxdiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXDIFFS; }
+    else if (a == "-mindiffs") { filt.mindiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINDIFFS; }
     else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
     else if (a == "-matched") matchedpath = val(); else if (a == "-notmatched") notmatchedpath = val();
     else if (a == "-dbmatched") dbmatchedpath = val(); else if (a == "-dbnotmatched") dbnotmatchedpath = val();
@@ -239,6 +249,9 @@ int main(int argc, char **argv)
   if (maxrej >= 0) p.max_rejects = maxrej;
   if (big >= 0) p.big = (uint32_t)big;
   if (stepwords >= 0) p.stepwords = (uint32_t)stepwords;
+  p.filter_mask = filt.filter_mask; p.maxid = filt.maxid; p.mincols = filt.mincols; p.maxgaps = filt.maxgaps;
+  p.query_cov = filt.query_cov; p.max_query_cov = filt.max_query_cov; p.target_cov = filt.target_cov;
+  p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
   if (from_udb) { p.dbmask = 0; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
     if (path.empty()) return nullptr;

@@ -48,6 +48,10 @@ struct UgsDbView {
   int32_t open2, ext2, topen2, text2;   // internal / terminal gap penalties x2 (alnparams.cpp:380-384)
   double  id_accept;
   int32_t id_set;
+  // optional accept filters (Accepter::IsAcceptLo accepter.cpp:41-91), UGS_F_* bits
+  uint32_t filter_mask;
+  float maxid, query_cov, max_query_cov, target_cov, max_target_cov;
+  uint32_t mincols, maxgaps, maxdiffs, mindiffs;
   int32_t max_accepts, max_rejects;
   int32_t is_nucleo;
   uint32_t max_tlen;

@@ -345,6 +345,9 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.min_hsp_len_opt = p->minhsp; v.band = p->band;
   v.open2 = p->is_nucleo ? -20 : -34; v.ext2 = -2; v.topen2 = -1; v.text2 = -1;   // alnparams.cpp:380-384
   v.id_accept = p->id_accept; v.id_set = p->id_set;
+  v.filter_mask = p->filter_mask; v.maxid = p->maxid; v.query_cov = p->query_cov; v.max_query_cov = p->max_query_cov;
+  v.target_cov = p->target_cov; v.max_target_cov = p->max_target_cov;
+  v.mincols = p->mincols; v.maxgaps = p->maxgaps; v.maxdiffs = p->maxdiffs; v.mindiffs = p->mindiffs;
   v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
   db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
