@@ -89,9 +89,17 @@ struct ScanCtx {
   const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
   uint32_t *hist;            // non-null: count emitted entries per (count,row) class
   uint64_t *ebuf; uint64_t ecap;
+  uint64_t *s_ebuf;          // the first UGS_ELDS emitted keys of a unit stay in LDS (the usual case), the rest go to ebuf
   uint32_t ns, np, gsize, tbl_words;
   int wave, wpb, lane; bool small_path;
 };
+
+#define UGS_ELDS 1024u
+__device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)
+{
+  if (idx < UGS_ELDS) s.s_ebuf[idx] = key;
+  else if (idx < s.ecap) s.ebuf[idx] = key;
+}
 
 // emit the lanes with e==true (at most `take` of them, in lane order) into the WG's candidate buffer
 __device__ __forceinline__ void emit_lanes(const ScanCtx &s, bool e, uint32_t take_cap, uint64_t key)
@@ -105,7 +113,7 @@ __device__ __forceinline__ void emit_lanes(const ScanCtx &s, bool e, uint32_t ta
   uint32_t base = 0;
   if (s.lane == 0) base = atomicAdd(&s.sh->emit_n, take);
   base = __builtin_amdgcn_readfirstlane(base);
-  if (e && rank < take && (uint64_t)base + rank < s.ecap) s.ebuf[base + rank] = key;
+  if (e && rank < take) put_key(s, (uint64_t)base + rank, key);
 }
 
 // sub-row [a,b) of row `slot` restricted to targets [lo_t, hi_t); the partition table gives the
@@ -237,7 +245,7 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
           const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
           const uint64_t tt = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
           if (cc == 1 && tt < fill_limit) {
-            if (rr < take && (uint64_t)base + rr < s.ecap) s.ebuf[base + rr] = make_key(1, tt);
+            if (rr < take) put_key(s, (uint64_t)base + rr, make_key(1, tt));
             ++rr;
           }
         }
@@ -443,7 +451,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
       const uint64_t pos = s.small_path ? (uint64_t)vsel : (((uint64_t)rsel << 32) | vsel);
       atomicMin(&s.s_fp[csel], (unsigned long long)pos);          // fire-and-forget LDS atomics
       if (s.hist) atomicAdd(&s.hist[csel * 16 + rsel], 1u);
-      if ((uint64_t)o < s.ecap) s.ebuf[o] = make_key(csel, pos);
+      put_key(s, o, make_key(csel, pos));
       ++o;
     };
     {
@@ -653,14 +661,11 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   size_t off = 0;
   RankShared *sh = (RankShared *)(smem + off); off += (sizeof(RankShared) + 15) & ~(size_t)15;
   unsigned long long *s_fp = (unsigned long long *)(smem + off); off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;
-  uint32_t *s_words = (uint32_t *)(smem + off); off += (size_t)maxq * 4;
+  uint64_t *s_ebuf = (uint64_t *)(smem + off); off += (size_t)UGS_ELDS * 8;
   uint32_t *s_slots = (uint32_t *)(smem + off); off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;
-  uint8_t *s_q = (uint8_t *)(smem + off); off += maxq;
-  uint8_t *s_first = (uint8_t *)(smem + off); off += maxq;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
   uint64_t *s_wsel = (uint64_t *)(smem + off); off += (size_t)4 * UGS_KMAX * 8;                 // per-wave selections
-  uint8_t *s_udb = (uint8_t *)(smem + off); off += 256;                                 // UDB letter table
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * (tbl_words + 64);      // +64 dummy words per wave
 
@@ -672,7 +677,6 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   uint64_t *ebuf = bv.emit_buf + (uint64_t)blockIdx.x * bv.emit_cap;
   const uint64_t ecap = bv.emit_cap;
 
-  for (int k = tid; k < 256; k += nthr) s_udb[k] = tab->udb_letter[k];
   // counter tables must start clean; pass 2 restores that invariant after every partition
   for (uint32_t k = lane; k < tbl_words + 64; k += 64) tbl[k] = 0;
 
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
     sc.s_part = use_part_cache ? s_part : nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
-    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
+    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.s_ebuf = s_ebuf; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
           const uint32_t k = k0 + tid;
           uint64_t key = 0; bool take = false;
           if (k < N) {
-            key = ebuf[k];
+            key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
             const uint32_t cc = key_count(key), ii = (uint32_t)(key >> 32) & 0xfffu;
             take = cc >= cmin && ((Mx - cc) * 16 + ii) <= qcut;
           }
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
           for (int e = 0; e < SELQ; ++e) {
             const uint32_t k = (lane + e * 64) * wpb + wave;
             uint64_t key = KEY_INF;
-            if (k < N) { key = ebuf[k]; if (!kept(key) || !((nsel == 0 && last == 0) || key > last)) key = KEY_INF; }
+            if (k < N) { key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k]; if (!kept(key) || !((nsel == 0 && last == 0) || key > last)) key = KEY_INF; }
             ent[e] = key;
           }
           uint64_t llast = 0; bool lfirst = true;
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
         while (nsel < K) {
           uint64_t best = KEY_INF;
           for (uint32_t k = tid; k < N; k += nthr) {
-            const uint64_t key = ebuf[k];
+            const uint64_t key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
             if (((nsel == 0 && last == 0) || key > last) && key < best && kept(key)) best = key;
           }
           best = block_min_u64(best, sh, wave, wpb, lane);
@@ -955,12 +959,10 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   size_t off = 0;
   off += (sizeof(RankShared) + 15) & ~(size_t)15;
   off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;        // s_fp
-  off += maxq * 4;                                             // s_words
+  off += (size_t)UGS_ELDS * 8;                                 // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
-  off += maxq; off += maxq;                                    // s_q, s_first
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
   off += (size_t)4 * UGS_KMAX * 8;                             // s_wsel
-  off += 256;                                                  // s_udb
   off += (size_t)part_words * 4;                               // s_part
   return (off + 15) & ~(size_t)15;
 }
