@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   uint32_t *s_slots = (uint32_t *)(smem + off); off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
-  uint64_t *s_wsel = (uint64_t *)(smem + off); off += (size_t)4 * UGS_KMAX * 8;                 // per-wave selections
+  uint64_t *s_wsel = (uint64_t *)(smem + off); off += ((size_t)4 * UGS_KMAX + 8) * 8;           // per-wave selections (+8 pad)
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * (tbl_words + 64);      // +64 dummy words per wave
 
@@ -831,12 +831,25 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
         __syncthreads();
         const uint32_t ncl = sh->ncl;
         if (ncl <= 64u * (uint32_t)wpb && ncl <= 4 * UGS_KMAX) {
+          if ((uint32_t)tid < 8u && ncl + (uint32_t)tid < 4 * UGS_KMAX + 8) s_wsel[ncl + tid] = KEY_INF;      // padding for the 8-wide ranking loop
+          __syncthreads();
           // all-pairs ranking: wave w ranks entries [64w, 64w+64) against the whole list (LDS broadcast reads)
           const uint32_t me = wave * 64 + lane;
           const uint64_t mykey = me < ncl ? s_wsel[me] : KEY_INF;
           uint32_t rank = 0;
-          if (wave * 64u < ncl)
-            for (uint32_t j = 0; j < ncl; ++j) rank += s_wsel[j] < mykey ? 1u : 0u;
+          if (wave * 64u < ncl) {
+            // 128-bit LDS broadcast reads, 8 keys in flight per trip: the list is padded to a multiple of 8 with
+            // KEY_INF (never below a real key), so the loop has no tail and the loads of one trip are independent
+            const uint4 *w4 = (const uint4 *)s_wsel;
+            const uint32_t n8 = (ncl + 7u) & ~7u;
+            for (uint32_t j = 0; j < n8; j += 8) {
+              const uint4 x0 = w4[(j >> 1) + 0], x1 = w4[(j >> 1) + 1], x2 = w4[(j >> 1) + 2], x3 = w4[(j >> 1) + 3];
+              rank += ((((uint64_t)x0.y << 32) | x0.x) < mykey) + ((((uint64_t)x0.w << 32) | x0.z) < mykey);
+              rank += ((((uint64_t)x1.y << 32) | x1.x) < mykey) + ((((uint64_t)x1.w << 32) | x1.z) < mykey);
+              rank += ((((uint64_t)x2.y << 32) | x2.x) < mykey) + ((((uint64_t)x2.w << 32) | x2.z) < mykey);
+              rank += ((((uint64_t)x3.y << 32) | x3.x) < mykey) + ((((uint64_t)x3.w << 32) | x3.z) < mykey);
+            }
+          }
           const uint32_t nout = ncl < K ? ncl : K;
           if (me < ncl && rank < K) {
             bv.cand[(uint64_t)unit * K + rank] = key_target(mykey);
@@ -962,7 +975,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   off += (size_t)UGS_ELDS * 8;                                 // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
-  off += (size_t)4 * UGS_KMAX * 8;                             // s_wsel
+  off += ((size_t)4 * UGS_KMAX + 8) * 8;                       // s_wsel (+8 pad)
   off += (size_t)part_words * 4;                               // s_part
   return (off + 15) & ~(size_t)15;
 }
