@@ -1,0 +1,58 @@
+"""Randomised differential test: the HIP path (through the C-ABI) against the oracle on seeded random
+configurations - small databases of sequence families with low-complexity runs, wildcards and lower-case stretches,
+odd lengths (down to shorter than a word), duplicated sequences, random option mixes (identity, accepts/rejects,
+both strands, small/Big ranker, -stepwords, -bump, accept filters).  Every hit record and path must be identical."""
+import numpy as np
+import pytest
+
+import orc
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def config(seed):
+    rng = np.random.default_rng([seed, 0xF022])
+    aa = bool(rng.random() < 0.3)
+    lmin = int(rng.choice([4, 12, 30, 60, 150]))
+    lmax = lmin + int(rng.choice([0, 20, 100, 300]))
+    n_fam, fam = int(rng.integers(5, 200)), int(rng.integers(1, 12))
+    nq = int(rng.integers(50, 600))
+    kw = dict(max_accepts=int(rng.integers(1, 5)), max_rejects=int(rng.choice([1, 4, 8, 16, 32])))
+    if not aa and rng.random() < 0.5:
+        kw["strand_both"] = 1
+    if rng.random() < 0.6:
+        kw["big"] = int(rng.choice([1, 50, 400]))             # force the Big ranker on small databases
+    if rng.random() < 0.3:
+        kw["stepwords"] = int(rng.choice([0, 1, 3, 20]))
+    if rng.random() < 0.2:
+        kw["bump_pct"] = int(rng.choice([0, 10, 90]))
+    ident = float(rng.choice([0.5, 0.7, 0.8, 0.9, 0.97, 0.99, 1.0])) if not aa else float(rng.choice([0.5, 0.6, 0.8, 0.95]))
+    if rng.random() < 0.35:
+        opts = dict(maxid=0.995, mincols=int(lmin * 0.8), maxgaps=int(rng.integers(0, 6)), query_cov=0.8, max_query_cov=0.99,
+                    target_cov=0.7, max_target_cov=0.98, maxdiffs=int(rng.integers(1, 30)), mindiffs=int(rng.integers(1, 4)))
+        for k in rng.choice(sorted(opts), size=int(rng.integers(1, 4)), replace=False):
+            kw[str(k)] = opts[str(k)]
+    return aa, lmin, lmax, n_fam, fam, nq, ident, kw
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configuration_matches_oracle(seed):
+    aa, lmin, lmax, n_fam, fam, nq, ident, kw = config(seed)
+    db, qs = synth.make_hard(1000 + seed, n_fam, fam, nq, lmin=lmin, lmax=lmax, aa=aa)
+    if kw.get("strand_both"):
+        qs = synth.revcomp_some(seed, qs)
+    if seed % 5 == 0:                                           # exact duplicates in the database (ties everywhere)
+        seqs = [np.frombuffer(db.seq(i), np.uint8) for i in list(range(db.n)) + list(range(0, db.n, 3))]
+        offs = np.zeros(len(seqs) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in seqs])
+        db = synth.SeqSet(np.concatenate(seqs), offs, lambda i: "d%d" % i)
+    hits, nh, pool = capi.UgsDB(capi.params(is_nucleo=not aa, id=ident, **kw), db.seqs, db.offs, device=0).search(qs.seqs, qs.offs)
+    oh, onh, opool = orc.OrcDB(orc.params(is_nucleo=not aa, id=ident, **kw), db.seqs, db.offs).search(qs.seqs, qs.offs, nthreads=4)
+    assert np.array_equal(nh, onh), (seed, kw)
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(hits[f], oh[f]), (seed, f, kw)
+    for a, b in zip(hits, oh):
+        assert np.array_equal(pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])],
+                              opool[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])]), (seed, kw)

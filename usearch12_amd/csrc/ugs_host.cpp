@@ -571,8 +571,11 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
   HIPCHK(hipEventRecord(b->ev1, db->stream));
+  const bool dbg = getenv("UGS_DEBUG_SYNC") != nullptr;             // fault isolation: finish each stage before the next
+  if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] ranking stage done\n"); }
   if (b->nq) RCCHK(enqueue_align(b));
   HIPCHK(hipEventRecord(b->ev2, db->stream));
+  if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
   b->searched = true; b->synced = false;
   return UGS_OK;
 }

@@ -24,6 +24,8 @@
 // (count desc, first-touch position asc) are selected, after applying the reference's
 // "MinValue = prevMax/2" (and, on the small path, -bump) cut-offs exactly.
 #include "ugs_dev.h"
+#include <cstdlib>
+#include <cstdio>
 #include <algorithm>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
@@ -692,6 +694,10 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
     for (uint32_t c = tid; c <= ns_max; c += nthr) s_fp[c] = KEY_INF;
     const uint32_t ns = __builtin_amdgcn_readfirstlane(bv.unit_ns[unit]);
+    if (ns == 0) {                       // no valid word in the query (shorter than a word, or wildcards throughout): nothing to rank
+      if (tid == 0) bv.cand_n[unit] = 0;
+      continue;
+    }
     for (uint32_t i = tid; i < ns; i += nthr) s_slots[i] = bv.unit_slots[(uint64_t)unit * ns_max + i];
     __syncthreads();
     // ---- the scan; counter width by the largest possible count (= ns)
@@ -996,6 +1002,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (units) hipLaunchKernelGGL(k_rank_setup, dim3(sgrid), dim3(256), slds, st, db, b, L.ns_max);
     HIPCHK(hipGetLastError());
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
+    if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
   HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
