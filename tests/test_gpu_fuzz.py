@@ -2,6 +2,8 @@
 configurations - small databases of sequence families with low-complexity runs, wildcards and lower-case stretches,
 odd lengths (down to shorter than a word), duplicated sequences, random option mixes (identity, accepts/rejects,
 both strands, small/Big ranker, -stepwords, -bump, accept filters).  Every hit record and path must be identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,9 +16,10 @@ pytestmark = pytest.mark.gpu
 def config(seed):
     rng = np.random.default_rng([seed, 0xF022])
     aa = bool(rng.random() < 0.3)
-    lmin = int(rng.choice([4, 12, 30, 60, 150]))
+    big_shape = os.environ.get("UGS_FUZZ_BIG") is not None          # ad-hoc sweeps: longer sequences, larger databases
+    lmin = int(rng.choice([4, 12, 30, 60, 150] + ([600, 1500] if big_shape else [])))
     lmax = lmin + int(rng.choice([0, 20, 100, 300]))
-    n_fam, fam = int(rng.integers(5, 200)), int(rng.integers(1, 12))
+    n_fam, fam = int(rng.integers(5, 2000 if big_shape else 200)), int(rng.integers(1, 12))
     nq = int(rng.integers(50, 600))
     kw = dict(max_accepts=int(rng.integers(1, 5)), max_rejects=int(rng.choice([1, 4, 8, 16, 32])))
     if not aa and rng.random() < 0.5:
@@ -36,7 +39,7 @@ def config(seed):
     return aa, lmin, lmax, n_fam, fam, nq, ident, kw
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("UGS_FUZZ_FROM", 0)), int(os.environ.get("UGS_FUZZ_TO", 48))))
 def test_random_configuration_matches_oracle(seed):
     aa, lmin, lmax, n_fam, fam, nq, ident, kw = config(seed)
     db, qs = synth.make_hard(1000 + seed, n_fam, fam, nq, lmin=lmin, lmax=lmax, aa=aa)
