@@ -19,12 +19,12 @@ def pack(seqs):
     return np.frombuffer("".join(seqs).encode(), np.uint8).copy(), offs
 
 
-def run_cases(is_nucleo, x, cases):
+def run_cases(is_nucleo, x, cases, **pk):
     """cases: list of (mode, a, b, anc) -> list of (score, loi, loj, leni, lenj, path)"""
     jobs = np.zeros(len(cases), XDROP_JOB_DTYPE)
     for k, (mode, a, b, anc) in enumerate(cases):
         jobs[k] = (k, k, anc[0], anc[1], anc[2], mode)
-    p = capi.xdrop_params(is_nucleo, xdrop=x)
+    p = capi.xdrop_params(is_nucleo, xdrop=x, **pk)
     hsps, pool = capi.xdrop_batch(p, pack([c[1] for c in cases]), pack([c[2] for c in cases]), jobs)
     out = []
     for h in hsps:
@@ -119,3 +119,22 @@ def test_xdrop_bad_arguments():
     jobs[0] = (0, 3, 0, 0, 0, XDROP_FWD)                  # sequence index out of range
     with pytest.raises(capi.UgsError):
         capi.xdrop_batch(p, pack(["ACGTACGT"]), pack(["ACGTACGT"]), jobs)
+
+
+@pytest.mark.parametrize("aa,x,pk", [(False, 20.5, dict(local_open=-5.0, local_ext=-2.0, mismatch=-3.0)),
+                                      (False, 7.0, dict(local_open=-2.5, local_ext=-0.5, match=2.0, mismatch=-1.5)),
+                                      (True, 40.0, dict(local_open=-11.0, local_ext=-1.0))])
+def test_xdrop_non_default_scoring(aa, x, pk):
+    """gap penalties / nt scores / X other than the defaults (all multiples of 0.5, as the integer DP requires)"""
+    cases = _random_batch(11, aa, 600, 5, 500)
+    got = run_cases(not aa, x, cases, **pk)
+    p = orc.xdrop_params(not aa, x)
+    for k, v in pk.items():
+        setattr(p, k, v)
+    bad = []
+    for (mode, a, b, anc), g in zip(cases, got):
+        o = orc.xdrop_job(p, a, b, mode, anc)
+        want = o[:6] if mode != XDROP_FWD else (o[0], 0, 0, o[3], o[4], o[5])
+        if g != want:
+            bad.append((mode, len(a), len(b), anc, g[:5], want[:5]))
+    assert not bad, (len(bad), bad[:5])
