@@ -19,6 +19,7 @@
 // Scores are int32 in units of 0.5 (all reference scores are exact half-integers);
 // MINUS_INFINITY is a saturating sentinel so that -inf + x == -inf and -inf >= -inf hold as in fp32.
 #include "ugs_dev.h"
+#include <algorithm>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
@@ -28,8 +29,8 @@
 #define TB_IM 2
 #define TB_MD 4
 #define TB_MI 8
-#define LTB 2048               // per-wave LDS traceback bytes (holes up to ~80x36 cells)
-#define LRUNS 64               // runs kept in LDS per wave before spilling to HBM scratch
+#define LTB 1024               // per-wave LDS traceback bytes (holes up to ~25x36 cells)
+#define LRUNS 32               // runs kept in LDS per wave before spilling to HBM scratch
 
 __device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : x + c; }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -652,7 +653,7 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
   viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
 }
 
-__global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
+__global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
@@ -692,19 +693,23 @@ __global__ __launch_bounds__(256, 3) void k_align(UgsDbView db, UgsBatchView bv,
   c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_tb = wb + off; off += LTB;
   c.nt = db.is_nucleo != 0;
-  c.qsort = (uint32_t *)(wb + off); off += (size_t)q2 * 4;
+  // union region: the seed list lives only inside UngappedBlast, the chainer scratch only inside the chainer, the DP
+  // rows only in the holes after it
+  const size_t uo = std::max(2 * ((size_t)maxt + 8) * 4, (size_t)hsp_cap * 7 * 4);
+  const size_t us = std::max((size_t)seed_cap * 4, uo);
+  c.union_words = (uint32_t)(us / 4);
+  // the sorted query words need a power-of-two array only for the bitonic fallback; when every query of the batch
+  // takes the counting sort (word table present and its scratch fits the union region) maxq entries do
+  const bool always_counting = c.wstart != nullptr && (uint64_t)maxq * 3 / 2 + 16 <= c.union_words;
+  c.qsort = (uint32_t *)(wb + off); off += (size_t)(always_counting ? maxq : q2) * 4;
   c.hsps = (HSPd *)(wb + off); off += (size_t)hsp_cap * sizeof(HSPd);
   c.chain = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 4;
-  // union region: the seed list lives only inside UngappedBlast; the chainer scratch and the DP rows only after it
   {
     unsigned char *u = wb + off;
     c.seeds = (uint32_t *)u; c.seed_cap = seed_cap;
-    size_t uo = 0;
-    c.Mrow = (int32_t *)(u + uo) + 4; uo += ((size_t)maxt + 8) * 4;
-    c.Drow = (int32_t *)(u + uo); uo += ((size_t)maxt + 8) * 4;
-    c.csc = (uint32_t *)(u + uo); uo += (size_t)hsp_cap * 7 * 4;
-    const size_t us = (size_t)seed_cap * 4 > uo ? (size_t)seed_cap * 4 : uo;
-    c.union_words = (uint32_t)(us / 4);
+    c.Mrow = (int32_t *)u + 4;
+    c.Drow = (int32_t *)(u + ((size_t)maxt + 8) * 4);
+    c.csc = (uint32_t *)u;
     off += (us + 15) & ~(size_t)15;
   }
   c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl;
