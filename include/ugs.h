@@ -296,6 +296,14 @@ int ugs_userfields_check(const char *fields);
 int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
                        const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
                        const char *tseq, uint32_t tl, char *buf, int cap);
+/* -alnout: ugs_format_alnout_header = OutputSink::OutputReport (outputsink.cpp:243-258,338-356: "Query >label" and the
+ * %Id / TLen / Target table of the query's reported hits; empty for a query without hits), then one
+ * ugs_format_alnout_hit = WriteAln (alnout.cpp:41-171) per hit: rows of 80 columns with 1-based position labels,
+ * the annotation row (| identical, + IUPAC match / : . BLOSUM62 >= 2 / > 0) and the summary line. */
+int ugs_format_alnout_header(const ugs_hit *hits, uint32_t n, const char *qlabel, const char *const *tlabels, char *buf, int cap);
+int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel, const char *tlabel,
+                          const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
+
 /* OutputBlast6NoHits blast6out.cpp:82-103 (-output_no_hits) */
 int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap);
 /* SeqToFasta seqdb.cpp:62-90 (-matched / -notmatched / -dbmatched / -dbnotmatched records) */

@@ -43,7 +43,7 @@ def format_run(run):
     m = MAN[run]
     c, db, qs, _, _ = G.load(m["case"])
     extra = m["extra"]
-    fields = opt(extra, "-userfields").encode()
+    fields = (opt(extra, "-userfields") or "query").encode()
     maxhits = int(opt(extra, "-maxhits", 0))
     top1, tops, nohits = "-top_hit_only" in extra, "-top_hits_only" in extra, "-output_no_hits" in extra
     nucleo = not c["aa"]
@@ -53,7 +53,7 @@ def format_run(run):
     masked = odb.masked().tobytes()
     qlabels, tlabels = qs.labels(), db.labels()
     buf = C.create_string_buffer(1 << 20)
-    out = {k: [] for k in ("user", "b6", "uc", "matched", "notmatched", "dbmatched", "dbnotmatched")}
+    out = {k: [] for k in ("user", "b6", "uc", "matched", "notmatched", "dbmatched", "dbnotmatched", "aln")}
     dbcount = np.zeros(db.n, np.int64)
     L.ugs_format_userout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
                                      C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
@@ -61,6 +61,9 @@ def format_run(run):
     L.ugs_hits_to_report.restype = C.c_uint32
     L.ugs_format_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
     L.ugs_format_blast6_nohit.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.ugs_format_alnout_header.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+    L.ugs_format_alnout_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32,
+                                        C.c_char_p, C.c_int]
     qbytes, k = qs.seqs.tobytes(), 0
 
     def take(n):
@@ -82,6 +85,8 @@ def format_run(run):
                 out["user"].append(take(L.ugs_format_userout(None, None, int(nucleo), fields, qlab, None, qseq, ql, None, 0, buf, len(buf))))
             out["notmatched"].append(take(L.ugs_format_fasta(qlab, qseq, ql, buf, len(buf))))
             continue
+        tl_arr = (C.c_char_p * n)(*[tlabels[int(h[j]["target"])].encode() for j in range(n)])
+        out["aln"].append(take(L.ugs_format_alnout_header(h.ctypes.data, n, qlab, tl_arr, buf, len(buf))))
         for j in range(n):
             t = int(h[j]["target"])
             tlab = tlabels[t].encode()
@@ -90,6 +95,7 @@ def format_run(run):
             out["b6"].append(take(L.ugs_format_blast6(hp, qlab, tlab, buf, len(buf))))
             out["uc"].append(take(L.ugs_format_uc_hit(hp, pool.ctypes.data, int(nucleo), qlab, tlab, buf, len(buf))))
             out["user"].append(take(L.ugs_format_userout(hp, pool.ctypes.data, int(nucleo), fields, qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
+            out["aln"].append(take(L.ugs_format_alnout_hit(hp, pool.ctypes.data, int(nucleo), qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
             dbcount[t] += 1
         out["matched"].append(take(L.ugs_format_fasta(qlab, qseq, ql, buf, len(buf))))
     for t in range(db.n):
@@ -128,7 +134,7 @@ def test_cli_outputs_identical_to_reference(tmp_path, run):
         if o in c:
             cmd += ["-" + o, str(c[o])]
     cmd += m["extra"]
-    names = {"user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
+    names = {"aln": "-alnout", "user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
              "dbmatched": "-dbmatched", "dbnotmatched": "-dbnotmatched"}
     for kind in m["files"]:
         cmd += [names[kind], os.path.join(tmp, "o." + kind)]

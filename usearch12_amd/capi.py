@@ -23,7 +23,7 @@ EXPORTS = [
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
     "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
-    "ugs_db_masked_letters",
+    "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
 ]
 

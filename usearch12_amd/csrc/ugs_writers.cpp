@@ -409,3 +409,107 @@ extern "C" int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64
   if (total) *total = t->total;
   return UGS_OK;
 }
+
+// ---------------------------------------------------------------- -alnout
+// OutputSink::OutputReport / OutputReportGlobal outputsink.cpp:243-258,338-356 (per-query hit table) and WriteAln
+// alnout.cpp:41-171 (the alignment in rows of -rowlen 80 columns with position labels, annotation row
+// arscorer.cpp:12-45,481-504 and the summary line), global-alignment semantics, no ORFs.
+namespace {
+unsigned ndig(unsigned n) { return n < 10 ? 1 : n < 100 ? 2 : n < 1000 ? 3 : n < 10000 ? 4 : n < 100000 ? 5 : n < 1000000 ? 6 : 10; }   // alnout.cpp:8-23
+
+// Pos is the offset of the first letter, returns the offset of the last one (alnout.cpp:25-39)
+unsigned advance_pos(unsigned pos, const char *row, unsigned n, bool *all_gaps)
+{
+  unsigned np = pos; bool got = false;
+  for (unsigned i = 0; i < n; ++i) if (row[i] != '-') { if (got) ++np; else got = true; }
+  *all_gaps = !got;
+  return np;
+}
+}  // namespace
+
+extern "C" int ugs_format_alnout_header(const ugs_hit *hits, uint32_t n, const char *qlabel, const char *const *tlabels, char *buf, int cap)
+{
+  if (n == 0) { if (buf && cap > 0) buf[0] = 0; return 0; }            // OutputReport prints nothing for a query without hits
+  if (!hits || !qlabel || !tlabels) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  std::string o = "\nQuery >";
+  o += qlabel; o += "\n %Id   TLen  Target\n";
+  for (uint32_t i = 0; i < n; ++i) {
+    const double pct = 100.0 * (hits[i].aln_len == 0 ? 0.0 : (double)hits[i].ids / (double)hits[i].aln_len);
+    app(o, "%3.0f%%  %5u  ", pct, hits[i].tl);
+    o += tlabels[i]; o.push_back('\n');
+  }
+  return finish(o, buf, cap);
+}
+
+extern "C" int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel,
+                                     const char *tlabel, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
+                                     char *buf, int cap)
+{
+  if (!h || !cigar_pool || !qlabel || !tlabel || !qseq || !tseq) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (ql != h->ql || tl != h->tl) { ugs_set_error("sequence lengths do not match the hit record"); return UGS_E_ARG; }
+  const MatchTables &T = tables();
+  std::string Q(qseq, ql);
+  if (h->strand) for (uint32_t k = 0; k < ql; ++k) { const unsigned char c = (unsigned char)qseq[ql - 1 - k]; const unsigned char cc = T.comp[c]; Q[k] = (char)(cc == '?' ? c : cc); }
+  std::string path;
+  for (uint32_t k = 0; k < h->cigar_len; ++k) { const uint32_t r = cigar_pool[h->cigar_off + k]; path.append(r >> 2, "MDI"[r & 3]); }
+  const size_t firstM = path.find('M'), lastM = path.rfind('M');
+  if (firstM == std::string::npos) { ugs_set_error("path has no match column"); return UGS_E_ARG; }
+  std::string qrow, trow, arow;
+  {
+    uint32_t qp = h->qlo, tp = h->tlo;
+    for (size_t c = firstM; c <= lastM; ++c) {
+      const char op = path[c];
+      const unsigned char qc = (op == 'M' || op == 'D') ? (unsigned char)Q[qp] : 0, tc = (op == 'M' || op == 'I') ? (unsigned char)tseq[tp] : 0;
+      qrow.push_back(qc ? (char)toupper(qc) : '-'); trow.push_back(tc ? (char)toupper(tc) : '-');
+      char sym = ' ';
+      if (op == 'M') {
+        if (is_nucleo) {                                        // GetNucleoSym arscorer.cpp:27-36
+          const bool acgtu_q = strchr("ACGTU", toupper(qc)) != nullptr, acgtu_t = strchr("ACGTU", toupper(tc)) != nullptr;
+          if (toupper(qc) == toupper(tc) && acgtu_q && acgtu_t) sym = '|';
+          else if (T.nt[qc][tc]) sym = '+';
+        } else {                                                // GetAminoSym arscorer.cpp:12-25
+          if (T.aa[qc][tc]) sym = '|';
+          else {
+            const char *pi = isalpha(qc) ? strchr(UGS_B62_ORDER, toupper(qc)) : nullptr, *pj = isalpha(tc) ? strchr(UGS_B62_ORDER, toupper(tc)) : nullptr;
+            const int sc = (pi && pj && *pi && *pj) ? UGS_B62[pi - UGS_B62_ORDER][pj - UGS_B62_ORDER] : (qc == '*' && tc == '*' ? 1 : ((qc == '*' || tc == '*') ? -4 : 0));
+            sym = sc >= 2 ? ':' : (sc > 0 ? '.' : ' ');
+          }
+        }
+      }
+      arow.push_back(sym);
+      if (qc) ++qp;
+      if (tc) ++tp;
+    }
+  }
+  const unsigned aln = (unsigned)qrow.size();
+  const unsigned mx = ql > tl ? ql : tl, w = ndig(mx);
+  const char *unit = is_nucleo ? "nt" : "aa";
+  const char qstrand = !is_nucleo ? '.' : (h->strand ? '-' : '+'), tstrand = !is_nucleo ? '.' : '+';
+  const bool show_strand = qstrand != '.';
+  std::string o = "\n";
+  app(o, " Query %*u%s >", (int)w, ql, unit); o += qlabel; o.push_back('\n');
+  app(o, "Target %*u%s >", (int)w, tl, unit); o += tlabel; o.push_back('\n');
+  o.push_back('\n');
+  const unsigned rowlen = 80;
+  unsigned qpos = h->qlo, tpos = h->tlo;
+  bool qgaps = false, tgaps = false;
+  auto ipos_q = [&](unsigned pos) { return h->strand ? ql - pos - 1 : pos; };       // PosToIPosQ arscorer.cpp:598-645 (no ORF)
+  for (unsigned from = 0; from < aln; from += rowlen) {
+    const unsigned n = aln - from < rowlen ? aln - from : rowlen;
+    const unsigned qfrom = ipos_q(qpos) + (qgaps ? 0 : 1), tfrom = tpos + (tgaps ? 0 : 1);     // PosToIPosQ1 / T1 with the PREVIOUS row's all-gaps flag
+    qpos = advance_pos(qpos, qrow.c_str() + from, n, &qgaps);
+    tpos = advance_pos(tpos, trow.c_str() + from, n, &tgaps);
+    const unsigned qto = ipos_q(qpos) + (qgaps ? 0 : 1), tto = tpos + (tgaps ? 0 : 1);
+    if (!qgaps) ++qpos;
+    if (!tgaps) ++tpos;
+    app(o, "Qry %*u", (int)w, qfrom); if (show_strand) { o.push_back(' '); o.push_back(qstrand); }
+    o.push_back(' '); o.append(qrow, from, n); app(o, " %u\n", qto);
+    o += "    "; o.append(w, ' '); if (show_strand) o += "  ";
+    o.push_back(' '); o.append(arow, from, n); o.push_back('\n');
+    app(o, "Tgt %*u", (int)w, tfrom); if (show_strand) { o.push_back(' '); o.push_back(tstrand); }
+    o.push_back(' '); o.append(trow, from, n); app(o, " %u\n", tto);
+    o.push_back('\n');
+  }
+  app(o, "%u cols, %u ids (%.1f%%), %u gaps (%.1f%%)\n", aln, h->ids, 100.0 * ratio(h->ids, aln), h->gaps_int, 100.0 * ratio(h->gaps_int, aln));
+  return finish(o, buf, cap);
+}
