@@ -133,7 +133,7 @@ def main():
         tb = time.time()
         t_parts["search_sync"] += tb - ta
         if dist is None:
-            out = bat.fetch()
+            out = bat.fetch(reuse=True)     # result buffers owned by the batch, page-locked once (a streaming caller's setup)
             t_parts["fetch"] += time.time() - tb
             return out
         # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)

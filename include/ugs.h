@@ -136,7 +136,7 @@ int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint
  * Replaces the Thread() loop calling Searcher::Search per query (search.cpp:51-87,
  * searcher.cpp:122-161): search a whole batch; hits come back grouped by query in
  * query order, each group sorted as HitMgr::Sort orders them (hitmgr.cpp:477-483).
- * nhits_per_query[nq] receives the group sizes.  Returns UGS_E_CAPACITY if hits_cap or
+ * nhits_per_query[nq] receives the group sizes.  Returns UGS_E_CAPACITY (cigar_used = runs needed) if hits_cap or
  * cigar_cap (uint32 units) is too small (hits_cap = nq * max_accepts * (1+strand_both)
  * always suffices).
  */
@@ -329,6 +329,12 @@ void ugs_otutab_destroy(ugs_otutab *t);
 int ugs_otutab_add(ugs_otutab *t, const char *qlabel, const char *top_hit_tlabel, char *map_line, int cap);
 int ugs_otutab_write(const ugs_otutab *t, const char *path);
 int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64_t *total);
+
+/* Page-lock / unlock a caller-owned host buffer (hipHostRegister): result buffers that are reused from batch to batch
+ * are then filled by direct DMA instead of through the runtime's staging copies.  Optional; any host pointer works
+ * with the fetch calls. */
+int ugs_host_register(void *ptr, uint64_t bytes);
+int ugs_host_unregister(void *ptr);
 
 const char *ugs_last_error(void);
 

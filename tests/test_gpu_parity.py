@@ -235,3 +235,20 @@ def test_gpu_full_size_properties():
     assert np.array_equal(nh[500_000:503_000], onh)
     for f in ("target", "ids", "mism", "gaps_int", "aln_len", "opens", "qlo", "qhi", "tlo", "thi", "cigar_len", "cols"):
         assert np.array_equal(hits[f][sel], oh[f]), f
+
+
+def test_gpu_fetch_into_reused_pinned_buffers():
+    """fetch(reuse=True): page-locked result buffers owned by the batch (grown on UGS_E_CAPACITY) hold the same records"""
+    c, db, qs, b6, uc = G.load("hard_acc")
+    p = capi.params(is_nucleo=True, id=c["id"], **G.params_kw(c))
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    h0, n0, p0 = bat.fetch()
+    for _ in range(2):
+        h1, n1, p1 = bat.fetch(reuse=True)
+        assert np.array_equal(n0, n1) and np.array_equal(p0, p1)
+        for f in h0.dtype.names:
+            assert np.array_equal(h0[f], h1[f]), f
+        bat.search(); bat.sync()
+    bat.close()

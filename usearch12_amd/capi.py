@@ -23,7 +23,7 @@ EXPORTS = [
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
     "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
-    "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit",
+    "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
 ]
 
@@ -68,6 +68,8 @@ def lib():
         L.ugs_xdrop_params_init.restype = None
         L.ugs_xdrop_batch.argtypes = [i32, C.POINTER(XdropParams), vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, u64, C.POINTER(u64)]
         L.ugs_xdrop_last_stats.argtypes = [C.POINTER(C.c_float), C.POINTER(u64)]
+        L.ugs_host_register.argtypes = [vp, u64]
+        L.ugs_host_unregister.argtypes = [vp]
         L.ugs_udb_stat.argtypes = [C.c_char_p, C.POINTER(UdbInfo)]
         L.ugs_udb_read.argtypes = [C.c_char_p, vp, vp, vp, vp, vp]
         L.ugs_udb_write.argtypes = [C.c_char_p, vp, vp, u64]
@@ -160,6 +162,7 @@ class UgsBatch:
 
     def close(self):
         if getattr(self, "h", None):
+            self._release_out()
             lib().ugs_batch_destroy(self.h)
             self.h = None
 
@@ -179,17 +182,45 @@ class UgsBatch:
     def sync(self):
         _chk(lib().ugs_batch_sync(self.h))
 
-    def fetch(self):
+    def fetch(self, reuse=False):
+        """Hits of the last synced search -> (hits, nhits_per_query, run pool).  reuse=True fills result buffers owned by
+        this batch (page-locked once, valid until the next fetch) instead of fresh arrays - what a streaming caller does."""
         p = self.db.p
         cap = self.nq * max(1, p.max_accepts) * (2 if p.strand_both else 1) + 1
-        hits = np.zeros(cap, dtype=HIT_DTYPE)
-        nh = np.zeros(self.nq + 1, dtype=np.uint32)
         cig_cap = self.nletters * 2 + 64 * self.nq + 1024
-        pool = np.zeros(cig_cap, dtype=np.uint32)
-        used = C.c_uint64(0)
-        _chk(lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
-        nh = nh[:self.nq]
-        return hits[:int(nh.sum())], nh, pool[:used.value]
+        if not reuse:
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            nh = np.zeros(self.nq + 1, dtype=np.uint32)
+            pool = np.zeros(cig_cap, dtype=np.uint32)
+            used = C.c_uint64(0)
+            _chk(lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
+            nh = nh[:self.nq]
+            return hits[:int(nh.sum())], nh, pool[:used.value]
+        bufs = getattr(self, "_out", None)
+        if bufs is None or len(bufs[0]) < cap or len(bufs[1]) < self.nq + 1:
+            self._release_out()
+            bufs = [np.zeros(cap, dtype=HIT_DTYPE), np.zeros(self.nq + 1, dtype=np.uint32),
+                    np.zeros(min(cig_cap, 24 * self.nq + 4096), dtype=np.uint32)]
+            for a in bufs:
+                _chk(lib().ugs_host_register(a.ctypes.data, a.nbytes))
+            self._out = bufs
+        while True:
+            hits, nh, pool = bufs
+            used = C.c_uint64(0)
+            rc = lib().ugs_batch_fetch(self.h, hits.ctypes.data, len(hits), nh.ctypes.data, pool.ctypes.data, len(pool), C.byref(used))
+            if rc == -5 and used.value > len(pool):               # UGS_E_CAPACITY: grow the run pool to the demanded size
+                lib().ugs_host_unregister(pool.ctypes.data)
+                bufs[2] = np.zeros(int(used.value * 1.25) + 4096, dtype=np.uint32)
+                _chk(lib().ugs_host_register(bufs[2].ctypes.data, bufs[2].nbytes))
+                continue
+            _chk(rc)
+            nq = self.nq
+            return hits[:int(nh[:nq].sum())], nh[:nq], pool[:used.value]
+
+    def _release_out(self):
+        for a in getattr(self, "_out", None) or []:
+            lib().ugs_host_unregister(a.ctypes.data)
+        self._out = None
 
     def stats(self):
         st = BatchStats()

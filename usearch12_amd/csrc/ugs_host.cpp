@@ -642,7 +642,11 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   HIPCHK(hipMemcpyAsync(nhits_per_query, b->d_qn, (size_t)nq * 4, hipMemcpyDeviceToHost, db->stream));
   HIPCHK(hipStreamSynchronize(db->stream));
   const uint64_t total = (uint64_t)last_off + last_n;
-  if (total > hits_cap || b->cigar_used_host > cigar_cap) { ugs_set_error("output buffers too small"); return UGS_E_CAPACITY; }
+  if (total > hits_cap || b->cigar_used_host > cigar_cap) {
+    if (cigar_used) *cigar_used = b->cigar_used_host;            // the demand, so that the caller can size the run pool
+    ugs_set_error("output buffers too small (%llu hits, %llu runs)", (unsigned long long)total, (unsigned long long)b->cigar_used_host);
+    return UGS_E_CAPACITY;
+  }
   if (total) HIPCHK(hipMemcpyAsync(hits, b->d_compact, total * sizeof(ugs_hit), hipMemcpyDeviceToHost, db->stream));
   if (b->cigar_used_host) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost, db->stream));
   HIPCHK(hipStreamSynchronize(db->stream));
@@ -720,6 +724,20 @@ extern "C" int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *q
   if (rc == UGS_OK) rc = ugs_batch_fetch(b, hits, hits_cap, nhits_per_query, cigar_pool, cigar_cap, cigar_used);
   ugs_batch_destroy(b);
   return rc;
+}
+
+extern "C" int ugs_host_register(void *ptr, uint64_t bytes)
+{
+  if (!ptr || !bytes) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+  return UGS_OK;
+}
+
+extern "C" int ugs_host_unregister(void *ptr)
+{
+  if (!ptr) return UGS_E_ARG;
+  HIPCHK(hipHostUnregister(ptr));
+  return UGS_OK;
 }
 
 // ---------------------------------------------------------------- text writers
