@@ -247,8 +247,12 @@ def test_gpu_fetch_into_reused_pinned_buffers():
     h0, n0, p0 = bat.fetch()
     for _ in range(2):
         h1, n1, p1 = bat.fetch(reuse=True)
-        assert np.array_equal(n0, n1) and np.array_equal(p0, p1)
+        assert np.array_equal(n0, n1)
         for f in h0.dtype.names:
-            assert np.array_equal(h0[f], h1[f]), f
+            if f != "cigar_off":                      # the pool is filled in allocation order, which differs between searches
+                assert np.array_equal(h0[f], h1[f]), f
+        for a, b in zip(h0, h1):
+            assert np.array_equal(p0[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])],
+                                  p1[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])])
         bat.search(); bat.sync()
     bat.close()
