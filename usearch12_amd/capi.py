@@ -218,9 +218,15 @@ class UgsBatch:
             return hits[:int(nh[:nq].sum())], nh[:nq], pool[:used.value]
 
     def _release_out(self):
-        for a in getattr(self, "_out", None) or []:
-            lib().ugs_host_unregister(a.ctypes.data)
+        bufs = getattr(self, "_out", None) or []
         self._out = None
+        if _lib is None:                 # interpreter shutdown: the process is about to drop the mappings anyway
+            return
+        for a in bufs:
+            try:
+                _lib.ugs_host_unregister(a.ctypes.data)
+            except Exception:
+                pass
 
     def stats(self):
         st = BatchStats()
