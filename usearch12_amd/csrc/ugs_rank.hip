@@ -694,11 +694,9 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
     for (uint32_t c = tid; c <= ns_max; c += nthr) s_fp[c] = KEY_INF;
     const uint32_t ns = __builtin_amdgcn_readfirstlane(bv.unit_ns[unit]);
-    if (ns == 0) {                       // no valid word in the query (shorter than a word, or wildcards throughout): nothing to rank
-      if (tid == 0) bv.cand_n[unit] = 0;
-      continue;
-    }
-    for (uint32_t i = tid; i < ns; i += nthr) s_slots[i] = bv.unit_slots[(uint64_t)unit * ns_max + i];
+    // (a query without a valid word has ns == 0: slot 0 stands in so that the row descriptors below never read an
+    // uninitialised LDS word; every sub-row then has length 0 and nothing is ranked)
+    for (uint32_t i = tid; i < (ns ? ns : 1u); i += nthr) s_slots[i] = ns ? bv.unit_slots[(uint64_t)unit * ns_max + i] : 0u;
     __syncthreads();
     // ---- the scan; counter width by the largest possible count (= ns)
     const int cb0 = ns <= 15 ? 4 : (ns <= 255 ? 8 : 16);
