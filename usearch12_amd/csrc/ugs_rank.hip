@@ -653,6 +653,9 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
 }
 
+// SMALL: the database is at or below -big (small ranking path) - a per-database constant, so the two rankers are two
+// instantiations and each carries only its own branches through the hot loop
+template <bool SMALL>
 __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   const uint32_t units = bv.nq * bv.nstrand;
   const uint32_t K = bv.K;
   const int W = db.word_len;
-  const bool small_path = !db.big;
+  constexpr bool small_path = SMALL;
   uint64_t *ebuf = bv.emit_buf + (uint64_t)blockIdx.x * bv.emit_cap;
   const uint64_t ecap = bv.emit_cap;
 
@@ -964,8 +967,10 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
 int ugs_rank_blocks_per_cu(int threads, size_t lds)
 {
   int n = 0;
-  if (hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank, threads, lds) != hipSuccess || n < 1) n = 1;
+  // (both instantiations have the same register budget; the Big one is asked)
+  if (hipFuncSetAttribute((const void *)k_rank<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void *)k_rank<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false>, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
@@ -1002,8 +1007,13 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
-  HIPCHK(hipFuncSetAttribute((const void *)k_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-  hipLaunchKernelGGL(k_rank, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
+  if (db.big) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_rank<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+    hipLaunchKernelGGL(k_rank<false>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void *)k_rank<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+    hipLaunchKernelGGL(k_rank<true>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
+  }
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }
