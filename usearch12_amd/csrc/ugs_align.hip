@@ -725,7 +725,14 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
 
   unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0, tq;
   unsigned long long w_tletters = 0, w_pairs = 0;
-  for (uint32_t unit = gw; unit < units; unit += nw) {
+  // units are handed out dynamically: a query without a hit walks all its candidates (32x the work of a query that
+  // accepts its first one), so a static stride leaves most waves idle while the unlucky ones finish
+  (void)gw; (void)nw;
+  for (;;) {
+    uint32_t unit = 0;
+    if (lane == 0) unit = (uint32_t)atomicAdd(&ctr[UGS_CTR_NEXT_UNIT], 1ull);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    if (unit >= units) break;
     tq = clock64();
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
