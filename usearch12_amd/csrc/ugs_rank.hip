@@ -686,11 +686,13 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   for (uint32_t k = lane; k < tbl_words + 64; k += 64) tbl[k] = 0;
 
   unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0;
-  for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
-    const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
-    const uint64_t qo = bv.qoffs[qi];
-    const uint32_t L = (uint32_t)(bv.qoffs[qi + 1] - qo);
-    __syncthreads();
+  // units are handed out dynamically (one atomic per unit, fetched a unit ahead by thread 0)
+  uint32_t next_unit = 0;
+  if (tid == 0) sh->pad1 = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
+  __syncthreads();
+  for (uint32_t unit = sh->pad1; unit < units; unit = sh->pad1) {
+    __syncthreads();                     // everyone has read sh->pad1
+    if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
     const unsigned long long tk0 = clock64();
     // ---- the sampled index rows of this unit were chosen by k_rank_setup
     if (tid == 0) { sh->emit_n = 0; sh->n_sel = 0; sh->last_key = 0; sh->ncl = 0; }
@@ -954,7 +956,9 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     if (tid == 0) {
       bv.cand_n[unit] = sh->n_sel;
       if (sh->emit_n > ecap) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
+      sh->pad1 = next_unit;
     }
+    __syncthreads();
   }
   if (tid == 0) {
     atomicAdd(&bv.counters[UGS_CTR_T0], tacc0); atomicAdd(&bv.counters[UGS_CTR_T1], tacc1);
