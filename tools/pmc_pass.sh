@@ -16,7 +16,7 @@ files = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % tag, recursiv
 acc = collections.defaultdict(float)
 for f in files:
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if not k.startswith(("k_rank", "k_align")):
             continue
         acc[(k, row["Counter_Name"])] += float(row["Counter_Value"])

@@ -692,7 +692,6 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
   __syncthreads();
   for (uint32_t unit = sh->pad1; unit < units; unit = sh->pad1) {
     __syncthreads();                     // everyone has read sh->pad1
-    if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
     const unsigned long long tk0 = clock64();
     // ---- the sampled index rows of this unit were chosen by k_rank_setup
     if (tid == 0) { sh->emit_n = 0; sh->n_sel = 0; sh->last_key = 0; sh->ncl = 0; }
@@ -723,6 +722,9 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
     scan_dispatch<false>(sc, cb, 0, 0);
+    // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
+    // for the atomic's latency to hide behind the selection
+    if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
     const unsigned long long tk2w = clock64();
     __threadfence_block();
     __syncthreads();
