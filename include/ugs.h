@@ -304,6 +304,12 @@ int ugs_format_alnout_header(const ugs_hit *hits, uint32_t n, const char *qlabel
 int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel, const char *tlabel,
                           const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
 
+/* -fastapairs (OutputFastaPairs outputsink.cpp:231-241) and -qsegout / -tsegout (OutputQSeg/OutputTSeg :203-229,
+ * RowToFasta :30-55; which = 0 query, 1 target): the aligned rows of a hit as FASTA */
+int ugs_format_fastapairs(const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel, const char *tlabel,
+                          const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
+int ugs_format_segout(const ugs_hit *h, const uint32_t *cigar_pool, int which, const char *qlabel, const char *tlabel,
+                      const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
 /* OutputBlast6NoHits blast6out.cpp:82-103 (-output_no_hits) */
 int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap);
 /* SeqToFasta seqdb.cpp:62-90 (-matched / -notmatched / -dbmatched / -dbnotmatched records) */

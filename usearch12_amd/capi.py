@@ -24,6 +24,7 @@ EXPORTS = [
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
     "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
+    "ugs_format_fastapairs", "ugs_format_segout",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
 ]
 

@@ -86,7 +86,7 @@ class Searcher {
 
 // the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
 struct Outputs {
-  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr;
+  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr, *pairs = nullptr, *qseg = nullptr, *tseg = nullptr;
   std::string userfields;
   bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
   uint32_t maxhits = 0;
@@ -136,6 +136,12 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   for (uint32_t j = 0; j < n; ++j) {
     const uint32_t t = h[j].target;
     const char *tl = db.labels[t].c_str();
+    if (O.pairs || O.qseg || O.tseg) {
+      const char *tsq = O.db_masked + db.offs[t]; const uint32_t tlen = (uint32_t)(db.offs[t + 1] - db.offs[t]);
+      if (O.pairs) put(O.pairs, ugs_format_fastapairs(&h[j], pool, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
+      if (O.qseg) put(O.qseg, ugs_format_segout(&h[j], pool, 0, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
+      if (O.tseg) put(O.tseg, ugs_format_segout(&h[j], pool, 1, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
+    }
     if (O.aln) put(O.aln, ugs_format_alnout_hit(&h[j], pool, p.is_nucleo, qlab, tl, qs, ql, O.db_masked + db.offs[t],
                                                 (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
     if (O.b6) put(O.b6, ugs_format_blast6(&h[j], qlab, tl, line.data(), (int)line.size()));
@@ -186,7 +192,7 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
-  std::string otutabout, mapout, alnpath; bool otutab_cmd = false; long stepwords = -1;
+  std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
@@ -209,7 +215,8 @@ int main(int argc, char **argv)
     else if (a == "-max_target_cov") { filt.max_target_cov = (float)atof(val()); filt.filter_mask |= UGS_F_MAX_TARGET_COV; }
     else if (a == "-maxdiffs") { filt.maxdiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXDIFFS; }
     else if (a == "-mindiffs") { filt.mindiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINDIFFS; }
-    else if (a == "-alnout") alnpath = val();
+    else if (a == "-alnout") alnpath = val(); else if (a == "-fastapairs") pairspath = val();
+    else if (a == "-qsegout") qsegpath = val(); else if (a == "-tsegout") tsegpath = val();
     else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
     else if (a == "-matched") matchedpath = val(); else if (a == "-notmatched") notmatchedpath = val();
     else if (a == "-dbmatched") dbmatchedpath = val(); else if (a == "-dbnotmatched") dbnotmatchedpath = val();
@@ -271,12 +278,12 @@ int main(int argc, char **argv)
     if (O.userfields.empty()) { fprintf(stderr, "--userout requires --userfields\n"); return 1; }
     if (ugs_userfields_check(O.userfields.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
   }
-  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath);
+  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
   O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   Searcher searcher(p, db, device);
   std::string masked;
-  if (O.user || O.aln || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
+  if (O.user || O.aln || O.pairs || O.qseg || O.tseg || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
     masked.resize(db.letters.size());
     if (ugs_db_masked_letters(searcher.handle(), &masked[0]) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
     O.db_masked = masked.data();
@@ -296,7 +303,7 @@ int main(int argc, char **argv)
     }
     total += q.size();
   }
-  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln}) if (f) fclose(f);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg}) if (f) fclose(f);
   if (O.otutab) {                                                     // OTUTableSink::OnAllDone otutabsink.cpp:60-76
     uint64_t assigned = 0, tot = 0;
     ugs_otutab_totals(O.otutab, &assigned, &tot);

@@ -513,3 +513,63 @@ extern "C" int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_poo
   app(o, "%u cols, %u ids (%.1f%%), %u gaps (%.1f%%)\n", aln, h->ids, 100.0 * ratio(h->ids, aln), h->gaps_int, 100.0 * ratio(h->gaps_int, aln));
   return finish(o, buf, cap);
 }
+
+// ---------------------------------------------------------------- -fastapairs / -qsegout / -tsegout
+// OutputSink::OutputFastaPairs outputsink.cpp:231-241, OutputQSeg / OutputTSeg :203-229 with RowToFasta :30-55
+// (the aligned rows of AlignResult::GetQueryRow / GetTargetRow, arscorer.cpp:305-324,506-525).
+namespace {
+int aligned_rows(const ugs_hit *h, const uint32_t *cigar_pool, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
+                 std::string &qrow, std::string &trow)
+{
+  if (!h || !cigar_pool || !qseq || !tseq) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (ql != h->ql || tl != h->tl) { ugs_set_error("sequence lengths do not match the hit record"); return UGS_E_ARG; }
+  const MatchTables &T = tables();
+  std::string Q(qseq, ql);
+  if (h->strand) for (uint32_t k = 0; k < ql; ++k) { const unsigned char c = (unsigned char)qseq[ql - 1 - k]; const unsigned char cc = T.comp[c]; Q[k] = (char)(cc == '?' ? c : cc); }
+  std::string path;
+  for (uint32_t k = 0; k < h->cigar_len; ++k) { const uint32_t r = cigar_pool[h->cigar_off + k]; path.append(r >> 2, "MDI"[r & 3]); }
+  const size_t firstM = path.find('M'), lastM = path.rfind('M');
+  if (firstM == std::string::npos) { ugs_set_error("path has no match column"); return UGS_E_ARG; }
+  uint32_t qp = h->qlo, tp = h->tlo;
+  qrow.clear(); trow.clear();
+  for (size_t c = firstM; c <= lastM; ++c) {
+    const char op = path[c];
+    qrow.push_back((op == 'M' || op == 'D') ? (char)toupper((unsigned char)Q[qp++]) : '-');
+    trow.push_back((op == 'M' || op == 'I') ? (char)toupper((unsigned char)tseq[tp++]) : '-');
+  }
+  return UGS_OK;
+}
+
+void row_to_fasta(std::string &o, const char *label, const std::string &row)     // RowToFasta outputsink.cpp:30-55
+{
+  o.push_back('>'); o += label;
+  unsigned out = 0;
+  for (char c : row) {
+    if (c == '-' || c == '.') continue;
+    if (out % 80 == 0) o.push_back('\n');
+    o.push_back(c); ++out;
+  }
+  o.push_back('\n');
+}
+}  // namespace
+
+extern "C" int ugs_format_fastapairs(const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel, const char *tlabel,
+                                     const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap)
+{
+  std::string qrow, trow;
+  const int rc = aligned_rows(h, cigar_pool, qseq, ql, tseq, tl, qrow, trow);
+  if (rc != UGS_OK) return rc;
+  std::string o = ">"; o += qlabel; o.push_back('\n'); o += qrow; o += "\n>"; o += tlabel; o.push_back('\n'); o += trow; o += "\n\n";
+  return finish(o, buf, cap);
+}
+
+// which = 0: -qsegout (the aligned part of the query), 1: -tsegout (of the target)
+extern "C" int ugs_format_segout(const ugs_hit *h, const uint32_t *cigar_pool, int which, const char *qlabel, const char *tlabel,
+                                 const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap)
+{
+  std::string qrow, trow, o;
+  const int rc = aligned_rows(h, cigar_pool, qseq, ql, tseq, tl, qrow, trow);
+  if (rc != UGS_OK) return rc;
+  if (which == 0) row_to_fasta(o, qlabel, qrow); else row_to_fasta(o, tlabel, trow);
+  return finish(o, buf, cap);
+}
