@@ -143,7 +143,7 @@ def main():
         t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
         got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
         if rank == 0:
-            return multigpu.merge_tables(got[0], got[1], got[2])
+            return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3])
         return None
 
     for _ in range(args.warmup):

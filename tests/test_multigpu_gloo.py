@@ -36,7 +36,7 @@ def _worker(rank, world, port, case, out_path):
     t_p = torch.from_numpy(pool.astype(np.uint32).view(np.uint8).copy())
     got = multigpu.gather_tables(dist, torch, t_h, t_n, t_p, rank, world, dst=0)
     if rank == 0:
-        ghits, gcnt, gpool = multigpu.merge_tables(got[0], got[1], got[2])
+        ghits, gcnt, gpool = multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3])
         assert int(gcnt.sum()) == len(ghits) and len(gcnt) == qs.n
         np.save(out_path + ".hits.npy", ghits)
         np.save(out_path + ".pool.npy", gpool)
