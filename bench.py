@@ -197,7 +197,8 @@ def main():
             n_hits = int(len(out[0]))
         threads = os.cpu_count() or 1
         sample_q = args.cpu_sample or max(2000, min(qs.n, 1500 * threads))
-        cb = cpu_baseline(args.cpu_baseline, db, qs, args.id, sample_q, threads)
+        # the CPU baseline is a single-GPU-run item (rank 0 at N=1): the other ranks of a multi-GPU run would only wait for it
+        cb = cpu_baseline(args.cpu_baseline if world == 1 else "none", db, qs, args.id, sample_q, threads)
         line = {
             "metric": "query-seqs/s usearch_global -id 0.97 (search phase, queries resident in HBM -> hit table on host)",
             "value": value, "unit": "query-seqs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
