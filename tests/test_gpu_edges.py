@@ -1,0 +1,79 @@
+"""Edge cases of the C-ABI on the GPU: empty batches, one-sequence databases, sequences shorter than a word or made of
+wildcards only, queries beyond the device envelope (must fail with an error code, never crash), capacity errors."""
+import numpy as np
+import pytest
+
+import orc
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(seqs):
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return np.frombuffer("".join(seqs).encode(), np.uint8).copy(), offs
+
+
+def both(db, qs, aa=False, ident=0.9, **kw):
+    dseq, doff = pack(db)
+    qseq, qoff = pack(qs)
+    g = capi.UgsDB(capi.params(is_nucleo=not aa, id=ident, **kw), dseq, doff, device=0).search(qseq, qoff)
+    o = orc.OrcDB(orc.params(is_nucleo=not aa, id=ident, **kw), dseq, doff).search(qseq, qoff)
+    assert np.array_equal(g[1], o[1])
+    for f in g[0].dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(g[0][f], o[0][f]), f
+    return g
+
+
+def test_empty_query_batch():
+    dseq, doff = pack(["ACGTACGTACGTTTGACCA" * 5])
+    db = capi.UgsDB(capi.params(True, 0.9), dseq, doff, device=0)
+    hits, nh, pool = db.search(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(hits) == 0 and len(nh) == 0
+
+
+def test_single_sequence_database_and_tiny_queries():
+    t = "ACGTTGCAAGGCTTACCGATAGGCTATTCGATCGGATATCGCGATATAGCGCTATAGCTAGGATCGATCGGCTAGCTA"
+    both([t], [t, t[:30], t[3:60], "ACG", "A", "NNNNNNNNNNNNNNNNNNNN", "acgttgcaaggcttaccgat", t[::-1]], big=0)
+    both([t], [t, "ACGTACGT", "NNNNACGTNNNN"])                     # small ranking path
+
+
+def test_wildcard_only_and_masked_database_sequences():
+    db = ["N" * 50, "A" * 60, "ACGTTGCAAGGCTTACCGATAGGCTATTCGATCGGATATCGCGATATAGCG", "AC" * 30]
+    both(db, [db[2], "A" * 60, "AC" * 30, "N" * 50], big=0, strand_both=1)
+
+
+def test_protein_short_sequences():
+    t = "MKVLAAGIVGLCAKQWERTYHPLMNDFSCV"
+    both([t, t[:4], "X" * 20], [t, t[5:25], "MKV", "XXXXXXXX", t.lower()], aa=True, ident=0.5, big=0)
+
+
+def test_query_beyond_envelope_is_an_error_not_a_crash():
+    rng = np.random.default_rng(3)
+    dseq, doff = pack(["".join("ACGT"[i] for i in rng.integers(0, 4, 300))])
+    db = capi.UgsDB(capi.params(True, 0.9), dseq, doff, device=0)
+    big_q = "".join("ACGT"[i] for i in rng.integers(0, 4, 70000))
+    qseq, qoff = pack([big_q])
+    with pytest.raises(capi.UgsError) as e:
+        db.search(qseq, qoff)
+    assert e.value.code in (-6, -1)
+    # the handle stays usable
+    qseq, qoff = pack(["".join("ACGT"[i] for i in rng.integers(0, 4, 100))])
+    db.search(qseq, qoff)
+
+
+def test_fetch_capacity_error_reports_demand():
+    db0 = synth.make_db(9, 500, 200)
+    qs = synth.make_queries(9, db0, 200, 200)
+    db = capi.UgsDB(capi.params(True, 0.9), db0.seqs, db0.offs, device=0)
+    bat = capi.UgsBatch(db, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    import ctypes as C
+    hits = np.zeros(qs.n + 1, capi.HIT_DTYPE); nh = np.zeros(qs.n + 1, np.uint32); pool = np.zeros(4, np.uint32)
+    used = C.c_uint64(0)
+    rc = capi.lib().ugs_batch_fetch(bat.h, hits.ctypes.data, len(hits), nh.ctypes.data, pool.ctypes.data, len(pool), C.byref(used))
+    assert rc == -5 and used.value > 4
+    h, n, p = bat.fetch()
+    assert len(p) == used.value
