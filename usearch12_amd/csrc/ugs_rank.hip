@@ -586,7 +586,17 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   const int W = db.word_len;
   const bool small_path = !db.big;
   unsigned long long psum = 0;
-  for (uint32_t unit = blockIdx.x * wpb + wave; unit < units; unit += gridDim.x * wpb) {
+  (void)wpb;
+  // units are handed out dynamically in chunks of 16 per wave (one same-address atomic per unit would take longer than
+  // this whole kernel)
+  for (uint32_t unit = 0, chunk_end = 0;; ++unit) {
+    if (unit >= chunk_end) {
+      uint32_t c0 = 0;
+      if (lane == 0) c0 = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_SETUP], 16ull);
+      unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+      chunk_end = unit + 16;
+    }
+    if (unit >= units) break;
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t L = (uint32_t)(bv.qoffs[qi + 1] - qo);
