@@ -52,13 +52,33 @@ class FastaReader {
     return n;
   }
  private:
+  // one line without its end-of-line ('\r' dropped); reads the file in 4 MiB blocks and finds line ends with memchr
   bool next_line() {
     line_.clear();
-    int c;
     bool any = false;
-    while ((c = fgetc(f_)) != EOF) { any = true; if (c == '\n') break; if (c != '\r') line_.push_back((char)c); }
+    for (;;) {
+      if (pos_ == len_) {
+        len_ = fread(buf_.data(), 1, buf_.size(), f_);
+        pos_ = 0;
+        if (len_ == 0) break;
+      }
+      any = true;
+      const char *b = buf_.data() + pos_;
+      const char *nl = (const char *)memchr(b, '\n', len_ - pos_);
+      const size_t n = nl ? (size_t)(nl - b) : len_ - pos_;
+      line_.append(b, n);
+      pos_ += n + (nl ? 1 : 0);
+      if (nl) break;
+    }
+    if (!line_.empty() && line_.find('\r') != std::string::npos) {
+      size_t w = 0;
+      for (char c : line_) if (c != '\r') line_[w++] = c;
+      line_.resize(w);
+    }
     return any;
   }
+  std::vector<char> buf_ = std::vector<char>(4u << 20);
+  size_t pos_ = 0, len_ = 0;
   FILE *f_; std::string line_; bool have_;
 };
 
@@ -272,6 +292,7 @@ int main(int argc, char **argv)
     if (path.empty()) return nullptr;
     FILE *f = fopen(path.c_str(), "w");
     if (!f) { fprintf(stderr, "cannot create %s\n", path.c_str()); exit(1); }
+    setvbuf(f, nullptr, _IOFBF, 4u << 20);
     return f;
   };
   if (!userpath.empty()) {                                            // outputsink.cpp:96-103
