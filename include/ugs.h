@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define UGS_ABI_VERSION 2   /* 2: ugs_params gained the accept/pair filters, ugs_batch_stats the setup-kernel time */
+#define UGS_ABI_VERSION 3   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
+                             * (ugs_params.local..., ugs_hit.raw_score/flags) */
 
 /* error codes */
 #define UGS_OK            0
@@ -57,6 +58,16 @@ extern "C" {
  *                 values are compared as (double)(float)value like every option (opts.cpp:265).  A hit that fails
  *                 one is a reject for the terminator, exactly like a failed -id.  (The pair filters of
  *                 Accepter::RejectPair - -self, -selfid, -minqt ... - are not implemented.)
+ *   local         0 = usearch_global; 1 = usearch_local: the same U-sort candidate walk, but every candidate goes
+ *                 through LocalAligner2::AlignMulti (localmulti.cpp:9-118: seed every hsp_word_len-mer the target
+ *                 shares with the query, LocalAligner::AlignPos localaligner.cpp:101-222: ungapped x-drop xdrop_u,
+ *                 anchor, gapped x-drop xdrop_g, e-value gate) and may yield several HSPs.  id may be left unset
+ *                 (ranking then uses 0.5, makedbsearcher.cpp:172: oget_fltd(OPT_id, 0.5)).
+ *   evalue        -evalue (required by usearch_local), compared as (double)(float)
+ *   ka_dbsize     -ka_dbsize; its default 1e9 counts as "filled" (o_defaults.inc:2, opts.cpp:187-192), so the DB
+ *                 letter count is never used (makedbsearcher.cpp:89-95)
+ *   local_open/local_ext  -lopen/-lext as penalties: -10 / -1 for both alphabets (alnparams.cpp:362-369)
+ *   max_hsps      hit slots per (query strand, accepted target); more HSPs than that => UGS_E_CAPACITY
  */
 enum {
   UGS_F_MAXID = 1, UGS_F_MINCOLS = 2, UGS_F_MAXGAPS = 4, UGS_F_QUERY_COV = 8, UGS_F_MAX_QUERY_COV = 16,
@@ -84,6 +95,14 @@ typedef struct ugs_params {
   uint32_t filter_mask;    /* UGS_F_* bits                             */
   float    maxid, query_cov, max_query_cov, target_cov, max_target_cov;
   uint32_t mincols, maxgaps, maxdiffs, mindiffs;
+  int32_t  local;
+  float    evalue;
+  float    xdrop_u;        /* 16 (o_defaults.inc:22)                   */
+  float    xdrop_g;        /* 32 (o_defaults.inc:20)                   */
+  float    local_open;     /* -10                                      */
+  float    local_ext;      /* -1                                       */
+  float    ka_dbsize;      /* 1e9                                      */
+  uint32_t max_hsps;       /* 8                                        */
   uint32_t reserved_[2];
 } ugs_params;
 
@@ -109,13 +128,22 @@ typedef struct ugs_hit {
   uint64_t cigar_off;    /* into the cigar pool, in uint32 units           */
   uint32_t cigar_len;    /* number of runs                                 */
   uint32_t cols;         /* total path columns incl. terminal gaps         */
+  float    raw_score;    /* local hits: HSP raw score (AlignResult::GetRawScore arscorer.cpp:87-103); 0 for global */
+  uint32_t flags;        /* UGS_HIT_LOCAL: a usearch_local HSP - qlo..thi are the HSP (m_HSP), the path covers only it */
 } ugs_hit;
+#define UGS_HIT_LOCAL 1u
 
 typedef struct ugs_db ugs_db;       /* opaque: masked DB + UDB index resident in HBM */
 typedef struct ugs_batch ugs_batch; /* opaque: one query batch resident in HBM       */
 
 /* Fill *p with the reference defaults for usearch_global (o_defaults.inc, terminator.cpp:26-31). */
 int ugs_params_init(ugs_params *p, int is_nucleo, double id);
+/* Switch *p to usearch_local (cmd_usearch_local searchcmd.cpp:42-45, makedbsearcher.cpp:87-121): -evalue is required;
+ * id_set = 0 means no -id on the command line (no identity filter, ranking with 0.5). */
+int ugs_params_set_local(ugs_params *p, double evalue, int id_set);
+/* Karlin-Altschul numbers of a local hit (EStats::RawScoreToBitScore / RawScoreToEvalue estats.cpp:72-96 with the
+ * BLAST gapped constants and -ka_dbsize), evaluated exactly as the reference binary does (see ugs_host.cpp). */
+int ugs_local_evalue(const ugs_params *p, double raw_score, uint32_t ql, double *evalue, double *bits);
 
 int ugs_abi_version(void);
 int ugs_device_count(void);
@@ -204,6 +232,8 @@ int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void **d_hits, u
  * line (with trailing '\n') into buf; return the length that was / would be written.
  */
 int ugs_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
+/* -blast6out line of a usearch_local hit (blast6out.cpp:27-80, local branch :71-77) */
+int ugs_format_blast6_local(const ugs_params *p, const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
 int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
                       const char *qlabel, const char *tlabel, char *buf, int cap);
 int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);

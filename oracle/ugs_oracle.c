@@ -14,6 +14,7 @@
 
 #include <ctype.h>
 #include <limits.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -191,6 +192,18 @@ void orc_params_init(ugs_params *p, int is_nucleo, double id)
   p->mismatch = -2.0f;
   p->hsp_word_len = is_nucleo ? 5 : 3;       /* alnheuristics.cpp:36,44 */
   p->dbmask = 1;
+  p->xdrop_u = 16.0f; p->xdrop_g = 32.0f;    /* o_defaults.inc:20,22 */
+  p->local_open = -10.0f; p->local_ext = -1.0f;
+  p->ka_dbsize = 1e9f;                       /* o_defaults.inc:2 */
+  p->max_hsps = 8;
+}
+
+/* usearch_local: -evalue is required, -id optional (ranking falls back to 0.5, makedbsearcher.cpp:172) */
+void orc_params_set_local(ugs_params *p, double evalue, int id_set)
+{
+  p->local = 1;
+  p->evalue = (float)evalue;
+  if (!id_set) { p->id = 0.5f; p->id_accept = 0.5; p->id_set = 0; }
 }
 
 /* ------------------------------------------------------------------ db */
@@ -1210,6 +1223,314 @@ static int is_accept_lo(const ugs_params *p, const ugs_hit *h)
   return 1;
 }
 
+
+/* ================================================================== usearch_local driver
+ * Searcher::Align non-global branch (searcher.cpp:28-50) -> LocalAligner2::AlignMulti (localmulti.cpp:9-118)
+ * -> LocalAligner::AlignPos (localaligner.cpp:101-222) -> XDropAlignMem, gated by Karlin-Altschul
+ * statistics (estats.cpp:25-99). */
+int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const char *b, uint32_t lb,
+                  const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells);
+
+typedef struct { double GappedLambda, UngappedLambda, GappedK, UngappedK, LogGappedK, LogUngappedK, DBSize, MaxEvalue; } EStats;
+
+static void es_init(EStats *es, const ugs_params *p)          /* estats.cpp:25-58, makedbsearcher.cpp:89-96 */
+{
+  if (p->is_nucleo) { es->GappedLambda = 1.280; es->UngappedLambda = 1.330; es->GappedK = 0.460; es->UngappedK = 0.621; }
+  else { es->GappedLambda = 0.267; es->UngappedLambda = 0.311; es->GappedK = 0.0410; es->UngappedK = 0.128; }
+  es->LogGappedK = log(es->GappedK); es->LogUngappedK = log(es->UngappedK);
+  es->DBSize = (double)p->ka_dbsize;                          /* float DBSize, widened */
+  es->MaxEvalue = (double)p->evalue;                          /* (float) oget_flt(OPT_evalue) */
+}
+/* The reference is built with -O3 -ffast-math (its Makefile:11-14), and the e-values it PRINTS depend on that: gcc
+ * folds (x/Log2)*Log2, turns /Log2 into a multiplication by 1/ln 2 and NM/pow(2,b) into exp2(-b)*DBSize*QL, which
+ * keeps e-values below 1e-292 representable (plain pow(2, bits > 1024) would overflow to E = 0).  The three functions
+ * below are the operations of the compiled code (objdump of estats.o, gcc 11.4), not of the source text. */
+static double es_min_ungapped(const EStats *es, unsigned QL)  /* estats.cpp:63-70 */
+{
+  return ((log((double)QL * es->DBSize) + es->LogUngappedK) - log(es->MaxEvalue)) / es->UngappedLambda;
+}
+static double es_bits(const EStats *es, double Raw, int Gapped)      /* estats.cpp:78-84 */
+{
+  double Lambda = Gapped ? es->GappedLambda : es->UngappedLambda, LogK = Gapped ? es->LogGappedK : es->LogUngappedK;
+  return (Raw * Lambda - LogK) * 1.4426950408889634;          /* 0x3ff71547652b82fe */
+}
+static double es_evalue(const EStats *es, double Raw, unsigned QL, int Gapped)   /* estats.cpp:72-76,87-96 */
+{
+  return (exp2(-es_bits(es, Raw, Gapped)) * es->DBSize) * (double)QL;
+}
+void orc_local_evalue(const ugs_params *p, double raw, uint32_t ql, double *evalue, double *bits)
+{
+  EStats es; es_init(&es, p);
+  if (bits) *bits = es_bits(&es, raw, 1);
+  if (evalue) *evalue = es_evalue(&es, raw, ql, 1);
+}
+
+typedef struct {
+  unsigned W, Alpha, Dict, AlphaHi;
+  uint32_t *QueryWords, *QueryPosVec, *Counts, *Counts2, *Base; unsigned nwords, qcap;
+  uint32_t *TargetWords; unsigned tcap;
+  EStats es; float MinUngapped;
+  ugs_xdrop_params xp;
+  /* ARs of the current target */
+  struct LAR { unsigned Loi, Loj, Leni, Lenj; float Score; char *Path; } *ars; unsigned nars, arcap;
+  char *path; size_t pathcap;
+} LocalWork;
+
+static unsigned long g_local_rescore_diffs = 0;   /* GetRawScore (path rescoring) != x-drop score; tests only */
+unsigned long orc_local_rescore_diffs(void) { return g_local_rescore_diffs; }
+
+static LocalWork *lw_new(const orc_db *db)
+{
+  LocalWork *lw = (LocalWork *)calloc(1, sizeof *lw);
+  lw->W = (unsigned)db->p.hsp_word_len;                       /* makedbsearcher.cpp:107-121: -hspw, 5 nt / 3 aa */
+  lw->Alpha = db->alpha;
+  lw->Dict = 1; for (unsigned i = 0; i < lw->W; ++i) lw->Dict *= lw->Alpha;
+  lw->AlphaHi = lw->Dict / lw->Alpha;
+  lw->Counts = (uint32_t *)calloc(lw->Dict, 4); lw->Counts2 = (uint32_t *)calloc(lw->Dict, 4);
+  lw->Base = (uint32_t *)calloc(lw->Dict, 4);
+  es_init(&lw->es, &db->p);
+  orc_xdrop_params_init(&lw->xp, db->p.is_nucleo);
+  lw->xp.match = db->p.match; lw->xp.mismatch = db->p.mismatch;
+  lw->xp.local_open = db->p.local_open; lw->xp.local_ext = db->p.local_ext; lw->xp.xdrop = db->p.xdrop_g;
+  return lw;
+}
+static void lw_free(LocalWork *lw)
+{
+  if (!lw) return;
+  for (unsigned k = 0; k < lw->arcap; ++k) free(lw->ars[k].Path);
+  free(lw->QueryWords); free(lw->QueryPosVec); free(lw->Counts); free(lw->Counts2); free(lw->Base);
+  free(lw->TargetWords); free(lw->ars); free(lw->path); free(lw);
+}
+
+/* rolling words with wildcards as letter 0 (localaligner2.cpp:82-112, localmulti.cpp:31-56) */
+static unsigned lw_words(const LocalWork *lw, const byte *c2l, const byte *S, unsigned L, uint32_t *Words)
+{
+  uint32_t Word = 0; const byte *Front = S, *Back = S; unsigned n = 0;
+  for (unsigned i = 0; i + 1 < lw->W; ++i) { unsigned Letter = c2l[*Front++]; if (Letter >= lw->Alpha) Letter = 0; Word = Word * lw->Alpha + Letter; }
+  for (unsigned Pos = lw->W - 1; Pos < L; ++Pos) {
+    unsigned Letter = c2l[*Front++]; if (Letter >= lw->Alpha) Letter = 0;
+    Word = Word * lw->Alpha + Letter;
+    Words[n++] = Word;
+    Letter = c2l[*Back++]; if (Letter >= lw->Alpha) Letter = 0;
+    Word -= Letter * lw->AlphaHi;
+  }
+  return n;
+}
+
+/* LocalAligner2::SetQueryImpl localaligner2.cpp:62-145 (+ LocalAligner::SetQueryImpl localaligner.cpp:231-235) */
+static void lw_set_query(LocalWork *lw, const orc_db *db, const byte *Q, unsigned QL)
+{
+  /* OnQueryDoneImpl of the previous query (localaligner2.cpp:147-158) */
+  for (unsigned k = 0; k < lw->nwords; ++k) { lw->Counts[lw->QueryWords[k]] = 0; lw->Counts2[lw->QueryWords[k]] = 0; }
+  lw->MinUngapped = (float)es_min_ungapped(&lw->es, QL);
+  if (QL <= lw->W) { lw->nwords = 0; return; }               /* :72-73 (the reference leaves the old words; they are zeroed above) */
+  if (QL > lw->qcap) { lw->qcap = QL + 256; lw->QueryWords = (uint32_t *)xrealloc(lw->QueryWords, lw->qcap * 4); lw->QueryPosVec = (uint32_t *)xrealloc(lw->QueryPosVec, lw->qcap * 4); }
+  unsigned n = lw_words(lw, db->c2l, Q, QL, lw->QueryWords);
+  lw->nwords = n;
+  for (unsigned k = 0; k < n; ++k) ++lw->Counts2[lw->QueryWords[k]];
+  unsigned Base = 0;
+  for (unsigned k = 0; k < n; ++k) {
+    uint32_t Word = lw->QueryWords[k]; unsigned c = lw->Counts2[Word];
+    if (c == 0) continue;
+    lw->Base[Word] = Base; lw->Counts2[Word] = 0; Base += c;
+  }
+  for (unsigned k = 0; k < n; ++k) {
+    uint32_t Word = lw->QueryWords[k]; unsigned c = lw->Counts[Word];
+    lw->Counts[Word] = c + 1;
+    lw->QueryPosVec[lw->Base[Word] + c] = k;
+  }
+}
+
+/* GetAnchor localaligner.cpp:11-58: best run of positive-scoring columns inside the ungapped segment */
+static float lw_get_anchor(const float (*Sub)[256], const byte *Q, const byte *T, unsigned Loi, unsigned Loj, unsigned L,
+                           unsigned *AncLoi, unsigned *AncLoj, unsigned *AncLen)
+{
+  unsigned Startk = UINT_MAX, BestStartk = UINT_MAX, Length = 0;
+  float AnchorScore = 0.0f, BestScore = 0.0f;
+  for (unsigned k = 0; k < L; ++k) {
+    float Score = Sub[Q[Loi + k]][T[Loj + k]];
+    if (Score > 0) {
+      if (Startk == UINT_MAX) { Startk = k; AnchorScore = Score; } else AnchorScore += Score;
+    } else {
+      if (AnchorScore > BestScore) { BestScore = AnchorScore; BestStartk = Startk; Length = k - Startk; }
+      Startk = UINT_MAX;
+    }
+  }
+  if (AnchorScore > BestScore) { BestScore = AnchorScore; BestStartk = Startk; Length = L - Startk; }
+  *AncLoi = Loi + BestStartk; *AncLoj = Loj + BestStartk; *AncLen = Length;
+  return BestScore;
+}
+
+/* LocalAligner::AlignPos localaligner.cpp:101-222.  Returns 1 and fills *ar (path in lw->path) when an AR comes back. */
+static int lw_align_pos(Work *w, LocalWork *lw, const byte *Q, unsigned QL, const byte *T, unsigned TL,
+                        unsigned QueryPos, unsigned TargetPos, struct LAR *ar)
+{
+  const orc_db *db = w->db;
+  const float (*Sub)[256] = (const float (*)[256])db->subst;
+  const float XDropU = db->p.xdrop_u;
+  float LeftScore = 0.0f, LeftTotal = 0.0f; unsigned LeftLength = 0, k = 0;
+  int i = (int)QueryPos, j = (int)TargetPos;
+  ++w->st.ungapped_calls;
+  while (i >= 0 && j >= 0) {
+    ++k;
+    LeftTotal += Sub[Q[i]][T[j]];
+    if (LeftTotal > LeftScore) { LeftScore = LeftTotal; LeftLength = k; }
+    else if (LeftScore - LeftTotal > XDropU) break;
+    --i; --j;
+  }
+  float RightScore = 0.0f, RightTotal = 0.0f; unsigned RightLength = 0;
+  i = (int)QueryPos + 1; j = (int)TargetPos + 1; k = 0;
+  while (i < (int)QL && j < (int)TL) {
+    ++k;
+    RightTotal += Sub[Q[i]][T[j]];
+    if (RightTotal > RightScore) { RightScore = RightTotal; RightLength = k; }
+    else if (RightScore - RightTotal > XDropU) break;
+    ++i; ++j;
+  }
+  const float Score = LeftScore + RightScore;
+  if (Score < lw->MinUngapped) return 0;
+  unsigned Loi = (QueryPos + 1) - LeftLength, Loj = (TargetPos + 1) - LeftLength, SegLength = LeftLength + RightLength;
+  unsigned AncLoi, AncLoj, AncLen;
+  float AncRaw = lw_get_anchor(Sub, Q, T, Loi, Loj, SegLength, &AncLoi, &AncLoj, &AncLen);
+  if (AncRaw <= 0.0f) return 0;
+  if ((size_t)QL + TL + 8 > lw->pathcap) { lw->pathcap = (size_t)QL + TL + 256; lw->path = (char *)xrealloc(lw->path, lw->pathcap); }
+  ugs_xdrop_job job; memset(&job, 0, sizeof job);
+  job.anc_loi = AncLoi; job.anc_loj = AncLoj; job.anc_len = AncLen; job.mode = UGS_XDROP_ALIGN;
+  ugs_xdrop_hsp hsp; uint64_t cells = 0;
+  orc_xdrop_job(&lw->xp, (const char *)Q, QL, (const char *)T, TL, &job, &hsp, lw->path, &cells);
+  w->st.dp_cells += cells; ++w->st.dp_calls;
+  if (hsp.score <= 0.0f) return 0;
+  if (es_evalue(&lw->es, (double)hsp.score, QL, 1) > (double)db->p.evalue) return 0;
+  ar->Loi = hsp.loi; ar->Loj = hsp.loj; ar->Leni = hsp.leni; ar->Lenj = hsp.lenj; ar->Score = hsp.score;
+  return 1;
+}
+
+/* HSPData::OverlapFract hsp.h:74-89 (unsigned products, Hi - Lo without the +1) */
+static double lar_overlap(const struct LAR *a, const struct LAR *b)
+{
+  if (a->Leni == 0 || a->Lenj == 0) return 0.0;
+  unsigned MaxLoi = a->Loi > b->Loi ? a->Loi : b->Loi, MaxLoj = a->Loj > b->Loj ? a->Loj : b->Loj;
+  unsigned aHii = a->Loi + a->Leni - 1, bHii = b->Loi + b->Leni - 1, aHij = a->Loj + a->Lenj - 1, bHij = b->Loj + b->Lenj - 1;
+  unsigned MinHii = aHii < bHii ? aHii : bHii, MinHij = aHij < bHij ? aHij : bHij;
+  unsigned Ovi = (MinHii < MaxLoi) ? 0 : MinHii - MaxLoi, Ovj = (MinHij < MaxLoj) ? 0 : MinHij - MaxLoj;
+  return (double)(Ovi * Ovj) / (double)(a->Leni * a->Lenj);
+}
+
+/* LocalAligner2::AlignMulti localmulti.cpp:9-118 */
+static void lw_align_multi(Work *w, LocalWork *lw, const byte *Q, unsigned QL, const byte *T, unsigned TL)
+{
+  lw->nars = 0;
+  if (TL < 2 * lw->W) return;
+  if (TL > lw->tcap) { lw->tcap = TL + 256; lw->TargetWords = (uint32_t *)xrealloc(lw->TargetWords, lw->tcap * 4); }
+  const unsigned TargetWordCount = lw_words(lw, w->db->c2l, T, TL, lw->TargetWords);
+  for (unsigned TargetPos = 0; TargetPos < TargetWordCount;) {
+    uint32_t TargetWord = lw->TargetWords[TargetPos];
+    unsigned N = lw->Counts[TargetWord];
+    int skipped = 0;
+    for (unsigned i = 0; i < N; ++i) {
+      unsigned QueryPos = lw->QueryPosVec[lw->Base[TargetWord] + i];
+      struct LAR ar;
+      if (!lw_align_pos(w, lw, Q, QL, T, TL, QueryPos, TargetPos, &ar)) continue;
+      int keep = 1;                                           /* KeepAR localaligner2.cpp:228-246 */
+      for (unsigned a = 0; a < lw->nars; ++a) if (lar_overlap(&ar, &lw->ars[a]) > 0.5) { keep = 0; break; }
+      if (!keep) continue;
+      if (lw->nars + 1 > lw->arcap) {
+        unsigned nc = lw->arcap * 2 + 8;
+        lw->ars = (struct LAR *)xrealloc(lw->ars, nc * sizeof *lw->ars);
+        memset(lw->ars + lw->arcap, 0, (nc - lw->arcap) * sizeof *lw->ars);
+        lw->arcap = nc;
+      }
+      struct LAR *dst = &lw->ars[lw->nars++];
+      char *keepbuf = dst->Path;
+      *dst = ar;
+      size_t n = strlen(lw->path) + 1;
+      dst->Path = (char *)xrealloc(keepbuf, n);
+      memcpy(dst->Path, lw->path, n);
+      unsigned NewTargetPos = ar.Loj + ar.Lenj - 1 + 1;       /* HSP.GetHij() + 1 */
+      if (NewTargetPos > TargetPos) TargetPos = NewTargetPos; else ++TargetPos;
+      skipped = 1;
+      break;
+    }
+    if (!skipped) ++TargetPos;
+  }
+}
+
+/* AlnParams::ScoreLocalPathIgnoreMask alnparams.cpp:447-500 (what AlignResult::GetRawScore reports) */
+static float lw_rescore(const orc_db *db, const byte *A, const byte *B, const char *Path)
+{
+  const float (*Sub)[256] = (const float (*)[256])db->subst;
+  float Score = 0.0f; char Last = 'M';
+  for (const char *p = Path; *p; ++p) {
+    if (*p == 'M') Score += Sub[toupper(*A++)][toupper(*B++)];
+    else if (*p == 'D') { Score += (Last == 'M' ? db->p.local_open : db->p.local_ext); ++A; }
+    else { Score += (Last == 'M' ? db->p.local_open : db->p.local_ext); ++B; }
+    Last = *p;
+  }
+  return Score;
+}
+
+/* Accepter::IsAcceptLo accepter.cpp:24-91 for a local AR (coverages arscorer.cpp:122-154 local branches) */
+static int is_accept_local(const ugs_params *p, const EStats *es, const ugs_hit *h)
+{
+  const unsigned m = p->filter_mask;
+  if (p->id_set) {
+    double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+    if (FractId < p->id_accept) return 0;
+    if ((m & UGS_F_MAXID) && FractId > (double)p->maxid) return 0;
+  }
+  if ((m & UGS_F_MINCOLS) && h->aln_len < p->mincols) return 0;
+  if ((m & UGS_F_MAXGAPS) && h->gaps_int > p->maxgaps) return 0;
+  if (es_evalue(es, (double)h->raw_score, h->ql, 1) > (double)p->evalue) return 0;
+  if (m & (UGS_F_QUERY_COV | UGS_F_MAX_QUERY_COV)) {
+    double Cov = (double)(h->qhi - h->qlo + 1) / (double)h->ql;
+    if ((m & UGS_F_QUERY_COV) && Cov < (double)p->query_cov) return 0;
+    if ((m & UGS_F_MAX_QUERY_COV) && Cov > (double)p->max_query_cov) return 0;
+  }
+  if (m & (UGS_F_TARGET_COV | UGS_F_MAX_TARGET_COV)) {
+    double Cov = (double)(h->thi - h->tlo + 1) / (double)h->tl;
+    if ((m & UGS_F_TARGET_COV) && Cov < (double)p->target_cov) return 0;
+    if ((m & UGS_F_MAX_TARGET_COV) && Cov > (double)p->max_target_cov) return 0;
+  }
+  if ((m & UGS_F_MAXDIFFS) && h->mism + h->gaps_int > p->maxdiffs) return 0;
+  if ((m & UGS_F_MINDIFFS) && h->mism + h->gaps_int < p->mindiffs) return 0;
+  return 1;
+}
+
+
+static void search_strand_local(Work *w, LocalWork *lw, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb)
+{
+  orc_db *db = w->db;
+  if (db->big) rank_big(w, q, QL); else rank_small(w, q, QL);
+  lw_set_query(lw, db, q, QL);
+  w->st.query_letters += QL;
+  int AcceptCount = 0, RejectCount = 0;
+  for (unsigned k = 0; k < w->ntop; ++k) {
+    uint32_t t = w->cand_t[k];
+    const byte *T = (const byte *)db->seqs + db->offs[t];
+    unsigned TL = (unsigned)(db->offs[t + 1] - db->offs[t]);
+    w->st.target_letters += TL; ++w->st.pairs_aligned;
+    lw_align_multi(w, lw, q, QL, T, TL);
+    int AnyAccepts = 0;                                       /* searcher.cpp:31-49 */
+    for (unsigned a = 0; a < lw->nars; ++a) {
+      const struct LAR *ar = &lw->ars[a];
+      ugs_hit h; memset(&h, 0, sizeof h);
+      fill_hit(db, ar->Path, q + ar->Loi, QL, T + ar->Loj, TL, &h);
+      h.qlo = ar->Loi; h.qhi = ar->Loi + ar->Leni - 1; h.tlo = ar->Loj; h.thi = ar->Loj + ar->Lenj - 1;   /* m_HSP */
+      h.raw_score = lw_rescore(db, q + ar->Loi, T + ar->Loj, ar->Path);
+      if (h.raw_score != ar->Score) ++g_local_rescore_diffs;
+      h.flags = UGS_HIT_LOCAL;
+      if (is_accept_local(&db->p, &lw->es, &h)) {
+        AnyAccepts = 1;
+        h.query = qindex; h.target = t; h.strand = (uint32_t)strand;
+        hb_push(hb, &h, ar->Path); ++w->st.hits;
+      }
+    }
+    if (AnyAccepts) ++AcceptCount; else ++RejectCount;
+    if (db->p.max_accepts > 0 && AcceptCount == db->p.max_accepts) break;
+    if (db->p.max_rejects > 0 && RejectCount == db->p.max_rejects) break;
+  }
+}
+
 static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb)
 {
   orc_db *db = w->db;
@@ -1247,26 +1568,27 @@ static void *job_run(void *arg)
   Job *J = (Job *)arg;
   orc_db *db = J->db;
   Work *w = work_new(db);
+  LocalWork *lw = db->p.local ? lw_new(db) : NULL;
   char *rc = NULL; size_t rccap = 0;
   for (uint32_t qi = J->q0; qi < J->q1; ++qi) {
     const byte *q = (const byte *)J->qseqs + J->qoffs[qi];
     unsigned QL = (unsigned)(J->qoffs[qi + 1] - J->qoffs[qi]);
     unsigned first = J->hb.nhits;
-    search_strand(w, qi, q, QL, 0, &J->hb);
+    if (lw) search_strand_local(w, lw, qi, q, QL, 0, &J->hb); else search_strand(w, qi, q, QL, 0, &J->hb);
     if (db->p.strand_both && db->p.is_nucleo) {
       if (rccap < QL + 1) { rccap = QL + 256; rc = (char *)xrealloc(rc, rccap); }
       orc_revcomp((const char *)q, QL, rc);
-      search_strand(w, qi, (const byte *)rc, QL, 1, &J->hb);
+      if (lw) search_strand_local(w, lw, qi, (const byte *)rc, QL, 1, &J->hb); else search_strand(w, qi, (const byte *)rc, QL, 1, &J->hb);
     }
     unsigned n = J->hb.nhits - first;
     J->nhits[qi] = n;
-    if (n > 1) {     /* hitmgr.cpp:477-483 Sort by float(FractId) desc */
+    if (n > 1) {     /* hitmgr.cpp:477-483 Sort by AlignResult::GetScore desc: float(FractId), local: float(raw score) */
       float *sc = (float *)malloc(n * sizeof(float));
       unsigned *ord = (unsigned *)malloc(n * sizeof(unsigned));
       ugs_hit *tmp = (ugs_hit *)malloc(n * sizeof(ugs_hit));
       for (unsigned i = 0; i < n; ++i) {
         const ugs_hit *h = &J->hb.hits[first + i];
-        sc[i] = (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len);
+        sc[i] = lw ? h->raw_score : (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len);
         ord[i] = i; tmp[i] = *h;
       }
       qs_order_desc(sc, 0, (int)n - 1, ord);
@@ -1276,6 +1598,7 @@ static void *job_run(void *arg)
   }
   J->st = w->st;
   free(rc);
+  lw_free(lw);
   work_free(w);
   return NULL;
 }
@@ -1375,6 +1698,20 @@ int orc_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, 
   if (h->strand) { TLo = h->tl; THi = 1; }
   return snprintf(buf, (size_t)cap, "%s\t%s\t%.1f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t*\t*\n", qlabel, tlabel,
                   PctId, h->aln_len, h->mism, h->opens, 1u, h->ql, TLo, THi);
+}
+
+/* blast6out.cpp:27-80 for a local hit: 1-based HSP coordinates, target pair swapped for a reverse-complemented
+ * query (arscorer.cpp:688-806), e-value %.2g and bit score %.1f */
+int orc_format_blast6_local(const ugs_params *p, const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  double PctId = 100.0 * FractId;
+  unsigned QLo = h->qlo + 1, QHi = h->qhi + 1, TLo = h->tlo + 1, THi = h->thi + 1;
+  if (h->strand) { QLo = h->ql - h->qhi; QHi = h->ql - h->qlo; unsigned t = TLo; TLo = THi; THi = t; }
+  double E, Bits;
+  orc_local_evalue(p, (double)h->raw_score, h->ql, &E, &Bits);
+  return snprintf(buf, (size_t)cap, "%s\t%s\t%.1f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%.2g\t%.1f\n", qlabel, tlabel,
+                  PctId, h->aln_len, h->mism, h->opens, QLo, QHi, TLo, THi, E, Bits);
 }
 
 /* outputuc.cpp:45-93 + comppath.cpp:7-48 */

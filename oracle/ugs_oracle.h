@@ -68,6 +68,7 @@ void orc_revcomp(const char *seq, uint32_t len, char *out);
 
 /* text writers (blast6out.cpp:27-80, outputuc.cpp:10-93) */
 int orc_format_blast6(const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
+int orc_format_blast6_local(const ugs_params *p, const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap);
 int orc_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
                       const char *qlabel, const char *tlabel, char *buf, int cap);
 int orc_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, int cap);
@@ -84,6 +85,13 @@ int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const c
                   const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells);
 
 void orc_params_init(ugs_params *p, int is_nucleo, double id);
+/* switch a parameter block to usearch_local (searcher.cpp:28-50, localmulti.cpp, localaligner.cpp, estats.cpp);
+ * id_set = 0 drops the identity filter and ranks with the 0.5 fallback */
+void orc_params_set_local(ugs_params *p, double evalue, int id_set);
+/* Karlin-Altschul numbers of a local hit (estats.cpp:72-96): E = QL * DBSize / 2^bits */
+void orc_local_evalue(const ugs_params *p, double raw, uint32_t ql, double *evalue, double *bits);
+/* test statistic: local hits whose rescored path (AlignResult::GetRawScore) differs from the x-drop score */
+unsigned long orc_local_rescore_diffs(void);
 
 #ifdef __cplusplus
 }

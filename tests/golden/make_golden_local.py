@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Known answers for the usearch_local row, produced by the UNMODIFIED reference
+(oracle/_ref/usearch12 -usearch_local ...) on seeded synthetic inputs.  Runs only where /root/reference
+exists.  Committed per case: <case>.b6 (-blast6out, -threads 1 => query order) and local_manifest.json with
+the generator arguments, the reference command line and sha256 digests of the regenerated inputs."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from usearch12_amd import synth  # noqa: E402
+from make_golden import digest, REF, FILTER_OPTS  # noqa: E402
+
+CASES = {
+    "loc_nt":       dict(seed=41, n_fam=250, fam=6, q_n=900, aa=False, evalue=1e-6, strand="plus"),
+    "loc_nt_both":  dict(seed=42, n_fam=250, fam=6, q_n=900, aa=False, evalue=1e-3, strand="both", maxaccepts=3, maxrejects=8),
+    "loc_nt_id":    dict(seed=43, n_fam=250, fam=6, q_n=900, aa=False, evalue=1e-9, strand="both", id=0.9, maxaccepts=2, maxrejects=6,
+                         mincols=60, maxgaps=8, query_cov=0.3),
+    "loc_nt_big":   dict(seed=44, n_fam=250, fam=6, q_n=600, aa=False, evalue=1e-6, strand="plus", id=0.8, big=100),
+    "loc_aa":       dict(seed=45, n_fam=250, fam=6, q_n=900, aa=True, evalue=1e-6),
+    "loc_aa_acc":   dict(seed=46, n_fam=250, fam=6, q_n=900, aa=True, evalue=10.0, maxaccepts=4, maxrejects=4, target_cov=0.2, maxdiffs=60),
+    "loc_nt_long":  dict(seed=47, n_fam=40, fam=4, q_n=120, aa=False, evalue=1e-6, strand="both", lmin=800, lmax=3000),
+}
+
+
+def make_inputs(c):
+    db, _ = synth.make_hard(c["seed"], c["n_fam"], c["fam"], 1, lmin=c.get("lmin", 150), lmax=c.get("lmax", 400), aa=c["aa"])
+    qs = synth.make_local_queries(c["seed"], db, c["q_n"], aa=c["aa"])
+    if c.get("strand") == "both":
+        qs = synth.revcomp_some(c["seed"], qs)
+    return db, qs
+
+
+def ref_cmd(c, qfa, dbfa, prefix):
+    cmd = [REF, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-blast6out", prefix + ".b6", "-threads", "1"]
+    if not c["aa"]:
+        cmd += ["-strand", c["strand"]]
+    for opt in ("id", "big", "maxaccepts", "maxrejects") + FILTER_OPTS:
+        if opt in c:
+            cmd += ["-" + opt, str(c[opt])]
+    return cmd
+
+
+def main():
+    assert os.path.exists(REF), "build the reference first: oracle/build_ref.sh"
+    manifest = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, c in CASES.items():
+            db, qs = make_inputs(c)
+            dbfa, qfa = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa")
+            db.write_fasta(dbfa)
+            qs.write_fasta(qfa)
+            prefix = os.path.join(HERE, name)
+            cmd = ref_cmd(c, qfa, dbfa, prefix)
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            lines = open(prefix + ".b6").read().splitlines()
+            pairs = {}
+            for ln in lines:
+                f = ln.split("\t")
+                pairs[(f[0], f[1])] = pairs.get((f[0], f[1]), 0) + 1
+            manifest[name] = dict(c, db_sha256=digest(db), q_sha256=digest(qs), n_hits=len(lines),
+                                  n_multi_hsp_pairs=sum(1 for v in pairs.values() if v > 1),
+                                  cmd=" ".join(["usearch12"] + [os.path.basename(x) if x.startswith(tmp) else x
+                                                                 for x in cmd[1:]]).replace(HERE + "/", ""))
+            print(name, "hits", len(lines), "pairs with >1 HSP", manifest[name]["n_multi_hsp_pairs"])
+    json.dump(manifest, open(os.path.join(HERE, "local_manifest.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

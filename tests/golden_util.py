@@ -67,3 +67,30 @@ def load_xdrop(name):
             want = (float(r[1]), None, None, int(r[2]), int(r[3]), "" if r[4] == "-" else r[4])
         out.append(dict(mode=mode, x=x, a=a, b=b, anc=anc, want=want))
     return out
+
+
+# ---- usearch_local cases (tests/golden/local_manifest.json, make_golden_local.py)
+LOCAL_MANIFEST = json.load(open(os.path.join(GOLD, "local_manifest.json")))
+_spec_l = importlib.util.spec_from_file_location("make_golden_local", os.path.join(GOLD, "make_golden_local.py"))
+_mgl = importlib.util.module_from_spec(_spec_l)
+_spec_l.loader.exec_module(_mgl)
+
+
+def local_case_names():
+    return sorted(LOCAL_MANIFEST)
+
+
+def load_local(name):
+    c = LOCAL_MANIFEST[name]
+    db, qs = _mgl.make_inputs(c)
+    assert _mg.digest(db) == c["db_sha256"], "generator drift (db) for " + name
+    assert _mg.digest(qs) == c["q_sha256"], "generator drift (queries) for " + name
+    return c, db, qs, open(os.path.join(GOLD, name + ".b6")).read()
+
+
+def local_params_kw(c):
+    """keyword arguments for orc.params()/capi.params(): usearch_local with or without -id"""
+    kw = params_kw(c)
+    kw["local_evalue"] = c["evalue"]
+    kw["id"] = c.get("id")
+    return kw

@@ -53,6 +53,11 @@ def lib():
         L.orc_format_uc_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.orc_format_uc_nohit.restype = C.c_int
         L.orc_format_uc_nohit.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_params_set_local.argtypes = [C.POINTER(Params), C.c_double, C.c_int]
+        L.orc_local_evalue.argtypes = [C.POINTER(Params), C.c_double, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_local_rescore_diffs.restype = C.c_ulong
+        L.orc_format_blast6_local.restype = C.c_int
+        L.orc_format_blast6_local.argtypes = [C.POINTER(Params), C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.orc_xdrop_params_init.argtypes = [C.POINTER(XdropParams), C.c_int]
         L.orc_xdrop_job.restype = C.c_int
         L.orc_xdrop_job.argtypes = [C.POINTER(XdropParams), C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_void_p,
@@ -85,9 +90,12 @@ def xdrop_job(p, a, b, mode, anc=(0, 0, 0)):
     return float(h["score"]), int(h["loi"]), int(h["loj"]), int(h["leni"]), int(h["lenj"]), path.value.decode(), cells.value
 
 
-def params(is_nucleo=True, id=0.97, **kw):
+def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
+    """id=None with local_evalue set: usearch_local without -id"""
     p = Params()
-    lib().orc_params_init(C.byref(p), 1 if is_nucleo else 0, float(id))
+    lib().orc_params_init(C.byref(p), 1 if is_nucleo else 0, float(0.5 if id is None else id))
+    if local_evalue is not None:
+        lib().orc_params_set_local(C.byref(p), float(local_evalue), 0 if id is None else 1)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -135,10 +143,10 @@ class OrcDB:
         qseqs = as_u8(qseqs)
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         nq = len(qoffs) - 1
-        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) + 1
+        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) * (64 if self.p.local else 1) + 1
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         nh = np.zeros(nq + 1, dtype=np.uint32)
-        cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
+        cig_cap = (int(qoffs[-1]) * 2 + 64 * nq + 1024) * (8 if self.p.local else 1)
         pool = np.zeros(cig_cap, dtype=np.uint32)
         used = C.c_uint64(0)
         rc = lib().orc_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
@@ -225,3 +233,19 @@ def run_reference(qfa, dbfa, out_prefix, id=0.97, strand="plus", threads=1, extr
     cmd += list(extra)
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out_prefix + ".b6").read(), open(out_prefix + ".uc").read()
+
+
+def format_blast6_local(fmt_lib, prefix, p, hits, nh, qlabels, tlabels):
+    """blast6 text of usearch_local hits in query order ('orc' = oracle writer, 'ugs' = product writer)"""
+    out = []
+    buf = C.create_string_buffer(1 << 16)
+    f = getattr(fmt_lib, prefix + "_format_blast6_local")
+    k = 0
+    for qi, n in enumerate(nh):
+        ql = qlabels[qi].encode()
+        for j in range(int(n)):
+            h = hits[k:k + 1]
+            f(C.byref(p), h.ctypes.data, ql, tlabels[int(h["target"][0])].encode(), buf, len(buf))
+            out.append(buf.value.decode())
+            k += 1
+    return "".join(out)

@@ -1,0 +1,81 @@
+"""usearch_local on the GPU (-m gpu): k_local through the C-ABI vs (a) the reference's golden -blast6out text
+(identities, HSP coordinates, e-values, bit scores) and (b) the oracle's hit records and paths, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import orc
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(c, db, qs, **extra):
+    kw = G.local_params_kw(c)
+    kw.update(extra)
+    p = capi.params(is_nucleo=not c["aa"], **kw)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    hits, nh, pool = gdb.search(qs.seqs, qs.offs)
+    return p, hits, nh, pool
+
+
+def _same_records(hits, nh, pool, ohits, onh, opool):
+    assert np.array_equal(nh, onh)
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(hits[f], ohits[f]), f
+    for h, o in zip(hits, ohits):
+        assert np.array_equal(pool[int(h["cigar_off"]):int(h["cigar_off"]) + int(h["cigar_len"])],
+                              opool[int(o["cigar_off"]):int(o["cigar_off"]) + int(o["cigar_len"])])
+
+
+@pytest.mark.parametrize("name", G.local_case_names())
+def test_gpu_local_matches_reference_text(name):
+    c, db, qs, b6 = G.load_local(name)
+    p, hits, nh, pool = _run_gpu(c, db, qs)
+    got = orc.format_blast6_local(capi.lib(), "ugs", p, hits, nh, qs.labels(), db.labels())
+    assert got == b6
+    assert np.all(hits["flags"] == 1)
+
+
+@pytest.mark.parametrize("name", ["loc_nt_both", "loc_aa_acc", "loc_nt_long", "loc_nt_id"])
+def test_gpu_local_hits_equal_oracle_records(name):
+    c, db, qs, b6 = G.load_local(name)
+    p, hits, nh, pool = _run_gpu(c, db, qs)
+    odb = orc.OrcDB(orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c)), db.seqs, db.offs)
+    _same_records(hits, nh, pool, *odb.search(qs.seqs, qs.offs, nthreads=4))
+
+
+@pytest.mark.parametrize("seed,aa", [(101, False), (102, True), (103, False)])
+def test_gpu_local_fuzz_vs_oracle(seed, aa):
+    """fresh seeds, non-default gates: loose e-value (many weak HSPs), several accepts, odd x-drops"""
+    db, _ = synth.make_hard(seed, 120, 5, 1, lmin=60, lmax=500, aa=aa)
+    qs = synth.make_local_queries(seed, db, 500, aa=aa)
+    kw = dict(id=None, local_evalue=[10.0, 1e-2, 1e-12][seed % 3], max_accepts=3, max_rejects=5, max_hsps=16,
+              strand_both=0 if aa else 1, xdrop_u=[16.0, 9.5, 30.0][seed % 3], xdrop_g=[32.0, 20.0, 12.0][seed % 3])
+    if not aa:
+        qs = synth.revcomp_some(seed, qs)
+    p = capi.params(is_nucleo=not aa, **kw)
+    hits, nh, pool = capi.UgsDB(p, db.seqs, db.offs, device=0).search(qs.seqs, qs.offs)
+    odb = orc.OrcDB(orc.params(is_nucleo=not aa, **kw), db.seqs, db.offs)
+    _same_records(hits, nh, pool, *odb.search(qs.seqs, qs.offs, nthreads=4))
+    assert len(hits) > 100
+
+
+def test_gpu_local_hit_slot_overflow_is_loud():
+    c, db, qs, b6 = G.load_local("loc_nt_both")
+    with pytest.raises(capi.UgsError) as e:
+        _run_gpu(c, db, qs, max_hsps=1)
+    assert e.value.code == -5      # UGS_E_CAPACITY
+
+
+def test_local_evalue_matches_oracle():
+    p = capi.params(True, id=None, local_evalue=1e-6)
+    op = orc.params(True, id=None, local_evalue=1e-6)
+    for raw, ql in ((302.0, 344), (15.5, 20), (2051.5, 3000), (1.0, 1)):
+        e, b, oe, ob = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        capi.lib().ugs_local_evalue(C.byref(p), raw, ql, C.byref(e), C.byref(b))
+        orc.lib().orc_local_evalue(C.byref(op), raw, ql, C.byref(oe), C.byref(ob))
+        assert (e.value, b.value) == (oe.value, ob.value)

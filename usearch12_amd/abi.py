@@ -20,6 +20,8 @@ class Params(C.Structure):
         ("maxid", C.c_float), ("query_cov", C.c_float), ("max_query_cov", C.c_float), ("target_cov", C.c_float),
         ("max_target_cov", C.c_float),
         ("mincols", C.c_uint32), ("maxgaps", C.c_uint32), ("maxdiffs", C.c_uint32), ("mindiffs", C.c_uint32),
+        ("local", C.c_int32), ("evalue", C.c_float), ("xdrop_u", C.c_float), ("xdrop_g", C.c_float),
+        ("local_open", C.c_float), ("local_ext", C.c_float), ("ka_dbsize", C.c_float), ("max_hsps", C.c_uint32),
         ("reserved_", C.c_uint32 * 2),
     ]
 
@@ -33,11 +35,12 @@ FILTER_BITS = dict(maxid=F_MAXID, mincols=F_MINCOLS, maxgaps=F_MAXGAPS, query_co
 
 HIT_DTYPE = np.dtype({
     "names": ["query", "target", "ids", "mism", "gaps_int", "aln_len", "opens",
-              "qlo", "qhi", "tlo", "thi", "ql", "tl", "strand", "cigar_off", "cigar_len", "cols"],
-    "formats": ["<u4"] * 14 + ["<u8", "<u4", "<u4"],
-    "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 64, 68],
-    "itemsize": 72,
+              "qlo", "qhi", "tlo", "thi", "ql", "tl", "strand", "cigar_off", "cigar_len", "cols", "raw_score", "flags"],
+    "formats": ["<u4"] * 14 + ["<u8", "<u4", "<u4", "<f4", "<u4"],
+    "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 64, 68, 72, 76],
+    "itemsize": 80,
 })
+HIT_LOCAL = 1
 
 
 class BatchStats(C.Structure):

@@ -22,7 +22,7 @@ EXPORTS = [
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
-    "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
+    "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_format_fastapairs", "ugs_format_segout",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
@@ -62,6 +62,9 @@ def lib():
         L.ugs_batch_device_results.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
+        L.ugs_params_set_local.argtypes = [C.POINTER(Params), C.c_double, i32]
+        L.ugs_local_evalue.argtypes = [C.POINTER(Params), C.c_double, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ugs_format_blast6_local.argtypes = [C.POINTER(Params), vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_hit.argtypes = [vp, vp, i32, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_format_uc_nohit.argtypes = [u32, C.c_char_p, C.c_char_p, i32]
         L.ugs_last_error.restype = C.c_char_p
@@ -83,9 +86,14 @@ def _chk(rc):
         raise UgsError(rc, lib().ugs_last_error().decode())
 
 
-def params(is_nucleo=True, id=0.97, **kw):
+def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
+    """reference defaults of usearch_global, or - with local_evalue - of usearch_local (id=None: no -id given)"""
     p = Params()
-    lib().ugs_params_init(C.byref(p), 1 if is_nucleo else 0, float(id))
+    lib().ugs_params_init(C.byref(p), 1 if is_nucleo else 0, float(0.5 if id is None else id))
+    if local_evalue is not None:
+        rc = lib().ugs_params_set_local(C.byref(p), float(local_evalue), 0 if id is None else 1)
+        if rc != 0:
+            raise UgsError(rc, last_error())
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -138,7 +146,7 @@ class UgsDB:
         qseqs = as_u8(qseqs)
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         nq = len(qoffs) - 1
-        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) + 1
+        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) * (self.p.max_hsps if self.p.local else 1) + 1
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         nh = np.zeros(nq + 1, dtype=np.uint32)
         cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
@@ -187,7 +195,7 @@ class UgsBatch:
         """Hits of the last synced search -> (hits, nhits_per_query, run pool).  reuse=True fills result buffers owned by
         this batch (page-locked once, valid until the next fetch) instead of fresh arrays - what a streaming caller does."""
         p = self.db.p
-        cap = self.nq * max(1, p.max_accepts) * (2 if p.strand_both else 1) + 1
+        cap = self.nq * max(1, p.max_accepts) * (2 if p.strand_both else 1) * (p.max_hsps if p.local else 1) + 1
         cig_cap = self.nletters * 2 + 64 * self.nq + 1024
         if not reuse:
             hits = np.zeros(cap, dtype=HIT_DTYPE)

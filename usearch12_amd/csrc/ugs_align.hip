@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
                 ugs_hit *h = &bv.hits[(uint64_t)unit * max_acc + nacc];
                 h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = alen;
                 h->opens = opens; h->qlo = qlo; h->qhi = qhi; h->tlo = tlo; h->thi = thi; h->ql = LA; h->tl = LB;
-                h->strand = strand; h->cigar_off = coff; h->cigar_len = nr; h->cols = cols;
+                h->strand = strand; h->cigar_off = coff; h->cigar_len = nr; h->cols = cols; h->raw_score = 0.0f; h->flags = 0;
                 atomicAdd(&ctr[UGS_CTR_HITS], 1ull);
               }
             }

@@ -91,7 +91,21 @@ struct UgsBatchView {
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
        UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_N };  // T*: phase clocks (profiling)
-enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8 };
+enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32 };
+
+// usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates
+struct UgsLocalView {
+  const int8_t *sub2; const uint8_t *cls;   // x-drop score table / letter class (ugs_xdrop_tables)
+  int open2, ext2; float xdrop_g, abs_open, abs_ext, xdrop_u;
+  uint32_t seed_w;                          // seed word length (-hspw)
+  const int2 *qthr;                         // [nq] smallest ungapped / gapped score (half-units) that passes the e-value gates
+  uint32_t W;                               // LDS row width of the x-drop rows
+  uint8_t *tb; unsigned long long tb_cap;   // per wave
+  uint2 *rowinfo; uint32_t rows_cap;        // per wave
+  uint32_t *runbuf; uint32_t runbuf_cap;    // per wave: forward runs, backward runs, merged path
+  uint32_t hit_slots;                       // hit table entries per unit
+  uint32_t seed_cap;                        // seeds listed per round (>= max_qlen + 64)
+};
 
 // launch descriptors computed on the host
 struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; };
@@ -113,6 +127,10 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
 size_t ugs_compact_tmp_bytes(uint32_t nq);
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
+size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t seed_cap);
+int ugs_local_blocks_per_cu(int threads, size_t lds);
+int ugs_launch_local(const UgsDbView &db, const UgsBatchView &b, const UgsLocalView &lv, int grid, int wpb, size_t lds, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);
+void ugs_xdrop_tables(int is_nucleo, float m2, float mm2, int8_t sub2[1024], uint8_t cls[256]);   // ugs_xdrop.hip
 extern const char UGS_B62_ORDER[];          // the 23 alphabetic BLOSUM62 symbols
 extern const signed char UGS_B62[23][23];

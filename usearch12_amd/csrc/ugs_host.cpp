@@ -36,6 +36,9 @@ struct ugs_db {
   std::vector<uint32_t> step;       // host copy: step[Nu]
   uint64_t n_postings, hbm_bytes;
   uint32_t max_row, max_tlen;
+  // usearch_local
+  int8_t *d_xsub2; uint8_t *d_xcls;
+  UgsLocalView lv;
 };
 
 struct ugs_batch {
@@ -48,6 +51,11 @@ struct ugs_batch {
   uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
   ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
   uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
+  // usearch_local
+  uint32_t hit_slots;               // hit table entries per unit
+  int2 *d_qthr; uint8_t *d_ltb; uint2 *d_lrow; uint32_t *d_lruns;
+  uint64_t ltb_alloc, lrow_alloc, lruns_alloc;
+  UgsLocalView lv; int lgrid, lwpb; size_t llds;
   unsigned long long *d_cigar_used, *d_ctr;
   uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
   int rank_grid_alloc, align_waves_alloc;
@@ -86,6 +94,50 @@ extern "C" int ugs_params_init(ugs_params *p, int is_nucleo, double id)
   p->match = 1.0f; p->mismatch = -2.0f;
   p->hsp_word_len = is_nucleo ? 5 : 3;
   p->dbmask = 1;
+  p->xdrop_u = 16.0f; p->xdrop_g = 32.0f;         // o_defaults.inc:20,22
+  p->local_open = -10.0f; p->local_ext = -1.0f;   // alnparams.cpp:362-369 (the -lopen/-lext defaults count as set)
+  p->ka_dbsize = 1e9f;                            // o_defaults.inc:2
+  p->max_hsps = 8;
+  return UGS_OK;
+}
+
+// usearch_local: -evalue is required; without -id the accepter has no identity test and the ranking uses 0.5
+// (makedbsearcher.cpp:172 oget_fltd(OPT_id, 0.5))
+extern "C" int ugs_params_set_local(ugs_params *p, double evalue, int id_set)
+{
+  if (!p || !(evalue > 0.0)) { ugs_set_error("usearch_local needs -evalue > 0"); return UGS_E_ARG; }
+  p->local = 1;
+  p->evalue = (float)evalue;
+  if (!id_set) { p->id = 0.5f; p->id_accept = 0.5; p->id_set = 0; }
+  return UGS_OK;
+}
+
+// Karlin-Altschul statistics, estats.cpp:25-99.  The reference is built with -O3 -ffast-math (its Makefile:11-14)
+// and what it prints depends on that: gcc folds (x/Log2)*Log2, multiplies by 1/ln 2 instead of dividing and turns
+// NM/pow(2,bits) into exp2(-bits)*DBSize*QL (which keeps e-values below 1e-292 representable).  These are the
+// operations of the compiled code (estats.o, gcc 11.4).
+namespace {
+struct EStats {
+  double GappedLambda, UngappedLambda, LogGappedK, LogUngappedK, DBSize, MaxEvalue;
+  explicit EStats(const ugs_params &p)
+  {
+    if (p.is_nucleo) { GappedLambda = 1.280; UngappedLambda = 1.330; LogGappedK = log(0.460); LogUngappedK = log(0.621); }
+    else { GappedLambda = 0.267; UngappedLambda = 0.311; LogGappedK = log(0.0410); LogUngappedK = log(0.128); }
+    DBSize = (double)p.ka_dbsize;                 // makedbsearcher.cpp:89-95: a float
+    MaxEvalue = (double)p.evalue;
+  }
+  double min_ungapped(uint32_t QL) const { return ((log((double)QL * DBSize) + LogUngappedK) - log(MaxEvalue)) / UngappedLambda; }
+  double bits(double raw) const { return (raw * GappedLambda - LogGappedK) * 1.4426950408889634; }
+  double evalue(double raw, uint32_t QL) const { return (exp2(-bits(raw)) * DBSize) * (double)QL; }
+};
+}  // namespace
+
+extern "C" int ugs_local_evalue(const ugs_params *p, double raw_score, uint32_t ql, double *evalue, double *bits)
+{
+  if (!p) return UGS_E_ARG;
+  const EStats es(*p);
+  if (bits) *bits = es.bits(raw_score);
+  if (evalue) *evalue = es.evalue(raw_score, ql);
   return UGS_OK;
 }
 
@@ -223,7 +275,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   if (!db) return;
   (void)hipSetDevice(db->device);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
-  (void)hipFree(db->d_step); (void)hipFree(db->d_tab);
+  (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls);
   if (db->stream) (void)hipStreamDestroy(db->stream);
   delete db;
 }
@@ -263,6 +315,16 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     ugs_set_error("unsupported word_len/hsp_word_len/band (band 0 = full DP is not implemented)"); return UGS_E_ENVELOPE;
   }
   if (p->strand_both && !p->is_nucleo) { ugs_set_error("strand_both needs a nucleotide search"); return UGS_E_ARG; }
+  if (p->local) {
+    const float o2 = p->local_open * 2.0f, e2 = p->local_ext * 2.0f;
+    if (!(p->evalue > 0.0f) || !(p->ka_dbsize > 0.0f) || p->max_hsps < 1 || !(p->xdrop_u >= 0.0f) || !(p->xdrop_g >= 0.0f)) {
+      ugs_set_error("usearch_local needs evalue > 0, ka_dbsize > 0, max_hsps >= 1, xdrop_u/xdrop_g >= 0"); return UGS_E_ARG;
+    }
+    if (o2 != floorf(o2) || e2 != floorf(e2) || !(o2 < 0) || !(e2 < 0) || o2 < -2000 || e2 < -2000) {
+      ugs_set_error("local_open/local_ext must be negative multiples of 0.5"); return UGS_E_ENVELOPE;
+    }
+    if ((uint64_t)p->max_accepts * p->max_hsps > 4096) { ugs_set_error("max_accepts * max_hsps > 4096"); return UGS_E_ENVELOPE; }
+  }
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -270,7 +332,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
-  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr;
+  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr;
+  memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;
   auto fail = [&](int code) { ugs_db_destroy(db); return code; };
   if (hipStreamCreate(&db->stream) != hipSuccess) { ugs_set_error("hipStreamCreate failed"); return fail(UGS_E_HIP); }
@@ -352,6 +415,19 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
   if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
+  if (p->local) {   // x-drop tables (the ones ugs_xdrop_batch uses) and the constants of LocalAligner / XDropAlignMem
+    int8_t xsub2[1024]; uint8_t xcls[256];
+    ugs_xdrop_tables(p->is_nucleo, p->match * 2.0f, p->mismatch * 2.0f, xsub2, xcls);
+    if (hipMalloc(&db->d_xsub2, 1024) != hipSuccess || hipMalloc(&db->d_xcls, 256) != hipSuccess ||
+        hipMemcpy(db->d_xsub2, xsub2, 1024, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db->d_xcls, xcls, 256, hipMemcpyHostToDevice) != hipSuccess) { ugs_set_error("x-drop tables: HIP error"); return fail(UGS_E_HIP); }
+    UgsLocalView &lv = db->lv;
+    lv.sub2 = db->d_xsub2; lv.cls = db->d_xcls;
+    lv.open2 = (int)(p->local_open * 2.0f); lv.ext2 = (int)(p->local_ext * 2.0f);
+    lv.xdrop_g = p->xdrop_g; lv.abs_open = -p->local_open; lv.abs_ext = -p->local_ext; lv.xdrop_u = p->xdrop_u;
+    lv.seed_w = (uint32_t)p->hsp_word_len;
+    lv.W = std::min<uint32_t>(max_tlen, 4096) + 4;
+  }
   *out = db;
   return UGS_OK;
 }
@@ -392,6 +468,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
   (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots);
+  (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
@@ -410,6 +487,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   b->nstrand = db->p.strand_both ? 2 : 1;
   b->K = (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
   const uint64_t units = (uint64_t)max_queries * b->nstrand;
+  b->hit_slots = (uint32_t)db->p.max_accepts * (db->p.local ? db->p.max_hsps : 1u);
   int rc = UGS_OK;
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); ugs_batch_destroy(b); return UGS_E_HIP; } } while (0)
   BCHK(hipMalloc(&b->d_qseqs, max_letters ? max_letters : 16));
@@ -418,12 +496,13 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cand_cnt, std::max<uint64_t>(units * b->K, 1) * 4));
   BCHK(hipMalloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
   BCHK(hipMalloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
-  BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * db->p.max_accepts, 1) * sizeof(ugs_hit)));
+  BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
   b->cigar_cap = units * db->p.max_accepts * 12 + 4096;
+  if (db->p.local) BCHK(hipMalloc(&b->d_qthr, std::max<uint64_t>(max_queries, 1) * sizeof(int2)));
   BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
   BCHK(hipMalloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
   BCHK(hipMalloc(&b->d_qoff, ((uint64_t)max_queries + 1) * 4));
-  BCHK(hipMalloc(&b->d_compact, std::max<uint64_t>(units * db->p.max_accepts, 1) * sizeof(ugs_hit)));
+  BCHK(hipMalloc(&b->d_compact, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
   b->scan_tmp_bytes = ugs_compact_tmp_bytes(max_queries);
   BCHK(hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes));
   BCHK(hipMalloc(&b->d_cigar_used, 8));
@@ -432,6 +511,46 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
 #undef BCHK
   (void)rc;
   *out = b;
+  return UGS_OK;
+}
+
+// launch geometry and scratch of k_local (ugs_local.hip)
+static int plan_local(ugs_batch *b)
+{
+  ugs_db *db = b->db;
+  UgsLocalView &lv = b->lv;
+  lv = db->lv;
+  const uint32_t sideq = std::min<uint32_t>(b->max_qlen, 4096), sidet = std::min<uint32_t>(db->max_tlen, 4096);
+  lv.seed_cap = std::max<uint32_t>(1024, ((b->max_qlen + 15u) & ~15u) + 64);
+  lv.hit_slots = b->hit_slots;
+  lv.tb_cap = ((unsigned long long)(sideq + 2) * (sidet + 4) + 256 + 63) & ~63ull;
+  lv.rows_cap = sideq + 4;
+  lv.runbuf_cap = b->max_qlen + db->max_tlen + 8;
+  const size_t wave_lds = ugs_local_wave_lds(lv.W, b->max_qlen, lv.seed_cap);
+  int wpb = 4;
+  while (wpb > 1 && 2560 + wpb * wave_lds > LDS_MAX) wpb >>= 1;
+  if (2560 + wpb * wave_lds > LDS_MAX) { ugs_set_error("usearch_local LDS footprint %zu exceeds 160 KiB (sequences too long)", 2560 + wave_lds); return UGS_E_ENVELOPE; }
+  const size_t lds = 2560 + wpb * wave_lds;
+  int per_cu = std::max(1, std::min(ugs_local_blocks_per_cu(64 * wpb, lds), 8));
+  const uint64_t units = (uint64_t)b->nq * b->nstrand;
+  uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu * wpb));
+  const uint64_t tb_budget = 24ull << 30;                       // HBM the traceback scratch may take
+  waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, tb_budget / lv.tb_cap));
+  b->lgrid = (int)((waves + wpb - 1) / wpb); b->lwpb = wpb; b->llds = lds;
+  const uint64_t nw = (uint64_t)b->lgrid * wpb;
+  if (!b->d_ltb || nw * lv.tb_cap > b->ltb_alloc) {
+    if (b->d_ltb) HIPCHK(hipFree(b->d_ltb));
+    HIPCHK(hipMalloc(&b->d_ltb, nw * lv.tb_cap)); b->ltb_alloc = nw * lv.tb_cap;
+  }
+  if (!b->d_lrow || nw * lv.rows_cap > b->lrow_alloc) {
+    if (b->d_lrow) HIPCHK(hipFree(b->d_lrow));
+    HIPCHK(hipMalloc(&b->d_lrow, nw * lv.rows_cap * sizeof(uint2))); b->lrow_alloc = nw * lv.rows_cap;
+  }
+  if (!b->d_lruns || nw * 3 * lv.runbuf_cap > b->lruns_alloc) {
+    if (b->d_lruns) HIPCHK(hipFree(b->d_lruns));
+    HIPCHK(hipMalloc(&b->d_lruns, nw * 3 * lv.runbuf_cap * 4)); b->lruns_alloc = nw * 3 * lv.runbuf_cap;
+  }
+  lv.tb = b->d_ltb; lv.rowinfo = b->d_lrow; lv.runbuf = b->d_lruns; lv.qthr = b->d_qthr;
   return UGS_OK;
 }
 
@@ -481,6 +600,16 @@ static int plan_launch(ugs_batch *b)
     b->emit_cap_alloc = ecap * (uint64_t)b->rl.grid;
   }
   b->v.emit_cap = ecap;
+  {   // sampled rows per unit (k_rank_setup -> k_rank)
+    const uint64_t need = (uint64_t)units * b->rl.ns_max;
+    if (!b->d_unit_ns) HIPCHK(hipMalloc(&b->d_unit_ns, (size_t)b->max_queries * 2 * 4));
+    if (!b->d_unit_slots || need > b->unit_slots_alloc) {
+      if (b->d_unit_slots) HIPCHK(hipFree(b->d_unit_slots));
+      HIPCHK(hipMalloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
+      b->unit_slots_alloc = need;
+    }
+  }
+  if (p.local) return plan_local(b);
   // ---- alignment geometry
   const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
@@ -515,15 +644,6 @@ static int plan_launch(ugs_batch *b)
     b->runs_alloc = (uint64_t)runs_stride * waves;
   }
   b->v.tb_stride = tb_stride; b->v.runs_stride = runs_stride;
-  {   // sampled rows per unit (k_rank_setup -> k_rank)
-    const uint64_t need = (uint64_t)units * b->rl.ns_max;
-    if (!b->d_unit_ns) HIPCHK(hipMalloc(&b->d_unit_ns, (size_t)b->max_queries * 2 * 4));
-    if (!b->d_unit_slots || need > b->unit_slots_alloc) {
-      if (b->d_unit_slots) HIPCHK(hipFree(b->d_unit_slots));
-      HIPCHK(hipMalloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
-      b->unit_slots_alloc = need;
-    }
-  }
   return UGS_OK;
 }
 
@@ -544,6 +664,28 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   for (uint32_t i = 0; i <= nq; ++i) rel[i] = qoffs[i] - qoffs[0];
   if (b->q_letters) HIPCHK(hipMemcpyAsync(b->d_qseqs, qseqs + qoffs[0], b->q_letters, hipMemcpyHostToDevice, db->stream));
   HIPCHK(hipMemcpyAsync(b->d_qoffs, rel.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, db->stream));
+  if (db->p.local && nq) {
+    // the two e-value gates of LocalAligner::AlignPos as integer score thresholds (half-units), per query length:
+    //   ungapped: Score < (float)GetMinUngappedRawScore(QL) rejects            (localmulti.cpp:15, localaligner.cpp:163-168)
+    //   gapped:   RawScoreToEvalue(score, QL, true) > -evalue rejects; E is monotone in the score (localaligner.cpp:199-205)
+    const EStats es(db->p);
+    std::vector<int2> thr(nq);
+    std::vector<int2> memo(maxl + 1, make_int2(0, -1));
+    for (uint32_t i = 0; i < nq; ++i) {
+      const uint32_t QL = (uint32_t)(qoffs[i + 1] - qoffs[i]);
+      int2 &m = memo[QL];
+      if (m.y < 0) {
+        const double mu = 2.0 * (double)(float)es.min_ungapped(QL ? QL : 1);
+        m.x = mu > 2e9 ? 2000000000 : (mu < -2e9 ? -2000000000 : (int)ceil(mu));
+        int lo = 1, hi = 1 << 24;
+        if (!(es.evalue(hi * 0.5, QL) <= (double)db->p.evalue)) lo = hi = 0x7fffffff;   // nothing passes
+        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (es.evalue(mid * 0.5, QL) <= (double)db->p.evalue) hi = mid; else lo = mid + 1; }
+        m.y = lo;
+      }
+      thr[i] = m;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_qthr, thr.data(), (size_t)nq * sizeof(int2), hipMemcpyHostToDevice, db->stream));
+  }
   HIPCHK(hipStreamSynchronize(db->stream));
   RCCHK(plan_launch(b));
   UgsBatchView &v = b->v;
@@ -560,6 +702,7 @@ static int enqueue_align(ugs_batch *b)
 {
   ugs_db *db = b->db;
   HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
+  if (db->p.local) return ugs_launch_local(db->v, b->v, b->lv, b->lgrid, b->lwpb, b->llds, db->stream);
   return ugs_launch_align(db->v, b->v, b->al, db->stream);
 }
 
@@ -591,7 +734,11 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
     if (b->ctr[UGS_CTR_ERR]) {
-      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer)", b->ctr[UGS_CTR_ERR]);
+      if (b->ctr[UGS_CTR_ERR] == UGS_ERR_LOCAL_HITS) {
+        ugs_set_error("more than max_hsps = %u HSPs on one accepted target; raise ugs_params.max_hsps", db->p.max_hsps);
+        return UGS_E_CAPACITY;
+      }
+      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots)", b->ctr[UGS_CTR_ERR]);
       return UGS_E_ENVELOPE;
     }
     if (b->cigar_used_host <= b->cigar_cap) { b->synced = true; return UGS_OK; }
@@ -630,7 +777,7 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   if (!b || !b->synced || !nhits_per_query) return UGS_E_ARG;
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
-  const uint32_t nq = b->nq, ns = b->nstrand, ma = (uint32_t)db->p.max_accepts;
+  const uint32_t nq = b->nq, ns = b->nstrand, ma = b->hit_slots;
   if (cigar_used) *cigar_used = 0;
   if (nq == 0) return UGS_OK;
   // group by query on the device (count, exclusive scan, gather), then three plain D2H copies
@@ -659,7 +806,8 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
       const uint32_t n = nhits_per_query[q];
       if (n > 1) {
         tmp.assign(hits + k, hits + k + n); sc.resize(n); ord.resize(n);
-        for (uint32_t i = 0; i < n; ++i) { sc[i] = (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
+        // AlignResult::GetScore arscorer.cpp:818-824: fractional identity, local: raw score
+        for (uint32_t i = 0; i < n; ++i) { sc[i] = db->p.local ? tmp[i].raw_score : (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
         qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
         for (uint32_t i = 0; i < n; ++i) hits[k + i] = tmp[ord[i]];
       }
@@ -754,6 +902,21 @@ extern "C" int ugs_format_blast6(const ugs_hit *h, const char *qlabel, const cha
                   h->aln_len, h->mism, h->opens, 1u, h->ql, TLo, THi);
 }
 
+// blast6out.cpp:27-80 for a usearch_local hit: 1-based HSP coordinates (query coordinates on the plus strand, target
+// pair swapped for a reverse-complemented query: arscorer.cpp:688-806), e-value %.2g, bit score %.1f
+extern "C" int ugs_format_blast6_local(const ugs_params *p, const ugs_hit *h, const char *qlabel, const char *tlabel, char *buf, int cap)
+{
+  if (!p || !h) return UGS_E_ARG;
+  const double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
+  const double PctId = 100.0 * FractId;
+  unsigned QLo = h->qlo + 1, QHi = h->qhi + 1, TLo = h->tlo + 1, THi = h->thi + 1;
+  if (h->strand) { QLo = h->ql - h->qhi; QHi = h->ql - h->qlo; std::swap(TLo, THi); }
+  double E = 0, Bits = 0;
+  ugs_local_evalue(p, (double)h->raw_score, h->ql, &E, &Bits);
+  return snprintf(buf, (size_t)cap, "%s\t%s\t%.1f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%.2g\t%.1f\n", qlabel, tlabel, PctId,
+                  h->aln_len, h->mism, h->opens, QLo, QHi, TLo, THi, E, Bits);
+}
+
 // outputuc.cpp:45-93 with CompressPath (comppath.cpp:7-48): run of n>1 prints "nC", n==1 prints "C"
 extern "C" int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo,
                                  const char *qlabel, const char *tlabel, char *buf, int cap)
@@ -791,7 +954,7 @@ extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void 
   if (!b || !b->synced) return UGS_E_ARG;
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
-  const uint32_t nq = b->nq, ns = b->nstrand, ma = (uint32_t)db->p.max_accepts;
+  const uint32_t nq = b->nq, ns = b->nstrand, ma = b->hit_slots;
   uint64_t total = 0;
   if (nq) {
     RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,

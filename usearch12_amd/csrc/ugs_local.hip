@@ -1,0 +1,365 @@
+// ugs_local.hip - usearch_local on gfx950: the candidate walk of one query strand per wavefront, every candidate
+// through LocalAligner2::AlignMulti.  The only caller of the gapped x-drop kernels in the reference (SURVEY.md 8a
+// X1-X3, 8f-4).
+//
+// What it replaces (reference):
+//   Searcher::Align, non-global branch     searcher.cpp:28-50   (IsAccept per AR, one accept/reject per TARGET)
+//   LocalAligner2::SetQueryImpl/AlignMulti localaligner2.cpp:62-145, localmulti.cpp:9-118
+//   LocalAligner::AlignPos + GetAnchor     localaligner.cpp:11-58,101-222
+//   LocalAligner2::KeepAR / OverlapFract   localaligner2.cpp:228-246, hsp.h:74-89
+//   XDropAlignMem                          xdropalignmem.cpp:26-244 (device code shared with k_xdrop: ugs_xdrop_dev.h)
+//   Accepter::IsAcceptLo (local branches)  accepter.cpp:24-91, arscorer.cpp:122-154
+//
+// Mapping.  The reference walks the target word by word; every query position holding the same word is a seed that
+// is extended without gaps (x-drop 16), gated by a minimum raw score, anchored, extended with gaps (x-drop 32) and
+// gated by an e-value; an accepted HSP moves the walk past its end.  The ungapped extension and the anchor of a seed
+// depend on nothing but the seed, so they are computed speculatively, one seed per lane, 64 seeds at a time in walk
+// order; only the few seeds that survive go through the sequential part (gapped extension by the whole wave, overlap
+// test against the HSPs kept so far, walk pointer).  The two Karlin-Altschul gates are monotone in the score, so the
+// host turns them into per-query integer thresholds (half-units) with the reference's own arithmetic; the device
+// never evaluates a logarithm.  Scores are exact half-unit integers as in k_xdrop.
+#include "ugs_dev.h"
+#include "ugs_xdrop_dev.h"
+#include <algorithm>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+
+namespace {
+
+constexpr uint32_t LOC_MAXARS = 32;      // HSPs kept per (query strand, target) for the overlap test
+constexpr uint32_t LOC_BT = 256;         // target positions listed per round
+
+struct LocWave {
+  uint8_t *Aq;          // query strand, raw letters (what the x-drop code reads)
+  uint8_t *Ax;          // x-drop score class of each query letter
+  uint16_t *qw;         // seed word at each query position
+  uint32_t *seeds;      // (target pos << 16) | query pos, walk order
+  uint32_t *ars;        // kept HSPs: Loi, Loj, Leni, Lenj
+};
+
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int lane)
+{
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, UgsLocalView lv, uint32_t wave_lds)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  int8_t *s_sub2 = (int8_t *)smem;                     // 1024: x-drop score table
+  uint8_t *s_xcls = smem + 1024;                       // 256 : x-drop letter class
+  uint8_t *s_cls = smem + 1280;                        // 256 : identity class (letter | 32 lower-case, 31 non-alpha)
+  uint8_t *s_comp = smem + 1536;                       // 256
+  uint8_t *s_hl = smem + 1792;                         // 256 : seed letter, wildcards -> 0 (localaligner2.cpp:96-98)
+  uint64_t *s_match = (uint64_t *)(smem + 2048);       // 512
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = blockDim.x >> 6;
+  const UgsTables *tab = db.tab;
+  for (int k = tid; k < 1024; k += blockDim.x) s_sub2[k] = lv.sub2[k];
+  for (int k = tid; k < 256; k += blockDim.x) { s_xcls[k] = lv.cls[k]; s_cls[k] = tab->cls[k]; s_comp[k] = tab->comp[k]; s_hl[k] = tab->hsp_letter[k]; }
+  for (int k = tid; k < 64; k += blockDim.x) s_match[k] = tab->match[k];
+  __syncthreads();
+
+  const uint32_t maxq = (bv.max_qlen + 15u) & ~15u;
+  unsigned char *wb = smem + 2560 + (size_t)wave * wave_lds;
+  XdWave w;
+  w.lane = lane;
+  w.M0 = (int *)wb; w.M1 = w.M0 + lv.W; w.D = w.M1 + lv.W; w.Bc = (uint8_t *)(w.D + lv.W);
+  w.sub2 = s_sub2; w.cls = s_xcls;
+  size_t off = ((size_t)lv.W * 13 + 15) & ~(size_t)15;
+  LocWave L;
+  L.Aq = wb + off; off += maxq;
+  L.Ax = wb + off; off += maxq;
+  L.qw = (uint16_t *)(wb + off); off += (size_t)maxq * 2;
+  L.seeds = (uint32_t *)(wb + off); off += (size_t)lv.seed_cap * 4;
+  L.ars = (uint32_t *)(wb + off);
+  const uint32_t gw = blockIdx.x * wpb + (uint32_t)wave;
+  w.tb = lv.tb + (size_t)gw * lv.tb_cap;
+  w.rowinfo = lv.rowinfo + (size_t)gw * lv.rows_cap;
+  uint32_t *runsF = lv.runbuf + (size_t)gw * 3 * lv.runbuf_cap, *runsB = runsF + lv.runbuf_cap, *mruns = runsB + lv.runbuf_cap;
+  XdView xv;                                           // the fields xd_extend reads
+  xv.tb_cap = lv.tb_cap; xv.runbuf_cap = lv.runbuf_cap; xv.open2 = lv.open2; xv.ext2 = lv.ext2;
+  xv.X = lv.xdrop_g; xv.abs_open = lv.abs_open; xv.abs_ext = lv.abs_ext;
+
+  const uint32_t units = bv.nq * bv.nstrand, K = bv.K;
+  const uint32_t max_acc = (uint32_t)db.max_accepts, max_rej = (uint32_t)db.max_rejects;
+  const uint32_t SW = lv.seed_w, alpha = (uint32_t)db.alpha;
+  unsigned long long *ctr = bv.counters;
+  unsigned long long cells = 0, w_tletters = 0, w_pairs = 0, w_hits = 0;
+
+  for (;;) {
+    uint32_t unit = 0;
+    if (lane == 0) unit = (uint32_t)atomicAdd(&ctr[UGS_CTR_NEXT_UNIT], 1ull);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    if (unit >= units) break;
+    const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
+    const uint64_t qo = bv.qoffs[qi];
+    const uint32_t QL = (uint32_t)(bv.qoffs[qi + 1] - qo);
+    const uint32_t ncand = bv.cand_n[unit];
+    const int2 thr = lv.qthr[qi];                      // (ungapped, gapped) minimum scores in half-units
+    uint32_t nhit = 0, nacc = 0, nrej = 0;
+    const uint32_t nqw = QL > SW ? QL - SW + 1 : 0;    // localaligner2.cpp:72-73: QL <= W leaves the query without words
+    if (ncand) {
+      for (uint32_t p = lane; p < QL; p += 64) {
+        const uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (QL - 1 - p)]];
+        L.Aq[p] = ch; L.Ax[p] = s_xcls[ch];
+      }
+      wave_sync();
+      for (uint32_t p = lane; p < nqw; p += 64) {
+        uint32_t wd = 0;
+        for (uint32_t i = 0; i < SW; ++i) wd = wd * alpha + s_hl[L.Aq[p + i]];
+        L.qw[p] = (uint16_t)wd;
+      }
+      wave_sync();
+    }
+    uint32_t ct = 0, clen = 0; uint64_t cto = 0;
+    if ((uint32_t)lane < ncand) {
+      ct = bv.cand[(uint64_t)unit * K + lane];
+      cto = db.offs[ct];
+      clen = (uint32_t)(db.offs[ct + 1] - cto);
+    }
+    for (uint32_t k = 0; k < ncand; ++k) {
+      const uint32_t t = (uint32_t)rl((int)ct, (int)k);
+      const uint64_t to = rl64(cto, (int)k);
+      const uint32_t TL = (uint32_t)rl((int)clen, (int)k);
+      const uint8_t *B = db.seqs + to;
+      w_tletters += TL; ++w_pairs;
+      bool any_accept = false;
+      uint32_t nars = 0;
+      if (TL >= 2 * SW && nqw) {                       // localmulti.cpp:17-20
+        const uint32_t TWC = TL - SW + 1;
+        uint32_t curT = 0;                             // the reference's TargetPos
+        uint32_t fLoi = 0xffffffffu, fLoj = 0, fLen = 0;   // last anchor whose gapped extension was not kept
+        while (curT < TWC) {
+          // ---- list the seeds of target positions [curT, tend) in walk order: position ascending, then query position
+          uint32_t tend = min(curT + LOC_BT, TWC), nseeds = 0;
+          for (uint32_t t0 = curT; t0 < tend; t0 += 64) {
+            uint32_t twv = 0;
+            if (t0 + lane < tend) for (uint32_t i = 0; i < SW; ++i) twv = twv * alpha + s_hl[B[t0 + lane + i]];
+            const uint32_t nt = min(64u, tend - t0);
+            for (uint32_t x = 0; x < nt; ++x) {
+              const uint32_t tw = (uint32_t)rl((int)twv, (int)x);
+              const uint32_t n_at_pos = nseeds;
+              for (uint32_t q0 = 0; q0 < nqw; q0 += 64) {
+                const uint32_t q = q0 + lane;
+                const uint64_t m = __ballot(q < nqw && L.qw[q] == tw);
+                if (m) {
+                  if (nseeds + 64 > lv.seed_cap) { tend = t0 + x; nseeds = n_at_pos; goto listed; }    // the round ends before this position
+                  if ((m >> lane) & 1) L.seeds[nseeds + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = ((t0 + x) << 16) | q;
+                  nseeds += (uint32_t)__popcll(m);
+                }
+              }
+            }
+          }
+        listed:
+          if (tend == curT) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); break; }   // one position overflowed the list
+          wave_sync();
+          uint32_t cur = curT;
+          for (uint32_t g0 = 0; g0 < nseeds && cur < tend; g0 += 64) {
+            // ---- one seed per lane: ungapped x-drop both ways (localaligner.cpp:107-160) and the anchor (:11-58)
+            const uint32_t s = g0 + lane;
+            const uint32_t sd = s < nseeds ? L.seeds[s] : 0;
+            const uint32_t st = sd >> 16, sq = sd & 0xffffu;
+            bool pass = false;
+            uint32_t aLoi = 0, aLoj = 0, aLen = 0;
+            if (s < nseeds && st >= cur) {
+              int tot = 0, best = 0; uint32_t len = 0, kk = 0;
+              int i = (int)sq, j = (int)st;
+              while (i >= 0 && j >= 0) {
+                ++kk;
+                tot += s_sub2[((int)L.Ax[i] << 5) | s_xcls[B[j]]];
+                if (tot > best) { best = tot; len = kk; }
+                else if ((float)(best - tot) * 0.5f > lv.xdrop_u) break;
+                --i; --j;
+              }
+              const int left = best; const uint32_t leftlen = len;
+              tot = 0; best = 0; len = 0; kk = 0;
+              i = (int)sq + 1; j = (int)st + 1;
+              while (i < (int)QL && j < (int)TL) {
+                ++kk;
+                tot += s_sub2[((int)L.Ax[i] << 5) | s_xcls[B[j]]];
+                if (tot > best) { best = tot; len = kk; }
+                else if ((float)(best - tot) * 0.5f > lv.xdrop_u) break;
+                ++i; ++j;
+              }
+              if (left + best >= thr.x) {
+                const uint32_t Loi = sq + 1 - leftlen, Loj = st + 1 - leftlen, SegLen = leftlen + len;
+                uint32_t startk = 0xffffffffu, beststart = 0xffffffffu, blen = 0;
+                int asc = 0, bsc = 0;
+                for (uint32_t x = 0; x < SegLen; ++x) {
+                  const int sc = s_sub2[((int)L.Ax[Loi + x] << 5) | s_xcls[B[Loj + x]]];
+                  if (sc > 0) {
+                    if (startk == 0xffffffffu) { startk = x; asc = sc; } else asc += sc;
+                  } else {
+                    if (asc > bsc) { bsc = asc; beststart = startk; blen = x - startk; }
+                    startk = 0xffffffffu;
+                  }
+                }
+                if (asc > bsc) { bsc = asc; beststart = startk; blen = SegLen - startk; }
+                if (bsc > 0) { pass = true; aLoi = Loi + beststart; aLoj = Loj + beststart; aLen = blen; }
+              }
+            }
+            // ---- the survivors, in walk order
+            uint64_t pm = __ballot(pass);
+            while (pm) {
+              const int l = __ffsll((long long)pm) - 1;
+              pm &= pm - 1;
+              const uint32_t tt = (uint32_t)rl((int)st, l);
+              if (tt < cur) continue;
+              const uint32_t AncLoi = (uint32_t)rl((int)aLoi, l), AncLoj = (uint32_t)rl((int)aLoj, l), AncLen = (uint32_t)rl((int)aLen, l);
+              if (AncLen <= 1) continue;               // xdropalignmem.cpp:44-49: score 0
+              if (AncLoi == fLoi && AncLoj == fLoj && AncLen == fLen) continue;   // same extension, same verdict
+              // XDropAlignMem xdropalignmem.cpp:26-214
+              const uint32_t AncHii = AncLoi + AncLen - 1, AncHij = AncLoj + AncLen - 1;
+              uint32_t bi = 0, bj = 0, fi = 0, fj = 0, nb = 0, nf = 0;
+              bool ovf = false;
+              const int bwd = xd_side(xv, w, L.Aq + AncLoi, -1, AncLoi + 1, B + AncLoj, -1, AncLoj + 1,
+                                      AncLoi > XD_MAXL || AncLoj > XD_MAXL, bi, bj, runsB, nb, ovf, cells);
+              int fwd = 0;
+              if (!ovf) fwd = xd_side(xv, w, L.Aq + AncHii, 1, QL - AncHii, B + AncHij, 1, TL - AncHij,
+                                      (QL - AncHii) > XD_MAXL || (TL - AncHij) > XD_MAXL, fi, fj, runsF, nf, ovf, cells);
+              if (ovf || nb > lv.runbuf_cap || nf > lv.runbuf_cap) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); continue; }
+              int anc = 0;
+              for (uint32_t x = lane; x < AncLen; x += 64) anc += s_sub2[((int)L.Ax[AncLoi + x] << 5) | s_xcls[B[AncLoj + x]]];
+              for (int o = 32; o; o >>= 1) anc += __shfl_xor(anc, o);
+              const int dupe = s_sub2[((int)L.Ax[AncLoi] << 5) | s_xcls[B[AncLoj]]] + s_sub2[((int)L.Ax[AncHii] << 5) | s_xcls[B[AncHij]]];
+              const int score2 = bwd + fwd + anc - dupe;                                   // :176
+              const uint32_t Loi = AncLoi + 1 - bi, Loj = AncLoj + 1 - bj;
+              const uint32_t Leni = bi + fi + AncLen - 2, Lenj = bj + fj + AncLen - 2;
+              bool keep = score2 > 0 && score2 >= thr.y;                                  // localaligner.cpp:193-205
+              if (keep) {                                                                 // KeepAR
+                bool ov = false;
+                if ((uint32_t)lane < nars) {
+                  const uint32_t oLoi = L.ars[lane * 4], oLoj = L.ars[lane * 4 + 1], oLeni = L.ars[lane * 4 + 2], oLenj = L.ars[lane * 4 + 3];
+                  const uint32_t MaxLoi = max(Loi, oLoi), MaxLoj = max(Loj, oLoj);
+                  const uint32_t MinHii = min(Loi + Leni - 1, oLoi + oLeni - 1), MinHij = min(Loj + Lenj - 1, oLoj + oLenj - 1);
+                  const uint32_t Ovi = MinHii < MaxLoi ? 0 : MinHii - MaxLoi, Ovj = MinHij < MaxLoj ? 0 : MinHij - MaxLoj;
+                  ov = 2ull * (uint64_t)(Ovi * Ovj) > (uint64_t)(Leni * Lenj) && Leni && Lenj;   // OverlapFract > 0.5
+                }
+                if (__ballot(ov)) keep = false;
+              }
+              if (!keep) { fLoi = AncLoi; fLoj = AncLoj; fLen = AncLen; continue; }
+              if (nars >= LOC_MAXARS) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); break; }
+              if (lane == 0) { L.ars[nars * 4] = Loi; L.ars[nars * 4 + 1] = Loj; L.ars[nars * 4 + 2] = Leni; L.ars[nars * 4 + 3] = Lenj; }
+              ++nars;
+              // ---- path = reverse(backward side) + M x (AncLen-2) + forward side, adjacent equal ops merged
+              uint32_t nm = 0;
+              if (lane == 0) {
+                uint32_t cop = 0, clen2 = 0;
+                auto put = [&](uint32_t r) {
+                  if (clen2 && (r & 3u) == cop) clen2 += r >> 2;
+                  else { if (clen2) mruns[nm++] = (clen2 << 2) | cop; cop = r & 3u; clen2 = r >> 2; }
+                };
+                for (uint32_t x = 0; x < nb; ++x) put(runsB[nb - 1 - x]);
+                if (AncLen > 2) put((AncLen - 2) << 2);
+                for (uint32_t x = 0; x < nf; ++x) put(runsF[x]);
+                if (clen2) mruns[nm++] = (clen2 << 2) | cop;
+              }
+              nm = (uint32_t)__builtin_amdgcn_readfirstlane((int)nm);
+              wave_sync();
+              // ---- AlignResult::FillLo on the run list (arscorer.cpp:201-296)
+              uint32_t qpos = Loi, tpos = Loj, ids = 0, mcols = 0, gaps = 0, opens = 0, cols = 0, lastop = 0;
+              for (uint32_t r = 0; r < nm; ++r) {
+                const uint32_t run = mruns[r], op = run & 3u, len = run >> 2;
+                if (op == 0) {
+                  for (uint32_t x0 = 0; x0 < len; x0 += 64) {
+                    const uint32_t x = x0 + lane;
+                    const bool idn = x < len && ((s_match[s_cls[L.Aq[qpos + x]]] >> s_cls[B[tpos + x]]) & 1ull);
+                    ids += (uint32_t)__popcll(__ballot(idn));
+                  }
+                  mcols += len; qpos += len; tpos += len;
+                } else {
+                  gaps += len;
+                  if (lastop == 0) ++opens;
+                  if (op == 1) qpos += len; else tpos += len;
+                }
+                cols += len; lastop = op;
+              }
+              // ---- Accepter::IsAcceptLo, local branches (the e-value was tested above with the same score)
+              bool accept = true;
+              if (db.id_set) {
+                const double FractId = cols == 0 ? 0.0 : (double)ids / (double)cols;
+                if (FractId < db.id_accept) accept = false;
+                if ((db.filter_mask & UGS_F_MAXID) && FractId > (double)db.maxid) accept = false;
+              }
+              if (db.filter_mask) {
+                const uint32_t fm = db.filter_mask, diffs = (mcols - ids) + gaps;
+                if ((fm & UGS_F_MINCOLS) && cols < db.mincols) accept = false;
+                if ((fm & UGS_F_MAXGAPS) && gaps > db.maxgaps) accept = false;
+                if (fm & (UGS_F_QUERY_COV | UGS_F_MAX_QUERY_COV)) {
+                  const double Cov = (double)Leni / (double)QL;                           // arscorer.cpp:126-130
+                  if ((fm & UGS_F_QUERY_COV) && Cov < (double)db.query_cov) accept = false;
+                  if ((fm & UGS_F_MAX_QUERY_COV) && Cov > (double)db.max_query_cov) accept = false;
+                }
+                if (fm & (UGS_F_TARGET_COV | UGS_F_MAX_TARGET_COV)) {
+                  const double Cov = (double)Lenj / (double)TL;                           // arscorer.cpp:143-147
+                  if ((fm & UGS_F_TARGET_COV) && Cov < (double)db.target_cov) accept = false;
+                  if ((fm & UGS_F_MAX_TARGET_COV) && Cov > (double)db.max_target_cov) accept = false;
+                }
+                if ((fm & UGS_F_MAXDIFFS) && diffs > db.maxdiffs) accept = false;
+                if ((fm & UGS_F_MINDIFFS) && diffs < db.mindiffs) accept = false;
+              }
+              if (accept) {
+                any_accept = true;
+                if (nhit >= lv.hit_slots) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL_HITS);
+                else {
+                  unsigned long long coff = 0;
+                  if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nm);
+                  coff = rl64(coff, 0);
+                  if (coff + nm <= bv.cigar_cap)
+                    for (uint32_t r = lane; r < nm; r += 64) bv.cigar_pool[coff + r] = mruns[r];
+                  if (lane == 0) {
+                    ugs_hit *h = &bv.hits[(uint64_t)unit * lv.hit_slots + nhit];
+                    h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = cols;
+                    h->opens = opens; h->qlo = Loi; h->qhi = Loi + Leni - 1; h->tlo = Loj; h->thi = Loj + Lenj - 1; h->ql = QL; h->tl = TL;
+                    h->strand = strand; h->cigar_off = coff; h->cigar_len = nm; h->cols = cols;
+                    h->raw_score = (float)score2 * 0.5f; h->flags = UGS_HIT_LOCAL;
+                  }
+                  ++nhit; ++w_hits;
+                }
+              }
+              wave_sync();
+              // localmulti.cpp:104-110: the walk resumes behind the HSP
+              const uint32_t NewT = Loj + Lenj;                                           // GetHij() + 1
+              cur = NewT > tt ? NewT : tt + 1;
+            }
+          }
+          curT = max(cur, tend);
+        }
+      }
+      // Terminator::Terminate (terminator.cpp:64-100): one accept or reject per target
+      if (any_accept) ++nacc; else ++nrej;
+      if (nacc == max_acc || nrej == max_rej) break;
+      wave_sync();
+    }
+    if (lane == 0) bv.hit_n[unit] = nhit;
+    wave_sync();
+  }
+  if (lane == 0) {
+    atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs);
+    atomicAdd(&ctr[UGS_CTR_CELLS], cells); atomicAdd(&ctr[UGS_CTR_HITS], w_hits);
+  }
+}
+
+size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t seed_cap)
+{
+  const size_t maxq = (max_qlen + 15u) & ~15u;
+  return ((((size_t)W * 13 + 15) & ~(size_t)15) + maxq * 4 + (size_t)seed_cap * 4 + LOC_MAXARS * 16 + 15) & ~(size_t)15;
+}
+
+int ugs_local_blocks_per_cu(int threads, size_t lds)
+{
+  int n = 0;
+  if (hipFuncSetAttribute((const void *)k_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_local, threads, lds) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
+int ugs_launch_local(const UgsDbView &db, const UgsBatchView &b, const UgsLocalView &lv, int grid, int wpb, size_t lds, hipStream_t st)
+{
+  const uint32_t wave_lds = (uint32_t)((lds - 2560) / wpb);
+  HIPCHK(hipFuncSetAttribute((const void *)k_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_local, dim3(grid), dim3(64 * wpb), lds, st, db, b, lv, wave_lds);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}

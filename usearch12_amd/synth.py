@@ -237,3 +237,80 @@ def make_hard(seed, n_fam, fam_size, n_queries, lmin=150, lmax=400, aa=False):
     srcl = list(src)
     qset = SeqSet(np.concatenate(qs), qoffs, lambda i: "q%d;src=%s" % (i, "rand" if srcl[i] < 0 else "t%d" % srcl[i]))
     return db, qset
+
+
+def make_local_queries(seed, db, n_queries, aa=False):
+    """usearch_local parity workload on top of an existing DB (normally make_hard's families): fragments of a
+    target between unrelated flanks, two fragments of one target split by junk (several HSPs on one target),
+    chimeras of two targets, repeats of one fragment, distant homologs near the e-value gate, unrelated
+    sequences and very short queries; some lower-case stretches and ambiguity codes."""
+    rng = np.random.default_rng([seed, 0x10CA])
+    alphabet, freq = (AA, RR_FREQ) if aa else (NT, None)
+    k = len(alphabet)
+    wild = np.frombuffer(b"XBZ" if aa else b"NRYKMSWN", dtype=np.uint8)
+
+    def rnd(n):
+        return _random_letters(rng, int(n), alphabet, freq)
+
+    def mutate(s, p_sub, p_indel):
+        s = s.copy()
+        u = rng.random(len(s))
+        sub = u < p_sub
+        if sub.any():
+            s[sub] = alphabet[rng.integers(0, k, size=int(sub.sum()))]
+        s = s[~((u >= p_sub) & (u < p_sub + p_indel))]
+        insp = np.flatnonzero(rng.random(len(s)) < p_indel)
+        if len(insp):
+            s = np.insert(s, insp, alphabet[rng.integers(0, k, size=len(insp))])
+        return s
+
+    def target(t):
+        return db.seqs[int(db.offs[t]):int(db.offs[t + 1])]
+
+    def frag(t, fmin=0.3, fmax=1.0):
+        s = target(t)
+        n = max(12, int(len(s) * rng.uniform(fmin, fmax)))
+        a = int(rng.integers(0, max(1, len(s) - n + 1)))
+        return s[a:a + n]
+
+    qs, src = [], []
+    for q in range(n_queries):
+        r = rng.random()
+        t = int(rng.integers(0, db.n))
+        div = (rng.uniform(0.0, 0.12), rng.uniform(0.0, 0.01))
+        if r < 0.08:
+            s = rnd(rng.integers(40, 400)); t = -1
+        elif r < 0.30:
+            s = np.concatenate([rnd(rng.integers(0, 80)), mutate(frag(t), *div), rnd(rng.integers(0, 80))])
+        elif r < 0.50:      # two pieces of the same target, junk between them
+            base = target(t)
+            cut = int(len(base) * rng.uniform(0.3, 0.7))
+            s = np.concatenate([mutate(base[:cut], *div), rnd(rng.integers(40, 160)), mutate(base[cut:], *div)])
+        elif r < 0.62:      # chimera
+            t2 = int(rng.integers(0, db.n))
+            s = np.concatenate([mutate(frag(t, 0.3, 0.6), *div), mutate(frag(t2, 0.3, 0.6), *div)])
+        elif r < 0.70:      # the same fragment twice
+            f = mutate(frag(t, 0.2, 0.5), *div)
+            s = np.concatenate([f, rnd(rng.integers(5, 40)), mutate(f, 0.02, 0.002)])
+        elif r < 0.85:      # distant
+            s = mutate(target(t), rng.uniform(0.15, 0.45 if aa else 0.30), rng.uniform(0.0, 0.03))
+        elif r < 0.90:      # very short
+            s = mutate(frag(t, 0.02, 0.12), 0.02, 0.0)[: int(rng.integers(1, 30))]
+        else:
+            s = mutate(target(t), *div)
+        if len(s) == 0:
+            s = rnd(1)
+        s = s.copy()
+        if rng.random() < 0.2 and len(s) > 10:
+            pos = rng.integers(0, len(s), size=int(rng.integers(1, 4)))
+            s[pos] = wild[rng.integers(0, len(wild), size=len(pos))]
+        if rng.random() < 0.15 and len(s) > 30:
+            a = int(rng.integers(0, len(s) - 20)); b = a + int(rng.integers(5, 20))
+            s[a:b] = np.char.lower(s[a:b].view("S1")).view(np.uint8)
+        qs.append(s); src.append(t)
+    qoffs = np.zeros(len(qs) + 1, dtype=np.uint64)
+    qoffs[1:] = np.cumsum([len(s) for s in qs])
+    srcl = list(src)
+    out = SeqSet(np.concatenate(qs), qoffs, lambda i: "q%d;src=%s" % (i, "rand" if srcl[i] < 0 else "t%d" % srcl[i]))
+    out.src = np.array(src)
+    return out
