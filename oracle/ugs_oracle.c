@@ -375,6 +375,7 @@ int orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, u
   for (uint32_t t = 0; t < nseq; ++t) {
     uint32_t L = (uint32_t)(offs[t + 1] - offs[t]);
     if (L > maxlen) maxlen = L;
+    if (p->dbmask == 2) continue;                             /* LoadUDB loaddb.cpp:100-125: stored letters used as they are */
     if (p->dbmask) orc_fastmask(db->seqs + offs[t], L);
     else for (uint32_t i = 0; i < L; ++i) db->seqs[offs[t] + i] = (char)toupper((byte)db->seqs[offs[t] + i]);
   }

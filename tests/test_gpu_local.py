@@ -79,3 +79,25 @@ def test_local_evalue_matches_oracle():
         capi.lib().ugs_local_evalue(C.byref(p), raw, ql, C.byref(e), C.byref(b))
         orc.lib().orc_local_evalue(C.byref(op), raw, ql, C.byref(oe), C.byref(ob))
         assert (e.value, b.value) == (oe.value, ob.value)
+
+
+def test_cli_usearch_local_text_identical_to_reference(tmp_path):
+    """ugs_cli -usearch_local: FASTA in, -blast6out byte-identical to the reference's file (incl. a .udb database)"""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    for name in ("loc_nt_both", "loc_aa_acc", "loc_nt_id"):
+        c, db, qs, b6 = G.load_local(name)
+        dbfa, qfa, out = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "o.b6")
+        db.write_fasta(dbfa); qs.write_fasta(qfa)
+        if name == "loc_nt_id":      # through -makeudb_usearch
+            subprocess.check_call([cli, "-makeudb_usearch", dbfa, "-output", str(tmp_path / "db.udb")], stderr=subprocess.DEVNULL)
+            dbfa = str(tmp_path / "db.udb")
+        cmd = [cli, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-blast6out", out, "-batch", "400"]
+        if not c["aa"]:
+            cmd += ["-strand", c["strand"]]
+        for opt in ("id", "big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:
+            if opt in c:
+                cmd += ["-" + opt, str(c[opt])]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        assert open(out).read() == b6, name

@@ -86,3 +86,25 @@ def test_cli_udb_round_trip(tmp_path):
                            "-blast6out", os.path.join(tmp, "o.b6"), "-uc", os.path.join(tmp, "o.uc")], stderr=subprocess.DEVNULL)
     assert open(os.path.join(tmp, "o.b6")).read() == open(os.path.join(golden_util.GOLD, "udb_nt.b6")).read()
     assert open(os.path.join(tmp, "o.uc")).read() == open(os.path.join(golden_util.GOLD, "udb_nt.uc")).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aa", [False, True])
+def test_stored_letters_are_used_as_they_are(aa):
+    """dbmask = 2 (what the CLI sets for -db x.udb): the stored, already masked letters are neither re-masked nor
+    upper-cased, so the index and every search result equal the ones built from the raw FASTA letters."""
+    from usearch12_amd import synth
+    db, qs = synth.make_hard(77 + aa, 200, 6, 600, aa=aa)
+    ident = 0.8 if aa else 0.9
+    g1 = capi.UgsDB(capi.params(is_nucleo=not aa, id=ident, max_accepts=3, max_rejects=8), db.seqs, db.offs, device=0)
+    masked, ro1, po1 = g1.debug_fetch()
+    assert np.any((masked >= ord("a")) & (masked <= ord("z"))), "fixture without masked letters"
+    g2 = capi.UgsDB(capi.params(is_nucleo=not aa, id=ident, max_accepts=3, max_rejects=8, dbmask=2), masked, db.offs, device=0)
+    m2, ro2, po2 = g2.debug_fetch()
+    assert np.array_equal(masked, m2) and np.array_equal(ro1, ro2) and np.array_equal(po1, po2)
+    h1, n1, p1 = g1.search(qs.seqs, qs.offs)
+    h2, n2, p2 = g2.search(qs.seqs, qs.offs)
+    assert np.array_equal(n1, n2) and len(h1) > 300
+    for f in h1.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(h1[f], h2[f]), f

@@ -4,6 +4,7 @@
 //   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
+//   ugs_cli -usearch_local q.fa -db db.fa|db.udb -evalue 1e-6 [-id ..] -strand plus|both -blast6out f
 //   ugs_cli -otutab reads.fa -otus otus.fa|-zotus ..|-db .. [-otutabout f] [-mapout f] [+ the usearch_global outputs]
 //           (cmd_otutab searchcmd.cpp:20-40: defaults -id 0.97 -maxaccepts 3 -maxrejects 32 -stepwords 0 -strand both)
 //
@@ -92,12 +93,16 @@ class Searcher {
   const ugs_db *handle() const { return db_; }
   void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
     const uint32_t nq = (uint32_t)q.size();
-    hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) + 1);
+    hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) * (p_.local ? p_.max_hsps : 1) + 1);
     nhits.assign(nq + 1, 0);
     pool.resize(q.letters.size() * 2 + 64 * (size_t)nq + 1024);
     uint64_t used = 0;
-    if (ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(),
-                         pool.size(), &used) != UGS_OK) die("ugs_search_batch");
+    int rc = ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+    if (rc == UGS_E_CAPACITY && used > pool.size()) {        // the demand comes back in `used`
+      pool.resize(used + 1024);
+      rc = ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+    }
+    if (rc != UGS_OK) die("ugs_search_batch");
   }
  private:
   [[noreturn]] static void die(const char *what) { fprintf(stderr, "%s: %s\n", what, ugs_last_error()); exit(1); }
@@ -164,7 +169,8 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
     }
     if (O.aln) put(O.aln, ugs_format_alnout_hit(&h[j], pool, p.is_nucleo, qlab, tl, qs, ql, O.db_masked + db.offs[t],
                                                 (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
-    if (O.b6) put(O.b6, ugs_format_blast6(&h[j], qlab, tl, line.data(), (int)line.size()));
+    if (O.b6) put(O.b6, p.local ? ugs_format_blast6_local(&p, &h[j], qlab, tl, line.data(), (int)line.size())
+                                : ugs_format_blast6(&h[j], qlab, tl, line.data(), (int)line.size()));
     if (O.uc) put(O.uc, ugs_format_uc_hit(&h[j], pool, p.is_nucleo, qlab, tl, line.data(), (int)line.size()));
     if (O.user) put(O.user, ugs_format_userout(&h[j], pool, p.is_nucleo, O.userfields.c_str(), qlab, tl, qs, ql,
                                                 O.db_masked + db.offs[t], (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
@@ -215,6 +221,7 @@ int main(int argc, char **argv)
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
+  bool local_cmd = false; double evalue = -1; double xdrop_u = -1, xdrop_g = -1, ka_dbsize = -1; long maxhsps = -1, hspw = -1;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -222,6 +229,9 @@ int main(int argc, char **argv)
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
     else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
     else if (a == "-otutabout") otutabout = val(); else if (a == "-mapout") mapout = val(); else if (a == "-stepwords") stepwords = atol(val());
+    else if (a == "-usearch_local") { qpath = val(); local_cmd = true; } else if (a == "-evalue") evalue = atof(val());
+    else if (a == "-xdrop_u") xdrop_u = atof(val()); else if (a == "-xdrop_g") xdrop_g = atof(val()); else if (a == "-ka_dbsize") ka_dbsize = atof(val());
+    else if (a == "-maxhsps") maxhsps = atol(val()); else if (a == "-hspw") hspw = atol(val());
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
@@ -279,6 +289,19 @@ int main(int argc, char **argv)
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
   p.id_set = id >= 0;
+  if (local_cmd) {                                                    // cmd_usearch_local searchcmd.cpp:42-45; -evalue is required (localaligner.cpp:200)
+    if (evalue <= 0) { fprintf(stderr, "Required option not set -evalue\n"); return 1; }
+    if (ugs_params_set_local(&p, evalue, id >= 0) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    if (xdrop_u >= 0) p.xdrop_u = (float)xdrop_u;
+    if (xdrop_g >= 0) p.xdrop_g = (float)xdrop_g;
+    if (ka_dbsize > 0) p.ka_dbsize = (float)ka_dbsize;
+    if (maxhsps > 0) p.max_hsps = (uint32_t)maxhsps;
+    if (!ucpath.empty() || !userpath.empty() || !alnpath.empty() || !pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd ||
+        O.top_hit_only || O.top_hits_only) {
+      fprintf(stderr, "-usearch_local writes -blast6out, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
+    }
+  }
+  if (hspw > 0) p.hsp_word_len = (int32_t)hspw;
   p.strand_both = nucleo && strand == "both";
   if (maxacc >= 0) p.max_accepts = maxacc;
   if (maxrej >= 0) p.max_rejects = maxrej;
@@ -287,7 +310,7 @@ int main(int argc, char **argv)
   p.filter_mask = filt.filter_mask; p.maxid = filt.maxid; p.mincols = filt.mincols; p.maxgaps = filt.maxgaps;
   p.query_cov = filt.query_cov; p.max_query_cov = filt.max_query_cov; p.target_cov = filt.target_cov;
   p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
-  if (from_udb) { p.dbmask = 0; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
+  if (from_udb) { p.dbmask = 2; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
     if (path.empty()) return nullptr;
     FILE *f = fopen(path.c_str(), "w");

@@ -64,6 +64,7 @@ __global__ void k_mask(uint8_t *seqs, const uint64_t *offs, uint32_t nseq, int d
 
 int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int dbmask, hipStream_t st)
 {
+  if (dbmask == 2) return UGS_OK;      // letters of a .udb: already masked, used as stored (LoadUDB loaddb.cpp:100-125)
   if (nseq == 0) return UGS_OK;
   hipLaunchKernelGGL(k_mask, dim3((nseq + 255) / 256), dim3(256), 0, st, d_seqs, d_offs, nseq, dbmask);
   HIPCHK(hipGetLastError());
