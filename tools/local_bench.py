@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Throughput of the usearch_local path on one GPU: Q mutated copies / local-style queries against
+an N x L database, -evalue 1e-6.  Prints one JSON line: queries/s of the resident-input search (k_rank + k_local,
+HIP events), the x-drop DP cells/s inside k_local, and the CPU baseline: the unmodified reference binary
+(oracle/_ref/usearch12 -usearch_local, all host cores) when present, else the oracle port, on a sample."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from usearch12_amd import capi, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--db", type=int, default=100000)
+    ap.add_argument("--queries", type=int, default=200000)
+    ap.add_argument("--len", type=int, default=250)
+    ap.add_argument("--aa", action="store_true")
+    ap.add_argument("--kind", choices=["copies", "local"], default="copies")
+    ap.add_argument("--both", action="store_true")
+    ap.add_argument("--id", type=float, default=None, help="-id (needed by the reference for a DB above -big)")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--check", type=int, default=2000, help="queries compared with the oracle")
+    args = ap.parse_args()
+    db = synth.make_db(9, args.db, args.len, args.aa)
+    if args.kind == "copies":
+        qs = synth.make_queries(9, db, args.queries, args.len, args.aa)
+    else:
+        qs = synth.make_local_queries(9, db, args.queries, aa=args.aa)
+    kw = dict(id=args.id, local_evalue=1e-6, strand_both=1 if (args.both and not args.aa) else 0)
+    p = capi.params(is_nucleo=not args.aa, **kw)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs)
+    best = None
+    for _ in range(args.reps + 1):
+        t0 = time.time()
+        bat.search(); bat.sync()
+        wall = time.time() - t0
+        st = bat.stats()
+        if best is None or st['ms_total'] < best[0]['ms_total']:
+            best = (st, wall)
+    st, wall = best
+    hits, nh, pool = bat.fetch()
+    out = dict(workload="usearch_local %s: %d queries x %d %s vs %d targets, evalue 1e-6%s%s" % (
+                   args.kind, qs.n, args.len, "aa" if args.aa else "nt", db.n, ", both strands" if kw["strand_both"] else "", "" if args.id is None else ", id %g" % args.id),
+               queries_per_s=qs.n / (st['ms_total'] * 1e-3), ms_total=st['ms_total'], ms_rank=st['ms_rank'] + st['ms_rank_setup'],
+               ms_local=st['ms_align'], hits=int(len(hits)), pairs=int(st['pairs_aligned']), xdrop_cells=int(st['dp_cells']),
+               gcells_per_s=st['dp_cells'] / (st['ms_align'] * 1e-3) / 1e9, wall_s=wall)
+    # parity on a sample
+    if args.check:
+        import orc
+        n = min(args.check, qs.n)
+        sub = qs.slice(0, n)
+        odb = orc.OrcDB(orc.params(is_nucleo=not args.aa, **kw), db.seqs, db.offs)
+        t0 = time.time()
+        oh, onh, opool = odb.search(sub.seqs, sub.offs, nthreads=1)
+        port_s = time.time() - t0
+        k = int(nh[:n].sum())
+        ok = np.array_equal(nh[:n], onh) and all(np.array_equal(hits[:k][f], oh[f]) for f in oh.dtype.names if f != "cigar_off")
+        out["parity_sample"] = dict(queries=n, ok=bool(ok))
+        out["cpu_port_queries_per_s_1core"] = n / port_s
+    ref = os.path.join(ROOT, "oracle", "_ref", "usearch12")
+    if os.path.exists(ref) and args.cpu_sample:
+        n = min(args.cpu_sample, qs.n)
+        with tempfile.TemporaryDirectory() as tmp:
+            dbfa, qfa = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa")
+            db.write_fasta(dbfa); qs.slice(0, n).write_fasta(qfa)
+            udb = os.path.join(tmp, "db.udb")
+            subprocess.check_call([ref, "-makeudb_usearch", dbfa, "-output", udb], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            cores = os.cpu_count() or 1
+            cmd = [ref, "-usearch_local", qfa, "-db", udb, "-evalue", "1e-6", "-blast6out", os.path.join(tmp, "o.b6"), "-threads", str(cores)]
+            if not args.aa:
+                cmd += ["-strand", "both" if kw["strand_both"] else "plus"]
+            if args.id is not None:
+                cmd += ["-id", str(args.id)]
+            t0 = time.time()
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.time() - t0
+            out["cpu_reference"] = dict(queries_per_s=n / dt, cores=cores, sample="%d queries incl. loading the .udb" % n, seconds=dt)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -526,7 +526,7 @@ static int plan_local(ugs_batch *b)
   lv.tb_cap = ((unsigned long long)(sideq + 2) * (sidet + 4) + 256 + 63) & ~63ull;
   lv.rows_cap = sideq + 4;
   lv.runbuf_cap = b->max_qlen + db->max_tlen + 8;
-  const size_t wave_lds = ugs_local_wave_lds(lv.W, b->max_qlen, lv.seed_cap);
+  const size_t wave_lds = ugs_local_wave_lds(lv.W, b->max_qlen, db->max_tlen, lv.seed_cap);
   int wpb = 4;
   while (wpb > 1 && 2560 + wpb * wave_lds > LDS_MAX) wpb >>= 1;
   if (2560 + wpb * wave_lds > LDS_MAX) { ugs_set_error("usearch_local LDS footprint %zu exceeds 160 KiB (sequences too long)", 2560 + wave_lds); return UGS_E_ENVELOPE; }

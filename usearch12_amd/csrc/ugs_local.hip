@@ -32,7 +32,8 @@ constexpr uint32_t LOC_BT = 256;         // target positions listed per round
 struct LocWave {
   uint8_t *Aq;          // query strand, raw letters (what the x-drop code reads)
   uint8_t *Ax;          // x-drop score class of each query letter
-  uint16_t *qw;         // seed word at each query position
+  uint32_t *qs;         // (seed word << 16) | query position, sorted; padded with ~0 to a power of two
+  uint8_t *Bx;          // x-drop score class of each target letter
   uint32_t *seeds;      // (target pos << 16) | query pos, walk order
   uint32_t *ars;        // kept HSPs: Loi, Loj, Leni, Lenj
 };
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
   LocWave L;
   L.Aq = wb + off; off += maxq;
   L.Ax = wb + off; off += maxq;
-  L.qw = (uint16_t *)(wb + off); off += (size_t)maxq * 2;
+  uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
+  L.qs = (uint32_t *)(wb + off); off += (size_t)q2 * 4;
+  L.Bx = wb + off; off += (db.max_tlen + 15u) & ~15u;
   L.seeds = (uint32_t *)(wb + off); off += (size_t)lv.seed_cap * 4;
   L.ars = (uint32_t *)(wb + off);
   const uint32_t gw = blockIdx.x * wpb + (uint32_t)wave;
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
   const uint32_t SW = lv.seed_w, alpha = (uint32_t)db.alpha;
   unsigned long long *ctr = bv.counters;
   unsigned long long cells = 0, w_tletters = 0, w_pairs = 0, w_hits = 0;
+  unsigned long long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tq;     // phase clocks: listing, ungapped + anchor, gapped, hit statistics
 
   for (;;) {
     uint32_t unit = 0;
@@ -105,12 +109,30 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
         L.Aq[p] = ch; L.Ax[p] = s_xcls[ch];
       }
       wave_sync();
-      for (uint32_t p = lane; p < nqw; p += 64) {
-        uint32_t wd = 0;
-        for (uint32_t i = 0; i < SW; ++i) wd = wd * alpha + s_hl[L.Aq[p + i]];
-        L.qw[p] = (uint16_t)wd;
+      // the query's seed words sorted by (word, position): LocalAligner2::SetQueryImpl's QueryPosVec, localaligner2.cpp:62-145
+      uint32_t n2 = 64; while (n2 < nqw) n2 <<= 1;
+      for (uint32_t p = lane; p < n2; p += 64) {
+        uint32_t key = 0xffffffffu;
+        if (p < nqw) {
+          uint32_t wd = 0;
+          for (uint32_t i = 0; i < SW; ++i) wd = wd * alpha + s_hl[L.Aq[p + i]];
+          key = (wd << 16) | p;
+        }
+        L.qs[p] = key;
       }
       wave_sync();
+      if (nqw > 1)
+        for (uint32_t kk = 2; kk <= n2; kk <<= 1)
+          for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = lane; i < n2; i += 64) {
+              const uint32_t l = i ^ j;
+              if (l > i) {
+                const uint32_t x = L.qs[i], y = L.qs[l];
+                if ((x > y) == ((i & kk) == 0)) { L.qs[i] = y; L.qs[l] = x; }
+              }
+            }
+            wave_sync();
+          }
     }
     uint32_t ct = 0, clen = 0; uint64_t cto = 0;
     if ((uint32_t)lane < ncand) {
@@ -124,6 +146,8 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
       const uint32_t TL = (uint32_t)rl((int)clen, (int)k);
       const uint8_t *B = db.seqs + to;
       w_tletters += TL; ++w_pairs;
+      for (uint32_t p = lane; p < TL; p += 64) L.Bx[p] = s_xcls[B[p]];
+      wave_sync();
       bool any_accept = false;
       uint32_t nars = 0;
       if (TL >= 2 * SW && nqw) {                       // localmulti.cpp:17-20
@@ -132,31 +156,37 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
         uint32_t fLoi = 0xffffffffu, fLoj = 0, fLen = 0;   // last anchor whose gapped extension was not kept
         while (curT < TWC) {
           // ---- list the seeds of target positions [curT, tend) in walk order: position ascending, then query position
+          tq = clock64();
           uint32_t tend = min(curT + LOC_BT, TWC), nseeds = 0;
           for (uint32_t t0 = curT; t0 < tend; t0 += 64) {
-            uint32_t twv = 0;
-            if (t0 + lane < tend) for (uint32_t i = 0; i < SW; ++i) twv = twv * alpha + s_hl[B[t0 + lane + i]];
-            const uint32_t nt = min(64u, tend - t0);
-            for (uint32_t x = 0; x < nt; ++x) {
-              const uint32_t tw = (uint32_t)rl((int)twv, (int)x);
-              const uint32_t n_at_pos = nseeds;
-              for (uint32_t q0 = 0; q0 < nqw; q0 += 64) {
-                const uint32_t q = q0 + lane;
-                const uint64_t m = __ballot(q < nqw && L.qw[q] == tw);
-                if (m) {
-                  if (nseeds + 64 > lv.seed_cap) { tend = t0 + x; nseeds = n_at_pos; goto listed; }    // the round ends before this position
-                  if ((m >> lane) & 1) L.seeds[nseeds + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = ((t0 + x) << 16) | q;
-                  nseeds += (uint32_t)__popcll(m);
-                }
-              }
+            // lane = target position: its word's slice of the sorted query words is its seeds, already in query order
+            const uint32_t tp = t0 + lane;
+            uint32_t lb = 0, cnt = 0;
+            if (tp < tend) {
+              uint32_t tw = 0;
+              for (uint32_t i = 0; i < SW; ++i) tw = tw * alpha + s_hl[B[tp + i]];
+              uint32_t lo = 0, hi = nqw;
+              const uint32_t k0 = tw << 16; const uint64_t k1 = (uint64_t)(tw + 1) << 16;
+              while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (L.qs[mid] < k0) lo = mid + 1; else hi = mid; }
+              lb = lo; hi = nqw;
+              while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)L.qs[mid] < k1) lo = mid + 1; else hi = mid; }
+              cnt = lo - lb;
             }
+            uint32_t incl = cnt;                         // inclusive prefix sum over the lanes
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+            const uint64_t over = __ballot(nseeds + incl > lv.seed_cap);
+            const int cut = over ? __ffsll((long long)over) - 1 : 64;      // the round ends before this position
+            if (lane < cut) for (uint32_t r = 0; r < cnt; ++r) L.seeds[nseeds + incl - cnt + r] = (tp << 16) | (L.qs[lb + r] & 0xffffu);
+            if (over) { nseeds += cut ? (uint32_t)rl((int)incl, cut - 1) : 0u; tend = t0 + (uint32_t)cut; break; }
+            nseeds += (uint32_t)rl((int)incl, 63);
           }
-        listed:
           if (tend == curT) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); break; }   // one position overflowed the list
           wave_sync();
+          tl0 += clock64() - tq;
           uint32_t cur = curT;
           for (uint32_t g0 = 0; g0 < nseeds && cur < tend; g0 += 64) {
             // ---- one seed per lane: ungapped x-drop both ways (localaligner.cpp:107-160) and the anchor (:11-58)
+            tq = clock64();
             const uint32_t s = g0 + lane;
             const uint32_t sd = s < nseeds ? L.seeds[s] : 0;
             const uint32_t st = sd >> 16, sq = sd & 0xffffu;
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               int i = (int)sq, j = (int)st;
               while (i >= 0 && j >= 0) {
                 ++kk;
-                tot += s_sub2[((int)L.Ax[i] << 5) | s_xcls[B[j]]];
+                tot += s_sub2[((int)L.Ax[i] << 5) | L.Bx[j]];
                 if (tot > best) { best = tot; len = kk; }
                 else if ((float)(best - tot) * 0.5f > lv.xdrop_u) break;
                 --i; --j;
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               i = (int)sq + 1; j = (int)st + 1;
               while (i < (int)QL && j < (int)TL) {
                 ++kk;
-                tot += s_sub2[((int)L.Ax[i] << 5) | s_xcls[B[j]]];
+                tot += s_sub2[((int)L.Ax[i] << 5) | L.Bx[j]];
                 if (tot > best) { best = tot; len = kk; }
                 else if ((float)(best - tot) * 0.5f > lv.xdrop_u) break;
                 ++i; ++j;
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                 uint32_t startk = 0xffffffffu, beststart = 0xffffffffu, blen = 0;
                 int asc = 0, bsc = 0;
                 for (uint32_t x = 0; x < SegLen; ++x) {
-                  const int sc = s_sub2[((int)L.Ax[Loi + x] << 5) | s_xcls[B[Loj + x]]];
+                  const int sc = s_sub2[((int)L.Ax[Loi + x] << 5) | L.Bx[Loj + x]];
                   if (sc > 0) {
                     if (startk == 0xffffffffu) { startk = x; asc = sc; } else asc += sc;
                   } else {
@@ -201,6 +231,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
             }
             // ---- the survivors, in walk order
             uint64_t pm = __ballot(pass);
+            tl1 += clock64() - tq;
             while (pm) {
               const int l = __ffsll((long long)pm) - 1;
               pm &= pm - 1;
@@ -210,6 +241,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               if (AncLen <= 1) continue;               // xdropalignmem.cpp:44-49: score 0
               if (AncLoi == fLoi && AncLoj == fLoj && AncLen == fLen) continue;   // same extension, same verdict
               // XDropAlignMem xdropalignmem.cpp:26-214
+              tq = clock64();
               const uint32_t AncHii = AncLoi + AncLen - 1, AncHij = AncLoj + AncLen - 1;
               uint32_t bi = 0, bj = 0, fi = 0, fj = 0, nb = 0, nf = 0;
               bool ovf = false;
@@ -220,10 +252,11 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                                       (QL - AncHii) > XD_MAXL || (TL - AncHij) > XD_MAXL, fi, fj, runsF, nf, ovf, cells);
               if (ovf || nb > lv.runbuf_cap || nf > lv.runbuf_cap) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); continue; }
               int anc = 0;
-              for (uint32_t x = lane; x < AncLen; x += 64) anc += s_sub2[((int)L.Ax[AncLoi + x] << 5) | s_xcls[B[AncLoj + x]]];
+              for (uint32_t x = lane; x < AncLen; x += 64) anc += s_sub2[((int)L.Ax[AncLoi + x] << 5) | L.Bx[AncLoj + x]];
               for (int o = 32; o; o >>= 1) anc += __shfl_xor(anc, o);
-              const int dupe = s_sub2[((int)L.Ax[AncLoi] << 5) | s_xcls[B[AncLoj]]] + s_sub2[((int)L.Ax[AncHii] << 5) | s_xcls[B[AncHij]]];
+              const int dupe = s_sub2[((int)L.Ax[AncLoi] << 5) | L.Bx[AncLoj]] + s_sub2[((int)L.Ax[AncHii] << 5) | L.Bx[AncHij]];
               const int score2 = bwd + fwd + anc - dupe;                                   // :176
+              tl2 += clock64() - tq; tq = clock64();
               const uint32_t Loi = AncLoi + 1 - bi, Loj = AncLoj + 1 - bj;
               const uint32_t Leni = bi + fi + AncLen - 2, Lenj = bj + fj + AncLen - 2;
               bool keep = score2 > 0 && score2 >= thr.y;                                  // localaligner.cpp:193-205
@@ -319,6 +352,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                 }
               }
               wave_sync();
+              tl3 += clock64() - tq;
               // localmulti.cpp:104-110: the walk resumes behind the HSP
               const uint32_t NewT = Loj + Lenj;                                           // GetHij() + 1
               cur = NewT > tt ? NewT : tt + 1;
@@ -339,12 +373,14 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
     atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs);
     atomicAdd(&ctr[UGS_CTR_CELLS], cells); atomicAdd(&ctr[UGS_CTR_HITS], w_hits);
   }
+  if (tid == 0) { atomicAdd(&ctr[UGS_CTR_T4], tl0); atomicAdd(&ctr[UGS_CTR_T5], tl1); atomicAdd(&ctr[UGS_CTR_T6], tl2); atomicAdd(&ctr[UGS_CTR_T7], tl3); }
 }
 
-size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t seed_cap)
+size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t max_tlen, uint32_t seed_cap)
 {
-  const size_t maxq = (max_qlen + 15u) & ~15u;
-  return ((((size_t)W * 13 + 15) & ~(size_t)15) + maxq * 4 + (size_t)seed_cap * 4 + LOC_MAXARS * 16 + 15) & ~(size_t)15;
+  const size_t maxq = (max_qlen + 15u) & ~15u, maxt = (max_tlen + 15u) & ~15u;
+  size_t q2 = 64; while (q2 < maxq) q2 <<= 1;
+  return ((((size_t)W * 13 + 15) & ~(size_t)15) + maxq * 2 + q2 * 4 + maxt + (size_t)seed_cap * 4 + LOC_MAXARS * 16 + 15) & ~(size_t)15;
 }
 
 int ugs_local_blocks_per_cu(int threads, size_t lds)

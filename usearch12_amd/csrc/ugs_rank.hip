@@ -186,12 +186,13 @@ __device__ __forceinline__ bool flat_rows_at(const FlatRows &fr, uint32_t f, uin
 // sub-row length; rows are walked in order and counters are cleared right after they are read, so
 // only the first touch of a target sees a non-zero count (no duplicates are emitted).
 // FILL=true: emit count-1 targets in scan order, at most `need` of them.
-template <int CB, bool FILL>
+template <int CB, bool FILL, bool BATCH = false>
 __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool split, uint32_t base_t, uint32_t hi_t,
                                               uint32_t need, uint64_t fill_limit, bool have_ab = false, uint64_t a_in = 0,
                                               uint64_t b_in = 0)
 {
   constexpr uint32_t EPW = 32 / CB;
+  constexpr int NB = 4;                                        // rows whose first loads are issued together (BATCH)
   const int lane = s.lane;
   const uint32_t ns = s.ns;
   uint32_t *tbl = s.tbl;
@@ -212,11 +213,35 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
       }
       continue;
     }
-    while (rows) {
-      const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
-      rows &= rows - 1;
-      const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
-      for (uint64_t k = ra + lane; k < rbb; k += 64) Tbl<CB>::inc(tbl, postings[k] - base_t);
+    if constexpr (!BATCH) {                                    // (launches with 4-bit tables keep the shape the hot path was tuned with)
+      while (rows) {
+        const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+        rows &= rows - 1;
+        const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
+        for (uint64_t k = ra + lane; k < rbb; k += 64) Tbl<CB>::inc(tbl, postings[k] - base_t);
+      }
+    } else {
+      // four rows at a time: their first 64 postings are requested together, so a wave keeps four loads in flight
+      // instead of waiting out one load per row (the mid-identity configurations, 16-255 sampled rows, live here)
+      while (rows) {
+        uint64_t ra[NB], rbb[NB]; uint32_t v[NB]; bool on[NB];
+  #pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          ra[u] = 0; rbb[u] = 0;
+          if (rows) {
+            const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+            rows &= rows - 1;
+            ra[u] = shfl64(a, r); rbb[u] = shfl64(b, r);
+          }
+          on[u] = ra[u] + lane < rbb[u];
+          v[u] = on[u] ? postings[ra[u] + lane] : 0u;
+        }
+  #pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (on[u]) Tbl<CB>::inc(tbl, v[u] - base_t);
+          for (uint64_t k = ra[u] + 64 + lane; k < rbb[u]; k += 64) Tbl<CB>::inc(tbl, postings[k] - base_t);
+        }
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -286,25 +311,53 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
       }
       continue;
     }
-    while (rows) {
-      const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
-      rows &= rows - 1;
-      const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
-      for (uint64_t k0 = ra; k0 < rbb; k0 += 64) {
-        const uint64_t k = k0 + lane;
-        const bool o2 = k < rbb;
-        uint32_t t2 = 0, c2 = 0;
-        if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
-        extract_one<CB, FILL>(s, o2, t2, base_t, i0 + r, c2, quota_left, fill_limit);
+    if constexpr (!BATCH) {
+      while (rows) {
+        const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+        rows &= rows - 1;
+        const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
+        for (uint64_t k0 = ra; k0 < rbb; k0 += 64) {
+          const uint64_t k = k0 + lane;
+          const bool o2 = k < rbb;
+          uint32_t t2 = 0, c2 = 0;
+          if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+          extract_one<CB, FILL>(s, o2, t2, base_t, i0 + r, c2, quota_left, fill_limit);
+        }
+      }
+    } else {
+      while (rows) {                                             // rows stay in order (first touch reports the row); loads are batched
+        uint64_t ra[NB], rbb[NB]; uint32_t v[NB], rr[NB];
+  #pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          ra[u] = 0; rbb[u] = 0; rr[u] = 0;
+          if (rows) {
+            rr[u] = (uint32_t)__ffsll((long long)rows) - 1;
+            rows &= rows - 1;
+            ra[u] = shfl64(a, rr[u]); rbb[u] = shfl64(b, rr[u]);
+          }
+          v[u] = ra[u] + lane < rbb[u] ? postings[ra[u] + lane] : 0u;
+        }
+  #pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          for (uint64_t k0 = ra[u]; k0 < rbb[u]; k0 += 64) {
+            const uint64_t k = k0 + lane;
+            const bool o2 = k < rbb[u];
+            uint32_t t2 = 0, c2 = 0;
+            if (o2) { t2 = k0 == ra[u] ? v[u] : postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+            extract_one<CB, FILL>(s, o2, t2, base_t, i0 + rr[u], c2, quota_left, fill_limit);
+          }
+        }
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int CB, bool FILL>
+template <int CB, bool FILL, bool BATCH = false>
 __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, uint64_t fill_limit)
 {
   constexpr uint32_t EPW = 32 / CB;
@@ -333,7 +386,7 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
         const uint64_t a = cur;
         while (cur < end && vcur < hi_t) { ++cur; vcur = cur < end ? s.postings[cur] : 0xffffffffu; }
         if (!__ballot(cur > a)) continue;                        // no sampled row has a posting in this range
-        range_generic<CB, FILL>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
+        range_generic<CB, FILL, BATCH>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
       }
     }
     return;
@@ -343,7 +396,7 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
       const uint32_t base_t = p * s.gsize + sub * tbl_targets;
       const uint32_t pend = (p + 1) * s.gsize;
       const uint32_t hi_t = split ? (base_t + tbl_targets < pend ? base_t + tbl_targets : pend) : 0;
-      range_generic<CB, FILL>(s, p, split, base_t, hi_t, need, fill_limit);
+      range_generic<CB, FILL, BATCH>(s, p, split, base_t, hi_t, need, fill_limit);
     }
 }
 
@@ -503,16 +556,16 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <bool FILL>
+template <bool FILL, bool BATCH>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
   if (cb == 4) {
     if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
       if (s.ns <= 8) scan_fast4<8>(s); else if (s.ns <= 11) scan_fast4<11>(s); else scan_fast4<12>(s);
     }
-    else scan_generic<4, FILL>(s, need, fill_limit);
-  } else if (cb == 8) scan_generic<8, FILL>(s, need, fill_limit);
-  else scan_generic<16, FILL>(s, need, fill_limit);
+    else scan_generic<4, FILL, BATCH>(s, need, fill_limit);
+  } else if (cb == 8) scan_generic<8, FILL, BATCH>(s, need, fill_limit);
+  else scan_generic<16, FILL, BATCH>(s, need, fill_limit);
 }
 
 // wave-uniform min of a u32 with DPP row shifts (no LDS crossbar): inclusive prefix-min inside each
@@ -665,7 +718,9 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
 
 // SMALL: the database is at or below -big (small ranking path) - a per-database constant, so the two rankers are two
 // instantiations and each carries only its own branches through the hot loop
-template <bool SMALL>
+// BATCH: launches whose tables are wider than 4 bits (16-255 sampled rows: mid-identity searches) walk the generic path
+// for every unit; their row loops keep four loads in flight.  The 4-bit launches keep the code the hot path was tuned with.
+template <bool SMALL, bool BATCH>
 __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -731,7 +786,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
-    scan_dispatch<false>(sc, cb, 0, 0);
+    scan_dispatch<false, BATCH>(sc, cb, 0, 0);
     // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
@@ -960,7 +1015,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
       const uint32_t need = K - nsel;
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
-      scan_dispatch<true>(sc, cb, need, fill_limit);
+      scan_dispatch<true, BATCH>(sc, cb, need, fill_limit);
       __threadfence_block();
       __syncthreads();
     }
@@ -984,9 +1039,8 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds)
 {
   int n = 0;
   // (both instantiations have the same register budget; the Big one is asked)
-  if (hipFuncSetAttribute((const void *)k_rank<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void *)k_rank<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false>, threads, lds) != hipSuccess || n < 1) n = 1;
+  if (hipFuncSetAttribute((const void *)k_rank<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
@@ -1023,12 +1077,13 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
-  if (db.big) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_rank<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_rank<false>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
-  } else {
-    HIPCHK(hipFuncSetAttribute((const void *)k_rank<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_rank<true>, grid, block, L.lds, st, db, b, L.ns_max, tbl_words, L.part_words);
+  const void *fn = db.big ? (L.bits == 4 ? (const void *)k_rank<false, false> : (const void *)k_rank<false, true>)
+                          : (L.bits == 4 ? (const void *)k_rank<true, false> : (const void *)k_rank<true, true>);
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+  {
+    UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
+    void *args[] = {&a0, &a1, &a2, &a3, &a4};
+    HIPCHK(hipLaunchKernel(fn, grid, block, args, L.lds, st));
   }
   HIPCHK(hipGetLastError());
   return UGS_OK;
