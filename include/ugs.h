@@ -208,6 +208,10 @@ typedef struct ugs_batch_stats {
 } ugs_batch_stats;
 int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st);
 
+/* HitMgr::Sort (hitmgr.cpp:477-483) on a hit table grouped by query, in place: the order ugs_batch_fetch returns.
+ * For tables taken from ugs_batch_device_results (multi-GPU gather), which are in candidate order.  Host only. */
+int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uint32_t nq, int local);
+
 /*
  * Stage-level entry point used by the parity tests: the ranked candidate list of every
  * query exactly as the reference's candidate loop would walk it

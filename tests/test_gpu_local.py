@@ -101,3 +101,25 @@ def test_cli_usearch_local_text_identical_to_reference(tmp_path):
                 cmd += ["-" + opt, str(c[opt])]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         assert open(out).read() == b6, name
+
+
+def test_device_results_plus_sort_equal_fetch():
+    """the multi-GPU result path: ugs_batch_device_results hands out candidate-order tables; ugs_hits_sort on the host
+    gives exactly what ugs_batch_fetch returns"""
+    import torch
+    from usearch12_amd import multigpu
+    c, db, qs, b6 = G.load_local("loc_aa_acc")
+    p = capi.params(is_nucleo=False, **G.local_params_kw(c))
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    hits, nh, pool = bat.fetch()
+    import bench
+    (ph, bh), (pn, bn), (pc, bc) = bat.device_results(0)
+    dh, dn, dp = (torch.as_tensor(bench.DevArray(ptr, n), device="cuda").cpu().numpy() for ptr, n in ((ph, bh), (pn, bn), (pc, bc)))
+    ghits, gcnt, gpool = multigpu.merge_tables([dh], [dn], [dp])
+    assert np.array_equal(gcnt, nh)
+    capi.sort_hits(ghits, gcnt, local=True)
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(ghits[f], hits[f]), f

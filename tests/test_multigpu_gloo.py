@@ -23,8 +23,12 @@ def _worker(rank, world, port, case, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    c, db, qs, b6, uc = G.load(case)
-    p = orc.params(is_nucleo=not c["aa"], id=c["id"], **G.params_kw(c))
+    if case.startswith("loc_"):                     # usearch_local: several HSPs per target, 80-byte records with raw scores
+        c, db, qs, b6 = G.load_local(case)
+        p = orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c))
+    else:
+        c, db, qs, b6, uc = G.load(case)
+        p = orc.params(is_nucleo=not c["aa"], id=c["id"], **G.params_kw(c))
     lo, hi = multigpu.shard_range(qs.n, world, rank)
     shard = qs.slice(lo, hi)
     odb = orc.OrcDB(p, db.seqs, db.offs)            # replica of the index on every rank
@@ -62,6 +66,51 @@ def test_two_rank_gather_equals_single_run(tmp_path):
         assert np.array_equal(ghits[f], hits[f]), f
     for a, b in zip(ghits[::37], hits[::37]):
         assert cigar_text(gpool, a["cigar_off"], a["cigar_len"]) == cigar_text(pool, b["cigar_off"], b["cigar_len"])
+
+
+def test_two_rank_gather_local_hits(tmp_path):
+    case = "loc_nt_both"
+    out = str(tmp_path / "g")
+    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    ghits = np.load(out + ".hits.npy")
+    gpool = np.load(out + ".pool.npy")
+    c, db, qs, b6 = G.load_local(case)
+    p = orc.params(is_nucleo=True, **G.local_params_kw(c))
+    hits, nh, pool = orc.OrcDB(p, db.seqs, db.offs).search(qs.seqs, qs.offs)
+    assert len(ghits) == len(hits) and np.all(ghits["flags"] == 1)
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(ghits[f], hits[f]), f
+    got = orc.format_blast6_local(orc.lib(), "orc", p, ghits, nh, qs.labels(), db.labels())
+    assert got == b6
+    for a, b in zip(ghits[::29], hits[::29]):
+        assert cigar_text(gpool, a["cigar_off"], a["cigar_len"]) == cigar_text(pool, b["cigar_off"], b["cigar_len"])
+
+
+def test_hits_sort_orders_a_candidate_order_table():
+    """ugs_hits_sort (host-only ABI entry): per query non-increasing score, same records; on a table that is already
+    in HitMgr order and has no tied scores it is the identity"""
+    from usearch12_amd import capi
+    c, db, qs, b6 = G.load_local("loc_aa_acc")
+    p = orc.params(is_nucleo=False, **G.local_params_kw(c))
+    hits, nh, pool = orc.OrcDB(p, db.seqs, db.offs).search(qs.seqs, qs.offs)
+    rng = np.random.default_rng(3)
+    shuffled = hits.copy()
+    k = 0
+    for n in nh:
+        n = int(n)
+        shuffled[k:k + n] = shuffled[k:k + n][rng.permutation(n)]
+        k += n
+    out = capi.sort_hits(shuffled.copy(), nh, local=True)
+    k = 0
+    for n in nh:
+        n = int(n)
+        a, b = out[k:k + n], hits[k:k + n]
+        assert np.all(np.diff(a["raw_score"]) <= 0)
+        assert sorted(a.tobytes()[i * 80:(i + 1) * 80] for i in range(n)) == sorted(b.tobytes()[i * 80:(i + 1) * 80] for i in range(n))
+        if len(set(b["raw_score"].tolist())) == n:
+            assert a.tobytes() == b.tobytes()
+        k += n
 
 
 def test_shard_ranges_cover():

@@ -22,7 +22,7 @@ EXPORTS = [
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
-    "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
+    "ugs_hits_sort", "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_format_fastapairs", "ugs_format_segout",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
@@ -62,6 +62,7 @@ def lib():
         L.ugs_batch_device_results.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
+        L.ugs_hits_sort.argtypes = [vp, vp, u32, i32]
         L.ugs_params_set_local.argtypes = [C.POINTER(Params), C.c_double, i32]
         L.ugs_local_evalue.argtypes = [C.POINTER(Params), C.c_double, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ugs_format_blast6_local.argtypes = [C.POINTER(Params), vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -101,6 +102,13 @@ def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
         if k in FILTER_BITS:            # an optional accept filter is active when its bit is set (include/ugs.h)
             p.filter_mask |= FILTER_BITS[k]
     return p
+
+
+def sort_hits(hits, counts, local=False):
+    """HitMgr::Sort of a merged table (multigpu.merge_tables output) in place; returns hits"""
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    _chk(lib().ugs_hits_sort(hits.ctypes.data, counts.ctypes.data, len(counts), 1 if local else 0))
+    return hits
 
 
 def device_count():

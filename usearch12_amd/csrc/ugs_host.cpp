@@ -771,6 +771,26 @@ static void qs_order_desc(const float *V, int left, int right, unsigned *Order)
   if (i < right) qs_order_desc(V, i, right, Order);
 }
 
+// HitMgr::Sort (hitmgr.cpp:477-483) on a hit table grouped by query: each query's hits in the order of the reference's
+// QuickSortOrderDesc over AlignResult::GetScore (arscorer.cpp:818-824: float fractional identity; local: float raw score)
+extern "C" int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uint32_t nq, int local)
+{
+  if ((!hits && nq) || !nhits_per_query) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  std::vector<ugs_hit> tmp; std::vector<float> sc; std::vector<unsigned> ord;
+  uint64_t k = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    const uint32_t n = nhits_per_query[q];
+    if (n > 1) {
+      tmp.assign(hits + k, hits + k + n); sc.resize(n); ord.resize(n);
+      for (uint32_t i = 0; i < n; ++i) { sc[i] = local ? tmp[i].raw_score : (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
+      qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
+      for (uint32_t i = 0; i < n; ++i) hits[k + i] = tmp[ord[i]];
+    }
+    k += n;
+  }
+  return UGS_OK;
+}
+
 extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
                                uint32_t *cigar_pool, uint64_t cigar_cap, uint64_t *cigar_used)
 {
@@ -799,21 +819,7 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   HIPCHK(hipStreamSynchronize(db->stream));
   if (cigar_used) *cigar_used = b->cigar_used_host;
   // HitMgr::Sort for the (rare) queries with several hits; cigar_off keeps pointing into the pool as copied
-  if (ma > 1 || ns > 1) {
-    std::vector<ugs_hit> tmp; std::vector<float> sc; std::vector<unsigned> ord;
-    uint64_t k = 0;
-    for (uint32_t q = 0; q < nq; ++q) {
-      const uint32_t n = nhits_per_query[q];
-      if (n > 1) {
-        tmp.assign(hits + k, hits + k + n); sc.resize(n); ord.resize(n);
-        // AlignResult::GetScore arscorer.cpp:818-824: fractional identity, local: raw score
-        for (uint32_t i = 0; i < n; ++i) { sc[i] = db->p.local ? tmp[i].raw_score : (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
-        qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
-        for (uint32_t i = 0; i < n; ++i) hits[k + i] = tmp[ord[i]];
-      }
-      k += n;
-    }
-  }
+  if (ma > 1 || ns > 1) return ugs_hits_sort(hits, nhits_per_query, nq, db->p.local);
   return UGS_OK;
 }
 
