@@ -371,6 +371,17 @@ int ugs_otutab_add(ugs_otutab *t, const char *qlabel, const char *top_hit_tlabel
 int ugs_otutab_write(const ugs_otutab *t, const char *path);
 int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64_t *total);
 
+/*
+ * closed_ref sink (cmd_closed_ref searchcmd.cpp:11-19: usearch_global with -id 0.97 -stepwords 0, terminator 4/16;
+ * ClosedRefSink::OnQueryDone closedrefsink.cpp:33-118).  _add takes one query's hits in HitMgr order with the label of
+ * every hit's target and returns the -tabbedout line.  -dbotus / -dataotus are not built (the reference crashes on them).
+ */
+typedef struct ugs_closedref ugs_closedref;
+ugs_closedref *ugs_closedref_create(void);
+void ugs_closedref_destroy(ugs_closedref *c);
+int ugs_closedref_add(ugs_closedref *c, const char *qlabel, const ugs_hit *hits, uint32_t n, const char *const *tlabels, char *line, int cap);
+int ugs_closedref_totals(const ugs_closedref *c, uint64_t *assigned, uint64_t *unassigned, uint32_t *otus);
+
 /* Page-lock / unlock a caller-owned host buffer (hipHostRegister): result buffers that are reused from batch to batch
  * are then filled by direct DMA instead of through the runtime's staging copies.  Optional; any host pointer works
  * with the fetch calls. */

@@ -5,6 +5,7 @@
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
 //   ugs_cli -usearch_local q.fa -db db.fa|db.udb -evalue 1e-6 [-id ..] -strand plus|both -blast6out f
+//   ugs_cli -closed_ref reads.fa -db ref.fa -strand plus|both -tabbedout f
 //   ugs_cli -otutab reads.fa -otus otus.fa|-zotus ..|-db .. [-otutabout f] [-mapout f] [+ the usearch_global outputs]
 //           (cmd_otutab searchcmd.cpp:20-40: defaults -id 0.97 -maxaccepts 3 -maxrejects 32 -stepwords 0 -strand both)
 //
@@ -116,6 +117,7 @@ struct Outputs {
   bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
   uint32_t maxhits = 0;
   ugs_otutab *otutab = nullptr; FILE *map = nullptr;   // OTUTableSink
+  ugs_closedref *closedref = nullptr; FILE *tabbed = nullptr;   // ClosedRefSink
   std::vector<uint32_t> db_hit_counts;      // DBHitSink::m_HitCounts
   const char *db_masked = nullptr;          // DB letters as the reference holds them (masked)
 };
@@ -142,6 +144,11 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
     uint32_t top = 0;
     if (n) ugs_hits_to_report(h, n_all, 0, 1, 0, &top);               // HitMgr::GetTopHit
     put_to(O.map, ugs_otutab_add(O.otutab, qlab, n ? db.labels[h[top].target].c_str() : nullptr, line.data(), (int)line.size()));
+  }
+  if (O.closedref) {                                                  // ClosedRefSink::OnQueryDone closedrefsink.cpp:33-118 (all raw hits)
+    std::vector<const char *> tls(n_all);
+    for (uint32_t j = 0; j < n_all; ++j) tls[j] = db.labels[h[j].target].c_str();
+    put_to(O.tabbed, ugs_closedref_add(O.closedref, qlab, h, n_all, tls.data(), line.data(), (int)line.size()));
   }
   h += first;
   if (n == 0) {                                                       // OutputMatchedFalse outputsink.cpp:392-403
@@ -218,6 +225,7 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
+  std::string tabbedout; bool closedref_cmd = false;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -228,6 +236,7 @@ int main(int argc, char **argv)
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
     else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
+    else if (a == "-closed_ref") { qpath = val(); closedref_cmd = true; } else if (a == "-tabbedout") tabbedout = val();
     else if (a == "-otutabout") otutabout = val(); else if (a == "-mapout") mapout = val(); else if (a == "-stepwords") stepwords = atol(val());
     else if (a == "-usearch_local") { qpath = val(); local_cmd = true; } else if (a == "-evalue") evalue = atof(val());
     else if (a == "-xdrop_u") xdrop_u = atof(val()); else if (a == "-xdrop_g") xdrop_g = atof(val()); else if (a == "-ka_dbsize") ka_dbsize = atof(val());
@@ -285,6 +294,12 @@ int main(int argc, char **argv)
     if (stepwords < 0) stepwords = 0;
     if (strand.empty()) strand = "both";
   }
+  if (closedref_cmd) {                                                // cmd_closed_ref searchcmd.cpp:11-19, terminator.cpp:16-20
+    if (id < 0) id = 0.97;
+    if (stepwords < 0) stepwords = 0;
+    if (maxacc < 0) maxacc = 4;
+    if (maxrej < 0) maxrej = 16;
+  }
   if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
@@ -325,6 +340,7 @@ int main(int argc, char **argv)
   O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
   O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
+  if (closedref_cmd) { O.closedref = ugs_closedref_create(); O.tabbed = open_out(tabbedout); }
   Searcher searcher(p, db, device);
   std::string masked;
   if (O.user || O.aln || O.pairs || O.qseg || O.tseg || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
@@ -347,7 +363,8 @@ int main(int argc, char **argv)
     }
     total += q.size();
   }
-  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg}) if (f) fclose(f);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed}) if (f) fclose(f);
+  if (O.closedref) ugs_closedref_destroy(O.closedref);
   if (O.otutab) {                                                     // OTUTableSink::OnAllDone otutabsink.cpp:60-76
     uint64_t assigned = 0, tot = 0;
     ugs_otutab_totals(O.otutab, &assigned, &tot);

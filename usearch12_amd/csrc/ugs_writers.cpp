@@ -410,6 +410,73 @@ extern "C" int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64
   return UGS_OK;
 }
 
+// ---------------------------------------------------------------- closed_ref sink
+// ClosedRefSink::OnQueryDone closedrefsink.cpp:33-118: the top hit's target becomes (or is) a reference OTU in order of
+// first use; -tabbedout gets one line per query.  (-dbotus / -dataotus, OnAllDone :120-164, are not built: the
+// reference itself crashes when either is given - it keeps pointers into recycled SeqInfo objects - so there is
+// nothing to pin them against.)
+namespace {
+}  // namespace
+
+struct ugs_closedref {
+  std::map<uint32_t, unsigned> target_to_otu;
+  std::vector<std::string> ref_labels;
+  std::vector<unsigned> total_size, members;
+  unsigned long long assigned = 0, unassigned = 0;
+};
+
+extern "C" ugs_closedref *ugs_closedref_create(void) { return new ugs_closedref(); }
+extern "C" void ugs_closedref_destroy(ugs_closedref *c) { delete c; }
+
+extern "C" int ugs_closedref_add(ugs_closedref *c, const char *qlabel, const ugs_hit *hits, uint32_t n, const char *const *tlabels, char *line, int cap)
+{
+  if (!c || !qlabel || (n && (!hits || !tlabels))) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (n == 0) { ++c->unassigned; return snprintf(line, line ? (size_t)cap : 0, "%s\t*\t*\t*\t*\t*\n", qlabel); }
+  const unsigned size = size_from_label(qlabel, 1);
+  uint32_t top = 0;
+  ugs_hits_to_report(hits, n, 0, 1, 0, &top);                                             // HitMgr::GetTopHit
+  ++c->assigned;
+  const uint32_t tt = hits[top].target;
+  auto fid = [&](uint32_t i) { return (float)(hits[i].aln_len == 0 ? 0.0 : (double)hits[i].ids / (double)hits[i].aln_len); };   // HitMgr::GetFractId
+  const double TopFractId = fid(0);
+  unsigned otu;
+  auto it = c->target_to_otu.find(tt);
+  if (it == c->target_to_otu.end()) {
+    otu = (unsigned)c->ref_labels.size();
+    c->target_to_otu[tt] = otu;
+    c->ref_labels.emplace_back(tlabels[top]);
+    c->total_size.push_back(0); c->members.push_back(0);
+  } else otu = it->second;
+  c->total_size[otu] += size;
+  const unsigned member = c->members[otu]++;
+  unsigned ties = 0;
+  std::string ties_str;
+  if (n > 1)
+    for (uint32_t i = 0; i < n; ++i) {
+      if ((double)fid(i) < TopFractId) break;
+      if (hits[i].target == tt) continue;
+      if (ties > 0) ties_str += ",";
+      ties_str += tlabels[i];
+      ++ties;
+    }
+  std::string out = std::string(qlabel) + "\t" + std::to_string(otu) + "\t" + std::to_string(member) + "\t" + tlabels[top];
+  char num[64];
+  snprintf(num, sizeof num, "\t%.1f\tties=%u", TopFractId * 100.0, ties);
+  out += num;
+  if (ties > 0) out += ":" + ties_str;
+  out += "\n";
+  return snprintf(line, line ? (size_t)cap : 0, "%s", out.c_str());
+}
+
+extern "C" int ugs_closedref_totals(const ugs_closedref *c, uint64_t *assigned, uint64_t *unassigned, uint32_t *otus)
+{
+  if (!c) return UGS_E_ARG;
+  if (assigned) *assigned = c->assigned;
+  if (unassigned) *unassigned = c->unassigned;
+  if (otus) *otus = (uint32_t)c->total_size.size();
+  return UGS_OK;
+}
+
 // ---------------------------------------------------------------- -alnout
 // OutputSink::OutputReport / OutputReportGlobal outputsink.cpp:243-258,338-356 (per-query hit table) and WriteAln
 // alnout.cpp:41-171 (the alignment in rows of -rowlen 80 columns with position labels, annotation row
