@@ -123,3 +123,73 @@ def test_device_results_plus_sort_equal_fetch():
     for f in hits.dtype.names:
         if f != "cigar_off":
             assert np.array_equal(ghits[f], hits[f]), f
+
+
+def _seqset(seqs, prefix):
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return synth.SeqSet(np.frombuffer(b"".join(seqs), dtype=np.uint8), offs, lambda i: "%s%d" % (prefix, i))
+
+
+def _vs_oracle(db, qs, aa=False, **kw):
+    p = capi.params(is_nucleo=not aa, **kw)
+    hits, nh, pool = capi.UgsDB(p, db.seqs, db.offs, device=0).search(qs.seqs, qs.offs)
+    odb = orc.OrcDB(orc.params(is_nucleo=not aa, **kw), db.seqs, db.offs)
+    oh, onh, opool = odb.search(qs.seqs, qs.offs, nthreads=4)
+    _same_records(hits, nh, pool, oh, onh, opool)
+    return hits, nh
+
+
+def test_gpu_local_edge_shapes():
+    """queries of 1..7 letters (QL <= W has no seed words), targets shorter than 2W, wildcard-only and low-complexity
+    sequences (hundreds of seeds per target position, the seed list is cut and resumed), lower-case input"""
+    rng = np.random.default_rng(5)
+    nt = b"ACGT"
+    rnd = lambda n: bytes(nt[i] for i in rng.integers(0, 4, n))
+    core = rnd(300)
+    targets = [core, core[:9], core[:10], core[:11], b"A" * 400, b"AC" * 150, b"N" * 80, rnd(7), core[100:260] + b"A" * 200, rnd(500)]
+    targets += [bytes(core[:150]) + rnd(150) for _ in range(40)]
+    queries = [core[:k] for k in range(1, 8)] + [core, core.lower(), b"A" * 300, b"AC" * 200, b"N" * 60, b"A" * 5 + core[5:120],
+               core[:120] + b"A" * 150 + core[120:], core[40:52], core[40:70], b"ACGTN" * 30, core[::-1]]
+    db, qs = _seqset(targets, "t"), _seqset(queries, "q")
+    for ev, acc in ((1e-6, 1), (10.0, 8)):
+        hits, nh = _vs_oracle(db, qs, id=None, local_evalue=ev, strand_both=1, max_accepts=acc, max_rejects=16, max_hsps=32)
+    assert nh[7] > 0 and nh[:5].sum() == 0
+
+
+def test_gpu_local_long_sequences_split_extension():
+    """sides longer than 4096 letters go through the split drivers inside k_local (XDropFwdSplit / XDropBwdSplit): queries
+    of up to 3 900 letters (the small ranking path samples every query word; its device envelope is 4 095 of them) placed
+    deep inside targets of up to 12 000"""
+    rng = np.random.default_rng(6)
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    tg, qr = [], []
+    for L in (9000, 6100, 4097, 4500, 12000):
+        t = nt[rng.integers(0, 4, L)]
+        q = t.copy()
+        m = rng.random(L) < 0.02
+        q[m] = nt[rng.integers(0, 4, int(m.sum()))]
+        q = np.delete(q, rng.integers(0, L, 6))
+        tg.append(t.tobytes()); qr += [q[:3900].tobytes(), q[-3800:].tobytes(), q[L // 2:L // 2 + 3000].tobytes()]
+    tg += [nt[rng.integers(0, 4, 5000)].tobytes() for _ in range(5)]
+    db, qs = _seqset(tg, "t"), _seqset(qr, "q")
+    hits, nh = _vs_oracle(db, qs, id=None, local_evalue=1e-6, strand_both=0, max_accepts=2, max_rejects=4)
+    assert np.all(nh >= 1) and int((hits["qhi"] - hits["qlo"]).max()) > 3700 and int(hits["tlo"].max()) > 8000
+
+
+def test_gpu_local_protein_wildcards_and_stops():
+    rng = np.random.default_rng(7)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    base = [aa[rng.integers(0, 20, int(rng.integers(40, 600)))] for _ in range(60)]
+    tg = [b.tobytes() for b in base]
+    qr = []
+    for b in base[:40]:
+        q = b.copy()
+        m = rng.random(len(q)) < 0.15
+        q[m] = aa[rng.integers(0, 20, int(m.sum()))]
+        q = q.tobytes()
+        k = len(q) // 2
+        qr += [q, q[:k] + b"X" * 6 + q[k:], q[:k] + b"*" + q[k:], q[:k].lower() + q[k:], b"B" + q[1:k] + b"ZJUO" + q[k:]]
+    db, qs = _seqset(tg, "t"), _seqset(qr, "q")
+    hits, nh = _vs_oracle(db, qs, aa=True, id=None, local_evalue=1e-3, max_accepts=3, max_rejects=8, max_hsps=16)
+    assert len(hits) > 150
