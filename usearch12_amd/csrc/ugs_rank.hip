@@ -556,6 +556,115 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// ---- mid-identity configuration: 16-255 sampled rows, 8-bit counters, table covers a whole partition.
+// The register-resident scheme of the 4-bit path without its SGPR-resident row descriptors (too many rows): lane r
+// holds row r's slot, row start and, per partition, its sub-row bounds (one vector load of the partition table for 64
+// rows); a row's load address is made wave-uniform with three readlanes.  Rows are handled NR at a time: NR loads in
+// flight, NR branch-free LDS atomics.  The postings are read twice (count, then ordered clear + extract); the second
+// read hits the L2.  A partition with a sub-row longer than a wavefront goes through the generic code.
+template <int NR>
+__device__ __forceinline__ void scan_fast8(const ScanCtx &s)
+{
+  typedef uint32_t __attribute__((address_space(3))) *lds32;
+  const int lane = s.lane;
+  const uint32_t ns = s.ns;
+  const uint32_t tb = (uint32_t)(uintptr_t)s.tbl;              // LDS byte address of the table (a multiple of 16)
+  const uint32_t dummy_x = (s.tbl_words + (uint32_t)lane) * 4u;   // lanes without a posting aim at a private word behind the table
+  unsigned long long cache1 = KEY_INF;
+  for (uint32_t p = s.wave; p < s.np; p += s.wpb) {
+    const uint32_t base_t = p * s.gsize;
+    bool tail = false;
+    uint32_t tot = 0, nrows = 0;
+    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+      uint32_t len = 0;
+      if (i0 + lane < ns) { const uint32_t *pp = s.part + (uint64_t)s.s_slots[i0 + lane] * (s.np + 1) + p; len = pp[1] - pp[0]; }
+      tail = tail || __ballot(len > 64) != 0;
+      tot += __builtin_amdgcn_readlane((int)wave_incl_sum_u32(len), 63);
+      nrows += (uint32_t)__popcll(__ballot(len != 0));
+    }
+    // a sub-row longer than a wavefront, or sparse sub-rows (protein indexes: a handful of postings per row and
+    // partition - the generic code flattens those row-major into full instructions): not this path's case
+    if (tail || tot < 32u * nrows) { range_generic<8, false, true>(s, p, false, base_t, 0, 0, 0); continue; }
+    for (int pass = 0; pass < 2; ++pass) {
+      for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+        uint64_t rstart = 0; uint32_t rlen = 0;                  // lane r: first posting and length of row i0+r's sub-row
+        if (i0 + lane < ns) {
+          const uint32_t slot = s.s_slots[i0 + lane];
+          const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
+          const uint32_t pa = pp[0];
+          rstart = s.row_off[slot] + pa; rlen = pp[1] - pa;
+        }
+        uint64_t rows = __ballot(rlen != 0);
+        while (rows) {
+          uint32_t v[NR], ad[NR], sh[NR], ln[NR], rix[NR];
+#pragma unroll
+          for (int u = 0; u < NR; ++u) {
+            ln[u] = 0; rix[u] = 0; v[u] = 0;
+            if (rows) {
+              const int r = __ffsll((long long)rows) - 1;
+              rows &= rows - 1;
+              const uint64_t st = shfl64(rstart, r);
+              ln[u] = (uint32_t)__builtin_amdgcn_readlane((int)rlen, r);
+              rix[u] = i0 + (uint32_t)r;
+              v[u] = (s.postings + st)[(uint32_t)lane];        // uniform base + lane: lanes beyond the sub-row read padding
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < NR; ++u) {
+            const uint32_t x = (uint32_t)lane < ln[u] ? v[u] - base_t : dummy_x;
+            ad[u] = tb + (x & ~3u);
+            sh[u] = (x & 3u) << 3;
+          }
+          if (pass == 0) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[u], 1u << sh[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
+          }
+          // ordered clears with return (LDS executes a wave's atomics in program order): only the first row holding a
+          // target sees its counter and gets the final count back, later rows read 0
+          uint32_t old[NR];
+#pragma unroll
+          for (int u = 0; u < NR; ++u) old[u] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[u], ~(255u << sh[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          uint32_t c[NR], cnt = 0;
+          const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
+#pragma unroll
+          for (int u = 0; u < NR; ++u) {
+            c[u] = (uint32_t)lane < ln[u] ? (old[u] >> sh[u]) & 255u : 0u;
+            cnt += c[u] >= 2u ? 1u : 0u;
+            if (s.small_path || rix[u] <= c1hi) {                // uniform: can this row still lower fp[1]?
+              const uint64_t pos = s.small_path ? (uint64_t)v[u] : (((uint64_t)rix[u] << 32) | v[u]);
+              const bool f1 = c[u] == 1 && pos < cache1;
+              if (__ballot(f1)) {
+                if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                cache1 = s.s_fp[1];
+              }
+            }
+          }
+          if (__ballot(cnt != 0)) {
+            const uint32_t incl = wave_incl_sum_u32(cnt);
+            const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s.sh->emit_n, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            uint32_t o = base + incl - cnt;
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+              if (c[u] >= 2u) {
+                const uint64_t pos = s.small_path ? (uint64_t)v[u] : (((uint64_t)rix[u] << 32) | v[u]);
+                atomicMin(&s.s_fp[c[u]], (unsigned long long)pos);
+                put_key(s, o, make_key(c[u], pos));
+                ++o;
+              }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <bool FILL, bool BATCH>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
@@ -564,7 +673,10 @@ __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t
       if (s.ns <= 8) scan_fast4<8>(s); else if (s.ns <= 11) scan_fast4<11>(s); else scan_fast4<12>(s);
     }
     else scan_generic<4, FILL, BATCH>(s, need, fill_limit);
-  } else if (cb == 8) scan_generic<8, FILL, BATCH>(s, need, fill_limit);
+  } else if (cb == 8) {
+    if (!FILL && BATCH && s.tbl_words * 4 >= s.gsize) scan_fast8<8>(s);
+    else scan_generic<8, FILL, BATCH>(s, need, fill_limit);
+  }
   else scan_generic<16, FILL, BATCH>(s, need, fill_limit);
 }
 
@@ -989,6 +1101,91 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
         }
         __syncthreads();
         nsel = sh->n_sel; last = sh->last_key; exhausted = sh->exhausted != 0;
+      } else if (BATCH) {
+        // ---- many emitted entries (mid-identity searches: ~1 % of the database shares two of 40 sampled words): radix
+        // select.  Byte by byte from the top of the key, a 256-bin histogram of the entries still in the running for
+        // the K-th place narrows the class that holds it; when the entries below the class plus the class itself fit
+        // the ranking buffer they are gathered and ranked all-pairs.  5 passes over the entries instead of K.
+        const uint32_t want = K - nsel;
+        const uint32_t cap = 4 * UGS_KMAX < 64u * (uint32_t)wpb ? 4 * UGS_KMAX : 64u * (uint32_t)wpb;
+        auto eligible = [&](uint64_t key) -> bool { return ((nsel == 0 && last == 0) || key > last) && kept(key); };
+        if (tid == 0) { sh->red[0] = 0; sh->red[1] = 0; sh->qcut = 0; sh->pad2 = 0xffffffffu; sh->pad3 = 0; sh->ncl = 0; }
+        __syncthreads();
+        for (int shift = 48; shift >= 0; shift -= 8) {
+          for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
+          __syncthreads();
+          const uint64_t pref = sh->red[0], pmask = sh->red[1];
+          for (uint32_t k = tid; k < N; k += nthr) {
+            const uint64_t key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
+            if ((key & pmask) == pref && eligible(key)) atomicAdd(&sh->hist[(uint32_t)(key >> shift) & 255u], 1u);
+          }
+          __syncthreads();
+          if (wave == 0) {
+            const uint32_t nb = sh->qcut, rem = want - nb;      // entries surely selected so far / still to come from this class
+            uint32_t loc[4], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { loc[e] = sh->hist[lane * 4 + e]; sum += loc[e]; }
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
+            uint32_t run = incl - sum, dsel = 0xffffffffu, before = 0, csz = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (dsel == 0xffffffffu && run + loc[e] >= rem) { dsel = lane * 4 + e; before = run; csz = loc[e]; } run += loc[e]; }
+            const uint64_t mk = __ballot(dsel != 0xffffffffu);
+            if (mk) {
+              const int Ls = __ffsll((long long)mk) - 1;
+              if (lane == Ls) {
+                sh->qcut = nb + before; sh->pad2 = csz;
+                sh->red[0] = pref | ((uint64_t)dsel << shift); sh->red[1] = pmask | (255ull << shift);
+              }
+            } else if (lane == 0) { sh->pad3 = 1; sh->pad2 = __builtin_amdgcn_readlane((int)incl, 63); }   // fewer than `want` entries in all: take them all
+          }
+          __syncthreads();
+          if (sh->pad3 || sh->qcut + sh->pad2 <= cap) break;
+        }
+        {
+          const uint64_t pref = sh->red[0], pmask = sh->red[1];
+          for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
+            const uint32_t k = k0 + tid;
+            uint64_t key = 0; bool take = false;
+            if (k < N) { key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k]; take = (key & pmask) <= pref && eligible(key); }
+            const uint64_t mk = __ballot(take);
+            if (mk) {
+              uint32_t base = 0;
+              if (lane == 0) base = atomicAdd(&sh->ncl, (uint32_t)__popcll(mk));
+              base = __builtin_amdgcn_readfirstlane(base);
+              const uint32_t slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+              if (take && slot < 4 * UGS_KMAX) s_wsel[slot] = key;
+            }
+          }
+          __syncthreads();
+          const uint32_t ncl = sh->ncl < cap ? sh->ncl : cap;
+          if ((uint32_t)tid < 8u && ncl + (uint32_t)tid < 4 * UGS_KMAX + 8) s_wsel[ncl + tid] = KEY_INF;
+          __syncthreads();
+          const uint32_t me = wave * 64 + lane;
+          const uint64_t mykey = me < ncl ? s_wsel[me] : KEY_INF;
+          uint32_t rank = 0;
+          if (wave * 64u < ncl) {
+            const uint4 *w4 = (const uint4 *)s_wsel;
+            const uint32_t n8 = (ncl + 7u) & ~7u;
+            for (uint32_t j = 0; j < n8; j += 8) {
+              const uint4 x0 = w4[(j >> 1) + 0], x1 = w4[(j >> 1) + 1], x2 = w4[(j >> 1) + 2], x3 = w4[(j >> 1) + 3];
+              rank += ((((uint64_t)x0.y << 32) | x0.x) < mykey) + ((((uint64_t)x0.w << 32) | x0.z) < mykey);
+              rank += ((((uint64_t)x1.y << 32) | x1.x) < mykey) + ((((uint64_t)x1.w << 32) | x1.z) < mykey);
+              rank += ((((uint64_t)x2.y << 32) | x2.x) < mykey) + ((((uint64_t)x2.w << 32) | x2.z) < mykey);
+              rank += ((((uint64_t)x3.y << 32) | x3.x) < mykey) + ((((uint64_t)x3.w << 32) | x3.z) < mykey);
+            }
+          }
+          const uint32_t nout = ncl < want ? ncl : want;
+          if (me < ncl && rank < want) {
+            bv.cand[(uint64_t)unit * K + nsel + rank] = key_target(mykey);
+            bv.cand_cnt[(uint64_t)unit * K + nsel + rank] = key_count(mykey);
+            if (rank + 1 == nout) sh->last_key = mykey;
+          }
+          __syncthreads();
+          if (tid == 0) { sh->n_sel = nsel + nout; sh->exhausted = ncl < want ? 1u : 0u; }
+          __syncthreads();
+          nsel = sh->n_sel; last = sh->last_key; exhausted = sh->exhausted != 0;
+        }
       } else {
         while (nsel < K) {
           uint64_t best = KEY_INF;
