@@ -181,7 +181,7 @@ def main():
         # HBM traffic per launch from the PMC passes of the same command (profiles/*_pmc.json, FETCH_SIZE
         # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
         traffic = None
-        for pmc_name in ("r01j_pmc.json", "r01i_pmc.json", "r01h_pmc.json", "r01g_pmc.json", "r01f_pmc.json", "r01_pmc.json"):       # newest PMC pass first
+        for pmc_name in ("r01k_pmc.json", "r01j_pmc.json", "r01i_pmc.json", "r01h_pmc.json", "r01g_pmc.json", "r01f_pmc.json", "r01_pmc.json"):       # newest PMC pass first
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
                 if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
