@@ -57,8 +57,18 @@ extern "C" {
  *                 tested when -id is set), -mincols, -maxgaps, -query_cov, -max_query_cov, -target_cov,
  *                 -max_target_cov, -maxdiffs, -mindiffs.  A filter is active when its UGS_F_* bit is set; float
  *                 values are compared as (double)(float)value like every option (opts.cpp:265).  A hit that fails
- *                 one is a reject for the terminator, exactly like a failed -id.  (The pair filters of
- *                 Accepter::RejectPair - -self, -selfid, -minqt ... - are not implemented.)
+ *                 one is a reject for the terminator, exactly like a failed -id.  UGS_F_ABSKEW (-abskew: target size /
+ *                 query size from the ;size= annotations, arscorer.cpp:809-816) needs the pair keys below.
+ *   pair_mask + values: the pair filters of Accepter::RejectPair (accepter.cpp:140-197): -self (equal labels), -notself,
+ *                 -selfid (same length and identical stored letters), -min_sizeratio, -minqt/-maxqt (query length /
+ *                 target length), -minsl/-maxsl (shorter / longer).  usearch_global only.  On the Big ranking path a
+ *                 rejected pair is a reject for the terminator (udbusortedsearcherbig.cpp:118-127); on the small path it is
+ *                 skipped without being counted (udbusortedsearcher.cpp:138-151 ignores SetTarget's result, the aligner
+ *                 then refuses the pair, searcher.cpp:63-67): there refused targets are dropped where the candidates are
+ *                 chosen (k_rank), except for -selfid, which needs the letters: the device keeps up to 32 candidates more
+ *                 per strand for it and ugs_batch_sync fails with UGS_E_ENVELOPE if a walk passes over more identical
+ *                 sequences than that (never a silently shortened walk).  Labels and sizes reach the
+ *                 device as integer keys: ugs_db_set_pair_keys / ugs_batch_set_pair_keys.
  *   local         0 = usearch_global; 1 = usearch_local: the same U-sort candidate walk, but every candidate goes
  *                 through LocalAligner2::AlignMulti (localmulti.cpp:9-118: seed every hsp_word_len-mer the target
  *                 shares with the query, LocalAligner::AlignPos localaligner.cpp:101-222: ungapped x-drop xdrop_u,
@@ -70,9 +80,14 @@ extern "C" {
  *   local_open/local_ext  -lopen/-lext as penalties: -10 / -1 for both alphabets (alnparams.cpp:362-369)
  *   max_hsps      hit slots per (query strand, accepted target); more HSPs than that => UGS_E_CAPACITY
  */
+/* pair filters of Accepter::RejectPair (accepter.cpp:140-197), ugs_params.pair_mask */
+enum {
+  UGS_P_SELF = 1, UGS_P_NOTSELF = 2, UGS_P_SELFID = 4, UGS_P_MIN_SIZERATIO = 8, UGS_P_MINQT = 16, UGS_P_MAXQT = 32,
+  UGS_P_MINSL = 64, UGS_P_MAXSL = 128
+};
 enum {
   UGS_F_MAXID = 1, UGS_F_MINCOLS = 2, UGS_F_MAXGAPS = 4, UGS_F_QUERY_COV = 8, UGS_F_MAX_QUERY_COV = 16,
-  UGS_F_TARGET_COV = 32, UGS_F_MAX_TARGET_COV = 64, UGS_F_MAXDIFFS = 128, UGS_F_MINDIFFS = 256
+  UGS_F_TARGET_COV = 32, UGS_F_MAX_TARGET_COV = 64, UGS_F_MAXDIFFS = 128, UGS_F_MINDIFFS = 256, UGS_F_ABSKEW = 512
 };
 typedef struct ugs_params {
   int32_t  is_nucleo;
@@ -104,7 +119,9 @@ typedef struct ugs_params {
   float    local_ext;      /* -1                                       */
   float    ka_dbsize;      /* 1e9                                      */
   uint32_t max_hsps;       /* 8                                        */
-  uint32_t reserved_[2];
+  uint32_t pair_mask;      /* UGS_P_* bits                             */
+  float    min_sizeratio, minqt, maxqt, minsl, maxsl, abskew;
+  uint32_t reserved_[1];
 } ugs_params;
 
 /*
@@ -159,6 +176,13 @@ int ugs_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs,
                   uint32_t nseq, int device, ugs_db **out);
 void ugs_db_destroy(ugs_db *db);
 /* introspection used by tests/bench: number of index postings, slots, bytes in HBM */
+/* Per-sequence keys for the pair filters and -abskew: label_key[i] identifies sequence i's label (equal labels <=> equal
+ * keys, the caller interns the strings; the same key space for DB and queries), size[i] is its ;size= annotation or
+ * UINT32_MAX when it has none (GetSizeFromLabel(label, UINT_MAX) accepter.cpp:150-151).  Either array may be NULL when no
+ * active filter needs it.  Required before a search whenever pair_mask or UGS_F_ABSKEW is set. */
+int ugs_db_set_pair_keys(ugs_db *db, const uint32_t *label_key, const uint32_t *size);
+int ugs_batch_set_pair_keys(ugs_batch *b, const uint32_t *label_key, const uint32_t *size);   /* after ugs_batch_upload */
+
 int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint64_t *hbm_bytes);
 
 /*

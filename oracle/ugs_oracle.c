@@ -238,6 +238,9 @@ struct orc_db {
   int big;              /* udbusortedsearcher.cpp:39-58 latch (DB is static here) */
   orc_stats stats;
   uint32_t maxlen;
+  /* pair filters / -abskew: label keys and ;size= annotations (UINT32_MAX = none) of the DB and of the current queries */
+  uint32_t *t_key, *t_size;
+  const uint32_t *q_key, *q_size;
 };
 
 /* fastmask.cpp:88-158 FastMaskSeq, soft mask (hardmask off), in place */
@@ -414,10 +417,20 @@ int orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, u
   return UGS_OK;
 }
 
+int orc_db_set_pair_keys(orc_db *db, const uint32_t *label_key, const uint32_t *size)
+{
+  free(db->t_key); free(db->t_size); db->t_key = db->t_size = NULL;
+  if (label_key) { db->t_key = (uint32_t *)malloc((size_t)db->nseq * 4 + 4); memcpy(db->t_key, label_key, (size_t)db->nseq * 4); }
+  if (size) { db->t_size = (uint32_t *)malloc((size_t)db->nseq * 4 + 4); memcpy(db->t_size, size, (size_t)db->nseq * 4); }
+  return 0;
+}
+/* keys of the queries of the NEXT orc_search_batch (borrowed pointers) */
+void orc_set_query_pair_keys(orc_db *db, const uint32_t *label_key, const uint32_t *size) { db->q_key = label_key; db->q_size = size; }
+
 void orc_db_destroy(orc_db *db)
 {
   if (!db) return;
-  free(db->seqs); free(db->offs); free(db->row_off); free(db->postings); free(db);
+  free(db->seqs); free(db->offs); free(db->row_off); free(db->postings); free(db->t_key); free(db->t_size); free(db);
 }
 
 const char *orc_db_masked(const orc_db *db) { return db->seqs; }
@@ -1197,6 +1210,34 @@ static void hb_push(HitBuf *hb, const ugs_hit *h, const char *path)
  * (searcher.cpp:52-61), Accepter::IsAcceptLo (accepter.cpp:27-94, default filters), Terminator
  * (terminator.cpp:64-100) */
 /* Accepter::IsAcceptLo accepter.cpp:24-91 on the FillLo statistics of a global hit (coverages: arscorer.cpp:122-154) */
+/* Accepter::RejectPair accepter.cpp:140-197 (Global accepter).  q is the strand's sequence as searched. */
+static int reject_pair(const orc_db *db, uint32_t qindex, const byte *q, unsigned QL, uint32_t t, const byte *T, unsigned TL)
+{
+  const ugs_params *p = &db->p;
+  const unsigned m = p->pair_mask;
+  if (!m) return 0;
+  if (m & (UGS_P_SELF | UGS_P_NOTSELF)) {
+    int same = db->q_key && db->t_key && db->q_key[qindex] == db->t_key[t];
+    if ((m & UGS_P_SELF) && same) return 1;
+    if ((m & UGS_P_NOTSELF) && !same) return 1;
+  }
+  if ((m & UGS_P_SELFID) && TL == QL && memcmp(q, T, QL) == 0) return 1;
+  if (m & UGS_P_MIN_SIZERATIO) {
+    unsigned QS = db->q_size ? db->q_size[qindex] : UINT_MAX, TS = db->t_size ? db->t_size[t] : UINT_MAX;
+    double Ratio = (double)TS / (double)QS;
+    if (Ratio < (double)p->min_sizeratio) return 1;
+  }
+  if (m & (UGS_P_MINQT | UGS_P_MAXQT | UGS_P_MINSL | UGS_P_MAXSL)) {
+    double qq = (double)QL, tt = (double)TL, ss = (double)(QL < TL ? QL : TL), ll = (double)(QL > TL ? QL : TL);
+    double qt = qq / tt, sl = ss / ll;
+    if ((m & UGS_P_MINQT) && qt < (double)p->minqt) return 1;
+    if ((m & UGS_P_MAXQT) && qt > (double)p->maxqt) return 1;
+    if ((m & UGS_P_MINSL) && sl < (double)p->minsl) return 1;
+    if ((m & UGS_P_MAXSL) && sl > (double)p->maxsl) return 1;
+  }
+  return 0;
+}
+
 static int is_accept_lo(const ugs_params *p, const ugs_hit *h)
 {
   const unsigned m = p->filter_mask;
@@ -1544,6 +1585,15 @@ static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, 
     const byte *T = (const byte *)db->seqs + db->offs[t];
     unsigned TL = (unsigned)(db->offs[t + 1] - db->offs[t]);
     w->st.target_letters += TL; ++w->st.pairs_aligned;
+    if (db->p.pair_mask && reject_pair(db, qindex, q, QL, t, T, TL)) {
+      /* Big path: SetTarget fails -> Terminate(HM, false) (udbusortedsearcherbig.cpp:118-127); small path: SetTarget's
+       * result is ignored and AlignPos returns without touching the terminator (udbusortedsearcher.cpp:145-147, searcher.cpp:63-67) */
+      --w->st.pairs_aligned; w->st.target_letters -= TL;
+      if (!db->big) continue;
+      ++RejectCount;
+      if (db->p.max_rejects > 0 && RejectCount == db->p.max_rejects) break;
+      continue;
+    }
     float fid;
     int aligned = global_align(w, T, TL, &fid);
     int Accept = 0;
@@ -1551,6 +1601,10 @@ static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, 
       ugs_hit h; memset(&h, 0, sizeof(h));
       fill_hit(db, w->path, q, QL, T, TL, &h);
       Accept = is_accept_lo(&db->p, &h);
+      if (Accept && (db->p.filter_mask & UGS_F_ABSKEW)) {       /* accepter.cpp:89-90, GetAbSkew arscorer.cpp:809-816 */
+        unsigned QS = db->q_size ? db->q_size[qindex] : UINT_MAX, TS = db->t_size ? db->t_size[t] : UINT_MAX;
+        if ((double)TS / (double)QS < (double)db->p.abskew) Accept = 0;
+      }
       if (Accept) { h.query = qindex; h.target = t; h.strand = (uint32_t)strand; hb_push(hb, &h, w->path); ++w->st.hits; }
     }
     if (Accept) ++AcceptCount; else ++RejectCount;

@@ -24,6 +24,9 @@ typedef struct orc_db orc_db;
 int  orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs,
                    uint32_t nseq, orc_db **out);
 void orc_db_destroy(orc_db *db);
+/* keys for the pair filters / -abskew (see include/ugs.h ugs_db_set_pair_keys); query keys are borrowed until the next search */
+int  orc_db_set_pair_keys(orc_db *db, const uint32_t *label_key, const uint32_t *size);
+void orc_set_query_pair_keys(orc_db *db, const uint32_t *label_key, const uint32_t *size);
 
 /* masked DB letters (same offsets as the input) */
 const char *orc_db_masked(const orc_db *db);

@@ -94,3 +94,46 @@ def local_params_kw(c):
     kw["local_evalue"] = c["evalue"]
     kw["id"] = c.get("id")
     return kw
+
+
+# ---- pair-filter cases (tests/golden/pairs_manifest.json, make_golden_pairs.py)
+PAIRS_MANIFEST = json.load(open(os.path.join(GOLD, "pairs_manifest.json")))
+_spec_p = importlib.util.spec_from_file_location("make_golden_pairs", os.path.join(GOLD, "make_golden_pairs.py"))
+_mgp = importlib.util.module_from_spec(_spec_p)
+_spec_p.loader.exec_module(_mgp)
+
+
+def pair_case_names():
+    return sorted(PAIRS_MANIFEST)
+
+
+def load_pairs(name):
+    c = PAIRS_MANIFEST[name]
+    db, qs = _mgp.make_inputs(c)
+    assert _mg.digest(db) == c["db_sha256"] and _mg.digest(qs) == c["q_sha256"], "generator drift for " + name
+    return c, db, qs, open(os.path.join(GOLD, name + ".b6")).read()
+
+
+def pair_params_kw(c):
+    kw = params_kw(c)
+    for k, v in c["opts"].items():
+        kw[k] = True if v is None else v
+    return kw
+
+
+def pair_keys(db, qs):
+    """(db label keys, db sizes, query label keys, query sizes): interned labels and ;size= annotations (UINT32_MAX = none)"""
+    ids = {}
+
+    def keys(ss):
+        k = np.zeros(ss.n, np.uint32)
+        z = np.full(ss.n, 0xffffffff, np.uint32)
+        for i, lab in enumerate(ss.labels()):
+            k[i] = ids.setdefault(lab, len(ids))
+            j = lab.find(";size=")
+            if j >= 0:
+                z[i] = int(lab[j + 6:].split(";")[0])
+        return k, z
+    tk, tz = keys(db)
+    qk, qz = keys(qs)
+    return tk, tz, qk, qz

@@ -4,7 +4,7 @@ import os
 import subprocess
 import numpy as np
 
-from usearch12_amd.abi import FILTER_BITS, Params, HIT_DTYPE, ptr, as_u8, cigar_text, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from usearch12_amd.abi import FILTER_BITS, PAIR_BITS, Params, HIT_DTYPE, ptr, as_u8, cigar_text, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
@@ -53,6 +53,8 @@ def lib():
         L.orc_format_uc_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.orc_format_uc_nohit.restype = C.c_int
         L.orc_format_uc_nohit.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_db_set_pair_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_query_pair_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_params_set_local.argtypes = [C.POINTER(Params), C.c_double, C.c_int]
         L.orc_local_evalue.argtypes = [C.POINTER(Params), C.c_double, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_local_rescore_diffs.restype = C.c_ulong
@@ -97,6 +99,12 @@ def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
     if local_evalue is not None:
         lib().orc_params_set_local(C.byref(p), float(local_evalue), 0 if id is None else 1)
     for k, v in kw.items():
+        if k in PAIR_BITS:              # pair filters of Accepter::RejectPair (-self, -minqt ...): flag or value + bit
+            if v is not None and v is not False:
+                p.pair_mask |= PAIR_BITS[k]
+                if k not in ("self", "notself", "selfid"):
+                    setattr(p, k, v)
+            continue
         if not hasattr(p, k):
             raise AttributeError(k)
         setattr(p, k, v)
@@ -138,6 +146,14 @@ class OrcDB:
         n = int(ro[-1])
         po = np.ctypeslib.as_array(C.cast(lib().orc_db_postings(self.h), C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
         return ro, po
+
+    def set_pair_keys(self, label_key, size):
+        self._tk = np.ascontiguousarray(label_key, np.uint32); self._tz = np.ascontiguousarray(size, np.uint32)
+        lib().orc_db_set_pair_keys(self.h, self._tk.ctypes.data, self._tz.ctypes.data)
+
+    def set_query_pair_keys(self, label_key, size):
+        self._qk = np.ascontiguousarray(label_key, np.uint32); self._qz = np.ascontiguousarray(size, np.uint32)
+        lib().orc_set_query_pair_keys(self.h, self._qk.ctypes.data, self._qz.ctypes.data)
 
     def search(self, qseqs, qoffs, nthreads=1):
         qseqs = as_u8(qseqs)

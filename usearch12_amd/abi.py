@@ -22,15 +22,19 @@ class Params(C.Structure):
         ("mincols", C.c_uint32), ("maxgaps", C.c_uint32), ("maxdiffs", C.c_uint32), ("mindiffs", C.c_uint32),
         ("local", C.c_int32), ("evalue", C.c_float), ("xdrop_u", C.c_float), ("xdrop_g", C.c_float),
         ("local_open", C.c_float), ("local_ext", C.c_float), ("ka_dbsize", C.c_float), ("max_hsps", C.c_uint32),
-        ("reserved_", C.c_uint32 * 2),
+        ("pair_mask", C.c_uint32), ("min_sizeratio", C.c_float), ("minqt", C.c_float), ("maxqt", C.c_float), ("minsl", C.c_float),
+        ("maxsl", C.c_float), ("abskew", C.c_float),
+        ("reserved_", C.c_uint32 * 1),
     ]
 
 
 # UGS_F_* bits of Params.filter_mask (include/ugs.h)
-F_MAXID, F_MINCOLS, F_MAXGAPS, F_QUERY_COV, F_MAX_QUERY_COV, F_TARGET_COV, F_MAX_TARGET_COV, F_MAXDIFFS, F_MINDIFFS = (
-    1, 2, 4, 8, 16, 32, 64, 128, 256)
+F_MAXID, F_MINCOLS, F_MAXGAPS, F_QUERY_COV, F_MAX_QUERY_COV, F_TARGET_COV, F_MAX_TARGET_COV, F_MAXDIFFS, F_MINDIFFS, F_ABSKEW = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512)
 FILTER_BITS = dict(maxid=F_MAXID, mincols=F_MINCOLS, maxgaps=F_MAXGAPS, query_cov=F_QUERY_COV, max_query_cov=F_MAX_QUERY_COV,
-                   target_cov=F_TARGET_COV, max_target_cov=F_MAX_TARGET_COV, maxdiffs=F_MAXDIFFS, mindiffs=F_MINDIFFS)
+                   target_cov=F_TARGET_COV, max_target_cov=F_MAX_TARGET_COV, maxdiffs=F_MAXDIFFS, mindiffs=F_MINDIFFS, abskew=F_ABSKEW)
+# UGS_P_* bits of Params.pair_mask; self/notself/selfid are flags (pass True), the others carry a value
+PAIR_BITS = dict(self=1, notself=2, selfid=4, min_sizeratio=8, minqt=16, maxqt=32, minsl=64, maxsl=128)
 
 
 HIT_DTYPE = np.dtype({

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .abi import FILTER_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from .abi import FILTER_BITS, PAIR_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libugs.so")
@@ -22,7 +22,7 @@ EXPORTS = [
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
     "ugs_udb_stat", "ugs_udb_read", "ugs_udb_write",
-    "ugs_closedref_create", "ugs_closedref_destroy", "ugs_closedref_add", "ugs_closedref_totals", "ugs_hits_sort", "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
+    "ugs_closedref_create", "ugs_closedref_destroy", "ugs_closedref_add", "ugs_closedref_totals", "ugs_db_set_pair_keys", "ugs_batch_set_pair_keys", "ugs_hits_sort", "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_format_fastapairs", "ugs_format_segout",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
@@ -63,6 +63,8 @@ def lib():
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
         L.ugs_hits_sort.argtypes = [vp, vp, u32, i32]
+        L.ugs_db_set_pair_keys.argtypes = [vp, vp, vp]
+        L.ugs_batch_set_pair_keys.argtypes = [vp, vp, vp]
         L.ugs_params_set_local.argtypes = [C.POINTER(Params), C.c_double, i32]
         L.ugs_local_evalue.argtypes = [C.POINTER(Params), C.c_double, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ugs_format_blast6_local.argtypes = [C.POINTER(Params), vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -96,6 +98,12 @@ def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
         if rc != 0:
             raise UgsError(rc, last_error())
     for k, v in kw.items():
+        if k in PAIR_BITS:              # pair filters of Accepter::RejectPair (-self, -minqt ...): flag or value + bit
+            if v is not None and v is not False:
+                p.pair_mask |= PAIR_BITS[k]
+                if k not in ("self", "notself", "selfid"):
+                    setattr(p, k, v)
+            continue
         if not hasattr(p, k):
             raise AttributeError(k)
         setattr(p, k, v)
@@ -149,11 +157,26 @@ class UgsDB:
         _chk(lib().ugs_db_debug_fetch(self.h, masked.ctypes.data, row_off.ctypes.data, postings.ctypes.data))
         return masked[:self.nletters], row_off, postings[:st["postings"]]
 
-    def search(self, qseqs, qoffs):
-        """One-shot ugs_search_batch."""
+    def set_pair_keys(self, label_key=None, size=None):
+        """label keys / ;size= annotations of the DB sequences for the pair filters and -abskew (ugs_db_set_pair_keys)"""
+        k = None if label_key is None else np.ascontiguousarray(label_key, np.uint32)
+        z = None if size is None else np.ascontiguousarray(size, np.uint32)
+        _chk(lib().ugs_db_set_pair_keys(self.h, None if k is None else k.ctypes.data, None if z is None else z.ctypes.data))
+
+    def search(self, qseqs, qoffs, pair_keys=None):
+        """One-shot ugs_search_batch; with pair_keys = (query label keys, query sizes) the staged calls (the one-shot
+        entry point has no room for per-query keys)."""
         qseqs = as_u8(qseqs)
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         nq = len(qoffs) - 1
+        if pair_keys is not None:
+            bat = UgsBatch(self, nq, int(qoffs[-1]))
+            bat.upload(qseqs, qoffs)
+            bat.set_pair_keys(*pair_keys)
+            bat.search(); bat.sync()
+            out = bat.fetch()
+            bat.close()
+            return out
         cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) * (self.p.max_hsps if self.p.local else 1) + 1
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         nh = np.zeros(nq + 1, dtype=np.uint32)
@@ -192,6 +215,12 @@ class UgsBatch:
         self.nq = len(qoffs) - 1
         self.nletters = int(qoffs[-1] - qoffs[0])
         _chk(lib().ugs_batch_upload(self.h, qseqs.ctypes.data, qoffs.ctypes.data, self.nq))
+
+    def set_pair_keys(self, label_key=None, size=None):
+        """per-query label keys / sizes of the uploaded batch (ugs_batch_set_pair_keys)"""
+        k = None if label_key is None else np.ascontiguousarray(label_key, np.uint32)
+        z = None if size is None else np.ascontiguousarray(size, np.uint32)
+        _chk(lib().ugs_batch_set_pair_keys(self.h, None if k is None else k.ctypes.data, None if z is None else z.ctypes.data))
 
     def search(self):
         _chk(lib().ugs_batch_search(self.h))

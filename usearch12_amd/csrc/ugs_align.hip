@@ -653,6 +653,9 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
   viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
 }
 
+// PAIR: the pair filters / -abskew are compiled into an instantiation of their own, so that the usual launch keeps the
+// code (and register allocation) it was tuned with
+template <bool PAIR>
 __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -785,8 +788,36 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       }
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
       if (k + 1 < ncand) prefetch(k + 1);
-      w_tletters += LB; ++w_pairs;
       wave_sync();
+      if constexpr (PAIR) if (db.pair_mask) {
+        // Accepter::RejectPair accepter.cpp:140-197.  Big path: the pair is a reject for the terminator
+        // (udbusortedsearcherbig.cpp:118-127); small path: it is passed over without a trace (searcher.cpp:63-67)
+        const uint32_t pm = db.pair_mask;
+        bool rej = false;
+        if (pm & (UGS_P_SELF | UGS_P_NOTSELF)) {
+          const bool same = bv.q_key[qi] == db.t_key[t];
+          rej = ((pm & UGS_P_SELF) && same) || ((pm & UGS_P_NOTSELF) && !same);
+        }
+        if (!rej && (pm & UGS_P_SELFID) && LB == LA) {         // same length and identical stored letters
+          bool diff = false;
+          for (uint32_t p0 = 0; p0 < LA && !diff; p0 += 64) { const uint32_t p = p0 + lane; diff = __ballot(p < LA && c.A[p] != c.B[p]) != 0; }
+          rej = !diff;
+        }
+        if (!rej && (pm & UGS_P_MIN_SIZERATIO)) rej = (double)db.t_size[t] / (double)bv.q_size[qi] < (double)db.min_sizeratio;
+        if (!rej && (pm & (UGS_P_MINQT | UGS_P_MAXQT | UGS_P_MINSL | UGS_P_MAXSL))) {
+          const double qt = (double)LA / (double)LB, sl = (double)(LA < LB ? LA : LB) / (double)(LA > LB ? LA : LB);
+          rej = ((pm & UGS_P_MINQT) && qt < (double)db.minqt) || ((pm & UGS_P_MAXQT) && qt > (double)db.maxqt) ||
+                ((pm & UGS_P_MINSL) && sl < (double)db.minsl) || ((pm & UGS_P_MAXSL) && sl > (double)db.maxsl);
+        }
+        if (rej) {
+          wave_sync();
+          if (!db.big) continue;
+          ++nrej;
+          if (nrej == max_rej) break;
+          continue;
+        }
+      }
+      w_tletters += LB; ++w_pairs;
       // ---- GlobalAlign_AllOpts (globalalignmem.cpp:129-236), FailIfNoHSPs = true
       uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
       if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
@@ -873,6 +904,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
               }
               if ((fm & UGS_F_MAXDIFFS) && diffs > db.maxdiffs) accept = false;
               if ((fm & UGS_F_MINDIFFS) && diffs < db.mindiffs) accept = false;
+              if constexpr (PAIR) if ((fm & UGS_F_ABSKEW) && (double)db.t_size[t] / (double)bv.q_size[qi] < (double)db.abskew) accept = false;   // arscorer.cpp:809-816
             }
             if (accept) {
               unsigned long long coff = 0;
@@ -897,6 +929,8 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       if (nacc == max_acc || nrej == max_rej) break;
       wave_sync();
     }
+    // small path with pair filters: passed-over pairs do not count, so the walk may want more candidates than were kept
+    if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
     if (lane == 0) bv.hit_n[unit] = nacc;
     wave_sync();
   }
@@ -909,16 +943,21 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
 int ugs_align_blocks_per_cu(int threads, size_t lds)
 {
   int n = 0;
-  if (hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_align, threads, lds) != hipSuccess || n < 1) n = 1;
+  if (hipFuncSetAttribute((const void *)k_align<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_align<false>, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
   const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);
-  HIPCHK(hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-  hipLaunchKernelGGL(k_align, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
+  if (db.pair_mask || (db.filter_mask & UGS_F_ABSKEW)) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_align<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+    hipLaunchKernelGGL(k_align<true>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void *)k_align<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+    hipLaunchKernelGGL(k_align<false>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
+  }
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 struct SeqSet {                       // SeqDB (seqdb.h:29-52) flattened: labels + concatenated letters
@@ -92,12 +93,44 @@ class Searcher {
   }
   ~Searcher() { ugs_db_destroy(db_); }
   const ugs_db *handle() const { return db_; }
+  bool pair_keys() const { return p_.pair_mask != 0 || (p_.filter_mask & UGS_F_ABSKEW) != 0; }
+  // labels as integer keys (equal labels <=> equal keys) and ;size= annotations (label.cpp:152-161) for the pair filters
+  void keys_of(const SeqSet &s, std::vector<uint32_t> &key, std::vector<uint32_t> &size) {
+    key.resize(s.size()); size.resize(s.size());
+    for (size_t i = 0; i < s.size(); ++i) {
+      auto it = label_ids_.find(s.labels[i]);
+      if (it == label_ids_.end()) it = label_ids_.emplace(s.labels[i], (uint32_t)label_ids_.size()).first;
+      key[i] = it->second;
+      const char *z = strstr(s.labels[i].c_str(), ";size=");
+      size[i] = z ? (uint32_t)atoi(z + 6) : 0xffffffffu;
+    }
+  }
+  void SetDbKeys(const SeqSet &db) {
+    std::vector<uint32_t> k, z;
+    keys_of(db, k, z);
+    if (ugs_db_set_pair_keys(db_, k.data(), z.data()) != UGS_OK) die("ugs_db_set_pair_keys");
+  }
   void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
     const uint32_t nq = (uint32_t)q.size();
     hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) * (p_.local ? p_.max_hsps : 1) + 1);
     nhits.assign(nq + 1, 0);
     pool.resize(q.letters.size() * 2 + 64 * (size_t)nq + 1024);
     uint64_t used = 0;
+    if (pair_keys()) {                                       // staged calls: the one-shot entry point has no room for per-query keys
+      std::vector<uint32_t> k, z;
+      keys_of(q, k, z);
+      ugs_batch *b = nullptr;
+      if (ugs_batch_create(db_, nq, q.letters.size(), &b) != UGS_OK) die("ugs_batch_create");
+      int rc = ugs_batch_upload(b, q.letters.data(), q.offs.data(), nq);
+      if (rc == UGS_OK) rc = ugs_batch_set_pair_keys(b, k.data(), z.data());
+      if (rc == UGS_OK) rc = ugs_batch_search(b);
+      if (rc == UGS_OK) rc = ugs_batch_sync(b);
+      if (rc == UGS_OK) rc = ugs_batch_fetch(b, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+      if (rc == UGS_E_CAPACITY && used > pool.size()) { pool.resize(used + 1024); rc = ugs_batch_fetch(b, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used); }
+      ugs_batch_destroy(b);
+      if (rc != UGS_OK) die("search with pair filters");
+      return;
+    }
     int rc = ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
     if (rc == UGS_E_CAPACITY && used > pool.size()) {        // the demand comes back in `used`
       pool.resize(used + 1024);
@@ -108,6 +141,7 @@ class Searcher {
  private:
   [[noreturn]] static void die(const char *what) { fprintf(stderr, "%s: %s\n", what, ugs_last_error()); exit(1); }
   ugs_params p_; ugs_db *db_ = nullptr;
+  std::unordered_map<std::string, uint32_t> label_ids_;
 };
 
 // the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
@@ -254,6 +288,14 @@ int main(int argc, char **argv)
     else if (a == "-max_target_cov") { filt.max_target_cov = (float)atof(val()); filt.filter_mask |= UGS_F_MAX_TARGET_COV; }
     else if (a == "-maxdiffs") { filt.maxdiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXDIFFS; }
     else if (a == "-mindiffs") { filt.mindiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINDIFFS; }
+    else if (a == "-self") filt.pair_mask |= UGS_P_SELF; else if (a == "-notself") filt.pair_mask |= UGS_P_NOTSELF;
+    else if (a == "-selfid") filt.pair_mask |= UGS_P_SELFID;
+    else if (a == "-min_sizeratio") { filt.min_sizeratio = (float)atof(val()); filt.pair_mask |= UGS_P_MIN_SIZERATIO; }
+    else if (a == "-minqt") { filt.minqt = (float)atof(val()); filt.pair_mask |= UGS_P_MINQT; }
+    else if (a == "-maxqt") { filt.maxqt = (float)atof(val()); filt.pair_mask |= UGS_P_MAXQT; }
+    else if (a == "-minsl") { filt.minsl = (float)atof(val()); filt.pair_mask |= UGS_P_MINSL; }
+    else if (a == "-maxsl") { filt.maxsl = (float)atof(val()); filt.pair_mask |= UGS_P_MAXSL; }
+    else if (a == "-abskew") { filt.abskew = (float)atof(val()); filt.filter_mask |= UGS_F_ABSKEW; }
     else if (a == "-alnout") alnpath = val(); else if (a == "-fastapairs") pairspath = val();
     else if (a == "-qsegout") qsegpath = val(); else if (a == "-tsegout") tsegpath = val();
     else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
@@ -325,6 +367,8 @@ int main(int argc, char **argv)
   p.filter_mask = filt.filter_mask; p.maxid = filt.maxid; p.mincols = filt.mincols; p.maxgaps = filt.maxgaps;
   p.query_cov = filt.query_cov; p.max_query_cov = filt.max_query_cov; p.target_cov = filt.target_cov;
   p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
+  p.pair_mask = filt.pair_mask; p.min_sizeratio = filt.min_sizeratio; p.minqt = filt.minqt; p.maxqt = filt.maxqt; p.minsl = filt.minsl;
+  p.maxsl = filt.maxsl; p.abskew = filt.abskew;
   if (from_udb) { p.dbmask = 2; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
     if (path.empty()) return nullptr;
@@ -342,6 +386,7 @@ int main(int argc, char **argv)
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   if (closedref_cmd) { O.closedref = ugs_closedref_create(); O.tabbed = open_out(tabbedout); }
   Searcher searcher(p, db, device);
+  if (searcher.pair_keys()) searcher.SetDbKeys(db);
   std::string masked;
   if (O.user || O.aln || O.pairs || O.qseg || O.tseg || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
     masked.resize(db.letters.size());

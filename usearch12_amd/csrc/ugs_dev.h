@@ -55,6 +55,10 @@ struct UgsDbView {
   int32_t max_accepts, max_rejects;
   int32_t is_nucleo;
   uint32_t max_tlen;
+  // pair filters (Accepter::RejectPair accepter.cpp:140-197) and -abskew: UGS_P_* bits, values, per-target keys
+  uint32_t pair_mask;
+  float min_sizeratio, minqt, maxqt, minsl, maxsl, abskew;
+  const uint32_t *t_key, *t_size;
 };
 
 struct UgsBatchView {
@@ -87,11 +91,12 @@ struct UgsBatchView {
   uint32_t runs_stride;
   // counters: [0]=postings [1]=target letters [2]=pairs [3]=dp cells [4]=hits [5]=error flags
   unsigned long long *counters;
+  const uint32_t *q_key, *q_size;   // per query: label key / ;size= annotation (pair filters, -abskew)
 };
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
        UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_N };  // T*: phase clocks (profiling)
-enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32 };
+enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64 };
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates
 struct UgsLocalView {

@@ -39,6 +39,8 @@ struct ugs_db {
   // usearch_local
   int8_t *d_xsub2; uint8_t *d_xcls;
   UgsLocalView lv;
+  // pair filters / -abskew
+  uint32_t *d_tkey, *d_tsize; bool have_tkey, have_tsize;
 };
 
 struct ugs_batch {
@@ -56,6 +58,7 @@ struct ugs_batch {
   int2 *d_qthr; uint8_t *d_ltb; uint2 *d_lrow; uint32_t *d_lruns;
   uint64_t ltb_alloc, lrow_alloc, lruns_alloc;
   UgsLocalView lv; int lgrid, lwpb; size_t llds;
+  uint32_t *d_qkey, *d_qsize; bool have_qkey, have_qsize;
   unsigned long long *d_cigar_used, *d_ctr;
   uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
   int rank_grid_alloc, align_waves_alloc;
@@ -275,7 +278,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   if (!db) return;
   (void)hipSetDevice(db->device);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
-  (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls);
+  (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls); (void)hipFree(db->d_tkey); (void)hipFree(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
   delete db;
 }
@@ -315,6 +318,10 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     ugs_set_error("unsupported word_len/hsp_word_len/band (band 0 = full DP is not implemented)"); return UGS_E_ENVELOPE;
   }
   if (p->strand_both && !p->is_nucleo) { ugs_set_error("strand_both needs a nucleotide search"); return UGS_E_ARG; }
+  if (p->local && (p->pair_mask || (p->filter_mask & UGS_F_ABSKEW))) {
+    // (the reference's small-path local walk aligns against the PREVIOUS target when SetTarget refuses a pair)
+    ugs_set_error("pair filters / -abskew are implemented for usearch_global only"); return UGS_E_ARG;
+  }
   if (p->local) {
     const float o2 = p->local_open * 2.0f, e2 = p->local_ext * 2.0f;
     if (!(p->evalue > 0.0f) || !(p->ka_dbsize > 0.0f) || p->max_hsps < 1 || !(p->xdrop_u >= 0.0f) || !(p->xdrop_g >= 0.0f)) {
@@ -332,7 +339,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
-  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr;
+  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false;
   memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;
   auto fail = [&](int code) { ugs_db_destroy(db); return code; };
@@ -412,6 +419,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.target_cov = p->target_cov; v.max_target_cov = p->max_target_cov;
   v.mincols = p->mincols; v.maxgaps = p->maxgaps; v.maxdiffs = p->maxdiffs; v.mindiffs = p->mindiffs;
   v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
+  v.pair_mask = p->pair_mask; v.min_sizeratio = p->min_sizeratio; v.minqt = p->minqt; v.maxqt = p->maxqt; v.minsl = p->minsl; v.maxsl = p->maxsl;
+  v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
   db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
   if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
@@ -429,6 +438,46 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     lv.W = std::min<uint32_t>(max_tlen, 4096) + 4;
   }
   *out = db;
+  return UGS_OK;
+}
+
+// keys for the pair filters / -abskew (include/ugs.h)
+static int upload_keys(uint32_t **d, const uint32_t *h, size_t n, bool *have, hipStream_t st)
+{
+  *have = false;
+  if (!h) return UGS_OK;
+  if (!*d) HIPCHK(hipMalloc(d, std::max<size_t>(n, 1) * 4));
+  if (n) HIPCHK(hipMemcpyAsync(*d, h, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *have = true;
+  return UGS_OK;
+}
+static bool sizes_missing(const uint32_t *size, size_t n) { for (size_t i = 0; i < n; ++i) if (size[i] == 0xffffffffu || size[i] == 0) return true; return false; }
+
+extern "C" int ugs_db_set_pair_keys(ugs_db *db, const uint32_t *label_key, const uint32_t *size)
+{
+  if (!db) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(db->device));
+  const bool need_size = (db->p.pair_mask & UGS_P_MIN_SIZERATIO) || (db->p.filter_mask & UGS_F_ABSKEW);
+  if (need_size && size && sizes_missing(size, db->v.nseq)) { ugs_set_error("Missing size= in a database label (-min_sizeratio / -abskew need it, label.cpp:152-161)"); return UGS_E_ARG; }
+  RCCHK(upload_keys(&db->d_tkey, label_key, db->v.nseq, &db->have_tkey, db->stream));
+  RCCHK(upload_keys(&db->d_tsize, size, db->v.nseq, &db->have_tsize, db->stream));
+  db->v.t_key = db->d_tkey; db->v.t_size = db->d_tsize;
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_set_pair_keys(ugs_batch *b, const uint32_t *label_key, const uint32_t *size)
+{
+  if (!b) return UGS_E_ARG;
+  ugs_db *db = b->db;
+  HIPCHK(hipSetDevice(db->device));
+  const bool need_size = (db->p.pair_mask & UGS_P_MIN_SIZERATIO) || (db->p.filter_mask & UGS_F_ABSKEW);
+  if (need_size && size && sizes_missing(size, b->nq)) { ugs_set_error("Missing size= in a query label (-min_sizeratio / -abskew need it, label.cpp:152-161)"); return UGS_E_ARG; }
+  if (b->d_qkey && label_key) { HIPCHK(hipFree(b->d_qkey)); b->d_qkey = nullptr; }     // sized for the uploaded batch
+  if (b->d_qsize && size) { HIPCHK(hipFree(b->d_qsize)); b->d_qsize = nullptr; }
+  RCCHK(upload_keys(&b->d_qkey, label_key, b->nq, &b->have_qkey, db->stream));
+  RCCHK(upload_keys(&b->d_qsize, size, b->nq, &b->have_qsize, db->stream));
+  b->v.q_key = b->d_qkey; b->v.q_size = b->d_qsize;
   return UGS_OK;
 }
 
@@ -468,6 +517,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
   (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots);
+  (void)hipFree(b->d_qkey); (void)hipFree(b->d_qsize);
   (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -486,6 +536,9 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   b->db = db; b->max_queries = max_queries; b->max_letters = max_letters;
   b->nstrand = db->p.strand_both ? 2 : 1;
   b->K = (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
+  // small path + pair filters: passed-over pairs are not counted (searcher.cpp:63-67), the walk can go deeper
+  // (only -selfid is left to the aligner on that path: the other pair filters are applied where candidates are chosen)
+  if ((db->p.pair_mask & UGS_P_SELFID) && !db->v.big) b->K = std::min<uint32_t>(UGS_KMAX, b->K + 32);
   const uint64_t units = (uint64_t)max_queries * b->nstrand;
   b->hit_slots = (uint32_t)db->p.max_accepts * (db->p.local ? db->p.max_hsps : 1u);
   int rc = UGS_OK;
@@ -694,6 +747,7 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   v.unit_ns = b->d_unit_ns; v.unit_slots = b->d_unit_slots;
   v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
   v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
+  b->have_qkey = b->have_qsize = false; b->v.q_key = nullptr; b->v.q_size = nullptr;     // keys belong to one uploaded batch
   b->searched = false; b->synced = false;
   return UGS_OK;
 }
@@ -711,6 +765,15 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   if (!b) return UGS_E_ARG;
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
+  if (b->nq) {
+    const bool need_key = (db->p.pair_mask & (UGS_P_SELF | UGS_P_NOTSELF)) != 0;
+    const bool need_size = (db->p.pair_mask & UGS_P_MIN_SIZERATIO) || (db->p.filter_mask & UGS_F_ABSKEW);
+    if ((need_key && !(db->have_tkey && b->have_qkey)) || (need_size && !(db->have_tsize && b->have_qsize))) {
+      ugs_set_error("the active pair filters need ugs_db_set_pair_keys and ugs_batch_set_pair_keys (labels%s)", need_size ? " and sizes" : "");
+      return UGS_E_ARG;
+    }
+  }
+  b->v.K = b->K;
   HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
@@ -738,7 +801,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
         ugs_set_error("more than max_hsps = %u HSPs on one accepted target; raise ugs_params.max_hsps", db->p.max_hsps);
         return UGS_E_CAPACITY;
       }
-      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots)", b->ctr[UGS_CTR_ERR]);
+      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots 64=a small-path walk with pair filters wanted more than 64 candidates)", b->ctr[UGS_CTR_ERR]);
       return UGS_E_ENVELOPE;
     }
     if (b->cigar_used_host <= b->cigar_cap) { b->synced = true; return UGS_OK; }

@@ -86,7 +86,34 @@ struct RankShared {
   uint32_t hist[256];        // emitted entries per (count, first row) class: hist[c*16 + i], 4-bit fast path only
 };
 
+// Pair filters on the small ranking path (Accepter::RejectPair accepter.cpp:140-197): there a refused pair leaves no
+// trace in the candidate walk (udbusortedsearcher.cpp:145-147 ignores SetTarget's result, searcher.cpp:63-67 returns
+// before the terminator), so refused targets are simply not candidates: they are dropped where candidates are chosen.
+// (-selfid needs the letters and stays in k_align.)
+struct PairQ {
+  uint32_t mask, ql, qkey, qsize;
+  float min_sizeratio, minqt, maxqt, minsl, maxsl;
+  const uint64_t *offs; const uint32_t *t_key, *t_size;
+};
+__device__ __forceinline__ bool pair_reject(const PairQ &q, uint32_t t)
+{
+  const uint32_t m = q.mask;
+  if (m & (UGS_P_SELF | UGS_P_NOTSELF)) {
+    const bool same = q.qkey == q.t_key[t];
+    if (((m & UGS_P_SELF) && same) || ((m & UGS_P_NOTSELF) && !same)) return true;
+  }
+  if ((m & UGS_P_MIN_SIZERATIO) && (double)q.t_size[t] / (double)q.qsize < (double)q.min_sizeratio) return true;
+  if (m & (UGS_P_MINQT | UGS_P_MAXQT | UGS_P_MINSL | UGS_P_MAXSL)) {
+    const uint32_t tl = (uint32_t)(q.offs[t + 1] - q.offs[t]), ql = q.ql;
+    const double qt = (double)ql / (double)tl, sl = (double)(ql < tl ? ql : tl) / (double)(ql > tl ? ql : tl);
+    if (((m & UGS_P_MINQT) && qt < (double)q.minqt) || ((m & UGS_P_MAXQT) && qt > (double)q.maxqt) ||
+        ((m & UGS_P_MINSL) && sl < (double)q.minsl) || ((m & UGS_P_MAXSL) && sl > (double)q.maxsl)) return true;
+  }
+  return false;
+}
+
 struct ScanCtx {
+  const PairQ *pq;           // non-null: small path with pair filters
   const uint64_t *row_off; const uint32_t *part; const uint32_t *postings;
   const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
   uint32_t *hist;            // non-null: count emitted entries per (count,row) class
@@ -147,7 +174,7 @@ __device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t 
     if (on && c >= 2 && s.hist) atomicAdd(&s.hist[c * 16 + i], 1u);
     emit_lanes(s, on && c >= 2, 0xffffffffu, make_key(c, pos));
   } else {
-    const bool e = on && c == 1 && pos < fill_limit;
+    const bool e = on && c == 1 && pos < fill_limit && !(s.pq && pair_reject(*s.pq, t));
     const uint32_t n = __popcll(__ballot(e));
     emit_lanes(s, e, quota_left, make_key(1, pos));
     quota_left = quota_left > n ? quota_left - n : 0;
@@ -257,7 +284,7 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
       for (uint32_t e2 = 0; e2 < EPW; ++e2) {
         const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
         const uint64_t tt = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
-        if (cc == 1 && tt < fill_limit) ++mine;
+        if (cc == 1 && tt < fill_limit && !(s.pq && pair_reject(*s.pq, (uint32_t)tt))) ++mine;
       }
       uint32_t incl = mine;
       for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up((int)incl, o); if (lane >= o) incl += x; }
@@ -271,7 +298,7 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
         for (uint32_t e2 = 0; e2 < EPW; ++e2) {
           const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
           const uint64_t tt = (uint64_t)base_t + (uint64_t)wi * EPW + e2;
-          if (cc == 1 && tt < fill_limit) {
+          if (cc == 1 && tt < fill_limit && !(s.pq && pair_reject(*s.pq, (uint32_t)tt))) {
             if (rr < take) put_key(s, (uint64_t)base + rr, make_key(1, tt));
             ++rr;
           }
@@ -891,6 +918,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
       __syncthreads();
     }
     ScanCtx sc;
+    sc.pq = nullptr;
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
     sc.s_part = use_part_cache ? s_part : nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
@@ -951,6 +979,16 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     const uint32_t nev = sh->nev;
 
     // kept(entry): count >= MinValue and (small path) count >= MinU in force at its position
+    PairQ pairq;
+    pairq.mask = SMALL ? (db.pair_mask & ~(uint32_t)UGS_P_SELFID) : 0u;
+    if (SMALL && pairq.mask) {
+      const uint32_t qi = unit / bv.nstrand;
+      pairq.ql = (uint32_t)(bv.qoffs[qi + 1] - bv.qoffs[qi]);
+      pairq.qkey = bv.q_key ? bv.q_key[qi] : 0u; pairq.qsize = bv.q_size ? bv.q_size[qi] : 0xffffffffu;
+      pairq.min_sizeratio = db.min_sizeratio; pairq.minqt = db.minqt; pairq.maxqt = db.maxqt; pairq.minsl = db.minsl; pairq.maxsl = db.maxsl;
+      pairq.offs = db.offs; pairq.t_key = db.t_key; pairq.t_size = db.t_size;
+      sc.pq = &pairq;                                        // the count-1 fill pass drops refused targets as it emits
+    }
     auto kept = [&](uint64_t key) -> bool {
       const uint32_t c = key_count(key);
       if (c < min_value) return false;
@@ -962,6 +1000,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
         for (uint32_t e = 0; e < nev; ++e) if (s_fp[s_ev_c[e]] < pos) { minu = s_ev_minu[e]; break; }
         if (c < minu) return false;
       }
+      if (SMALL && pairq.mask && pair_reject(pairq, key_target(key))) return false;
       return true;
     };
 
