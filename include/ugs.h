@@ -359,6 +359,15 @@ int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucl
  * %Id / TLen / Target table of the query's reported hits; empty for a query without hits), then one
  * ugs_format_alnout_hit = WriteAln (alnout.cpp:41-171) per hit: rows of 80 columns with 1-based position labels,
  * the annotation row (| identical, + IUPAC match / : . BLOSUM62 >= 2 / > 0) and the summary line. */
+/* -userout line of a usearch_local hit: HSP coordinates / segments / coverages, real evalue, raw, bits (userout.cpp:148-207
+ * over the local branches of the AlignResult getters) */
+int ugs_format_userout_local(const ugs_params *p, const ugs_hit *h, const uint32_t *cigar_pool, const char *fields,
+                             const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                             const char *tseq, uint32_t tl, char *buf, int cap);
+/* -alnout for usearch_local hits: OutputReportLocal outputsink.cpp:260-298, WriteAln's local summary alnout.cpp:151-163 */
+int ugs_format_alnout_header_local(const ugs_params *p, const ugs_hit *hits, uint32_t n, const char *qlabel, const char *const *tlabels, char *buf, int cap);
+int ugs_format_alnout_hit_local(const ugs_params *p, const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel, const char *tlabel,
+                                const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
 int ugs_format_alnout_header(const ugs_hit *hits, uint32_t n, const char *qlabel, const char *const *tlabels, char *buf, int cap);
 int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel, const char *tlabel,
                           const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);

@@ -46,6 +46,12 @@ def ref_cmd(c, qfa, dbfa, prefix):
     return cmd
 
 
+USER_FIELDS = ("query+target+clusternr+evalue+id+fractid+dist+mid+pctpv+pctgaps+pairs+gaps+allgaps+qlo+qhi+tlo+thi+qlor+qhir+tlor+thir+"
+               "qlot+qhit+qunt+tlot+thit+tunt+pv+ql+tl+qs+ts+alnlen+opens+exts+raw+bits+aln+caln+qseq+tseq+qseg+tseg+qstrand+tstrand+qrow+trow+"
+               "qrowdots+trowdots+qframe+tframe+orflo+orfhi+orfframe+mism+ids+qcov+tcov+diffs+diffsa+editdiffs")
+USER_CASES = ("loc_nt_both", "loc_aa_acc")      # -userout with every supported field: kept as sha256 + first 12 lines
+
+
 def main():
     assert os.path.exists(REF), "build the reference first: oracle/build_ref.sh"
     manifest = {}
@@ -57,13 +63,25 @@ def main():
             qs.write_fasta(qfa)
             prefix = os.path.join(HERE, name)
             cmd = ref_cmd(c, qfa, dbfa, prefix)
+            if name in USER_CASES:
+                cmd += ["-userout", os.path.join(tmp, "u.txt"), "-userfields", USER_FIELDS, "-alnout", os.path.join(tmp, "a.txt")]
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            user = None
+            if name in USER_CASES:
+                import hashlib
+                data = open(os.path.join(tmp, "u.txt"), "rb").read()
+                user = dict(sha256=hashlib.sha256(data).hexdigest(), lines=data.count(b"\n"), fields=USER_FIELDS)
+                open(prefix + ".user.head", "wb").write(b"".join(data.splitlines(True)[:12]))
+                aln = b"".join(open(os.path.join(tmp, "a.txt"), "rb").read().splitlines(True)[2:])     # minus the command-line / version banner
+                user["aln_sha256"] = hashlib.sha256(aln).hexdigest(); user["aln_lines"] = aln.count(b"\n")
+                open(prefix + ".aln.head", "wb").write(b"".join(aln.splitlines(True)[:60]))
+                cmd = cmd[:-6]
             lines = open(prefix + ".b6").read().splitlines()
             pairs = {}
             for ln in lines:
                 f = ln.split("\t")
                 pairs[(f[0], f[1])] = pairs.get((f[0], f[1]), 0) + 1
-            manifest[name] = dict(c, db_sha256=digest(db), q_sha256=digest(qs), n_hits=len(lines),
+            manifest[name] = dict(c, db_sha256=digest(db), q_sha256=digest(qs), n_hits=len(lines), userout=user,
                                   n_multi_hsp_pairs=sum(1 for v in pairs.values() if v > 1),
                                   cmd=" ".join(["usearch12"] + [os.path.basename(x) if x.startswith(tmp) else x
                                                                  for x in cmd[1:]]).replace(HERE + "/", ""))

@@ -193,3 +193,27 @@ def test_gpu_local_protein_wildcards_and_stops():
     db, qs = _seqset(tg, "t"), _seqset(qr, "q")
     hits, nh = _vs_oracle(db, qs, aa=True, id=None, local_evalue=1e-3, max_accepts=3, max_rejects=8, max_hsps=16)
     assert len(hits) > 150
+
+
+def test_cli_usearch_local_userout_identical_to_reference(tmp_path):
+    import hashlib
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    for name in ("loc_nt_both", "loc_aa_acc"):
+        c, db, qs, b6 = G.load_local(name)
+        u = G.LOCAL_MANIFEST[name]["userout"]
+        dbfa, qfa, out = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "o.txt")
+        db.write_fasta(dbfa); qs.write_fasta(qfa)
+        aln = str(tmp_path / "o.aln")
+        cmd = [cli, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-userout", out, "-userfields", u["fields"], "-alnout", aln]
+        if not c["aa"]:
+            cmd += ["-strand", c["strand"]]
+        for opt in ("id", "big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:
+            if opt in c:
+                cmd += ["-" + opt, str(c[opt])]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        got = open(out, "rb").read()
+        assert got.count(b"\n") == u["lines"] and hashlib.sha256(got).hexdigest() == u["sha256"], name
+        got = open(aln, "rb").read()
+        assert got.count(b"\n") == u["aln_lines"] and hashlib.sha256(got).hexdigest() == u["aln_sha256"], name

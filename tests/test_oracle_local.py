@@ -33,3 +33,86 @@ def test_local_evalue_formula():
     e, b = C.c_double(0), C.c_double(0)
     orc.lib().orc_local_evalue(C.byref(p), 302.0, 344, C.byref(e), C.byref(b))     # first line of the hard_small probe
     assert "%.1f" % b.value == "558.8" and "%.2g" % e.value == "2.1e-157"
+
+
+@pytest.mark.parametrize("name", [n for n in G.local_case_names() if G.LOCAL_MANIFEST[n].get("userout")])
+def test_local_userout_from_oracle_hits(name):
+    """ugs_format_userout_local (host C++) fed with the oracle's local hits reproduces the reference's -userout with every
+    supported field (sha256 of the whole file + its first lines): HSP coordinates, segments, coverages, evalue, raw, bits"""
+    import hashlib
+    import os
+    from usearch12_amd import capi
+    c, db, qs, b6 = G.load_local(name)
+    u = G.LOCAL_MANIFEST[name]["userout"]
+    p = orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c))
+    odb = orc.OrcDB(p, db.seqs, db.offs)
+    hits, nh, pool = odb.search(qs.seqs, qs.offs, nthreads=4)
+    masked = odb.masked()
+    L = capi.lib()
+    L.ugs_format_userout_local.restype = C.c_int
+    L.ugs_format_userout_local.argtypes = [C.POINTER(type(p)), C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]
+    pool = np.ascontiguousarray(pool, np.uint32)
+    buf = C.create_string_buffer(1 << 16)
+    out, k = [], 0
+    ql, tl = qs.labels(), db.labels()
+    for qi in range(qs.n):
+        q = np.ascontiguousarray(qs.seqs[int(qs.offs[qi]):int(qs.offs[qi + 1])])
+        for j in range(int(nh[qi])):
+            h = hits[k:k + 1]; k += 1
+            t = int(h["target"][0])
+            ts = np.ascontiguousarray(masked[int(db.offs[t]):int(db.offs[t + 1])])
+            n = L.ugs_format_userout_local(C.byref(p), h.ctypes.data, pool.ctypes.data, u["fields"].encode(), ql[qi].encode(), tl[t].encode(),
+                                           q.ctypes.data, len(q), ts.ctypes.data, len(ts), buf, len(buf))
+            assert 0 < n < len(buf), capi.last_error()
+            out.append(buf.raw[:n])
+    got = b"".join(out)
+    head = open(os.path.join(G.GOLD, name + ".user.head"), "rb").read()
+    assert got[:len(head)] == head
+    assert got.count(b"\n") == u["lines"] and hashlib.sha256(got).hexdigest() == u["sha256"]
+
+
+@pytest.mark.parametrize("name", [n for n in G.local_case_names() if G.LOCAL_MANIFEST[n].get("userout")])
+def test_local_alnout_from_oracle_hits(name):
+    """-alnout of usearch_local (hit table with scores / e-values / segments, alignment rows over the HSP, summary with
+    score, bits, e-value) from the oracle's hits: sha256 of the reference's whole file + its first 60 lines"""
+    import hashlib
+    import os
+    from usearch12_amd import capi
+    c, db, qs, b6 = G.load_local(name)
+    u = G.LOCAL_MANIFEST[name]["userout"]
+    p = orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c))
+    odb = orc.OrcDB(p, db.seqs, db.offs)
+    hits, nh, pool = odb.search(qs.seqs, qs.offs, nthreads=4)
+    masked = odb.masked()
+    L = capi.lib()
+    P = C.POINTER(type(p))
+    L.ugs_format_alnout_header_local.argtypes = [P, C.c_void_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+    L.ugs_format_alnout_hit_local.argtypes = [P, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]
+    pool = np.ascontiguousarray(pool, np.uint32)
+    buf = C.create_string_buffer(1 << 18)
+    out, k = [], 0
+    ql, tl = qs.labels(), db.labels()
+    for qi in range(qs.n):
+        n = int(nh[qi])
+        if n == 0:
+            continue
+        h = hits[k:k + n]
+        labs = (C.c_char_p * n)(*[tl[int(t)].encode() for t in h["target"]])
+        m = L.ugs_format_alnout_header_local(C.byref(p), h.ctypes.data, n, ql[qi].encode(), labs, buf, len(buf))
+        assert 0 < m < len(buf)
+        out.append(buf.raw[:m])
+        q = np.ascontiguousarray(qs.seqs[int(qs.offs[qi]):int(qs.offs[qi + 1])])
+        for j in range(n):
+            hj = hits[k + j:k + j + 1]
+            t = int(hj["target"][0])
+            ts = np.ascontiguousarray(masked[int(db.offs[t]):int(db.offs[t + 1])])
+            m = L.ugs_format_alnout_hit_local(C.byref(p), hj.ctypes.data, pool.ctypes.data, ql[qi].encode(), tl[t].encode(), q.ctypes.data, len(q),
+                                              ts.ctypes.data, len(ts), buf, len(buf))
+            assert 0 < m < len(buf), capi.last_error()
+            out.append(buf.raw[:m])
+        k += n
+    got = b"".join(out)
+    head = open(os.path.join(G.GOLD, name + ".aln.head"), "rb").read()
+    assert got[:len(head)] == head
+    assert got.count(b"\n") == u["aln_lines"] and hashlib.sha256(got).hexdigest() == u["aln_sha256"]

@@ -197,7 +197,8 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   if (O.aln) {                                                        // OutputReport outputsink.cpp:338-356
     std::vector<const char *> tls(n);
     for (uint32_t j = 0; j < n; ++j) tls[j] = db.labels[h[j].target].c_str();
-    put(O.aln, ugs_format_alnout_header(h, n, qlab, tls.data(), line.data(), (int)line.size()));
+    put(O.aln, p.local ? ugs_format_alnout_header_local(&p, h, n, qlab, tls.data(), line.data(), (int)line.size())
+                       : ugs_format_alnout_header(h, n, qlab, tls.data(), line.data(), (int)line.size()));
   }
   for (uint32_t j = 0; j < n; ++j) {
     const uint32_t t = h[j].target;
@@ -208,13 +209,17 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
       if (O.qseg) put(O.qseg, ugs_format_segout(&h[j], pool, 0, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
       if (O.tseg) put(O.tseg, ugs_format_segout(&h[j], pool, 1, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
     }
-    if (O.aln) put(O.aln, ugs_format_alnout_hit(&h[j], pool, p.is_nucleo, qlab, tl, qs, ql, O.db_masked + db.offs[t],
-                                                (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
+    if (O.aln) put(O.aln, p.local ? ugs_format_alnout_hit_local(&p, &h[j], pool, qlab, tl, qs, ql, O.db_masked + db.offs[t],
+                                                                (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size())
+                                  : ugs_format_alnout_hit(&h[j], pool, p.is_nucleo, qlab, tl, qs, ql, O.db_masked + db.offs[t],
+                                                          (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
     if (O.b6) put(O.b6, p.local ? ugs_format_blast6_local(&p, &h[j], qlab, tl, line.data(), (int)line.size())
                                 : ugs_format_blast6(&h[j], qlab, tl, line.data(), (int)line.size()));
     if (O.uc) put(O.uc, ugs_format_uc_hit(&h[j], pool, p.is_nucleo, qlab, tl, line.data(), (int)line.size()));
-    if (O.user) put(O.user, ugs_format_userout(&h[j], pool, p.is_nucleo, O.userfields.c_str(), qlab, tl, qs, ql,
-                                                O.db_masked + db.offs[t], (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
+    if (O.user) put(O.user, p.local ? ugs_format_userout_local(&p, &h[j], pool, O.userfields.c_str(), qlab, tl, qs, ql, O.db_masked + db.offs[t],
+                                                               (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size())
+                                    : ugs_format_userout(&h[j], pool, p.is_nucleo, O.userfields.c_str(), qlab, tl, qs, ql,
+                                                         O.db_masked + db.offs[t], (uint32_t)(db.offs[t + 1] - db.offs[t]), line.data(), (int)line.size()));
     if (!O.db_hit_counts.empty() && !(O.otutab && j > 0)) ++O.db_hit_counts[t];   // DBHitSink::OnQueryDone dbhitsink.cpp:117-140 (otutab: first hit only, :137)
   }
   if (O.matched) put(O.matched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
@@ -353,9 +358,9 @@ int main(int argc, char **argv)
     if (xdrop_g >= 0) p.xdrop_g = (float)xdrop_g;
     if (ka_dbsize > 0) p.ka_dbsize = (float)ka_dbsize;
     if (maxhsps > 0) p.max_hsps = (uint32_t)maxhsps;
-    if (!ucpath.empty() || !userpath.empty() || !alnpath.empty() || !pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd ||
+    if (!ucpath.empty() || !pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd ||
         O.top_hit_only || O.top_hits_only) {
-      fprintf(stderr, "-usearch_local writes -blast6out, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
+      fprintf(stderr, "-usearch_local writes -blast6out, -userout, -alnout, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
     }
   }
   if (hspw > 0) p.hsp_word_len = (int32_t)hspw;

@@ -123,10 +123,16 @@ extern "C" int ugs_userfields_check(const char *fields)
   return parse_fields(fields, f);
 }
 
-extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
-                                  const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
-                                  const char *tseq, uint32_t tl, char *buf, int cap)
+static int format_userout_impl(const ugs_params *lp, const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
+                               const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                               const char *tseq, uint32_t tl, char *buf, int cap)
 {
+  // usearch_local hits (UGS_HIT_LOCAL): the HSP replaces the whole-sequence "HSP" of a global alignment in the coordinate,
+  // segment and coverage getters (arscorer.cpp:122-154,688-806), and evalue / raw / bits are real (arscorer.cpp:69-120)
+  const bool local = h && (h->flags & UGS_HIT_LOCAL);
+  if (local && !lp) { ugs_set_error("local hits need the search parameters (ugs_format_userout_local)"); return UGS_E_ARG; }
+  double lE = -1.0, lBits = 0.0;
+  if (local) ugs_local_evalue(lp, (double)h->raw_score, h->ql, &lE, &lBits);
   std::vector<int> fs;
   const int rc = parse_fields(fields, fs);
   if (rc != UGS_OK) return rc;
@@ -192,7 +198,7 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
       case F_query: o += qlabel; break;
       case F_target: o += tlabel; break;
       case F_clusternr: app(o, "%u", h->target); break;
-      case F_evalue: app(o, "%.3g", -1.0); break;              // global: GetEvalue() = -1 (arscorer.cpp:69-73)
+      case F_evalue: app(o, "%.3g", lE); break;                // global: GetEvalue() = -1 (arscorer.cpp:69-73)
       case F_id: app(o, "%.1f", 100.0 * fract); break;
       case F_fractid: app(o, "%.4f", fract); break;
       case F_dist: app(o, "%.4f", 1.0 - fract); break;
@@ -202,13 +208,15 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
       case F_pairs: app(o, "%u", pairs); break;
       case F_gaps: app(o, "%u", h->gaps_int); break;
       case F_allgaps: app(o, "%u", h->gaps_int + term); break;
-      case F_qlo: app(o, "%u", 1u); break;                     // global HSP = whole sequences (alignresult.cpp:206-211)
-      case F_qhi: app(o, "%u", ql); break;
-      case F_tlo: app(o, "%u", 1u); break;
-      case F_thi: app(o, "%u", tl); break;
-      case F_qlor: case F_tlor: app(o, "%u", 0u); break;
-      case F_qhir: app(o, "%u", ql - 1); break;
-      case F_thir: app(o, "%u", tl - 1); break;
+      // global HSP = whole sequences (alignresult.cpp:206-211); local: GetIQLo1/GetIQHi1 on the plus strand (arscorer.cpp:688-750)
+      case F_qlo: app(o, "%u", !local ? 1u : (h->strand ? ql - h->qhi : h->qlo + 1)); break;
+      case F_qhi: app(o, "%u", !local ? ql : (h->strand ? ql - h->qlo : h->qhi + 1)); break;
+      case F_tlo: app(o, "%u", !local ? 1u : h->tlo + 1); break;
+      case F_thi: app(o, "%u", !local ? tl : h->thi + 1); break;
+      case F_qlor: app(o, "%u", !local ? 0u : h->qlo); break;
+      case F_tlor: app(o, "%u", !local ? 0u : h->tlo); break;
+      case F_qhir: app(o, "%u", !local ? ql - 1 : h->qhi); break;
+      case F_thir: app(o, "%u", !local ? tl - 1 : h->thi); break;
       case F_qlot: app(o, "%u", h->qlo); break;
       case F_qhit: app(o, "%u", h->qhi); break;
       case F_qunt: app(o, "%u", ql - h->qhi - 1); break;
@@ -216,12 +224,15 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
       case F_thit: app(o, "%u", h->thi); break;
       case F_tunt: app(o, "%u", tl - h->thi - 1); break;
       case F_pv: app(o, "%u", pv); break;
-      case F_ql: case F_qs: app(o, "%u", ql); break;
-      case F_tl: case F_ts: app(o, "%u", tl); break;
+      case F_ql: app(o, "%u", ql); break;
+      case F_tl: app(o, "%u", tl); break;
+      case F_qs: app(o, "%u", !local ? ql : h->qhi - h->qlo + 1); break;      // GetQuerySegLength: m_HSP.Leni
+      case F_ts: app(o, "%u", !local ? tl : h->thi - h->tlo + 1); break;
       case F_alnlen: app(o, "%u", aln); break;
       case F_opens: app(o, "%u", opens); break;
       case F_exts: app(o, "%u", exts); break;
-      case F_raw: case F_bits: app(o, "%.0f", 0.0); break;    // global: 0 (arscorer.cpp:87-91,105-109)
+      case F_raw: app(o, "%.0f", local ? (double)h->raw_score : 0.0); break;   // global: 0 (arscorer.cpp:87-91,105-109)
+      case F_bits: app(o, "%.0f", local ? lBits : 0.0); break;
       case F_aln: o += path; break;
       case F_caln:
         for (uint32_t k = 0; k < h->cigar_len; ++k) { const uint32_t r = cigar_pool[h->cigar_off + k]; if ((r >> 2) == 1) o.push_back("MDI"[r & 3]); else app(o, "%u%c", r >> 2, "MDI"[r & 3]); }
@@ -230,8 +241,8 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
       case F_tseq: o.append(tseq, tl); break;
       // the reference prints segment-LENGTH (= whole sequence for a global hit) letters starting at the first
       // aligned position, i.e. it reads past the end when the alignment has a leading gap; here: up to the end
-      case F_qseg: o.append(Q, h->qlo, std::string::npos); break;
-      case F_tseg: o.append(tseq + h->tlo, tl - h->tlo); break;
+      case F_qseg: if (local) o.append(Q, h->qlo, h->qhi - h->qlo + 1); else o.append(Q, h->qlo, std::string::npos); break;
+      case F_tseg: o.append(tseq + h->tlo, local ? h->thi - h->tlo + 1 : tl - h->tlo); break;
       case F_qstrand: o.push_back(!is_nucleo ? '.' : (h->strand ? '-' : '+')); break;
       case F_tstrand: o.push_back(!is_nucleo ? '.' : '+'); break;
       case F_qrow: o += qrow; break;
@@ -242,8 +253,8 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
       case F_orflo: case F_orfhi: app(o, "%u", 0u); break;
       case F_mism: app(o, "%u", h->mism); break;
       case F_ids: app(o, "%u", h->ids); break;
-      case F_qcov: app(o, "%.0f", 100.0 * ((double)(h->qhi - h->qlo + 1) / ql)); break;
-      case F_tcov: app(o, "%.0f", 100.0 * ((double)pairs / (double)tl)); break;
+      case F_qcov: app(o, "%.0f", 100.0 * (local ? (double)(h->qhi - h->qlo + 1) / (double)ql : (double)(h->qhi - h->qlo + 1) / ql)); break;
+      case F_tcov: app(o, "%.0f", 100.0 * (local ? (double)(h->thi - h->tlo + 1) / (double)tl : (double)pairs / (double)tl)); break;
       case F_diffs: app(o, "%u", h->mism + h->gaps_int); break;
       case F_diffsa: app(o, "%u", diffsa); break;
       case F_editdiffs: app(o, "%u", h->mism + h->gaps_int + term); break;
@@ -251,6 +262,22 @@ extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, 
   }
   o.push_back('\n');
   return finish(o, buf, cap);
+}
+
+extern "C" int ugs_format_userout(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *fields,
+                                  const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                                  const char *tseq, uint32_t tl, char *buf, int cap)
+{
+  return format_userout_impl(nullptr, h, cigar_pool, is_nucleo, fields, qlabel, tlabel, qseq, ql, tseq, tl, buf, cap);
+}
+
+// the same for usearch_local hits: p supplies the Karlin-Altschul constants for evalue / bits
+extern "C" int ugs_format_userout_local(const ugs_params *p, const ugs_hit *h, const uint32_t *cigar_pool, const char *fields,
+                                        const char *qlabel, const char *tlabel, const char *qseq, uint32_t ql,
+                                        const char *tseq, uint32_t tl, char *buf, int cap)
+{
+  if (!p) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  return format_userout_impl(p, h, cigar_pool, p->is_nucleo, fields, qlabel, tlabel, qseq, ql, tseq, tl, buf, cap);
 }
 
 // OutputBlast6NoHits blast6out.cpp:82-103 (written only under -output_no_hits)
@@ -508,9 +535,36 @@ extern "C" int ugs_format_alnout_header(const ugs_hit *hits, uint32_t n, const c
   return finish(o, buf, cap);
 }
 
-extern "C" int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel,
-                                     const char *tlabel, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
-                                     char *buf, int cap)
+// OutputReportLocal outputsink.cpp:260-298 (+ OutputReport :338-356): score, e-value, identity, query / target segment as
+// lo-hi(unaligned tail) in plus-strand query coordinates (FormatSeg :57-62), strand for nucleotide queries
+extern "C" int ugs_format_alnout_header_local(const ugs_params *p, const ugs_hit *hits, uint32_t n, const char *qlabel,
+                                              const char *const *tlabels, char *buf, int cap)
+{
+  if (n == 0) { if (buf && cap > 0) buf[0] = 0; return 0; }
+  if (!p || !hits || !qlabel || !tlabels) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  std::string o = "\nQuery >";
+  o += qlabel; o += "\n Score     Evalue   %Id    QueryLo-Hi(Un)   TargetLo-Hi(Un)";
+  if (p->is_nucleo) o += "  +";
+  o += "  Target\n";
+  for (uint32_t i = 0; i < n; ++i) {
+    const ugs_hit &h = hits[i];
+    double E = 0, bits = 0;
+    ugs_local_evalue(p, (double)h.raw_score, h.ql, &E, &bits);
+    const double pct = 100.0 * (h.aln_len == 0 ? 0.0 : (double)h.ids / (double)h.aln_len);
+    const unsigned qlo = h.strand ? h.ql - h.qhi - 1 : h.qlo, qhi = h.strand ? h.ql - h.qlo - 1 : h.qhi;      // GetIQLo / GetIQHi arscorer.cpp:688-750
+    char seg[64];
+    app(o, "%6.0f  %9.1g  %3.0f%%", (double)h.raw_score, E, pct);
+    snprintf(seg, sizeof seg, "%u-%u(%u)", qlo + 1, qhi + 1, h.ql - qhi - 1); app(o, "  %16s", seg);
+    snprintf(seg, sizeof seg, "%u-%u(%u)", h.tlo + 1, h.thi + 1, h.tl - h.thi - 1); app(o, "  %16s", seg);
+    if (p->is_nucleo) { o += "  "; o.push_back(h.strand ? '-' : '+'); }
+    o += "  "; o += tlabels[i]; o.push_back('\n');
+  }
+  return finish(o, buf, cap);
+}
+
+static int format_alnout_hit_impl(const ugs_params *lp, const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel,
+                                  const char *tlabel, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
+                                  char *buf, int cap)
 {
   if (!h || !cigar_pool || !qlabel || !tlabel || !qseq || !tseq) { ugs_set_error("null argument"); return UGS_E_ARG; }
   if (ql != h->ql || tl != h->tl) { ugs_set_error("sequence lengths do not match the hit record"); return UGS_E_ARG; }
@@ -577,8 +631,30 @@ extern "C" int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_poo
     o.push_back(' '); o.append(trow, from, n); app(o, " %u\n", tto);
     o.push_back('\n');
   }
-  app(o, "%u cols, %u ids (%.1f%%), %u gaps (%.1f%%)\n", aln, h->ids, 100.0 * ratio(h->ids, aln), h->gaps_int, 100.0 * ratio(h->gaps_int, aln));
+  app(o, "%u cols, %u ids (%.1f%%), %u gaps (%.1f%%)", aln, h->ids, 100.0 * ratio(h->ids, aln), h->gaps_int, 100.0 * ratio(h->gaps_int, aln));
+  if (lp && (h->flags & UGS_HIT_LOCAL)) {                              // alnout.cpp:151-163
+    double E = 0, bits = 0;
+    ugs_local_evalue(lp, (double)h->raw_score, h->ql, &E, &bits);
+    app(o, ", score %.1f (%.1f bits), Evalue %.2g", (double)h->raw_score, bits, E);
+  }
+  o.push_back('\n');
   return finish(o, buf, cap);
+}
+
+extern "C" int ugs_format_alnout_hit(const ugs_hit *h, const uint32_t *cigar_pool, int is_nucleo, const char *qlabel,
+                                     const char *tlabel, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
+                                     char *buf, int cap)
+{
+  return format_alnout_hit_impl(nullptr, h, cigar_pool, is_nucleo, qlabel, tlabel, qseq, ql, tseq, tl, buf, cap);
+}
+
+// WriteAln for a usearch_local hit: the same rows over the HSP, the summary line ends with score, bits and e-value
+extern "C" int ugs_format_alnout_hit_local(const ugs_params *p, const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel,
+                                           const char *tlabel, const char *qseq, uint32_t ql, const char *tseq, uint32_t tl,
+                                           char *buf, int cap)
+{
+  if (!p) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  return format_alnout_hit_impl(p, h, cigar_pool, p->is_nucleo, qlabel, tlabel, qseq, ql, tseq, tl, buf, cap);
 }
 
 // ---------------------------------------------------------------- -fastapairs / -qsegout / -tsegout
