@@ -150,6 +150,9 @@ typedef struct ugs_hit {
   uint32_t flags;        /* UGS_HIT_LOCAL: a usearch_local HSP - qlo..thi are the HSP (m_HSP), the path covers only it */
 } ugs_hit;
 #define UGS_HIT_LOCAL 1u
+/* flags bits 8..31: the hit's position in HitMgr's append order within its query (candidate order, plus strand first);
+ * HitMgr::GetTopHit (hitmgr.cpp:398-415) keeps the earlier of two hits with equal score and equal target */
+#define UGS_HIT_ORDER_SHIFT 8
 
 typedef struct ugs_db ugs_db;       /* opaque: masked DB + UDB index resident in HBM */
 typedef struct ugs_batch ugs_batch; /* opaque: one query batch resident in HBM       */

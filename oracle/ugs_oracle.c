@@ -1637,6 +1637,7 @@ static void *job_run(void *arg)
     }
     unsigned n = J->hb.nhits - first;
     J->nhits[qi] = n;
+    for (unsigned i = 0; i < n; ++i) J->hb.hits[first + i].flags |= i << UGS_HIT_ORDER_SHIFT;   /* append order, see include/ugs.h */
     if (n > 1) {     /* hitmgr.cpp:477-483 Sort by AlignResult::GetScore desc: float(FractId), local: float(raw score) */
       float *sc = (float *)malloc(n * sizeof(float));
       unsigned *ord = (unsigned *)malloc(n * sizeof(unsigned));

@@ -64,7 +64,7 @@ def main():
             prefix = os.path.join(HERE, name)
             cmd = ref_cmd(c, qfa, dbfa, prefix)
             if name in USER_CASES:
-                cmd += ["-userout", os.path.join(tmp, "u.txt"), "-userfields", USER_FIELDS, "-alnout", os.path.join(tmp, "a.txt")]
+                cmd += ["-userout", os.path.join(tmp, "u.txt"), "-userfields", USER_FIELDS, "-alnout", os.path.join(tmp, "a.txt"), "-uc", os.path.join(tmp, "c.uc")]
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             user = None
             if name in USER_CASES:
@@ -75,7 +75,15 @@ def main():
                 aln = b"".join(open(os.path.join(tmp, "a.txt"), "rb").read().splitlines(True)[2:])     # minus the command-line / version banner
                 user["aln_sha256"] = hashlib.sha256(aln).hexdigest(); user["aln_lines"] = aln.count(b"\n")
                 open(prefix + ".aln.head", "wb").write(b"".join(aln.splitlines(True)[:60]))
-                cmd = cmd[:-6]
+                ucd = open(os.path.join(tmp, "c.uc"), "rb").read()
+                user["uc_sha256"] = hashlib.sha256(ucd).hexdigest(); user["uc_lines"] = ucd.count(b"\n")
+                cmd = cmd[:-8]
+                # hit-count rules on local scores: -top_hits_only, -top_hit_only (HitMgr::GetHitCount / GetTopHit)
+                for flag in ("top_hits_only", "top_hit_only"):
+                    subprocess.check_call(cmd[:cmd.index("-blast6out")] + ["-blast6out", os.path.join(tmp, flag + ".b6"), "-" + flag] + cmd[cmd.index("-blast6out") + 2:],
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    d = open(os.path.join(tmp, flag + ".b6"), "rb").read()
+                    user[flag + "_sha256"] = hashlib.sha256(d).hexdigest(); user[flag + "_lines"] = d.count(b"\n")
             lines = open(prefix + ".b6").read().splitlines()
             pairs = {}
             for ln in lines:

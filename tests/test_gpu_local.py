@@ -37,7 +37,7 @@ def test_gpu_local_matches_reference_text(name):
     p, hits, nh, pool = _run_gpu(c, db, qs)
     got = orc.format_blast6_local(capi.lib(), "ugs", p, hits, nh, qs.labels(), db.labels())
     assert got == b6
-    assert np.all(hits["flags"] == 1)
+    assert np.all(hits["flags"] & 1 == 1)
 
 
 @pytest.mark.parametrize("name", ["loc_nt_both", "loc_aa_acc", "loc_nt_long", "loc_nt_id"])
@@ -205,8 +205,8 @@ def test_cli_usearch_local_userout_identical_to_reference(tmp_path):
         u = G.LOCAL_MANIFEST[name]["userout"]
         dbfa, qfa, out = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "o.txt")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
-        aln = str(tmp_path / "o.aln")
-        cmd = [cli, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-userout", out, "-userfields", u["fields"], "-alnout", aln]
+        aln, ucp = str(tmp_path / "o.aln"), str(tmp_path / "o.uc")
+        cmd = [cli, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-userout", out, "-userfields", u["fields"], "-alnout", aln, "-uc", ucp]
         if not c["aa"]:
             cmd += ["-strand", c["strand"]]
         for opt in ("id", "big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:
@@ -217,3 +217,10 @@ def test_cli_usearch_local_userout_identical_to_reference(tmp_path):
         assert got.count(b"\n") == u["lines"] and hashlib.sha256(got).hexdigest() == u["sha256"], name
         got = open(aln, "rb").read()
         assert got.count(b"\n") == u["aln_lines"] and hashlib.sha256(got).hexdigest() == u["aln_sha256"], name
+        got = open(ucp, "rb").read()
+        assert got.count(b"\n") == u["uc_lines"] and hashlib.sha256(got).hexdigest() == u["uc_sha256"], name
+        for flag in ("top_hits_only", "top_hit_only"):      # hit-count rules on local scores; GetTopHit's tie = earlier hit
+            b6p = str(tmp_path / (flag + ".b6"))
+            subprocess.check_call(cmd[:cmd.index("-userout")] + ["-blast6out", b6p, "-" + flag] + cmd[cmd.index("-uc") + 2:], stderr=subprocess.DEVNULL)
+            got = open(b6p, "rb").read()
+            assert got.count(b"\n") == u[flag + "_lines"] and hashlib.sha256(got).hexdigest() == u[flag + "_sha256"], (name, flag)

@@ -22,7 +22,7 @@ def test_oracle_local_matches_reference_text(name):
     got = orc.format_blast6_local(orc.lib(), "orc", p, hits, nh, qs.labels(), db.labels())
     assert got == b6
     assert len(hits) == c["n_hits"]
-    assert np.all(hits["flags"] == 1)
+    assert np.all(hits["flags"] & 1 == 1)
     # AlignResult::GetRawScore rescoring the path gives the x-drop score back, and local paths start and end on M
     assert orc.lib().orc_local_rescore_diffs() == before
     assert np.all(hits["cols"] == hits["aln_len"])
@@ -116,3 +116,47 @@ def test_local_alnout_from_oracle_hits(name):
     head = open(os.path.join(G.GOLD, name + ".aln.head"), "rb").read()
     assert got[:len(head)] == head
     assert got.count(b"\n") == u["aln_lines"] and hashlib.sha256(got).hexdigest() == u["aln_sha256"]
+
+
+@pytest.mark.parametrize("name", [n for n in G.local_case_names() if G.LOCAL_MANIFEST[n].get("userout")])
+def test_local_uc_and_hit_count_rules_from_oracle_hits(name):
+    """-uc of usearch_local (HSP start columns) and -top_hits_only / -top_hit_only on local scores (ugs_hits_to_report),
+    fed with the oracle's hits: sha256 of the reference's files"""
+    import hashlib
+    from usearch12_amd import capi
+    c, db, qs, b6 = G.load_local(name)
+    u = G.LOCAL_MANIFEST[name]["userout"]
+    p = orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c))
+    hits, nh, pool = orc.OrcDB(p, db.seqs, db.offs).search(qs.seqs, qs.offs, nthreads=4)
+    L = capi.lib()
+    L.ugs_hits_to_report.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    L.ugs_hits_to_report.restype = C.c_uint32
+    pool = np.ascontiguousarray(pool, np.uint32)
+    buf = C.create_string_buffer(1 << 16)
+    ql, tl = qs.labels(), db.labels()
+    qlens = np.diff(qs.offs.astype(np.int64))
+    uc, tops, top1 = [], [], []
+    k = 0
+    for qi in range(qs.n):
+        n = int(nh[qi])
+        h = hits[k:k + n]
+        if n == 0:
+            L.ugs_format_uc_nohit(int(qlens[qi]), ql[qi].encode(), buf, len(buf)); uc.append(buf.value)
+        for j in range(n):
+            L.ugs_format_uc_hit(h[j:j + 1].ctypes.data, pool.ctypes.data, 0 if c["aa"] else 1, ql[qi].encode(), tl[int(h["target"][j])].encode(), buf, len(buf))
+            uc.append(buf.value)
+        if n:
+            first = C.c_uint32(0)
+            m = L.ugs_hits_to_report(h.ctypes.data, n, 0, 0, 1, C.byref(first))
+            for j in range(m):
+                L.ugs_format_blast6_local(C.byref(p), h[first.value + j:first.value + j + 1].ctypes.data, ql[qi].encode(),
+                                          tl[int(h["target"][first.value + j])].encode(), buf, len(buf))
+                tops.append(buf.value)
+            m = L.ugs_hits_to_report(h.ctypes.data, n, 0, 1, 0, C.byref(first))
+            assert m == 1
+            L.ugs_format_blast6_local(C.byref(p), h[first.value:first.value + 1].ctypes.data, ql[qi].encode(), tl[int(h["target"][first.value])].encode(), buf, len(buf))
+            top1.append(buf.value)
+        k += n
+    for got, key in ((b"".join(uc), "uc"), (b"".join(tops), "top_hits_only"), (b"".join(top1), "top_hit_only")):
+        assert got.count(b"\n") == u[key + "_lines"], key
+        assert hashlib.sha256(got).hexdigest() == u[key + "_sha256"], key

@@ -45,6 +45,7 @@ HIT_DTYPE = np.dtype({
     "itemsize": 80,
 })
 HIT_LOCAL = 1
+HIT_ORDER_SHIFT = 8        # flags >> 8: position in HitMgr's append order within the query
 
 
 class BatchStats(C.Structure):

@@ -358,9 +358,8 @@ int main(int argc, char **argv)
     if (xdrop_g >= 0) p.xdrop_g = (float)xdrop_g;
     if (ka_dbsize > 0) p.ka_dbsize = (float)ka_dbsize;
     if (maxhsps > 0) p.max_hsps = (uint32_t)maxhsps;
-    if (!ucpath.empty() || !pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd ||
-        O.top_hit_only || O.top_hits_only) {
-      fprintf(stderr, "-usearch_local writes -blast6out, -userout, -alnout, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
+    if (!pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd || closedref_cmd) {
+      fprintf(stderr, "-usearch_local writes -blast6out, -uc, -userout, -alnout, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
     }
   }
   if (hspw > 0) p.hsp_word_len = (int32_t)hspw;

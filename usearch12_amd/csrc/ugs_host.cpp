@@ -993,7 +993,10 @@ extern "C" int ugs_format_uc_hit(const ugs_hit *h, const uint32_t *cigar_pool, i
   const double FractId = h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len;
   const double PctId = 100.0 * FractId;
   const char strand = !is_nucleo ? '.' : (h->strand ? '-' : '+');
-  int n = snprintf(buf, (size_t)cap, "H\t%u\t%u\t%.1f\t%c\t%u\t%u\t", h->target, h->ql, PctId, strand, 0u, 0u);
+  // columns 6-7: GetIQLo / GetITLo - 0 for a global alignment; the HSP start for a usearch_local hit (arscorer.cpp:688-716)
+  const bool local = (h->flags & UGS_HIT_LOCAL) != 0;
+  const unsigned iqlo = !local ? 0u : (h->strand ? h->ql - h->qhi - 1 : h->qlo), itlo = !local ? 0u : h->tlo;
+  int n = snprintf(buf, (size_t)cap, "H\t%u\t%u\t%.1f\t%c\t%u\t%u\t", h->target, h->ql, PctId, strand, iqlo, itlo);
   for (uint32_t k = 0; k < h->cigar_len; ++k) {
     const uint32_t r = cigar_pool[h->cigar_off + k];
     const char op = "MDI"[r & 3];

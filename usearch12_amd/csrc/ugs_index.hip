@@ -232,7 +232,9 @@ __global__ void k_hits_compact(const uint32_t *hit_n, const ugs_hit *table, cons
   uint32_t o = qoff[q];
   for (uint32_t s = 0; s < ns; ++s) {
     const uint32_t u = q * ns + s, n = hit_n[u];
-    for (uint32_t k = 0; k < n; ++k) { ugs_hit h = table[(uint64_t)u * ma + k]; h.query += query_base; out[o++] = h; }
+    // (the hit's place in HitMgr's append order - candidate order, plus strand first - goes into the upper flag bits:
+    //  GetTopHit breaks ties by it, hitmgr.cpp:398-415)
+    for (uint32_t k = 0; k < n; ++k) { ugs_hit h = table[(uint64_t)u * ma + k]; h.query += query_base; h.flags |= (o - qoff[q]) << UGS_HIT_ORDER_SHIFT; out[o++] = h; }
   }
 }
 

@@ -306,13 +306,15 @@ extern "C" uint32_t ugs_hits_to_report(const ugs_hit *hits, uint32_t n, uint32_t
 {
   if (first) *first = 0;
   if (n == 0) return 0;
-  auto score = [](const ugs_hit &h) { return h.aln_len == 0 ? 0.0f : (float)((double)h.ids / (double)h.aln_len); };
+  // AlignResult::GetScore arscorer.cpp:818-824: fractional identity; usearch_local hits: the raw score
+  auto score = [](const ugs_hit &h) { return (h.flags & UGS_HIT_LOCAL) ? h.raw_score : (h.aln_len == 0 ? 0.0f : (float)((double)h.ids / (double)h.aln_len)); };
   uint32_t count = n;
   if (maxhits && count > maxhits) count = maxhits;
   if (top_hit_only) {
     uint32_t best = 0;
     for (uint32_t i = 1; i < n; ++i)
-      if (score(hits[i]) > score(hits[best]) || (score(hits[i]) == score(hits[best]) && hits[i].target < hits[best].target)) best = i;
+      if (score(hits[i]) > score(hits[best]) || (score(hits[i]) == score(hits[best]) && (hits[i].target < hits[best].target ||
+          (hits[i].target == hits[best].target && (hits[i].flags >> UGS_HIT_ORDER_SHIFT) < (hits[best].flags >> UGS_HIT_ORDER_SHIFT))))) best = i;
     if (first) *first = best;
     return 1;
   }
