@@ -121,8 +121,11 @@ typedef struct ugs_params {
   uint32_t max_hsps;       /* 8                                        */
   uint32_t pair_mask;      /* UGS_P_* bits                             */
   float    min_sizeratio, minqt, maxqt, minsl, maxsl, abskew;
-  uint32_t reserved_[1];
+  uint32_t align_flags;    /* UGS_A_FULLDP | UGS_A_GAFORCE              */
 } ugs_params;
+/* -fulldp: no HSPs, one unbanded Viterbi over the whole pair (globalalignmem.cpp:148-152, ViterbiFastMem);
+ * -gaforce: a pair without good HSPs is aligned all the same (FailIfNoHSPs = false, globalaligner.cpp:9-12) */
+enum { UGS_A_FULLDP = 1, UGS_A_GAFORCE = 2 };
 
 /*
  * One accepted hit == one AlignResult appended to HitMgr (hitmgr.cpp:161-183), with

@@ -1104,11 +1104,17 @@ static int global_align(Work *w, const byte *B, unsigned LB, float *HSPFractIdOu
   if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
   if (MinHSPLength < 16) MinHSPLength = 16;
   float HSPFractId = -1.0f;
+  const int FailIfNoHSPs = !(db->p.align_flags & UGS_A_GAFORCE);            /* globalaligner.cpp:9-12 */
+  if (db->p.align_flags & UGS_A_FULLDP) {                                     /* globalalignmem.cpp:148-152: ViterbiFastMem = every diagonal */
+    if (HSPFractIdOut) *HSPFractIdOut = HSPFractId;
+    viterbi_band(w, w->A, LA, B, LB, 1, LA + LB - 1, &db->ap, w->path);
+    return 1;
+  }
   unsigned HSPCount = get_global_hsps(w, MinHSPLength, &HSPFractId);
   if (HSPFractIdOut) *HSPFractIdOut = HSPFractId;
-  if (HSPFractId < db->MinGlobalHSPFractId) return 0;
+  if (HSPFractId < db->MinGlobalHSPFractId && FailIfNoHSPs) return 0;
   if (HSPCount == 0) {
-    if (db->MinGlobalHSPLength > 0 && LA > 64) return 0;
+    if (db->MinGlobalHSPLength > 0 && LA > 64 && FailIfNoHSPs) return 0;
     viterbi_main_diag(w, w->A, LA, B, LB, db->BandRadius, &db->ap, w->path);
     return 1;
   }

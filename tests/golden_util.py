@@ -44,6 +44,8 @@ def params_kw(c):
         kw["max_accepts"] = c["maxaccepts"]
     if "maxrejects" in c:
         kw["max_rejects"] = c["maxrejects"]
+    if c.get("fulldp") or c.get("gaforce"):
+        kw["align_flags"] = (1 if c.get("fulldp") else 0) | (2 if c.get("gaforce") else 0)
     for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
         if opt in c:
             kw[opt] = c[opt]

@@ -653,7 +653,7 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
   viterbi_hole(c, Loi, Leni, Loj, Lenj, (uint32_t)db.band, P, counters);
 }
 
-// PAIR: the pair filters / -abskew are compiled into an instantiation of their own, so that the usual launch keeps the
+// PAIR: the pair filters, -abskew, -fulldp and -gaforce are compiled into an instantiation of their own, so that the usual launch keeps the
 // code (and register allocation) it was tuned with
 template <bool PAIR>
 __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
@@ -823,13 +823,18 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
       if (MinHSPLength < 16) MinHSPLength = 16;
       ta1 += clock64() - tq; tq = clock64();
-      if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
+      // -fulldp: no HSPs at all, the whole pair is one unbanded hole (globalalignmem.cpp:148-152); -gaforce: FailIfNoHSPs = false
+      const bool fulldp = PAIR ? (db.align_flags & UGS_A_FULLDP) != 0 : false;
+      const bool force_all = PAIR ? (db.align_flags & (UGS_A_FULLDP | UGS_A_GAFORCE)) != 0 : false;
+      if (!fulldp) {
+        if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
+      }
       ta2 += clock64() - tq; tq = clock64();
-      if (lane == 0) chain_lane0(c);
+      if (lane == 0) { if (fulldp) c.ws->nchain = 0; else chain_lane0(c); }
       wave_sync();
       const uint32_t nchain = c.ws->nchain;
       bool accept = false;
-      if (nchain) {
+      if (nchain || force_all) {
         uint32_t TotLen = 0, TotSame = 0;
         for (uint32_t q = 0; q < nchain; ++q) {
           const HSPd h = c.hsps[c.chain[q]];
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
           }
         }
         const float HSPFractId = TotLen == 0 ? 0.0f : (float)TotSame / (float)TotLen;
-        if (!(HSPFractId < db.min_hsp_fract_id)) {
+        if (force_all || !(HSPFractId < db.min_hsp_fract_id)) {
           // ---- stitch holes and HSPs into the path
           if (lane == 0) { c.ws->nruns = 0; c.ws->cur_len = 0; c.ws->cur_op = 0; c.ws->overflow = 0; }
           wave_sync();
@@ -951,7 +956,7 @@ int ugs_align_blocks_per_cu(int threads, size_t lds)
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
   const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);
-  if (db.pair_mask || (db.filter_mask & UGS_F_ABSKEW)) {
+  if (db.pair_mask || (db.filter_mask & UGS_F_ABSKEW) || db.align_flags) {
     HIPCHK(hipFuncSetAttribute((const void *)k_align<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
     hipLaunchKernelGGL(k_align<true>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
   } else {

@@ -318,6 +318,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     ugs_set_error("unsupported word_len/hsp_word_len/band (band 0 = full DP is not implemented)"); return UGS_E_ENVELOPE;
   }
   if (p->strand_both && !p->is_nucleo) { ugs_set_error("strand_both needs a nucleotide search"); return UGS_E_ARG; }
+  if (p->local && p->align_flags) { ugs_set_error("-fulldp / -gaforce belong to the global aligner"); return UGS_E_ARG; }
   if (p->local && (p->pair_mask || (p->filter_mask & UGS_F_ABSKEW))) {
     // (the reference's small-path local walk aligns against the PREVIOUS target when SetTarget refuses a pair)
     ugs_set_error("pair filters / -abskew are implemented for usearch_global only"); return UGS_E_ARG;
@@ -421,6 +422,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
   v.pair_mask = p->pair_mask; v.min_sizeratio = p->min_sizeratio; v.minqt = p->minqt; v.maxqt = p->maxqt; v.minsl = p->minsl; v.maxsl = p->maxsl;
   v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
+  v.align_flags = p->align_flags;
+  if (p->align_flags & UGS_A_FULLDP) v.band = 1 << 20;          // every diagonal: ViterbiFastMem (globalalignmem.cpp:148-152)
   db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
   if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
@@ -684,7 +687,8 @@ static int plan_launch(ugs_batch *b)
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
   b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
   const int waves = b->al.grid * awpb;
-  const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * p.band + 4) + 63) & ~63ull;
+  const uint64_t band_eff = (p.align_flags & UGS_A_FULLDP) ? std::max(b->max_qlen, db->max_tlen) : (uint64_t)p.band;
+  const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * band_eff + 4) + 63) & ~63ull;
   const uint32_t runs_stride = 2 * (b->max_qlen + db->max_tlen + 4);
   if (!b->d_tb || tb_stride * waves > b->tb_alloc) {
     if (b->d_tb) HIPCHK(hipFree(b->d_tb));
