@@ -52,6 +52,7 @@ extern "C" {
  *   band, minhsp, xdrop_nw, hsp_word_len                              (alnheuristics.cpp:26-62)
  *   match, mismatch (nt) ; aa uses BLOSUM62                           (alnparams.cpp:333,380-384)
  *   dbmask        0 = upper-case only, 1 = fastnucleo/fastamino       (makeudb.cpp:11-25);
+ *                 3 = fastnucleo/fastamino with -hardmask ('N' / 'X' instead of lower case, fastmask.cpp:98,117-150);
  *                 2 = letters are used as given: the stored, already masked letters of a .udb (loaddb.cpp:100-125)
  *   filter_mask + values: the optional accept filters of Accepter::IsAcceptLo (accepter.cpp:41-91): -maxid (only
  *                 tested when -id is set), -mincols, -maxgaps, -query_cov, -max_query_cov, -target_cov,

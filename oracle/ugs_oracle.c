@@ -244,7 +244,11 @@ struct orc_db {
 };
 
 /* fastmask.cpp:88-158 FastMaskSeq, soft mask (hardmask off), in place */
-void orc_fastmask(char *seq_, uint32_t L)
+static void fastmask_impl(char *seq_, uint32_t L, byte Hard);
+void orc_fastmask(char *seq_, uint32_t L) { fastmask_impl(seq_, L, 0); }
+/* Hard != 0: -hardmask, the masked letters become Hard ('N' / 'X') instead of lower case (fastmask.cpp:98,117-122,145-150);
+ * the reference masks in place (seqdb.cpp:446), so the dinucleotide pass reads the letters the first pass wrote */
+static void fastmask_impl(char *seq_, uint32_t L, byte Hard)
 {
   byte *Seq = (byte *)seq_;
   for (unsigned i = 0; i < L; ++i) Seq[i] = (byte)toupper(Seq[i]);
@@ -257,7 +261,7 @@ void orc_fastmask(char *seq_, uint32_t L)
     if (c != Lastc || i + 1 == L) {
       unsigned n1 = i - Start;               /* unsigned wrap with Start==UINT_MAX intended */
       if (n1 >= k1)
-        for (unsigned j = Start + j1; j < i; ++j) Seq[j] = (byte)tolower(Seq[j]);
+        for (unsigned j = Start + j1; j < i; ++j) Seq[j] = Hard ? Hard : (byte)tolower(Seq[j]);
       Start = i;
     }
     Lastc = c;
@@ -271,7 +275,7 @@ void orc_fastmask(char *seq_, uint32_t L)
       if (Pair != LastPair) {
         unsigned n2 = i - Start2;
         if (n2 >= k2)
-          for (unsigned j = Start2 + 2 * j2; j < i; ++j) Seq[j] = (byte)tolower(Seq[j]);
+          for (unsigned j = Start2 + (Hard ? j2 : 2 * j2); j < i; ++j) Seq[j] = Hard ? Hard : (byte)tolower(Seq[j]);
         Start2 = i;
       }
       LastPair = Pair;
@@ -379,7 +383,7 @@ int orc_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, u
     uint32_t L = (uint32_t)(offs[t + 1] - offs[t]);
     if (L > maxlen) maxlen = L;
     if (p->dbmask == 2) continue;                             /* LoadUDB loaddb.cpp:100-125: stored letters used as they are */
-    if (p->dbmask) orc_fastmask(db->seqs + offs[t], L);
+    if (p->dbmask) fastmask_impl(db->seqs + offs[t], L, p->dbmask == 3 ? (byte)(p->is_nucleo ? 'N' : 'X') : 0);
     else for (uint32_t i = 0; i < L; ++i) db->seqs[offs[t] + i] = (char)toupper((byte)db->seqs[offs[t] + i]);
   }
   db->maxlen = maxlen;

@@ -55,6 +55,8 @@ CASES = {
     "hard_fulldp":  dict(gen="hard", seed=33, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", lmin=20, lmax=300, maxaccepts=2, maxrejects=8, fulldp=1),
     "hard_gaforce": dict(gen="hard", seed=34, n_fam=250, fam=6, q_n=900, aa=False, id=0.85, strand="plus", big=100, lmin=20, lmax=300, gaforce=1),
     "hard_fulldp_aa": dict(gen="hard", seed=35, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, big=100, lmin=30, lmax=250, fulldp=1, gaforce=1),
+    "hard_hardmask": dict(gen="hard", seed=36, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", big=100, maxaccepts=2, maxrejects=8, hardmask=1),
+    "hard_hardmask_aa": dict(gen="hard", seed=37, n_fam=250, fam=6, q_n=700, aa=True, id=0.7, maxaccepts=2, maxrejects=8, hardmask=1),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
@@ -91,7 +93,7 @@ def ref_cmd(c, qfa, dbfa, prefix):
     for opt in ("big", "maxaccepts", "maxrejects") + FILTER_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
-    for flag in ("fulldp", "gaforce"):
+    for flag in ("fulldp", "gaforce", "hardmask"):
         if c.get(flag):
             cmd += ["-" + flag]
     return cmd

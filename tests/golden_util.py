@@ -46,6 +46,8 @@ def params_kw(c):
         kw["max_rejects"] = c["maxrejects"]
     if c.get("fulldp") or c.get("gaforce"):
         kw["align_flags"] = (1 if c.get("fulldp") else 0) | (2 if c.get("gaforce") else 0)
+    if c.get("hardmask"):
+        kw["dbmask"] = 3
     for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
         if opt in c:
             kw[opt] = c[opt]

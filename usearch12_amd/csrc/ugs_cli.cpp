@@ -268,6 +268,7 @@ int main(int argc, char **argv)
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
+  bool hardmask = false;
   bool local_cmd = false; double evalue = -1; double xdrop_u = -1, xdrop_g = -1, ka_dbsize = -1; long maxhsps = -1, hspw = -1;
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
@@ -293,6 +294,7 @@ int main(int argc, char **argv)
     else if (a == "-max_target_cov") { filt.max_target_cov = (float)atof(val()); filt.filter_mask |= UGS_F_MAX_TARGET_COV; }
     else if (a == "-maxdiffs") { filt.maxdiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXDIFFS; }
     else if (a == "-mindiffs") { filt.mindiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINDIFFS; }
+    else if (a == "-hardmask") hardmask = true;
     else if (a == "-fulldp") filt.align_flags |= UGS_A_FULLDP; else if (a == "-gaforce") filt.align_flags |= UGS_A_GAFORCE;
     else if (a == "-self") filt.pair_mask |= UGS_P_SELF; else if (a == "-notself") filt.pair_mask |= UGS_P_NOTSELF;
     else if (a == "-selfid") filt.pair_mask |= UGS_P_SELFID;
@@ -374,6 +376,7 @@ int main(int argc, char **argv)
   p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
   p.pair_mask = filt.pair_mask; p.min_sizeratio = filt.min_sizeratio; p.minqt = filt.minqt; p.maxqt = filt.maxqt; p.minsl = filt.minsl;
   p.maxsl = filt.maxsl; p.abskew = filt.abskew; p.align_flags = filt.align_flags;
+  if (hardmask) p.dbmask = 3;
   if (from_udb) { p.dbmask = 2; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
     if (path.empty()) return nullptr;

@@ -362,7 +362,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   DBCHK(hipMalloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
   if (nletters) DBCHK(hipMemcpy(db->d_seqs, seqs, nletters, hipMemcpyHostToDevice));
   DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask, db->stream)) != UGS_OK) return fail(rc);
+  if (p->dbmask < 0 || p->dbmask > 3) { ugs_set_error("dbmask must be 0..3"); return fail(UGS_E_ARG); }
+  if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask == 3 ? (1 | ((p->is_nucleo ? 'N' : 'X') << 8)) : p->dbmask, db->stream)) != UGS_OK) return fail(rc);
   const uint32_t slots = (uint32_t)slots64;
   if ((rc = ugs_build_index(db->d_tab, db->d_seqs, db->d_offs, nseq, nletters, p->word_len, alpha, slots,
                             &db->d_row_off, &db->d_postings, &db->n_postings, &db->max_row, db->stream)) != UGS_OK)

@@ -30,6 +30,7 @@ __global__ void k_mask(uint8_t *seqs, const uint64_t *offs, uint32_t nseq, int d
   const uint32_t L = (uint32_t)(offs[t + 1] - offs[t]);
   for (uint32_t i = 0; i < L; ++i) { uint8_t c = S[i]; if (c >= 'a' && c <= 'z') S[i] = c - 32; }
   if (!dbmask || L < 2) return;
+  const uint8_t hard = (uint8_t)(dbmask >> 8);        // -hardmask: 'N' / 'X' instead of lower case (fastmask.cpp:98,117-122,145-150)
   // homopolymer runs: fastmask.cpp:106-130 (k1=5, j1=2); unsigned wrap of i-Start is intended
   {
     uint8_t last = '?';
@@ -38,7 +39,7 @@ __global__ void k_mask(uint8_t *seqs, const uint64_t *offs, uint32_t nseq, int d
       uint8_t c = S[i]; if (c >= 'a' && c <= 'z') c -= 32;
       if (c != last || i + 1 == L) {
         uint32_t n1 = i - start;
-        if (n1 >= 5) for (uint32_t j = start + 2; j < i; ++j) { uint8_t x = S[j]; if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
+        if (n1 >= 5) for (uint32_t j = start + 2; j < i; ++j) { uint8_t x = S[j]; if (hard) S[j] = hard; else if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
         start = i;
       }
       last = c;
@@ -54,7 +55,8 @@ __global__ void k_mask(uint8_t *seqs, const uint64_t *offs, uint32_t nseq, int d
       uint32_t pair = ((uint32_t)c1 << 8) + c2;
       if (pair != lastpair) {
         uint32_t n2 = i - start;
-        if (n2 >= 5) for (uint32_t j = start + 2; j < i; ++j) { uint8_t x = S[j]; if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
+        // (the hard-mask branch starts one letter earlier: Start + j2 against Start + 2*j2, fastmask.cpp:146-151)
+        if (n2 >= 5) for (uint32_t j = start + (hard ? 1 : 2); j < i; ++j) { uint8_t x = S[j]; if (hard) S[j] = hard; else if (x >= 'A' && x <= 'Z') S[j] = x + 32; }
         start = i;
       }
       lastpair = pair;
