@@ -602,9 +602,17 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
     const uint32_t base_t = p * s.gsize;
     bool tail = false;
     uint32_t tot = 0, nrows = 0;
+    uint64_t rstart0 = 0; uint32_t rlen0 = 0;                     // rows 0..63 stay in registers for both passes (the usual case: ns <= 64)
     for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-      uint32_t len = 0;
-      if (i0 + lane < ns) { const uint32_t *pp = s.part + (uint64_t)s.s_slots[i0 + lane] * (s.np + 1) + p; len = pp[1] - pp[0]; }
+      uint64_t rs = 0; uint32_t len = 0;
+      if (i0 + lane < ns) {
+        const uint32_t slot = s.s_slots[i0 + lane];
+        const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
+        const uint32_t pa = pp[0];
+        len = pp[1] - pa;
+        if (i0 == 0) rs = s.row_off[slot] + pa;
+      }
+      if (i0 == 0) { rstart0 = rs; rlen0 = len; }
       tail = tail || __ballot(len > 64) != 0;
       tot += __builtin_amdgcn_readlane((int)wave_incl_sum_u32(len), 63);
       nrows += (uint32_t)__popcll(__ballot(len != 0));
@@ -614,12 +622,15 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
     if (tail || tot < 32u * nrows) { range_generic<8, false, true>(s, p, false, base_t, 0, 0, 0); continue; }
     for (int pass = 0; pass < 2; ++pass) {
       for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-        uint64_t rstart = 0; uint32_t rlen = 0;                  // lane r: first posting and length of row i0+r's sub-row
-        if (i0 + lane < ns) {
-          const uint32_t slot = s.s_slots[i0 + lane];
-          const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
-          const uint32_t pa = pp[0];
-          rstart = s.row_off[slot] + pa; rlen = pp[1] - pa;
+        uint64_t rstart = rstart0; uint32_t rlen = rlen0;          // lane r: first posting and length of row i0+r's sub-row
+        if (i0) {
+          rstart = 0; rlen = 0;
+          if (i0 + lane < ns) {
+            const uint32_t slot = s.s_slots[i0 + lane];
+            const uint32_t *pp = s.part + (uint64_t)slot * (s.np + 1) + p;
+            const uint32_t pa = pp[0];
+            rstart = s.row_off[slot] + pa; rlen = pp[1] - pa;
+          }
         }
         uint64_t rows = __ballot(rlen != 0);
         while (rows) {
