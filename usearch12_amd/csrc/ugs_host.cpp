@@ -41,6 +41,7 @@ struct ugs_db {
   UgsLocalView lv;
   // pair filters / -abskew
   uint32_t *d_tkey, *d_tsize; bool have_tkey, have_tsize;
+  bool sparse;                      // sparse dictionary (protein): short index rows
 };
 
 struct ugs_batch {
@@ -340,7 +341,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
-  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false;
+  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
   memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;
   auto fail = [&](int code) { ugs_db_destroy(db); return code; };
@@ -385,6 +386,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
       // number of resident waves, i.e. a small counter table (16 Ki targets x 8 bits = 16 KiB of LDS per wave).
       // The partition table may grow up to the size of the postings themselves for it.
       gs = 16384;
+      db->sparse = true;
       budget = std::max<uint64_t>(256ull << 20, db->n_postings * 4);
     }
     while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
@@ -646,6 +648,7 @@ static int plan_launch(ugs_batch *b)
   int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds);      // real residency (VGPRs, LDS, wave slots)
   per_cu = std::max(1, std::min(per_cu, 8));
   if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
+  b->rl.fast8 = bits >= 8 && !db->sparse;
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well

@@ -633,6 +633,30 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
           }
         }
         uint64_t rows = __ballot(rlen != 0);
+        if (pass == 0) {
+          // the count pass needs nothing but the postings: twice as many rows per trip, twice as many loads in flight
+          constexpr int NC = 2 * NR;
+          while (rows) {
+            uint32_t v[NC], ln[NC];
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+              ln[u] = 0; v[u] = 0;
+              if (rows) {
+                const int r = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                const uint64_t st = shfl64(rstart, r);
+                ln[u] = (uint32_t)__builtin_amdgcn_readlane((int)rlen, r);
+                v[u] = (s.postings + st)[(uint32_t)lane];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+              const uint32_t x = (uint32_t)lane < ln[u] ? v[u] - base_t : dummy_x;
+              __hip_atomic_fetch_add((lds32)(uintptr_t)(tb + (x & ~3u)), 1u << ((x & 3u) << 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          continue;
+        }
         while (rows) {
           uint32_t v[NR], ad[NR], sh[NR], ln[NR], rix[NR];
 #pragma unroll
@@ -652,11 +676,6 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
             const uint32_t x = (uint32_t)lane < ln[u] ? v[u] - base_t : dummy_x;
             ad[u] = tb + (x & ~3u);
             sh[u] = (x & 3u) << 3;
-          }
-          if (pass == 0) {
-#pragma unroll
-            for (int u = 0; u < NR; ++u) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[u], 1u << sh[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            continue;
           }
           // ordered clears with return (LDS executes a wave's atomics in program order): only the first row holding a
           // target sees its counter and gets the final count back, later rows read 0
@@ -703,7 +722,7 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <bool FILL, bool BATCH>
+template <bool FILL, bool BATCH, bool FAST8>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
   if (cb == 4) {
@@ -712,7 +731,7 @@ __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t
     }
     else scan_generic<4, FILL, BATCH>(s, need, fill_limit);
   } else if (cb == 8) {
-    if (!FILL && BATCH && s.tbl_words * 4 >= s.gsize) scan_fast8<8>(s);
+    if (!FILL && FAST8 && s.tbl_words * 4 >= s.gsize) scan_fast8<8>(s);
     else scan_generic<8, FILL, BATCH>(s, need, fill_limit);
   }
   else scan_generic<16, FILL, BATCH>(s, need, fill_limit);
@@ -870,7 +889,9 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
 // instantiations and each carries only its own branches through the hot loop
 // BATCH: launches whose tables are wider than 4 bits (16-255 sampled rows: mid-identity searches) walk the generic path
 // for every unit; their row loops keep four loads in flight.  The 4-bit launches keep the code the hot path was tuned with.
-template <bool SMALL, bool BATCH>
+// FAST8: dense indexes (nucleotide) take scan_fast8 for 8-bit tables; sparse dictionaries (protein) keep the generic code,
+// which flattens their short sub-rows - again an instantiation of its own, so that neither pays for the other's registers
+template <bool SMALL, bool BATCH, bool FAST8>
 __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -937,7 +958,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
-    scan_dispatch<false, BATCH>(sc, cb, 0, 0);
+    scan_dispatch<false, BATCH, FAST8>(sc, cb, 0, 0);
     // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
@@ -1262,7 +1283,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
       const uint32_t need = K - nsel;
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
-      scan_dispatch<true, BATCH>(sc, cb, need, fill_limit);
+      scan_dispatch<true, BATCH, FAST8>(sc, cb, need, fill_limit);
       __threadfence_block();
       __syncthreads();
     }
@@ -1286,8 +1307,8 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds)
 {
   int n = 0;
   // (both instantiations have the same register budget; the Big one is asked)
-  if (hipFuncSetAttribute((const void *)k_rank<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
+  if (hipFuncSetAttribute((const void *)k_rank<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
@@ -1324,8 +1345,9 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
-  const void *fn = db.big ? (L.bits == 4 ? (const void *)k_rank<false, false> : (const void *)k_rank<false, true>)
-                          : (L.bits == 4 ? (const void *)k_rank<true, false> : (const void *)k_rank<true, true>);
+  const int mode = L.bits == 4 ? 0 : (L.fast8 ? 2 : 1);
+  const void *fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false> : (const void *)k_rank<false, true, true>)
+                          : (mode == 0 ? (const void *)k_rank<true, false, false> : mode == 1 ? (const void *)k_rank<true, true, false> : (const void *)k_rank<true, true, true>);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
