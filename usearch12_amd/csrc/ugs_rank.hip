@@ -213,7 +213,8 @@ __device__ __forceinline__ bool flat_rows_at(const FlatRows &fr, uint32_t f, uin
 // sub-row length; rows are walked in order and counters are cleared right after they are read, so
 // only the first touch of a target sees a non-zero count (no duplicates are emitted).
 // FILL=true: emit count-1 targets in scan order, at most `need` of them.
-template <int CB, bool FILL, bool BATCH = false>
+// FLATPF: the sparse-dictionary kernel (protein) requests the flattened postings ahead of use
+template <int CB, bool FILL, bool BATCH = false, bool FLATPF = false>
 __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool split, uint32_t base_t, uint32_t hi_t,
                                               uint32_t need, uint64_t fill_limit, bool have_ab = false, uint64_t a_in = 0,
                                               uint64_t b_in = 0)
@@ -233,6 +234,18 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
     FlatRows fr;
     if (flat_rows_setup(fr, a, b, rows)) {
       // sparse sub-rows: lanes = postings of ALL rows of this range in row-major order
+      if constexpr (FLATPF) {
+        // two instructions' worth of postings are located and requested before either is counted
+        for (uint32_t f0 = 0; f0 < fr.T; f0 += 128) {
+          uint32_t row0, row1; uint64_t k0, k1;
+          const bool on0 = flat_rows_at(fr, f0 + (uint32_t)lane, row0, k0);
+          const bool on1 = f0 + 64 < fr.T && flat_rows_at(fr, f0 + 64 + (uint32_t)lane, row1, k1);
+          const uint32_t t0 = on0 ? postings[k0] : 0u, t1 = on1 ? postings[k1] : 0u;
+          if (on0) Tbl<CB>::inc(tbl, t0 - base_t);
+          if (on1) Tbl<CB>::inc(tbl, t1 - base_t);
+        }
+        continue;
+      }
       for (uint32_t f0 = 0; f0 < fr.T; f0 += 64) {
         uint32_t row; uint64_t k;
         const bool on = flat_rows_at(fr, f0 + (uint32_t)lane, row, k);
@@ -316,11 +329,21 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
     uint64_t rows = __ballot(b > a);
     FlatRows fr;
     if (flat_rows_setup(fr, a, b, rows)) {
+      uint32_t nrow = 0, nt2 = 0; bool no2 = false;             // (FLATPF) the next instruction's postings, requested one trip ahead
+      if constexpr (FLATPF) { uint64_t k; no2 = flat_rows_at(fr, (uint32_t)lane, nrow, k); nt2 = no2 ? postings[k] : 0u; }
       for (uint32_t f0 = 0; f0 < fr.T; f0 += 64) {
         uint32_t row; uint64_t k;
-        const bool o2 = flat_rows_at(fr, f0 + (uint32_t)lane, row, k);
+        bool o2;
         uint32_t t2 = 0, c2 = 0;
-        if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+        if constexpr (FLATPF) {
+          o2 = no2; row = nrow; t2 = nt2;
+          no2 = false;
+          if (f0 + 64 < fr.T) { no2 = flat_rows_at(fr, f0 + 64 + (uint32_t)lane, nrow, k); nt2 = no2 ? postings[k] : 0u; }
+          if (o2) c2 = Tbl<CB>::get(tbl, t2 - base_t);
+        } else {
+          o2 = flat_rows_at(fr, f0 + (uint32_t)lane, row, k);
+          if (o2) { t2 = postings[k]; c2 = Tbl<CB>::get(tbl, t2 - base_t); }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
         // one instruction now spans several rows: a target held by two of its lanes (count >= 2) is reported by the
@@ -384,7 +407,7 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int CB, bool FILL, bool BATCH = false>
+template <int CB, bool FILL, bool BATCH = false, bool FLATPF = false>
 __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, uint64_t fill_limit)
 {
   constexpr uint32_t EPW = 32 / CB;
@@ -413,7 +436,7 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
         const uint64_t a = cur;
         while (cur < end && vcur < hi_t) { ++cur; vcur = cur < end ? s.postings[cur] : 0xffffffffu; }
         if (!__ballot(cur > a)) continue;                        // no sampled row has a posting in this range
-        range_generic<CB, FILL, BATCH>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
+        range_generic<CB, FILL, BATCH, FLATPF>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
       }
     }
     return;
@@ -423,7 +446,7 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
       const uint32_t base_t = p * s.gsize + sub * tbl_targets;
       const uint32_t pend = (p + 1) * s.gsize;
       const uint32_t hi_t = split ? (base_t + tbl_targets < pend ? base_t + tbl_targets : pend) : 0;
-      range_generic<CB, FILL, BATCH>(s, p, split, base_t, hi_t, need, fill_limit);
+      range_generic<CB, FILL, BATCH, FLATPF>(s, p, split, base_t, hi_t, need, fill_limit);
     }
 }
 
@@ -729,12 +752,12 @@ __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t
     if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
       if (s.ns <= 8) scan_fast4<8>(s); else if (s.ns <= 11) scan_fast4<11>(s); else scan_fast4<12>(s);
     }
-    else scan_generic<4, FILL, BATCH>(s, need, fill_limit);
+    else scan_generic<4, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
   } else if (cb == 8) {
     if (!FILL && FAST8 && s.tbl_words * 4 >= s.gsize) scan_fast8<8>(s);
-    else scan_generic<8, FILL, BATCH>(s, need, fill_limit);
+    else scan_generic<8, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
   }
-  else scan_generic<16, FILL, BATCH>(s, need, fill_limit);
+  else scan_generic<16, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
 }
 
 // wave-uniform min of a u32 with DPP row shifts (no LDS crossbar): inclusive prefix-min inside each
