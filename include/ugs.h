@@ -386,6 +386,8 @@ int ugs_format_fastapairs(const ugs_hit *h, const uint32_t *cigar_pool, const ch
 int ugs_format_segout(const ugs_hit *h, const uint32_t *cigar_pool, int which, const char *qlabel, const char *tlabel,
                       const char *qseq, uint32_t ql, const char *tseq, uint32_t tl, char *buf, int cap);
 /* OutputBlast6NoHits blast6out.cpp:82-103 (-output_no_hits) */
+/* -trimout record (OutputTrim outputsink.cpp:401-415, GetTrimInfo arscorer.cpp:933-971): the query minus its overhang */
+int ugs_format_trimout(const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel, const char *qseq, uint32_t ql, char *buf, int cap);
 int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap);
 /* SeqToFasta seqdb.cpp:62-90 (-matched / -notmatched / -dbmatched / -dbnotmatched records) */
 int ugs_format_fasta(const char *label, const char *seq, uint32_t len, char *buf, int cap);

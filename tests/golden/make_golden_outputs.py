@@ -30,10 +30,10 @@ RUNS = {
     "nt_top1":  ("hard_acc_s", ["-userfields", "query+target+id", "-top_hit_only"], ["user"]),
     "aa_all":   ("hard_aa_s", ["-userfields", FIELDS], ["user", "b6", "notmatched"]),
     "nt_aln":   ("hard_acc_s", [], ["aln"]),
-    "nt_segs":  ("hard_acc_s", [], ["pairs", "qseg", "tseg"]),
+    "nt_segs":  ("hard_acc_s", [], ["pairs", "qseg", "tseg", "trim"]),
     "aa_aln":   ("hard_aa_s", [], ["aln"]),
 }
-OPT = {"pairs": "-fastapairs", "qseg": "-qsegout", "tseg": "-tsegout", "aln": "-alnout", "user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
+OPT = {"trim": "-trimout", "pairs": "-fastapairs", "qseg": "-qsegout", "tseg": "-tsegout", "aln": "-alnout", "user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
        "dbmatched": "-dbmatched", "dbnotmatched": "-dbnotmatched"}
 
 

@@ -53,7 +53,7 @@ def format_run(run):
     masked = odb.masked().tobytes()
     qlabels, tlabels = qs.labels(), db.labels()
     buf = C.create_string_buffer(1 << 20)
-    out = {k: [] for k in ("user", "b6", "uc", "matched", "notmatched", "dbmatched", "dbnotmatched", "aln", "pairs", "qseg", "tseg")}
+    out = {k: [] for k in ("user", "b6", "uc", "matched", "notmatched", "dbmatched", "dbnotmatched", "aln", "pairs", "qseg", "tseg", "trim")}
     dbcount = np.zeros(db.n, np.int64)
     L.ugs_format_userout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
                                      C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
@@ -62,6 +62,7 @@ def format_run(run):
     L.ugs_format_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
     L.ugs_format_blast6_nohit.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.ugs_format_fastapairs.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
+    L.ugs_format_trimout.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
     L.ugs_format_segout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
     L.ugs_format_alnout_header.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
     L.ugs_format_alnout_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32,
@@ -98,6 +99,7 @@ def format_run(run):
             out["uc"].append(take(L.ugs_format_uc_hit(hp, pool.ctypes.data, int(nucleo), qlab, tlab, buf, len(buf))))
             out["user"].append(take(L.ugs_format_userout(hp, pool.ctypes.data, int(nucleo), fields, qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
             out["pairs"].append(take(L.ugs_format_fastapairs(hp, pool.ctypes.data, qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
+            out["trim"].append(take(L.ugs_format_trimout(hp, pool.ctypes.data, qlab, qseq, ql, buf, len(buf))))
             out["qseg"].append(take(L.ugs_format_segout(hp, pool.ctypes.data, 0, qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
             out["tseg"].append(take(L.ugs_format_segout(hp, pool.ctypes.data, 1, qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
             out["aln"].append(take(L.ugs_format_alnout_hit(hp, pool.ctypes.data, int(nucleo), qlab, tlab, qseq, ql, tseq, len(tseq), buf, len(buf))))
@@ -139,7 +141,7 @@ def test_cli_outputs_identical_to_reference(tmp_path, run):
         if o in c:
             cmd += ["-" + o, str(c[o])]
     cmd += m["extra"]
-    names = {"pairs": "-fastapairs", "qseg": "-qsegout", "tseg": "-tsegout", "aln": "-alnout", "user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
+    names = {"trim": "-trimout", "pairs": "-fastapairs", "qseg": "-qsegout", "tseg": "-tsegout", "aln": "-alnout", "user": "-userout", "b6": "-blast6out", "uc": "-uc", "matched": "-matched", "notmatched": "-notmatched",
              "dbmatched": "-dbmatched", "dbnotmatched": "-dbnotmatched"}
     for kind in m["files"]:
         cmd += [names[kind], os.path.join(tmp, "o." + kind)]

@@ -146,7 +146,7 @@ class Searcher {
 
 // the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
 struct Outputs {
-  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr, *pairs = nullptr, *qseg = nullptr, *tseg = nullptr;
+  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr, *pairs = nullptr, *qseg = nullptr, *tseg = nullptr, *trim = nullptr;
   std::string userfields;
   bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
   uint32_t maxhits = 0;
@@ -203,6 +203,7 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   for (uint32_t j = 0; j < n; ++j) {
     const uint32_t t = h[j].target;
     const char *tl = db.labels[t].c_str();
+    if (O.trim) put(O.trim, ugs_format_trimout(&h[j], pool, qlab, qs, ql, line.data(), (int)line.size()));
     if (O.pairs || O.qseg || O.tseg) {
       const char *tsq = O.db_masked + db.offs[t]; const uint32_t tlen = (uint32_t)(db.offs[t + 1] - db.offs[t]);
       if (O.pairs) put(O.pairs, ugs_format_fastapairs(&h[j], pool, qlab, tl, qs, ql, tsq, tlen, line.data(), (int)line.size()));
@@ -264,7 +265,7 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
-  std::string tabbedout; bool closedref_cmd = false;
+  std::string tabbedout, trimpath; bool closedref_cmd = false;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -305,6 +306,7 @@ int main(int argc, char **argv)
     else if (a == "-maxsl") { filt.maxsl = (float)atof(val()); filt.pair_mask |= UGS_P_MAXSL; }
     else if (a == "-abskew") { filt.abskew = (float)atof(val()); filt.filter_mask |= UGS_F_ABSKEW; }
     else if (a == "-alnout") alnpath = val(); else if (a == "-fastapairs") pairspath = val();
+    else if (a == "-trimout") trimpath = val();
     else if (a == "-qsegout") qsegpath = val(); else if (a == "-tsegout") tsegpath = val();
     else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
     else if (a == "-matched") matchedpath = val(); else if (a == "-notmatched") notmatchedpath = val();
@@ -361,7 +363,7 @@ int main(int argc, char **argv)
     if (xdrop_g >= 0) p.xdrop_g = (float)xdrop_g;
     if (ka_dbsize > 0) p.ka_dbsize = (float)ka_dbsize;
     if (maxhsps > 0) p.max_hsps = (uint32_t)maxhsps;
-    if (!pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || otutab_cmd || closedref_cmd) {
+    if (!pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || !trimpath.empty() || otutab_cmd || closedref_cmd) {
       fprintf(stderr, "-usearch_local writes -blast6out, -uc, -userout, -alnout, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
     }
   }
@@ -389,7 +391,7 @@ int main(int argc, char **argv)
     if (O.userfields.empty()) { fprintf(stderr, "--userout requires --userfields\n"); return 1; }
     if (ugs_userfields_check(O.userfields.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
   }
-  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
+  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.trim = open_out(trimpath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
   O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   if (closedref_cmd) { O.closedref = ugs_closedref_create(); O.tabbed = open_out(tabbedout); }
@@ -416,7 +418,7 @@ int main(int argc, char **argv)
     }
     total += q.size();
   }
-  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed}) if (f) fclose(f);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed, O.trim}) if (f) fclose(f);
   if (O.closedref) ugs_closedref_destroy(O.closedref);
   if (O.otutab) {                                                     // OTUTableSink::OnAllDone otutabsink.cpp:60-76
     uint64_t assigned = 0, tot = 0;

@@ -280,6 +280,32 @@ extern "C" int ugs_format_userout_local(const ugs_params *p, const ugs_hit *h, c
   return format_userout_impl(p, h, cigar_pool, p->is_nucleo, fields, qlabel, tlabel, qseq, ql, tseq, tl, buf, cap);
 }
 
+// -trimout: OutputSink::OutputTrim outputsink.cpp:401-415 over AlignResult::GetTrimInfo arscorer.cpp:933-971: the query as
+// aligned without the letters that hang over the target's ends (leading / trailing D runs of the path), label
+// ":lo-hi" (1-based).  The reference copies positions [QLo, QHi) - the last kept letter is dropped - and so does this.
+extern "C" int ugs_format_trimout(const ugs_hit *h, const uint32_t *cigar_pool, const char *qlabel, const char *qseq, uint32_t ql, char *buf, int cap)
+{
+  if (!h || !cigar_pool || !qlabel || !qseq) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (ql != h->ql) { ugs_set_error("sequence length does not match the hit record"); return UGS_E_ARG; }
+  const MatchTables &T = tables();
+  std::string Q(qseq, ql);
+  if (h->strand) for (uint32_t k = 0; k < ql; ++k) { const unsigned char c = (unsigned char)qseq[ql - 1 - k]; const unsigned char cc = T.comp[c]; Q[k] = (char)(cc == '?' ? c : cc); }
+  uint32_t QLo = 0, QHi = ql ? ql - 1 : 0;
+  if (ql && h->cigar_len) {
+    const uint32_t r0 = cigar_pool[h->cigar_off], rn = cigar_pool[h->cigar_off + h->cigar_len - 1];
+    if ((r0 & 3) == 1) QLo = r0 >> 2;
+    if ((rn & 3) == 1) { const uint32_t NewQHi = ql - (rn >> 2) - 1; if (NewQHi > QLo) QHi = NewQHi; }
+  }
+  std::string label(qlabel);
+  app(label, ":%u-%u", QLo + 1, QHi + 1);
+  const std::string seg = QHi > QLo ? Q.substr(QLo, QHi - QLo) : std::string();
+  std::vector<char> rec(seg.size() + seg.size() / 80 + label.size() + 8);
+  const int n = ugs_format_fasta(label.c_str(), seg.data(), (uint32_t)seg.size(), rec.data(), (int)rec.size());
+  if (n < 0) return n;
+  if (buf && cap > 0) { const int m = n < cap - 1 ? n : cap - 1; memcpy(buf, rec.data(), (size_t)m); buf[m] = 0; }
+  return n;
+}
+
 // OutputBlast6NoHits blast6out.cpp:82-103 (written only under -output_no_hits)
 extern "C" int ugs_format_blast6_nohit(const char *qlabel, char *buf, int cap)
 {
