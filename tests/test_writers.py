@@ -148,3 +148,33 @@ def test_cli_outputs_identical_to_reference(tmp_path, run):
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     for kind in m["files"]:
         check(run, kind, open(os.path.join(tmp, "o." + kind), "rb").read())
+
+
+@pytest.mark.gpu
+def test_cli_fastq_queries_identical_to_reference(tmp_path):
+    """FASTQ query file (FASTQSeqSource fastqseqsource.cpp:7-107): same hits as the FASTA run, -matchedfq / -notmatchedfq
+    (SeqToFastq seqdb.cpp:14-29) byte-identical to the reference's files"""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(G.GOLD, "make_golden_fastq.py"))
+    mgf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgf)
+    man = json.load(open(os.path.join(G.GOLD, "fastq_manifest.json")))
+    c, db, qs, b6, _ = G.load(man["case"])
+    tmp = str(tmp_path)
+    dbfa, qfq = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fq")
+    db.write_fasta(dbfa)
+    mgf.write_fastq(qfq, qs)
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    cmd = [cli, "-usearch_global", qfq, "-db", dbfa, "-id", str(c["id"]), "-strand", c["strand"], "-maxaccepts", str(c["maxaccepts"]),
+           "-maxrejects", str(c["maxrejects"]), "-blast6out", os.path.join(tmp, "o.b6"), "-matchedfq", os.path.join(tmp, "o.matchedfq"),
+           "-notmatchedfq", os.path.join(tmp, "o.notmatchedfq"), "-batch", "700"]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    assert open(os.path.join(tmp, "o.b6")).read() == b6
+    for kind, want in man["files"].items():
+        got = open(os.path.join(tmp, "o." + kind), "rb").read()
+        assert got.count(b"\n") == want["lines"] and hashlib.sha256(got).hexdigest() == want["sha256"], kind
+    # a FASTA query file cannot feed -matchedfq
+    qfa = os.path.join(tmp, "q.fa")
+    qs.write_fasta(qfa)
+    r = subprocess.run([cli, "-usearch_global", qfa, "-db", dbfa, "-id", "0.9", "-strand", "plus", "-matchedfq", os.path.join(tmp, "x.fq")], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"Cannot convert FASTA to FASTQ" in r.stderr

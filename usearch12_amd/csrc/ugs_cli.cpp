@@ -16,6 +16,7 @@
 // HitMgr (hit grouping, done inside ugs_batch_fetch) and OutputSink (the text writers).
 #include "../../include/ugs.h"
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@
 struct SeqSet {                       // SeqDB (seqdb.h:29-52) flattened: labels + concatenated letters
   std::vector<std::string> labels;
   std::string letters;
+  std::string quals;                  // FASTQ input only: one quality character per letter (same offsets)
   std::vector<uint64_t> offs{0};
   size_t size() const { return labels.size(); }
 };
@@ -44,6 +46,23 @@ class FastaReader {
     size_t n = 0;
     while (n < max_seqs && have_) {
       if (line_.empty()) { have_ = next_line(); continue; }
+      if (line_[0] == '@' && (fastq_ || out.size() == 0 || !out.quals.empty())) {
+        // FASTQSeqSource::GetNextLo fastqseqsource.cpp:7-107: '@'label / letters / '+'... / qualities, one line each
+        fastq_ = true;
+        std::string label = line_.substr(1);
+        if (!next_line()) { fprintf(stderr, "Unexpected end-of-file in FASTQ file\n"); exit(1); }
+        for (unsigned char c : line_) if (!isalpha(c)) { fprintf(stderr, "Invalid sequence letter in FASTQ\n"); exit(1); }
+        const std::string seq = line_;
+        next_line();                                                   // '+' line: contents ignored
+        if (!next_line() || line_.size() != seq.size()) { fprintf(stderr, "Bad FASTQ record: %zu bases, %zu quals\n", seq.size(), line_.size()); exit(1); }
+        have_ = true;
+        if (!seq.empty()) {
+          out.letters += seq; out.quals += line_;
+          out.labels.push_back(label); out.offs.push_back(out.letters.size()); ++n;
+        }
+        have_ = next_line();
+        continue;
+      }
       if (line_[0] != '>') { fprintf(stderr, "bad FASTA: expected '>'\n"); exit(1); }
       std::string label = line_.substr(1);
       const size_t start = out.letters.size();
@@ -82,7 +101,7 @@ class FastaReader {
   }
   std::vector<char> buf_ = std::vector<char>(4u << 20);
   size_t pos_ = 0, len_ = 0;
-  FILE *f_; std::string line_; bool have_;
+  FILE *f_; std::string line_; bool have_; bool fastq_ = false;
 };
 
 // Searcher (searcher.h:21-96) as a batch object over one ugs_db
@@ -146,7 +165,7 @@ class Searcher {
 
 // the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
 struct Outputs {
-  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr, *pairs = nullptr, *qseg = nullptr, *tseg = nullptr, *trim = nullptr;
+  FILE *b6 = nullptr, *uc = nullptr, *user = nullptr, *matched = nullptr, *notmatched = nullptr, *aln = nullptr, *pairs = nullptr, *qseg = nullptr, *tseg = nullptr, *trim = nullptr, *matchedfq = nullptr, *notmatchedfq = nullptr;
   std::string userfields;
   bool output_no_hits = false, top_hit_only = false, top_hits_only = false;
   uint32_t maxhits = 0;
@@ -155,6 +174,14 @@ struct Outputs {
   std::vector<uint32_t> db_hit_counts;      // DBHitSink::m_HitCounts
   const char *db_masked = nullptr;          // DB letters as the reference holds them (masked)
 };
+
+// SeqToFastq seqdb.cpp:14-29 (-matchedfq / -notmatchedfq; "Cannot convert FASTA to FASTQ" without qualities)
+static void write_fastq(FILE *f, const SeqSet &q, uint32_t qi)
+{
+  if (q.quals.empty()) { fprintf(stderr, "Cannot convert FASTA to FASTQ\n"); exit(1); }
+  const size_t a = q.offs[qi], n = q.offs[qi + 1] - a;
+  fprintf(f, "@%s\n%.*s\n+\n%.*s\n", q.labels[qi].c_str(), (int)n, q.letters.data() + a, (int)n, q.quals.data() + a);
+}
 
 // OutputSink::OnQueryDone (outputsink.cpp:358-384): hits of one query, or the no-hit records
 static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const SeqSet &db, uint32_t qi,
@@ -192,6 +219,7 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
       if (O.user) put(O.user, ugs_format_userout(nullptr, nullptr, p.is_nucleo, O.userfields.c_str(), qlab, nullptr, qs, ql, nullptr, 0, line.data(), (int)line.size()));
     }
     if (O.notmatched) put(O.notmatched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
+    if (O.notmatchedfq) write_fastq(O.notmatchedfq, q, qi);
     return;
   }
   if (O.aln) {                                                        // OutputReport outputsink.cpp:338-356
@@ -224,6 +252,7 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
     if (!O.db_hit_counts.empty() && !(O.otutab && j > 0)) ++O.db_hit_counts[t];   // DBHitSink::OnQueryDone dbhitsink.cpp:117-140 (otutab: first hit only, :137)
   }
   if (O.matched) put(O.matched, ugs_format_fasta(qlab, qs, ql, line.data(), (int)line.size()));
+  if (O.matchedfq) write_fastq(O.matchedfq, q, qi);
 }
 
 // LoadUDB (loaddb.cpp:100-125): a .udb is recognised by its magic; its letters are used as stored (already masked)
@@ -265,7 +294,7 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
 int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
-  std::string tabbedout, trimpath; bool closedref_cmd = false;
+  std::string tabbedout, trimpath, matchedfqpath, notmatchedfqpath; bool closedref_cmd = false;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -309,6 +338,7 @@ int main(int argc, char **argv)
     else if (a == "-trimout") trimpath = val();
     else if (a == "-qsegout") qsegpath = val(); else if (a == "-tsegout") tsegpath = val();
     else if (a == "-userout") userpath = val(); else if (a == "-userfields") O.userfields = val();
+    else if (a == "-matchedfq") matchedfqpath = val(); else if (a == "-notmatchedfq") notmatchedfqpath = val();
     else if (a == "-matched") matchedpath = val(); else if (a == "-notmatched") notmatchedpath = val();
     else if (a == "-dbmatched") dbmatchedpath = val(); else if (a == "-dbnotmatched") dbnotmatchedpath = val();
     else if (a == "-output_no_hits") O.output_no_hits = true; else if (a == "-top_hit_only") O.top_hit_only = true;
@@ -391,7 +421,7 @@ int main(int argc, char **argv)
     if (O.userfields.empty()) { fprintf(stderr, "--userout requires --userfields\n"); return 1; }
     if (ugs_userfields_check(O.userfields.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
   }
-  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.trim = open_out(trimpath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
+  O.b6 = open_out(b6path); O.uc = open_out(ucpath); O.user = open_out(userpath); O.aln = open_out(alnpath); O.pairs = open_out(pairspath); O.trim = open_out(trimpath); O.matchedfq = open_out(matchedfqpath); O.notmatchedfq = open_out(notmatchedfqpath); O.qseg = open_out(qsegpath); O.tseg = open_out(tsegpath);
   O.matched = open_out(matchedpath); O.notmatched = open_out(notmatchedpath);
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   if (closedref_cmd) { O.closedref = ugs_closedref_create(); O.tabbed = open_out(tabbedout); }
@@ -418,7 +448,7 @@ int main(int argc, char **argv)
     }
     total += q.size();
   }
-  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed, O.trim}) if (f) fclose(f);
+  for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed, O.trim, O.matchedfq, O.notmatchedfq}) if (f) fclose(f);
   if (O.closedref) ugs_closedref_destroy(O.closedref);
   if (O.otutab) {                                                     // OTUTableSink::OnAllDone otutabsink.cpp:60-76
     uint64_t assigned = 0, tot = 0;
