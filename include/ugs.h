@@ -411,6 +411,7 @@ ugs_otutab *ugs_otutab_create(void);
 void ugs_otutab_destroy(ugs_otutab *t);
 int ugs_otutab_add(ugs_otutab *t, const char *qlabel, const char *top_hit_tlabel, char *map_line, int cap);
 int ugs_otutab_write(const ugs_otutab *t, const char *path);
+int ugs_otutab_write_biom(const ugs_otutab *t, const char *path);     /* -biomout: OTUTable::ToJsonFile json.cpp:32-103 */
 int ugs_otutab_totals(const ugs_otutab *t, uint64_t *assigned, uint64_t *total);
 
 /*

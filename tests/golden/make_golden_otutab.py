@@ -46,7 +46,10 @@ def main():
         db.write_fasta(dbfa)
         qs.write_fasta(qfa)
         subprocess.check_call([REF, "-otutab", qfa, "-otus", dbfa, "-otutabout", os.path.join(HERE, "otutab.tab"), "-mapout",
-                               os.path.join(HERE, "otutab.map"), "-threads", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                               os.path.join(HERE, "otutab.map"), "-biomout", os.path.join(tmp, "o.biom"), "-threads", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # -biomout: the "id" (output path) and "date" lines vary from run to run and are left out of the fixture
+        biom = [ln for ln in open(os.path.join(tmp, "o.biom")).read().splitlines(True) if not ln.startswith(('\t"id"', '\t"date"'))]
+        open(os.path.join(HERE, "otutab.biom"), "w").write("".join(biom))
     print(os.path.getsize(os.path.join(HERE, "otutab.tab")), os.path.getsize(os.path.join(HERE, "otutab.map")))
 
 

@@ -49,7 +49,13 @@ def test_otutab_from_oracle_hits(tmp_path):
         lines.append(buf.raw[:ln])
     out = os.path.join(str(tmp_path), "t.tab")
     assert L.ugs_otutab_write(tab, out.encode()) == 0
+    L.ugs_otutab_write_biom.argtypes = [C.c_void_p, C.c_char_p]
+    biom = os.path.join(str(tmp_path), "t.biom")
+    assert L.ugs_otutab_write_biom(tab, biom.encode()) == 0
     L.ugs_otutab_destroy(tab)
+    # -biomout (json.cpp:32-103); the "id" (= output path) and "date" lines differ from run to run
+    got = b"".join(ln for ln in open(biom, "rb").read().splitlines(True) if not ln.startswith((b'\t"id"', b'\t"date"')))
+    assert got == gold("otutab.biom")
     assert b"".join(lines) == gold("otutab.map")
     assert open(out, "rb").read() == gold("otutab.tab")
 
@@ -62,7 +68,9 @@ def test_cli_otutab_identical_to_reference(tmp_path):
     db.write_fasta(dbfa)
     qs.write_fasta(qfa)
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
-    subprocess.check_call([cli, "-otutab", qfa, "-otus", dbfa, "-otutabout", os.path.join(tmp, "o.tab"), "-mapout", os.path.join(tmp, "o.map")],
-                          stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "-otutab", qfa, "-otus", dbfa, "-otutabout", os.path.join(tmp, "o.tab"), "-mapout", os.path.join(tmp, "o.map"),
+                           "-biomout", os.path.join(tmp, "o.biom")], stderr=subprocess.DEVNULL)
+    got = b"".join(ln for ln in open(os.path.join(tmp, "o.biom"), "rb").read().splitlines(True) if not ln.startswith((b'\t"id"', b'\t"date"')))
+    assert got == gold("otutab.biom")
     assert open(os.path.join(tmp, "o.map"), "rb").read() == gold("otutab.map")
     assert open(os.path.join(tmp, "o.tab"), "rb").read() == gold("otutab.tab")

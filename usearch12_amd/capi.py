@@ -25,7 +25,7 @@ EXPORTS = [
     "ugs_closedref_create", "ugs_closedref_destroy", "ugs_closedref_add", "ugs_closedref_totals", "ugs_db_set_pair_keys", "ugs_batch_set_pair_keys", "ugs_hits_sort", "ugs_params_set_local", "ugs_local_evalue", "ugs_format_blast6_local", "ugs_format_trimout", "ugs_format_userout_local", "ugs_format_alnout_header_local", "ugs_format_alnout_hit_local", "ugs_userfields_check", "ugs_format_userout", "ugs_format_blast6_nohit", "ugs_format_fasta", "ugs_hits_to_report",
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_format_fastapairs", "ugs_format_segout",
-    "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_totals",
+    "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_write_biom", "ugs_otutab_totals",
 ]
 
 

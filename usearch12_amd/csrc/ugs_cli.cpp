@@ -295,6 +295,7 @@ int main(int argc, char **argv)
 {
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
   std::string tabbedout, trimpath, matchedfqpath, notmatchedfqpath; bool closedref_cmd = false;
+  std::string biomout;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -307,6 +308,7 @@ int main(int argc, char **argv)
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
     else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
     else if (a == "-closed_ref") { qpath = val(); closedref_cmd = true; } else if (a == "-tabbedout") tabbedout = val();
+    else if (a == "-biomout") biomout = val();
     else if (a == "-otutabout") otutabout = val(); else if (a == "-mapout") mapout = val(); else if (a == "-stepwords") stepwords = atol(val());
     else if (a == "-usearch_local") { qpath = val(); local_cmd = true; } else if (a == "-evalue") evalue = atof(val());
     else if (a == "-xdrop_u") xdrop_u = atof(val()); else if (a == "-xdrop_g") xdrop_g = atof(val()); else if (a == "-ka_dbsize") ka_dbsize = atof(val());
@@ -455,6 +457,7 @@ int main(int argc, char **argv)
     ugs_otutab_totals(O.otutab, &assigned, &tot);
     fprintf(stderr, "%llu / %llu mapped to OTUs (%.1f%%)\n", (unsigned long long)assigned, (unsigned long long)tot, tot ? 100.0 * assigned / tot : 0.0);
     if (!otutabout.empty() && ugs_otutab_write(O.otutab, otutabout.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    if (!biomout.empty() && ugs_otutab_write_biom(O.otutab, biomout.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
     ugs_otutab_destroy(O.otutab);
   }
   for (int m = 0; m < 2; ++m) {                                       // DBHitSink::ToFASTA dbhitsink.cpp:89-115

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -453,6 +454,35 @@ extern "C" int ugs_otutab_write(const ugs_otutab *t, const char *path)
     for (size_t s = 0; s < t->samples.size(); ++s) fprintf(f, "\t%u", t->counts[o][s]);
     fputc('\n', f);
   }
+  fclose(f);
+  return UGS_OK;
+}
+
+// OTUTable::ToJsonFile json.cpp:32-103 (-biomout): BIOM 1.0, sparse triples.  The comma after a triple is decided by the
+// triple's own indexes, not by whether another one follows (so a table whose last cell is zero ends in ",") - reproduced.
+extern "C" int ugs_otutab_write_biom(const ugs_otutab *t, const char *path)
+{
+  if (!t || !path) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  FILE *f = fopen(path, "w");
+  if (!f) { ugs_set_error("cannot create %s", path); return UGS_E_ARG; }
+  const unsigned no = (unsigned)t->otus.size(), nsam = (unsigned)t->samples.size();
+  time_t now = time(nullptr);
+  char ts[26];
+  memcpy(ts, asctime(localtime(&now)), 24); ts[24] = 0;
+  fprintf(f, "{\n\t\"id\":\"%s\",\n\t\"format\": \"Biological Observation Matrix 1.0\",\n\t\"format_url\": \"http://biom-format.org\",\n", path);
+  fprintf(f, "\t\"generated_by\": \"usearch\",\n\t\"type\": \"OTU table\",\n\t\"date\": \"%s\",\n\t\"matrix_type\": \"sparse\",\n", ts);
+  fprintf(f, "\t\"matrix_element_type\": \"float\",\n\t\"shape\": [%u,%u],\n\t\"rows\":[\n", no, nsam);
+  for (unsigned o = 0; o < no; ++o) fprintf(f, "\t\t{\"id\":\"%s\", \"metadata\":null}%s\n", t->otus[o].c_str(), o + 1 != no ? "," : "");
+  fprintf(f, "\t],\n\t\"columns\":[\n");
+  for (unsigned k = 0; k < nsam; ++k) fprintf(f, "\t\t{\"id\":\"%s\", \"metadata\":null}%s\n", t->samples[k].c_str(), k + 1 != nsam ? "," : "");
+  fprintf(f, "\t],\n\t\"data\": [\n");
+  for (unsigned o = 0; o < no; ++o)
+    for (unsigned k = 0; k < nsam; ++k) {
+      const unsigned c = t->counts[o][k];
+      if (c == 0) continue;
+      fprintf(f, "\t\t[%u,%u,%u]%s\n", o, k, c, (o + 1 < no || k + 1 < nsam) ? "," : "");
+    }
+  fprintf(f, "\t]\n}\n");
   fclose(f);
   return UGS_OK;
 }
