@@ -7,8 +7,13 @@
  * exact half-integers).  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may use this file; the product (usearch12_amd/) never does.
  *
- * Pinned against the compiled unmodified reference (oracle/_ref/usearch12) through the
- * golden fixtures in tests/golden/ (tests/test_oracle_golden.py).
+ * Pinned against the compiled unmodified reference (oracle/_ref/usearch12, oracle/_ref/ref_xdrop) through the
+ * golden fixtures in tests/golden/:
+ *   usearch_global incl. accept filters, -fulldp, -gaforce, -hardmask   tests/test_oracle_golden.py   (manifest.json)
+ *   pair filters of Accepter::RejectPair, -abskew                        tests/test_oracle_pairs.py    (pairs_manifest.json)
+ *   usearch_local (AlignMulti, AlignPos, EStats, local accept rules)     tests/test_oracle_local.py    (local_manifest.json)
+ *   gapped x-drop (XDropFwd/Bwd/Split/AlignMem)                          tests/test_oracle_xdrop.py    (xdrop_{nt,aa}.txt)
+ *   masking + index vs the reference's .udb                              tests/test_udb.py
  */
 #include "ugs_oracle.h"
 

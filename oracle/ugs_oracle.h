@@ -1,13 +1,14 @@
 /*
  * ugs_oracle.h - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * CPU restatement (plain C) of the reference's usearch_global hot path, used only as
+ * CPU restatement (plain C) of the reference's usearch_global hot path (+ usearch_local, the gapped x-drop, the pair
+ * filters), used only as
  * the parity checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg.  Nothing under usearch12_amd/ may include, link or call this.
  *
  * Pinning: validated bit-exact against the compiled, unmodified reference
  * (oracle/_ref/usearch12, built by oracle/build_ref.sh) on the golden fixtures under
- * tests/golden/ (see tests/golden/make_golden.py and tests/test_oracle_golden.py).
+ * tests/golden/ (generators tests/golden/make_golden*.py; tests/test_oracle_*.py, tests/test_udb.py).
  */
 #ifndef UGS_ORACLE_H
 #define UGS_ORACLE_H
