@@ -122,11 +122,14 @@ typedef struct ugs_params {
   uint32_t max_hsps;       /* 8                                        */
   uint32_t pair_mask;      /* UGS_P_* bits                             */
   float    min_sizeratio, minqt, maxqt, minsl, maxsl, abskew;
-  uint32_t align_flags;    /* UGS_A_FULLDP | UGS_A_GAFORCE              */
+  uint32_t align_flags;    /* UGS_A_FULLDP | UGS_A_GAFORCE | UGS_A_TERMID | UGS_A_TERMIDD */
+  float    termid, termidd;
 } ugs_params;
 /* -fulldp: no HSPs, one unbanded Viterbi over the whole pair (globalalignmem.cpp:148-152, ViterbiFastMem);
  * -gaforce: a pair without good HSPs is aligned all the same (FailIfNoHSPs = false, globalaligner.cpp:9-12) */
-enum { UGS_A_FULLDP = 1, UGS_A_GAFORCE = 2 };
+/* -termid / -termidd (terminator.cpp:66-87, usearch_global only): the walk of a query - both strands, they share the HitMgr -
+ * also ends once its worst hit is at or below termid, or its best and worst hits are more than termidd apart */
+enum { UGS_A_FULLDP = 1, UGS_A_GAFORCE = 2, UGS_A_TERMID = 4, UGS_A_TERMIDD = 8 };
 
 /*
  * One accepted hit == one AlignResult appended to HitMgr (hitmgr.cpp:161-183), with

@@ -1588,7 +1588,24 @@ static void search_strand_local(Work *w, LocalWork *lw, uint32_t qindex, const b
   }
 }
 
-static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb)
+/* Terminator::Terminate's -termid / -termidd tests (terminator.cpp:66-87) over the query's hits so far, both strands
+ * (HitMgr::GetMinFractId / GetMaxFractId hitmgr.cpp:508-532: floats, start values 1 and 0) */
+static int term_by_id(const ugs_params *p, const HitBuf *hb, unsigned qfirst)
+{
+  if (!(p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD)) || hb->nhits == qfirst) return 0;
+  float MinId = 1.0f, MaxId = 0.0f;
+  for (unsigned i = qfirst; i < hb->nhits; ++i) {
+    const ugs_hit *h = &hb->hits[i];
+    float f = (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len);
+    if (f < MinId) MinId = f;
+    if (f > MaxId) MaxId = f;
+  }
+  if ((p->align_flags & UGS_A_TERMID) && (double)MinId <= (double)p->termid) return 1;
+  if ((p->align_flags & UGS_A_TERMIDD) && (double)(MaxId - MinId) > (double)p->termidd) return 1;
+  return 0;
+}
+
+static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, int strand, HitBuf *hb, unsigned qfirst)
 {
   orc_db *db = w->db;
   if (db->big) rank_big(w, q, QL); else rank_small(w, q, QL);
@@ -1605,6 +1622,7 @@ static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, 
        * result is ignored and AlignPos returns without touching the terminator (udbusortedsearcher.cpp:145-147, searcher.cpp:63-67) */
       --w->st.pairs_aligned; w->st.target_letters -= TL;
       if (!db->big) continue;
+      if (term_by_id(&db->p, hb, qfirst)) break;
       ++RejectCount;
       if (db->p.max_rejects > 0 && RejectCount == db->p.max_rejects) break;
       continue;
@@ -1622,6 +1640,7 @@ static void search_strand(Work *w, uint32_t qindex, const byte *q, unsigned QL, 
       }
       if (Accept) { h.query = qindex; h.target = t; h.strand = (uint32_t)strand; hb_push(hb, &h, w->path); ++w->st.hits; }
     }
+    if (term_by_id(&db->p, hb, qfirst)) break;
     if (Accept) ++AcceptCount; else ++RejectCount;
     if (db->p.max_accepts > 0 && AcceptCount == db->p.max_accepts) break;
     if (db->p.max_rejects > 0 && RejectCount == db->p.max_rejects) break;
@@ -1644,11 +1663,11 @@ static void *job_run(void *arg)
     const byte *q = (const byte *)J->qseqs + J->qoffs[qi];
     unsigned QL = (unsigned)(J->qoffs[qi + 1] - J->qoffs[qi]);
     unsigned first = J->hb.nhits;
-    if (lw) search_strand_local(w, lw, qi, q, QL, 0, &J->hb); else search_strand(w, qi, q, QL, 0, &J->hb);
+    if (lw) search_strand_local(w, lw, qi, q, QL, 0, &J->hb); else search_strand(w, qi, q, QL, 0, &J->hb, first);
     if (db->p.strand_both && db->p.is_nucleo) {
       if (rccap < QL + 1) { rccap = QL + 256; rc = (char *)xrealloc(rc, rccap); }
       orc_revcomp((const char *)q, QL, rc);
-      if (lw) search_strand_local(w, lw, qi, (const byte *)rc, QL, 1, &J->hb); else search_strand(w, qi, (const byte *)rc, QL, 1, &J->hb);
+      if (lw) search_strand_local(w, lw, qi, (const byte *)rc, QL, 1, &J->hb); else search_strand(w, qi, (const byte *)rc, QL, 1, &J->hb, first);
     }
     unsigned n = J->hb.nhits - first;
     J->nhits[qi] = n;

@@ -57,6 +57,9 @@ CASES = {
     "hard_fulldp_aa": dict(gen="hard", seed=35, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, big=100, lmin=30, lmax=250, fulldp=1, gaforce=1),
     "hard_hardmask": dict(gen="hard", seed=36, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", big=100, maxaccepts=2, maxrejects=8, hardmask=1),
     "hard_hardmask_aa": dict(gen="hard", seed=37, n_fam=250, fam=6, q_n=700, aa=True, id=0.7, maxaccepts=2, maxrejects=8, hardmask=1),
+    # -termid / -termidd: the walk also ends on the identity of the hits collected so far (both strands share them)
+    "hard_termid":  dict(gen="hard", seed=38, n_fam=250, fam=8, q_n=900, aa=False, id=0.8, strand="both", big=100, maxaccepts=6, maxrejects=16, termid=0.93),
+    "hard_termidd": dict(gen="hard", seed=39, n_fam=250, fam=8, q_n=900, aa=False, id=0.8, strand="both", maxaccepts=6, maxrejects=16, termidd=0.04),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
@@ -91,6 +94,9 @@ def ref_cmd(c, qfa, dbfa, prefix):
     if not c["aa"]:
         cmd += ["-strand", c["strand"]]
     for opt in ("big", "maxaccepts", "maxrejects") + FILTER_OPTS:
+        if opt in c:
+            cmd += ["-" + opt, str(c[opt])]
+    for opt in ("termid", "termidd"):
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
     for flag in ("fulldp", "gaforce", "hardmask"):

@@ -48,6 +48,10 @@ def params_kw(c):
         kw["align_flags"] = (1 if c.get("fulldp") else 0) | (2 if c.get("gaforce") else 0)
     if c.get("hardmask"):
         kw["dbmask"] = 3
+    for opt, bit in (("termid", 4), ("termidd", 8)):
+        if opt in c:
+            kw["align_flags"] = kw.get("align_flags", 0) | bit
+            kw[opt] = c[opt]
     for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
         if opt in c:
             kw[opt] = c[opt]

@@ -129,7 +129,7 @@ def test_cli_text_identical_to_reference(tmp_path):
     FASTA in, -blast6out / -uc out, byte-identical to the reference's files."""
     import subprocess
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
-    for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask"):
+    for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask", "hard_termid", "hard_termidd"):
         c, db, qs, b6, uc = G.load(name)
         dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
@@ -141,6 +141,9 @@ def test_cli_text_identical_to_reference(tmp_path):
             if opt in c:
                 cmd += ["-" + opt, str(c[opt])]
         cmd += ["-" + f for f in ("fulldp", "gaforce", "hardmask") if c.get(f)]
+        for opt in ("termid", "termidd"):
+            if opt in c:
+                cmd += ["-" + opt, str(c[opt])]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         assert open(tmp_path / "o.b6").read() == b6, name
         assert open(tmp_path / "o.uc").read() == uc, name

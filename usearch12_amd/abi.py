@@ -24,7 +24,7 @@ class Params(C.Structure):
         ("local_open", C.c_float), ("local_ext", C.c_float), ("ka_dbsize", C.c_float), ("max_hsps", C.c_uint32),
         ("pair_mask", C.c_uint32), ("min_sizeratio", C.c_float), ("minqt", C.c_float), ("maxqt", C.c_float), ("minsl", C.c_float),
         ("maxsl", C.c_float), ("abskew", C.c_float),
-        ("align_flags", C.c_uint32),
+        ("align_flags", C.c_uint32), ("termid", C.c_float), ("termidd", C.c_float),
     ]
 
 
@@ -34,7 +34,7 @@ F_MAXID, F_MINCOLS, F_MAXGAPS, F_QUERY_COV, F_MAX_QUERY_COV, F_TARGET_COV, F_MAX
 FILTER_BITS = dict(maxid=F_MAXID, mincols=F_MINCOLS, maxgaps=F_MAXGAPS, query_cov=F_QUERY_COV, max_query_cov=F_MAX_QUERY_COV,
                    target_cov=F_TARGET_COV, max_target_cov=F_MAX_TARGET_COV, maxdiffs=F_MAXDIFFS, mindiffs=F_MINDIFFS, abskew=F_ABSKEW)
 # UGS_P_* bits of Params.pair_mask; self/notself/selfid are flags (pass True), the others carry a value
-A_FULLDP, A_GAFORCE = 1, 2
+A_FULLDP, A_GAFORCE, A_TERMID, A_TERMIDD = 1, 2, 4, 8
 PAIR_BITS = dict(self=1, notself=2, selfid=4, min_sizeratio=8, minqt=16, maxqt=32, minsl=64, maxsl=128)
 
 

@@ -735,7 +735,17 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     uint32_t unit = 0;
     if (lane == 0) unit = (uint32_t)atomicAdd(&ctr[UGS_CTR_NEXT_UNIT], 1ull);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    // -termid / -termidd (terminator.cpp:66-87) look at the hits of BOTH strands (one HitMgr per query): with them a wave takes a
+    // whole query and walks its strands one after the other
+    const uint32_t tflags = PAIR ? (db.align_flags & (UGS_A_TERMID | UGS_A_TERMIDD)) : 0u;
+    uint32_t strands_left = 1, t_hits = 0;
+    float t_min = 1.0f, t_max = 0.0f;                          // HitMgr::GetMinFractId / GetMaxFractId hitmgr.cpp:508-532
+    if constexpr (PAIR) if (tflags) {
+      if (unit >= bv.nq) break;
+      unit *= bv.nstrand; strands_left = bv.nstrand;
+    }
     if (unit >= units) break;
+  next_strand:
     tq = clock64();
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
@@ -812,6 +822,8 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
         if (rej) {
           wave_sync();
           if (!db.big) continue;
+          if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
+                                   ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) break;
           ++nrej;
           if (nrej == max_rej) break;
           continue;
@@ -911,6 +923,10 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
               if ((fm & UGS_F_MINDIFFS) && diffs < db.mindiffs) accept = false;
               if constexpr (PAIR) if ((fm & UGS_F_ABSKEW) && (double)db.t_size[t] / (double)bv.q_size[qi] < (double)db.abskew) accept = false;   // arscorer.cpp:809-816
             }
+            if constexpr (PAIR) if (accept && tflags) {
+              const float f = (float)(alen == 0 ? 0.0 : (double)ids / (double)alen);
+              ++t_hits; t_min = f < t_min ? f : t_min; t_max = f > t_max ? f : t_max;
+            }
             if (accept) {
               unsigned long long coff = 0;
               if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nr);
@@ -930,6 +946,11 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       }
       ta3 += clock64() - tq;
       // Terminator::Terminate (terminator.cpp:64-100)
+      if constexpr (PAIR) if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
+                                                    ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) {
+        if (accept) ++nacc;
+        break;
+      }
       if (accept) ++nacc; else ++nrej;
       if (nacc == max_acc || nrej == max_rej) break;
       wave_sync();
@@ -938,6 +959,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
     if (lane == 0) bv.hit_n[unit] = nacc;
     wave_sync();
+    if constexpr (PAIR) if (--strands_left) { ++unit; goto next_strand; }
   }
   if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs); }
   if (tid == 0) {

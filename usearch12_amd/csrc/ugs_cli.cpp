@@ -327,6 +327,8 @@ int main(int argc, char **argv)
     else if (a == "-maxdiffs") { filt.maxdiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXDIFFS; }
     else if (a == "-mindiffs") { filt.mindiffs = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINDIFFS; }
     else if (a == "-hardmask") hardmask = true;
+    else if (a == "-termid") { filt.termid = (float)atof(val()); filt.align_flags |= UGS_A_TERMID; }
+    else if (a == "-termidd") { filt.termidd = (float)atof(val()); filt.align_flags |= UGS_A_TERMIDD; }
     else if (a == "-fulldp") filt.align_flags |= UGS_A_FULLDP; else if (a == "-gaforce") filt.align_flags |= UGS_A_GAFORCE;
     else if (a == "-self") filt.pair_mask |= UGS_P_SELF; else if (a == "-notself") filt.pair_mask |= UGS_P_NOTSELF;
     else if (a == "-selfid") filt.pair_mask |= UGS_P_SELFID;
@@ -409,7 +411,7 @@ int main(int argc, char **argv)
   p.query_cov = filt.query_cov; p.max_query_cov = filt.max_query_cov; p.target_cov = filt.target_cov;
   p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
   p.pair_mask = filt.pair_mask; p.min_sizeratio = filt.min_sizeratio; p.minqt = filt.minqt; p.maxqt = filt.maxqt; p.minsl = filt.minsl;
-  p.maxsl = filt.maxsl; p.abskew = filt.abskew; p.align_flags = filt.align_flags;
+  p.maxsl = filt.maxsl; p.abskew = filt.abskew; p.align_flags = filt.align_flags; p.termid = filt.termid; p.termidd = filt.termidd;
   if (hardmask) p.dbmask = 3;
   if (from_udb) { p.dbmask = 2; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {

@@ -59,7 +59,8 @@ struct UgsDbView {
   uint32_t pair_mask;
   float min_sizeratio, minqt, maxqt, minsl, maxsl, abskew;
   const uint32_t *t_key, *t_size;
-  uint32_t align_flags;      // UGS_A_FULLDP | UGS_A_GAFORCE
+  uint32_t align_flags;      // UGS_A_FULLDP | UGS_A_GAFORCE | UGS_A_TERMID | UGS_A_TERMIDD
+  float termid, termidd;
 };
 
 struct UgsBatchView {

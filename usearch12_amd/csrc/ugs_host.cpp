@@ -425,7 +425,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
   v.pair_mask = p->pair_mask; v.min_sizeratio = p->min_sizeratio; v.minqt = p->minqt; v.maxqt = p->maxqt; v.minsl = p->minsl; v.maxsl = p->maxsl;
   v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
-  v.align_flags = p->align_flags;
+  v.align_flags = p->align_flags; v.termid = p->termid; v.termidd = p->termidd;
   if (p->align_flags & UGS_A_FULLDP) v.band = 1 << 20;          // every diagonal: ViterbiFastMem (globalalignmem.cpp:148-152)
   db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
