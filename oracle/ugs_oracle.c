@@ -246,7 +246,18 @@ struct orc_db {
   /* pair filters / -abskew: label keys and ;size= annotations (UINT32_MAX = none) of the DB and of the current queries */
   uint32_t *t_key, *t_size;
   const uint32_t *q_key, *q_size;
+  /* cluster_fast: the index grows by one centroid at a time (UDBData::AddSIToDB_CopyData udbbuild.cpp:286-291):
+   * rows are then per-slot growable arrays like the reference's m_UDBRows (udbbuild.cpp:74-128) instead of the CSR */
+  uint32_t **dyn_rows; uint32_t *dyn_size, *dyn_cap;
+  uint64_t seq_cap; uint32_t off_cap;
 };
+
+static inline const uint32_t *db_row(const orc_db *db, uint32_t word, uint64_t *size)
+{
+  if (db->dyn_rows) { *size = db->dyn_size[word]; return db->dyn_rows[word]; }
+  *size = db->row_off[word + 1] - db->row_off[word];
+  return db->postings + db->row_off[word];
+}
 
 /* fastmask.cpp:88-158 FastMaskSeq, soft mask (hardmask off), in place */
 static void fastmask_impl(char *seq_, uint32_t L, byte Hard);
@@ -439,6 +450,7 @@ void orc_set_query_pair_keys(orc_db *db, const uint32_t *label_key, const uint32
 void orc_db_destroy(orc_db *db)
 {
   if (!db) return;
+  if (db->dyn_rows) { for (uint64_t s = 0; s < db->slots; ++s) free(db->dyn_rows[s]); free(db->dyn_rows); free(db->dyn_size); free(db->dyn_cap); }
   free(db->seqs); free(db->offs); free(db->row_off); free(db->postings); free(db->t_key); free(db->t_size); free(db);
 }
 
@@ -477,12 +489,12 @@ typedef struct {
 
 static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (!q) abort(); return q; }
 
-static Work *work_new(orc_db *db)
+static Work *work_new_cap(orc_db *db, uint32_t nseq_cap)
 {
   Work *w = (Work *)calloc(1, sizeof(Work));
   w->db = db;
   w->wordfound = (byte *)calloc(db->slots, 1);
-  uint32_t n = db->nseq ? db->nseq : 1;
+  uint32_t n = nseq_cap ? nseq_cap : 1;
   w->U = (uint32_t *)calloc(n, 4);
   w->top_t = (uint32_t *)malloc(n * 4); w->top_u = (uint32_t *)malloc(n * 4);
   w->order = (uint32_t *)malloc(n * 4); w->top_t2 = (uint32_t *)malloc(n * 4);
@@ -491,6 +503,8 @@ static Work *work_new(orc_db *db)
   w->wposA = (unsigned *)malloc((size_t)db->HSPWordCount * MAXREPS * sizeof(unsigned));
   return w;
 }
+
+static Work *work_new(orc_db *db) { return work_new_cap(db, db->nseq); }
 
 static void work_free(Work *w)
 {
@@ -627,8 +641,8 @@ static void rank_small(Work *w, const byte *q, unsigned L)
   memset(w->U, 0, (size_t)SeqCount * 4);
   for (unsigned i = 0; i < w->nquniq; ++i) {
     uint32_t word = w->quniq[i];
-    const uint32_t *row = db->postings + db->row_off[word];
-    uint64_t size = db->row_off[word + 1] - db->row_off[word];
+    uint64_t size;
+    const uint32_t *row = db_row(db, word, &size);
     w->st.postings += size;
     for (uint64_t j = 0; j < size; ++j) ++w->U[row[j]];
   }
@@ -673,8 +687,8 @@ static void rank_big(Work *w, const byte *q, unsigned L)
   unsigned TopCount = 0;
   for (unsigned i = 0; i < w->nquniq; i += Step) {
     uint32_t word = w->quniq[i];
-    const uint32_t *row = db->postings + db->row_off[word];
-    uint64_t size = db->row_off[word + 1] - db->row_off[word];
+    uint64_t size;
+    const uint32_t *row = db_row(db, word, &size);
     w->st.postings += size;
     for (uint64_t j = 0; j < size; ++j) {
       uint32_t t = row[j];
@@ -1730,6 +1744,197 @@ int orc_search_batch(orc_db *db, const char *qseqs, const uint64_t *qoffs, uint3
   }
   if (cigar_used) *cigar_used = nc;
   free(jobs); free(th);
+  return rc;
+}
+
+
+/* ================================================================== cluster_fast (BASELINE config C3)
+ * clusterfast.cpp:81-133 ClusterFast: DerepFull (derepfull.cpp:130-212, at -threads 1: uniques in input order of their first
+ * member, derepresult.cpp:403-480) -> serial loop over the uniques in input order (-sort unset) -> Searcher::Search against
+ * the centroids found so far (terminator 1 accept / 8 rejects, terminator.cpp:10-14; small -> Big latch
+ * udbusortedsearcher.cpp:39-58) -> ClusterSink::OnQueryDone (clustersink.cpp:306-359): GetTopHit => member of that hit's
+ * cluster, no hit => new centroid, appended to the SeqDB and to every row of its distinct words
+ * (UDBData::AddSIToDB_CopyData udbbuild.cpp:286-291, AddSeqNoncoded :256-284, AddWord/GrowRow :74-128).
+ * No masking anywhere on this path: SeqDB::FromFastx keeps the letters as read (lower case voids a word). */
+
+/* SeqEq / SeqEqRC (seqhash.cpp:44-69): case-insensitive */
+static int cl_seq_eq(const byte *a, const byte *b, unsigned L)
+{
+  for (unsigned i = 0; i < L; ++i) if (toupper(a[i]) != toupper(b[i])) return 0;
+  return 1;
+}
+static int cl_seq_eq_rc(const byte *a, const byte *b, unsigned L)
+{
+  for (unsigned i = 0; i < L; ++i) if (toupper(a[i]) != toupper(g_comp[b[L - i - 1]])) return 0;
+  return 1;
+}
+/* SeqHash32 / SeqHashRC32 (seqhash.cpp:6-34); only the grouping matters at -threads 1, the function is kept all the same */
+static uint32_t cl_hash(const byte *s, unsigned L, int rc)
+{
+  unsigned a = 63689, b = 378551; uint32_t h = 0;
+  for (unsigned k = 0; k < L; ++k) { byte c = rc ? g_comp[s[L - k - 1]] : s[k]; h = h * a + (uint32_t)toupper(c); a *= b; }
+  return h;
+}
+
+/* derepfull.cpp:23-128 Thread() with one thread + derepresult.cpp:403-480: seq_unique[i] = index of input i's unique
+ * (uniques numbered by first appearance), uniq_seed[u] = input index of unique u's first member.  Returns the count. */
+uint32_t orc_derep_full(const char *seqs, const uint64_t *offs, uint32_t nseq, int revcomp, uint32_t *seq_unique, uint32_t *uniq_seed)
+{
+  init_tables();
+  uint64_t slots = (uint64_t)nseq * 8 + 7;
+  uint32_t *tab = (uint32_t *)malloc(slots * 4);
+  for (uint64_t i = 0; i < slots; ++i) tab[i] = UINT32_MAX;
+  uint32_t nu = 0;
+  for (uint32_t i = 0; i < nseq; ++i) {
+    const byte *q = (const byte *)seqs + offs[i];
+    unsigned L = (unsigned)(offs[i + 1] - offs[i]);
+    uint32_t h = cl_hash(q, L, 0);
+    if (revcomp) { uint32_t h2 = cl_hash(q, L, 1); if (h2 < h) h = h2; }
+    uint64_t k = h % slots;
+    for (;;) {
+      uint32_t u = tab[k];
+      if (u == UINT32_MAX) { tab[k] = nu; uniq_seed[nu] = i; seq_unique[i] = nu; ++nu; break; }
+      uint32_t si = uniq_seed[u];
+      unsigned UL = (unsigned)(offs[si + 1] - offs[si]);
+      if (UL == L) {
+        const byte *us = (const byte *)seqs + offs[si];
+        if (cl_seq_eq(q, us, L) || (revcomp && cl_seq_eq_rc(q, us, L))) { seq_unique[i] = u; break; }
+      }
+      k = (k + 1) % slots;
+    }
+  }
+  free(tab);
+  return nu;
+}
+
+/* UDBData::AddSIToDB_CopyData (udbbuild.cpp:286-291): letters appended as they are, every distinct valid word's row gets
+ * the new index at its end (AddSeqNoncoded :256-284: SetTargetWords + SetTargetUniqueWords) */
+static void cl_append(orc_db *db, const byte *seq, unsigned L, byte *stampw)
+{
+  uint64_t tot = db->offs[db->nseq];
+  if (tot + L > db->seq_cap) { db->seq_cap = (tot + L) * 2 + 1024; db->seqs = (char *)xrealloc(db->seqs, db->seq_cap); }
+  if (db->nseq + 2 > db->off_cap) { db->off_cap = db->off_cap * 2 + 1024; db->offs = (uint64_t *)xrealloc(db->offs, (size_t)db->off_cap * 8); }
+  memcpy(db->seqs + tot, seq, L);
+  db->offs[db->nseq + 1] = tot + L;
+  const uint32_t t = db->nseq;
+  const int W = db->p.word_len;
+  if (L >= (unsigned)W) {
+    for (unsigned pos = 0; pos + W <= L; ++pos) {
+      uint32_t w = seq_to_word(db, seq + pos);
+      if (w == BAD_WORD || stampw[w]) continue;
+      stampw[w] = 1;
+      if (db->dyn_size[w] == db->dyn_cap[w]) {
+        db->dyn_cap[w] = db->dyn_cap[w] ? db->dyn_cap[w] * 2 : 16;
+        db->dyn_rows[w] = (uint32_t *)xrealloc(db->dyn_rows[w], (size_t)db->dyn_cap[w] * 4);
+      }
+      db->dyn_rows[w][db->dyn_size[w]++] = t;
+    }
+    for (unsigned pos = 0; pos + W <= L; ++pos) { uint32_t w = seq_to_word(db, seq + pos); if (w != BAD_WORD) stampw[w] = 0; }
+  }
+  if (L > db->maxlen) db->maxlen = L;
+  db->nseq = t + 1;
+}
+
+/* sort.h:63-103 QuickSortOrderRecurse<unsigned, Desc=true> (ClusterSink::GetClusterSizeOrder clustersink.cpp:449-458) */
+static void qs_order_desc_u(const uint32_t *V, int left, int right, uint32_t *Order)
+{
+  int i = left, j = right;
+  uint32_t pivot = V[Order[(left + right) / 2]];
+  while (i <= j) {
+    while (V[Order[i]] > pivot) i++;
+    while (V[Order[j]] < pivot) j--;
+    if (i <= j) { uint32_t t = Order[i]; Order[i] = Order[j]; Order[j] = t; i++; j--; }
+  }
+  if (left < j) qs_order_desc_u(V, left, j, Order);
+  if (i < right) qs_order_desc_u(V, i, right, Order);
+}
+void orc_order_desc_u32(const uint32_t *values, uint32_t n, uint32_t *order)
+{
+  for (uint32_t i = 0; i < n; ++i) order[i] = i;
+  if (n) qs_order_desc_u(values, 0, (int)n - 1, order);
+}
+
+/* The greedy loop.  In: the input sequences (letters as read).  Out, all caller-allocated with nseq entries unless noted:
+ *   seq_unique[i]   unique (derep cluster) of input i;   uniq_seed[u] input index of unique u's first member
+ *   uniq_cluster[u] cluster of unique u;  uniq_nhits[u] hits of unique u (0 = it founded its cluster, else 1, or 2 with
+ *   -strand both);  centroid_uniq[c] the unique that founded cluster c;  cluster_size[c] members incl. duplicates
+ *   hits[]          all hits grouped by unique in order, each group in HitMgr::Sort order; .query = unique, .target = cluster
+ * p: terminator 1/8 and dbmask 2 are the caller's job (orc_params_set_cluster). */
+int orc_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                     uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *n_unique,
+                     uint32_t *uniq_cluster, uint32_t *uniq_nhits, uint32_t *centroid_uniq, uint32_t *cluster_size,
+                     uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
+                     uint64_t *n_hits, uint64_t *cigar_used)
+{
+  uint64_t zero = 0;
+  orc_db *db = NULL;
+  int rc = orc_db_create(p, "", &zero, 0, &db);
+  if (rc != UGS_OK) return rc;
+  db->dyn_rows = (uint32_t **)calloc(db->slots, sizeof(uint32_t *));
+  db->dyn_size = (uint32_t *)calloc(db->slots, 4);
+  db->dyn_cap = (uint32_t *)calloc(db->slots, 4);
+  db->off_cap = 1;
+  db->big = 0;
+  const int revcomp = p->strand_both && p->is_nucleo;
+  const uint32_t nu = orc_derep_full(seqs, offs, nseq, revcomp, seq_unique, uniq_seed);
+  *n_unique = nu;
+  uint32_t *usize = (uint32_t *)calloc(nu ? nu : 1, 4);          /* ClusterSink::GetSize without -sizein: member count */
+  for (uint32_t i = 0; i < nseq; ++i) ++usize[seq_unique[i]];
+  Work *w = work_new_cap(db, nu);
+  byte *stampw = (byte *)calloc(db->slots, 1);
+  HitBuf hb; memset(&hb, 0, sizeof(hb));
+  char *rcbuf = NULL; size_t rccap = 0;
+  uint32_t nc = 0;
+  for (uint32_t u = 0; u < nu; ++u) {
+    const uint32_t si = uniq_seed[u];
+    const byte *q = (const byte *)seqs + offs[si];
+    const unsigned QL = (unsigned)(offs[si + 1] - offs[si]);
+    const unsigned first = hb.nhits;
+    /* UDBUsortedSearcher::SetQueryImpl (udbusortedsearcher.cpp:39-58): the Big latch, tested once per strand search */
+    if (!db->big && db->nseq > p->big) { db->big = 1; memset(w->U, 0, (size_t)(nu ? nu : 1) * 4); }   /* :45-48 zeroes U at the latch */
+    search_strand(w, u, q, QL, 0, &hb, first);
+    if (revcomp) {
+      if (rccap < QL + 1) { rccap = QL + 256; rcbuf = (char *)xrealloc(rcbuf, rccap); }
+      orc_revcomp((const char *)q, QL, rcbuf);
+      if (!db->big && db->nseq > p->big) { db->big = 1; memset(w->U, 0, (size_t)(nu ? nu : 1) * 4); }
+      search_strand(w, u, (const byte *)rcbuf, QL, 1, &hb, first);
+    }
+    const unsigned n = hb.nhits - first;
+    uniq_nhits[u] = n;
+    if (n == 0) {                                               /* clustersink.cpp:318-329 */
+      cl_append(db, q, QL, stampw);
+      centroid_uniq[nc] = u; cluster_size[nc] = usize[u]; uniq_cluster[u] = nc; ++nc;
+    } else {
+      /* HitMgr::GetTopHit hitmgr.cpp:400-420: best float(FractId), ties to the smaller target index, else the earlier hit */
+      unsigned top = first; float tops = 0; uint32_t mint = 0;
+      for (unsigned i = first; i < hb.nhits; ++i) {
+        const ugs_hit *h = &hb.hits[i];
+        float sc = (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len);
+        if (i == first || sc > tops || (sc == tops && h->target < mint)) { top = i; tops = sc; mint = h->target; }
+      }
+      const uint32_t c = hb.hits[top].target;
+      uniq_cluster[u] = c; cluster_size[c] += usize[u];
+      for (unsigned i = 0; i < n; ++i) hb.hits[first + i].flags |= i << UGS_HIT_ORDER_SHIFT;
+      if (n > 1) {                                              /* HitMgr::Sort hitmgr.cpp:477-483 */
+        float sc[2]; unsigned ord[2] = {0, 1}; ugs_hit tmp[2];
+        if (n != 2) abort();
+        for (unsigned i = 0; i < 2; ++i) { const ugs_hit *h = &hb.hits[first + i]; sc[i] = (float)(h->aln_len == 0 ? 0.0 : (double)h->ids / (double)h->aln_len); tmp[i] = *h; }
+        qs_order_desc(sc, 0, 1, ord);
+        for (unsigned i = 0; i < 2; ++i) hb.hits[first + i] = tmp[ord[i]];
+      }
+    }
+  }
+  *n_clusters = nc;
+  if (n_hits) *n_hits = hb.nhits;
+  if (cigar_used) *cigar_used = hb.ncig;
+  if (hb.nhits > hits_cap || hb.ncig > cigar_cap) rc = UGS_E_CAPACITY;
+  else {
+    if (hb.nhits) memcpy(hits, hb.hits, (size_t)hb.nhits * sizeof(ugs_hit));
+    if (hb.ncig) memcpy(cigar_pool, hb.cig, (size_t)hb.ncig * 4);
+  }
+  free(hb.hits); free(hb.cig); free(rcbuf); free(stampw); free(usize);
+  work_free(w);
+  orc_db_destroy(db);
   return rc;
 }
 

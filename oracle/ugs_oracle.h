@@ -88,6 +88,15 @@ unsigned long orc_xdrop_wipes(void);
 int orc_xdrop_job(const ugs_xdrop_params *p, const char *a, uint32_t la, const char *b, uint32_t lb,
                   const ugs_xdrop_job *job, ugs_xdrop_hsp *hsp, char *path, uint64_t *cells);
 
+/* cluster_fast (clusterfast.cpp:81-133): see ugs_oracle.c for the output contract */
+uint32_t orc_derep_full(const char *seqs, const uint64_t *offs, uint32_t nseq, int revcomp, uint32_t *seq_unique, uint32_t *uniq_seed);
+void orc_order_desc_u32(const uint32_t *values, uint32_t n, uint32_t *order);
+int orc_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                     uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *n_unique,
+                     uint32_t *uniq_cluster, uint32_t *uniq_nhits, uint32_t *centroid_uniq, uint32_t *cluster_size,
+                     uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
+                     uint64_t *n_hits, uint64_t *cigar_used);
+
 void orc_params_init(ugs_params *p, int is_nucleo, double id);
 /* switch a parameter block to usearch_local (searcher.cpp:28-50, localmulti.cpp, localaligner.cpp, estats.cpp);
  * id_set = 0 drops the identity filter and ranks with the 0.5 fallback */

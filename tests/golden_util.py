@@ -145,3 +145,22 @@ def pair_keys(db, qs):
     tk, tz = keys(db)
     qk, qz = keys(qs)
     return tk, tz, qk, qz
+
+
+# ---- cluster_fast cases (tests/golden/cluster_manifest.json, make_golden_cluster.py)
+def cluster_cases():
+    return sorted(json.load(open(os.path.join(GOLD, "cluster_manifest.json"))).keys())
+
+
+def load_cluster(name):
+    """-> (case dict, reads SeqSet, the reference's -uc text, its -centroids text)"""
+    import gzip
+    spec = importlib.util.spec_from_file_location("make_golden_cluster", os.path.join(GOLD, "make_golden_cluster.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    c = json.load(open(os.path.join(GOLD, "cluster_manifest.json")))[name]
+    r = mg.make_reads(c)
+    assert mg.digest(r) == c["reads_sha256"], "generator drift (reads) for " + name
+    uc = gzip.open(os.path.join(GOLD, name + ".uc.gz"), "rb").read().decode()
+    cen = gzip.open(os.path.join(GOLD, name + ".cent.fa.gz"), "rb").read().decode()
+    return c, r, uc, cen

@@ -265,3 +265,95 @@ def format_blast6_local(fmt_lib, prefix, p, hits, nh, qlabels, tlabels):
             out.append(buf.value.decode())
             k += 1
     return "".join(out)
+
+
+# ---- cluster_fast (oracle/ugs_oracle.c orc_cluster_fast)
+def _vp(a):
+    return a.ctypes.data
+
+
+def cluster_params(id=0.97, strand_both=False, **kw):
+    """cmd_cluster_fast's searcher: terminator 1 accept / 8 rejects (terminator.cpp:10-14), letters used as read"""
+    return params(is_nucleo=True, id=id, max_accepts=1, max_rejects=8, dbmask=2, strand_both=1 if strand_both else 0, **kw)
+
+
+class ClusterResult:
+    pass
+
+
+def cluster_fast(p, seqs, offs):
+    L = lib()
+    seqs = as_u8(seqs)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    L.orc_cluster_fast.restype = C.c_int
+    L.orc_cluster_fast.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 2 + \
+        [C.POINTER(C.c_uint32)] + [C.c_void_p] * 4 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    r = ClusterResult()
+    r.seq_unique = np.zeros(n, np.uint32); r.uniq_seed = np.zeros(n, np.uint32)
+    r.uniq_cluster = np.zeros(n, np.uint32); r.uniq_nhits = np.zeros(n, np.uint32)
+    r.centroid_uniq = np.zeros(n, np.uint32); r.cluster_size = np.zeros(n, np.uint32)
+    nu, nc, nh, cu = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    hits = np.zeros(2 * n + 1, HIT_DTYPE)
+    pool = np.zeros(int(offs[-1]) // 2 + 64 * n + 1024, np.uint32)
+    rc = L.orc_cluster_fast(C.byref(p), _vp(seqs), _vp(offs), n, _vp(r.seq_unique), _vp(r.uniq_seed), C.byref(nu),
+                            _vp(r.uniq_cluster), _vp(r.uniq_nhits), _vp(r.centroid_uniq), _vp(r.cluster_size), C.byref(nc),
+                            _vp(hits), len(hits), _vp(pool), len(pool), C.byref(nh), C.byref(cu))
+    assert rc == 0, rc
+    r.n_unique, r.n_clusters = nu.value, nc.value
+    r.uniq_seed = r.uniq_seed[:r.n_unique]; r.uniq_cluster = r.uniq_cluster[:r.n_unique]; r.uniq_nhits = r.uniq_nhits[:r.n_unique]
+    r.centroid_uniq = r.centroid_uniq[:r.n_clusters]; r.cluster_size = r.cluster_size[:r.n_clusters]
+    r.hits = hits[:nh.value]; r.pool = pool[:cu.value]
+    return r
+
+
+def order_desc_u32(values):
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    order = np.zeros(len(values), np.uint32)
+    lib().orc_order_desc_u32.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib().orc_order_desc_u32(_vp(values), len(values), _vp(order))
+    return order
+
+
+def cluster_uc_text(r, labels, seqlens, is_nucleo=True):
+    """-uc of cluster_fast: per unique in order S / H records followed by its duplicates' H records (outputuc.cpp:10-93),
+    then the C records (clustersink.cpp:477-493).  labels / seqlens are per INPUT sequence."""
+    L = lib()
+    members = [[] for _ in range(r.n_unique)]
+    for i, u in enumerate(r.seq_unique):
+        members[u].append(i)
+    out = []
+    buf = C.create_string_buffer(1 << 16)
+    hp = 0
+    for u in range(r.n_unique):
+        seed = int(r.uniq_seed[u]); ql = labels[seed]; qlen = int(seqlens[seed])
+        nh = int(r.uniq_nhits[u])
+        if nh == 0:
+            c = int(r.uniq_cluster[u])
+            out.append("S\t%u\t%u\t*\t.\t*\t*\t*\t%s\t*\n" % (c, qlen, ql))
+            for m in members[u][1:]:
+                out.append("H\t%u\t%u\t100.0\t.\t0\t%u\t=\t%s\t%s\n" % (c, qlen, qlen, labels[m], ql))
+        for k in range(nh):
+            h = r.hits[hp + k]
+            tl = labels[int(r.uniq_seed[int(r.centroid_uniq[int(h["target"])])])]
+            for m in members[u]:
+                n = L.orc_format_uc_hit(h.ctypes.data if hasattr(h, "ctypes") else r.hits[hp + k:hp + k + 1].ctypes.data,
+                                        _vp(r.pool), int(is_nucleo), labels[m].encode(), tl.encode(), buf, len(buf))
+                out.append(buf.raw[:n].decode())
+        hp += nh
+    for c in range(r.n_clusters):
+        out.append("C\t%u\t%u\t*\t*\t*\t*\t*\t%s\t*\n" % (c, int(r.cluster_size[c]), labels[int(r.uniq_seed[int(r.centroid_uniq[c])])]))
+    return "".join(out)
+
+
+def cluster_centroids_text(r, labels, ss):
+    """-centroids: centroids by decreasing cluster size (QuickSortOrderDesc, clustersink.cpp:262-289), 80-column FASTA"""
+    order = order_desc_u32(r.cluster_size)
+    out = []
+    for c in order:
+        i = int(r.uniq_seed[int(r.centroid_uniq[int(c)])])
+        s = ss.seq(i).decode()
+        out.append(">%s\n" % labels[i])
+        out.extend(s[k:k + 80] + "\n" for k in range(0, len(s), 80))
+    return "".join(out)

@@ -145,6 +145,62 @@ def revcomp_some(seed, qs, frac=0.5):
     return out
 
 
+def make_reads(seed, n_reads, n_species=None, length=300, p_sub=0.01, p_del=0.001, p_ins=0.001, alpha=1.2,
+               chunk=200_000, dup_frac=0.0):
+    """cluster_fast workload: reads drawn from `n_species` random roots with Pareto(alpha)
+    abundances, each read = its root with per-base 1 % substitutions and 0.1 % / 0.1 % deletions / insertions.
+    dup_frac > 0 makes that share of the reads exact copies of an earlier read (dereplication fodder beyond the
+    error-free reads the model yields by itself).  Labels r<i>;sp=<species>.  Built in chunks (5 M x 300 fits)."""
+    rng = np.random.default_rng([seed, 0xC3])
+    if n_species is None:
+        n_species = max(1, n_reads // 100)
+    roots = _random_letters(rng, n_species * length, NT).reshape(n_species, length)
+    w = (1.0 - rng.random(n_species)) ** (-1.0 / alpha)
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    sp = np.searchsorted(cdf, rng.random(n_reads), side="right").astype(np.int64)
+    parts, lens_all = [], []
+    for lo in range(0, n_reads, chunk):
+        hi = min(n_reads, lo + chunk)
+        n = hi - lo
+        base = roots[sp[lo:hi]].copy()
+        u = rng.random((n, length), dtype=np.float32)
+        sub = u < p_sub
+        dele = (u >= p_sub) & (u < p_sub + p_del)
+        ins = (u >= p_sub + p_del) & (u < p_sub + p_del + p_ins)
+        nsub = int(sub.sum())
+        if nsub:
+            old_idx = np.searchsorted(NT, base[sub])
+            base[sub] = NT[(old_idx + rng.integers(1, 4, size=nsub)) % 4]
+        rep = np.ones((n, length), dtype=np.int8)
+        rep[dele] = 0
+        rep[ins] = 2
+        repf = rep.reshape(-1).astype(np.int64)
+        flat = np.repeat(base.reshape(-1), repf)
+        start = np.cumsum(repf) - repf
+        ins_pos = start[ins.reshape(-1)] + 1
+        if len(ins_pos):
+            flat[ins_pos] = _random_letters(rng, len(ins_pos), NT)
+        parts.append(flat)
+        lens_all.append(rep.sum(axis=1, dtype=np.int64))
+    lens = np.concatenate(lens_all)
+    offs = np.zeros(n_reads + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens).astype(np.uint64)
+    seqs = np.concatenate(parts)
+    if dup_frac > 0 and n_reads > 1:
+        # exact copies of an earlier read (same length only keeps the layout: copy letters when lengths agree)
+        dst = np.flatnonzero(rng.random(n_reads) < dup_frac)
+        dst = dst[dst > 0]
+        srcs = (rng.random(len(dst)) * dst).astype(np.int64)
+        for d, s0 in zip(dst, srcs):
+            if lens[d] == lens[s0]:
+                seqs[int(offs[d]):int(offs[d + 1])] = seqs[int(offs[s0]):int(offs[s0 + 1])]
+    spl = sp
+    rs = SeqSet(seqs, offs, lambda i: "r%d;sp=%d" % (i, spl[i]))
+    rs.species = sp
+    return rs
+
+
 CONFIGS = {
     # name: (seed, db_n, n_queries, length, aa, id)
     "C1": (1, 50_000, 10_000, 250, False, 0.97),
