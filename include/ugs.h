@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define UGS_ABI_VERSION 3   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
-                             * (ugs_params.local..., ugs_hit.raw_score/flags) */
+#define UGS_ABI_VERSION 4   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
+                             * (ugs_params.local..., ugs_hit.raw_score/flags); 4: ugs_db_append, cluster_fast (ugs_cluster_*) */
 
 /* error codes */
 #define UGS_OK            0
@@ -427,6 +427,62 @@ ugs_closedref *ugs_closedref_create(void);
 void ugs_closedref_destroy(ugs_closedref *c);
 int ugs_closedref_add(ugs_closedref *c, const char *qlabel, const ugs_hit *hits, uint32_t n, const char *const *tlabels, char *line, int cap);
 int ugs_closedref_totals(const ugs_closedref *c, uint64_t *assigned, uint64_t *unassigned, uint32_t *otus);
+
+
+/* ------------------------------------------------------------------------------------------
+ * cluster_fast (BASELINE config C3): the UCLUST greedy loop of ClusterFast (clusterfast.cpp:81-133).
+ *
+ * ugs_db_append = UDBData::AddSIToDB_CopyData (udbbuild.cpp:286-291; AddSeqNoncoded :256-284, AddWord/GrowRow :74-128) for n
+ * sequences at once: they become targets nseq .. nseq+n-1, their letters are stored as given and the index rows of their
+ * distinct valid words grow at the end - on the device.  Needs a database created with dbmask = 2 (an index over masked
+ * letters cannot grow: the cluster database is never masked, SeqDB::FromFastx keeps the letters as read).  The small -> Big
+ * ranking latch (udbusortedsearcher.cpp:39-58) follows the new size.  Batches uploaded before the call must be uploaded again.
+ */
+int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs, uint32_t n);
+
+/* cmd_cluster_fast's searcher settings on top of ugs_params_init: terminator 1 accept / 8 rejects (terminator.cpp:10-14),
+ * letters used as read (dbmask 2).  -id is required (makeclustersearcher.cpp:30-31). */
+int ugs_params_set_cluster(ugs_params *p);
+
+/*
+ * The whole command on one GPU: DerepFull in input order (= the reference at -threads 1, derepfull.cpp:130-212,
+ * derepresult.cpp:403-480; case-insensitive, both orientations with strand_both), then the greedy loop over the uniques in
+ * input order (-sort unset).  The loop runs in batches against the centroid index as it stood when the batch started; the
+ * centroids founded by earlier queries of the same batch are merged into every query's candidate walk exactly (word counts and
+ * pair alignments from the device, the reference's ordering / cut-off / terminator rules replayed in input order), so the
+ * result equals the serial loop's.  Results:
+ *   seq_unique[nseq]      unique (derep cluster) of every input sequence; uniques are numbered by their first member
+ *   uniq_seed[n_unique]   input index of a unique's first member (its letters and label stand for the unique)
+ *   uniq_cluster[n_unique] cluster of every unique;   uniq_nhits[n_unique] 0 = founded its cluster, else its hits (1, or 2
+ *                         with strand_both: HitMgr keeps one accept per strand)
+ *   centroid_uniq[n_clusters], cluster_size[n_clusters] (input sequences incl. duplicates, ClusterSink::GetSize clustersink.cpp:123-150)
+ *   hits[n_hits]          grouped by unique in order, each group in HitMgr::Sort order; .query = unique, .target = cluster
+ */
+typedef struct ugs_cluster ugs_cluster;
+typedef struct ugs_cluster_stats {
+  uint32_t batches;          /* device batches run                                                      */
+  uint32_t batches_cut;      /* batches ended early because a query could not be replayed from the device's data */
+  uint32_t max_batch;
+  uint32_t reserved_;
+  uint64_t queries_redone;   /* queries searched again in a later batch (cut batches, the small -> Big latch) */
+  uint64_t inbatch_entries;  /* (query strand, earlier query of the batch) pairs with shared words that could matter */
+  uint64_t pairs_in_batch;   /* of those, aligned on the device                                          */
+  uint64_t hits_in_batch;    /* accepted hits whose target was founded inside the query's own batch       */
+  uint64_t pairs_frozen;     /* pair alignments of the frozen-index walks                                 */
+  uint64_t postings;         /* algorithmic postings of the frozen-index scans            */
+  float    ms_rank, ms_align; /* summed device time of the frozen-index stages                            */
+} ugs_cluster_stats;
+int ugs_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq, int device, ugs_cluster **out);
+void ugs_cluster_destroy(ugs_cluster *c);
+int ugs_cluster_counts(const ugs_cluster *c, uint32_t *n_unique, uint32_t *n_clusters, uint64_t *n_hits, uint64_t *cigar_runs);
+int ugs_cluster_get(const ugs_cluster *c, uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *uniq_cluster, uint32_t *uniq_nhits,
+                    uint32_t *centroid_uniq, uint32_t *cluster_size, ugs_hit *hits, uint32_t *cigar_pool);
+int ugs_cluster_get_stats(const ugs_cluster *c, ugs_cluster_stats *st);
+/* -uc (S / H records per unique followed by its duplicates' records, then the C records: outputuc.cpp:10-93,
+ * clustersink.cpp:477-493) and -centroids (by decreasing size in QuickSortOrderDesc's order, 80 columns: clustersink.cpp:262-289).
+ * labels: the nseq input labels, NUL-terminated, concatenated in input order. */
+int ugs_cluster_write_uc(const ugs_cluster *c, const char *labels, const char *path);
+int ugs_cluster_write_centroids(const ugs_cluster *c, const char *labels, const char *path);
 
 /* Page-lock / unlock a caller-owned host buffer (hipHostRegister): result buffers that are reused from batch to batch
  * are then filled by direct DMA instead of through the runtime's staging copies.  Optional; any host pointer works

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from usearch12_amd import capi
-from usearch12_amd.abi import Params, HIT_DTYPE
+from usearch12_amd.abi import Params, HIT_DTYPE, ClusterStats
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,12 +27,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(capi.EXPORTS) == names
-    assert L.ugs_abi_version() == 3
+    assert L.ugs_abi_version() == 4
 
 
 def test_struct_layouts():
     assert C.sizeof(Params) == 192
     assert HIT_DTYPE.itemsize == 80
+    assert C.sizeof(ClusterStats) == 72
     p = capi.params(is_nucleo=True, id=0.97)
     assert (p.word_len, p.max_accepts, p.max_rejects, p.big, p.band, p.hsp_word_len) == (8, 1, 32, 100000, 16, 5)
     assert p.id_accept == float(np.float32(0.97))     # options are stored as float (opts.cpp:265)

@@ -1,0 +1,92 @@
+"""cluster_fast on the device (usearch12_amd/csrc/ugs_cluster.cpp through the C-ABI) against
+  * the reference's own -uc / -centroids files (tests/golden/cl_*.gz, byte-identical text), and
+  * the oracle's serial loop on fresh seeded inputs (every array and hit record),
+with small device batches forced as well, so that in-batch centroids, the latch cut and the pair stage are all exercised."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import orc
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cluster(c, r, batch=None):
+    kw = {"big": c["big"]} if "big" in c else {}
+    p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", **kw)
+    old = os.environ.pop("UGS_CLUSTER_BATCH", None)
+    if batch:
+        os.environ["UGS_CLUSTER_BATCH"] = str(batch)
+    try:
+        return capi.UgsCluster(p, r.seqs, r.offs)
+    finally:
+        os.environ.pop("UGS_CLUSTER_BATCH", None)
+        if old is not None:
+            os.environ["UGS_CLUSTER_BATCH"] = old
+
+
+@pytest.mark.parametrize("batch", [None, 37])
+@pytest.mark.parametrize("name", G.cluster_cases())
+def test_gpu_cluster_fast_files_identical_to_reference(name, batch, tmp_path):
+    c, r, uc, cen = G.load_cluster(name)
+    res = _cluster(c, r, batch)
+    assert res.n_clusters == c["n_clusters"]
+    labels = r.labels()
+    ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
+    res.write_uc(labels, ucp)
+    res.write_centroids(labels, cp)
+    assert open(ucp).read() == uc
+    assert open(cp).read() == cen
+
+
+def _same(res, o):
+    assert res.n_unique == o.n_unique and res.n_clusters == o.n_clusters
+    for f in ("seq_unique", "uniq_seed", "uniq_cluster", "uniq_nhits", "centroid_uniq", "cluster_size"):
+        assert np.array_equal(getattr(res, f), getattr(o, f)), f
+    assert len(res.hits) == len(o.hits)
+    for f in res.hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(res.hits[f], o.hits[f]), f
+    for a, b in zip(res.hits, o.hits):
+        assert np.array_equal(res.pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])],
+                              o.pool[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])])
+
+
+@pytest.mark.parametrize("seed,n,species,both,big,idv,batch", [
+    (101, 3000, 25, False, 100000, 0.97, None),
+    (102, 3000, 8, True, 150, 0.97, 500),
+    (103, 2500, 4, False, 90, 0.95, 64),
+    (104, 2000, 2, True, 100000, 0.93, 256),
+    (105, 6000, 60, False, 400, 0.97, 2048),
+])
+def test_gpu_cluster_fast_equals_oracle(seed, n, species, both, big, idv, batch):
+    r = synth.make_reads(seed, n, n_species=species, dup_frac=0.03)
+    if both:
+        r = synth.revcomp_some(seed, r)
+    c = dict(id=idv, strand="both" if both else "plus", big=big)
+    res = _cluster(c, r, batch)
+    o = orc.cluster_fast(orc.cluster_params(idv, strand_both=both, big=big), r.seqs, r.offs)
+    _same(res, o)
+    assert res.stats.batches >= 1
+
+
+def test_db_append_equals_building_at_once():
+    """ugs_db_append: a database grown in three steps searches exactly like one built from all sequences"""
+    db = synth.make_db(9, 3000, 200)
+    qs = synth.make_queries(9, db, 400, 200)
+    p = capi.params(is_nucleo=True, id=0.95, dbmask=2, big=1000)
+    whole = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    h0, n0, p0 = whole.search(qs.seqs, qs.offs)
+    part = db.slice(0, 700)
+    grown = capi.UgsDB(p, part.seqs, part.offs, device=0)
+    for lo, hi in ((700, 1900), (1900, 3000)):
+        s = db.slice(lo, hi)
+        capi._chk(capi.lib().ugs_db_append(grown.h, s.seqs.ctypes.data, s.offs.ctypes.data, s.n))
+    h1, n1, p1 = grown.search(qs.seqs, qs.offs)
+    assert np.array_equal(n0, n1)
+    for f in h0.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(h0[f], h1[f]), f

@@ -58,6 +58,14 @@ class BatchStats(C.Structure):
     ]
 
 
+class ClusterStats(C.Structure):
+    """mirror of ugs_cluster_stats (include/ugs.h)"""
+    _fields_ = [("batches", C.c_uint32), ("batches_cut", C.c_uint32), ("max_batch", C.c_uint32), ("reserved_", C.c_uint32),
+                ("queries_redone", C.c_uint64), ("inbatch_entries", C.c_uint64), ("pairs_in_batch", C.c_uint64),
+                ("hits_in_batch", C.c_uint64), ("pairs_frozen", C.c_uint64), ("postings", C.c_uint64),
+                ("ms_rank", C.c_float), ("ms_align", C.c_float)]
+
+
 class UdbInfo(C.Structure):
     """mirror of ugs_udb_info (include/ugs.h)"""
     _fields_ = [("is_nucleo", C.c_int32), ("word_len", C.c_uint32), ("nseq", C.c_uint64), ("nletters", C.c_uint64),

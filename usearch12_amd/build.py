@@ -6,8 +6,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip"]
-DEPS = SOURCES + ["ugs_dev.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
+DEPS = SOURCES + ["ugs_dev.h", "ugs_host.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 
 

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .abi import FILTER_BITS, PAIR_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
+from .abi import FILTER_BITS, PAIR_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, ClusterStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libugs.so")
@@ -26,6 +26,8 @@ EXPORTS = [
     "ugs_db_masked_letters", "ugs_format_alnout_header", "ugs_format_alnout_hit", "ugs_host_register", "ugs_host_unregister",
     "ugs_format_fastapairs", "ugs_format_segout",
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_write_biom", "ugs_otutab_totals",
+    "ugs_db_append", "ugs_params_set_cluster", "ugs_cluster_fast", "ugs_cluster_destroy", "ugs_cluster_counts", "ugs_cluster_get",
+    "ugs_cluster_get_stats", "ugs_cluster_write_uc", "ugs_cluster_write_centroids",
 ]
 
 
@@ -80,6 +82,16 @@ def lib():
         L.ugs_udb_stat.argtypes = [C.c_char_p, C.POINTER(UdbInfo)]
         L.ugs_udb_read.argtypes = [C.c_char_p, vp, vp, vp, vp, vp]
         L.ugs_udb_write.argtypes = [C.c_char_p, vp, vp, u64]
+        L.ugs_db_append.argtypes = [vp, vp, vp, u32]
+        L.ugs_params_set_cluster.argtypes = [C.POINTER(Params)]
+        L.ugs_cluster_fast.argtypes = [C.POINTER(Params), vp, vp, u32, i32, C.POINTER(vp)]
+        L.ugs_cluster_destroy.argtypes = [vp]
+        L.ugs_cluster_destroy.restype = None
+        L.ugs_cluster_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+        L.ugs_cluster_get.argtypes = [vp] * 9
+        L.ugs_cluster_get_stats.argtypes = [vp, C.POINTER(ClusterStats)]
+        L.ugs_cluster_write_uc.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.ugs_cluster_write_centroids.argtypes = [vp, C.c_char_p, C.c_char_p]
         _lib = L
     return _lib
 
@@ -363,3 +375,51 @@ def udb_write(path, db, labels):
     """Write db (a UgsDB) with the given labels as a reference-format .udb (index as built on the GPU)."""
     blob = b"".join(l.encode() + b"\0" for l in labels)
     _chk(lib().ugs_udb_write(path.encode(), db.h, blob, len(blob)))
+
+
+# ---- cluster_fast (include/ugs.h ugs_cluster_*)
+def cluster_params(id=0.97, strand_both=False, **kw):
+    p = params(is_nucleo=True, id=id, strand_both=1 if strand_both else 0, **kw)
+    _chk(lib().ugs_params_set_cluster(C.byref(p)))
+    return p
+
+
+class UgsCluster:
+    """ugs_cluster_fast on `device`; fields as the C-ABI returns them (see include/ugs.h)"""
+
+    def __init__(self, p, seqs, offs, device=0):
+        L = lib()
+        seqs = as_u8(seqs)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        self.h = C.c_void_p()
+        _chk(L.ugs_cluster_fast(C.byref(p), seqs.ctypes.data, offs.ctypes.data, n, device, C.byref(self.h)))
+        nu, nc, nh, nr = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        _chk(L.ugs_cluster_counts(self.h, C.byref(nu), C.byref(nc), C.byref(nh), C.byref(nr)))
+        self.n_unique, self.n_clusters = nu.value, nc.value
+        self.seq_unique = np.zeros(n, np.uint32); self.uniq_seed = np.zeros(nu.value, np.uint32)
+        self.uniq_cluster = np.zeros(nu.value, np.uint32); self.uniq_nhits = np.zeros(nu.value, np.uint32)
+        self.centroid_uniq = np.zeros(nc.value, np.uint32); self.cluster_size = np.zeros(nc.value, np.uint32)
+        self.hits = np.zeros(nh.value, HIT_DTYPE); self.pool = np.zeros(nr.value, np.uint32)
+        _chk(L.ugs_cluster_get(self.h, self.seq_unique.ctypes.data, self.uniq_seed.ctypes.data, self.uniq_cluster.ctypes.data,
+                               self.uniq_nhits.ctypes.data, self.centroid_uniq.ctypes.data, self.cluster_size.ctypes.data,
+                               self.hits.ctypes.data, self.pool.ctypes.data))
+        self.stats = ClusterStats()
+        _chk(L.ugs_cluster_get_stats(self.h, C.byref(self.stats)))
+
+    def write_uc(self, labels, path):
+        _chk(lib().ugs_cluster_write_uc(self.h, b"".join(l.encode() + b"\0" for l in labels), path.encode()))
+
+    def write_centroids(self, labels, path):
+        _chk(lib().ugs_cluster_write_centroids(self.h, b"".join(l.encode() + b"\0" for l in labels), path.encode()))
+
+    def close(self):
+        if self.h:
+            lib().ugs_cluster_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

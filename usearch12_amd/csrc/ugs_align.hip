@@ -747,11 +747,13 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     if (unit >= units) break;
   next_strand:
     tq = clock64();
-    const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
+    uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
+    if constexpr (PAIR) if (bv.unit_map) { const uint32_t m = bv.unit_map[unit]; qi = m >> 1; strand = m & 1u; }
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t LA = (uint32_t)(bv.qoffs[qi + 1] - qo);
     c.LA = LA;
     const uint32_t ncand = bv.cand_n[unit];
+    uint32_t nvis = 0;
     uint32_t nacc = 0, nrej = 0;
     if (ncand) {
       for (uint32_t p = lane; p < LA; p += 64) {
@@ -786,6 +788,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     if (ncand) prefetch(0);
     for (uint32_t k = 0; k < ncand; ++k) {
       tq = clock64();
+      nvis = k + 1;
       const uint32_t t = (uint32_t)rl((int)ct, (int)k);
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
@@ -952,12 +955,13 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
         break;
       }
       if (accept) ++nacc; else ++nrej;
-      if (nacc == max_acc || nrej == max_rej) break;
+      if (nacc == max_acc) break;
+      if (nrej == max_rej) { if constexpr (PAIR) { if (!(db.align_flags & UGS_A_NOTERM)) break; } else break; }
       wave_sync();
     }
     // small path with pair filters: passed-over pairs do not count, so the walk may want more candidates than were kept
     if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
-    if (lane == 0) bv.hit_n[unit] = nacc;
+    if (lane == 0) { bv.hit_n[unit] = nacc; if (bv.walk_n) bv.walk_n[unit] = nvis; }
     wave_sync();
     if constexpr (PAIR) if (--strands_left) { ++unit; goto next_strand; }
   }

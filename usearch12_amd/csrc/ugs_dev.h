@@ -94,7 +94,15 @@ struct UgsBatchView {
   // counters: [0]=postings [1]=target letters [2]=pairs [3]=dp cells [4]=hits [5]=error flags
   unsigned long long *counters;
   const uint32_t *q_key, *q_size;   // per query: label key / ;size= annotation (pair filters, -abskew)
+  // cluster_fast (ugs_cluster.cpp); all null outside it
+  uint64_t *cand_key;        // [units*K] full ranking key (count, first-touch position) of every candidate
+  uint64_t *cl_ev;           // [units*UGS_CL_EV] strict prefix maxima of the scan: count << 44 | position, descending
+  uint32_t *cl_info;         // [units*4] M, NextValue, number of prefix maxima, -
+  uint32_t *walk_n;          // [units] candidates the alignment walk visited
+  const uint32_t *unit_map;  // [units] pair stage: unit -> query << 1 | strand (several units per query)
 };
+#define UGS_CL_EV 16
+#define UGS_A_NOTERM 0x100u  // internal align flag: rejects never end a walk (the in-batch pair stage of cluster_fast)
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
        UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_N };  // T*: phase clocks (profiling)

@@ -1,7 +1,7 @@
 // ugs_host.cpp - the C-ABI (include/ugs.h) over the HIP kernels: handles, launch geometry,
 // HBM residency, hit gathering, and the blast6/uc text writers.  No CPU compute fallback:
 // every search entry point needs a gfx950 device.
-#include "ugs_dev.h"
+#include "ugs_host.h"
 
 #include <cctype>
 #include <cmath>
@@ -18,58 +18,6 @@ void ugs_set_error(const char *fmt, ...)
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char *ugs_last_error(void) { return g_err; }
-
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
-#define RCCHK(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
-
-static const size_t LDS_MAX = 160 * 1024;
-
-struct ugs_db {
-  ugs_params p;
-  int device;
-  hipStream_t stream;
-  int num_cu;
-  UgsDbView v;
-  // owned device memory
-  uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
-  uint32_t *d_step; UgsTables *d_tab;
-  std::vector<uint32_t> step;       // host copy: step[Nu]
-  uint64_t n_postings, hbm_bytes;
-  uint32_t max_row, max_tlen;
-  // usearch_local
-  int8_t *d_xsub2; uint8_t *d_xcls;
-  UgsLocalView lv;
-  // pair filters / -abskew
-  uint32_t *d_tkey, *d_tsize; bool have_tkey, have_tsize;
-  bool sparse;                      // sparse dictionary (protein): short index rows
-};
-
-struct ugs_batch {
-  ugs_db *db;
-  uint32_t max_queries; uint64_t max_letters;
-  uint32_t nq, max_qlen, K, nstrand;
-  UgsBatchView v;
-  uint8_t *d_qseqs; uint64_t *d_qoffs;
-  uint32_t *d_qn, *d_qoff; ugs_hit *d_compact; void *d_scan_tmp; size_t scan_tmp_bytes;
-  uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
-  ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
-  uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
-  // usearch_local
-  uint32_t hit_slots;               // hit table entries per unit
-  int2 *d_qthr; uint8_t *d_ltb; uint2 *d_lrow; uint32_t *d_lruns;
-  uint64_t ltb_alloc, lrow_alloc, lruns_alloc;
-  UgsLocalView lv; int lgrid, lwpb; size_t llds;
-  uint32_t *d_qkey, *d_qsize; bool have_qkey, have_qsize;
-  unsigned long long *d_cigar_used, *d_ctr;
-  uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
-  int rank_grid_alloc, align_waves_alloc;
-  UgsRankLaunch rl; UgsAlignLaunch al;
-  hipEvent_t ev0, ev0s, ev1, ev2;
-  bool searched, synced;
-  unsigned long long ctr[UGS_CTR_N];
-  unsigned long long cigar_used_host;
-  uint64_t q_letters;
-};
 
 extern "C" int ugs_abi_version(void) { return UGS_ABI_VERSION; }
 
@@ -297,6 +245,53 @@ static int db_step_table(ugs_db *db, uint32_t n)
   return UGS_OK;
 }
 
+// Partition size and table, the Big latch and the index-dependent fields of the device view; called when the index was
+// built (ugs_db_create) or grew (ugs_db_append).
+int ugs_db_replan(ugs_db *db)
+{
+  const uint32_t nseq = db->v.nseq, slots = db->v.slots;
+  // ~40 postings per (row, partition): a sub-row then (almost) never exceeds one wavefront
+  // (Poisson tail < 1e-3), while 60 % of the lanes of every row instruction carry a posting
+  uint32_t gsize = 8192;
+  {
+    double avg_row = db->n_postings ? (double)db->n_postings / (double)slots : 1.0;
+    double g = 40.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
+    uint64_t gs = ((uint64_t)g + 511) / 1024 * 1024;
+    if (gs < 1024) gs = 1024;
+    uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
+    db->sparse = false;
+    if (gs > 65536) {
+      // sparse rows (protein dictionaries: a few hundred postings per row): no partition size gives 40 postings per
+      // sub-row; the scan then flattens all sub-rows of a range into one instruction stream and what matters is the
+      // number of resident waves, i.e. a small counter table (16 Ki targets x 8 bits = 16 KiB of LDS per wave).
+      // The partition table may grow up to the size of the postings themselves for it.
+      gs = 16384;
+      db->sparse = true;
+      budget = std::max<uint64_t>(256ull << 20, db->n_postings * 4);
+    }
+    while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
+    gsize = (uint32_t)gs;
+    if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
+    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 16) gsize = 1u << v; }
+  }
+  const uint32_t np = nseq ? (uint32_t)(((uint64_t)nseq - 1) / gsize + 1) : 1;
+  const uint64_t need = (uint64_t)slots * (np + 1);
+  if (!db->d_part || need > db->part_cap) {
+    if (db->d_part) HIPCHK(hipFree(db->d_part));
+    db->d_part = nullptr;
+    db->part_cap = need + need / 4;
+    HIPCHK(hipMalloc(&db->d_part, (size_t)db->part_cap * sizeof(uint32_t)));
+  }
+  RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np, gsize, db->d_part, db->stream));
+  HIPCHK(hipStreamSynchronize(db->stream));
+  UgsDbView &v = db->v;
+  v.seqs = db->d_seqs; v.offs = db->d_offs; v.row_off = db->d_row_off; v.postings = db->d_postings; v.part = db->d_part;
+  v.np = np; v.gsize = gsize; v.big = nseq > db->p.big ? 1 : 0; v.max_tlen = db->max_tlen;
+  db->hbm_bytes = db->nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
+                  (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
+  return UGS_OK;
+}
+
 extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
                              int device, ugs_db **out)
 {
@@ -369,40 +364,13 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   if ((rc = ugs_build_index(db->d_tab, db->d_seqs, db->d_offs, nseq, nletters, p->word_len, alpha, slots,
                             &db->d_row_off, &db->d_postings, &db->n_postings, &db->max_row, db->stream)) != UGS_OK)
     return fail(rc);
-  // partition size: aim at ~32 postings per (row, partition): a sub-row then (almost) never exceeds
-  // one wavefront, which keeps the ranking kernel on its register-resident fast path
-  uint32_t gsize = 8192;
-  {
-    // ~40 postings per (row, partition): a sub-row then (almost) never exceeds one wavefront
-    // (Poisson tail < 1e-3), while 60 % of the lanes of every row instruction carry a posting
-    double avg_row = db->n_postings ? (double)db->n_postings / (double)slots : 1.0;
-    double g = 40.0 * (double)(nseq ? nseq : 1) / (avg_row > 1.0 ? avg_row : 1.0);
-    uint64_t gs = ((uint64_t)g + 511) / 1024 * 1024;
-    if (gs < 1024) gs = 1024;
-    uint64_t budget = std::max<uint64_t>(64ull << 20, db->n_postings);
-    if (gs > 65536) {
-      // sparse rows (protein dictionaries: a few hundred postings per row): no partition size gives 40 postings per
-      // sub-row; the scan then flattens all sub-rows of a range into one instruction stream and what matters is the
-      // number of resident waves, i.e. a small counter table (16 Ki targets x 8 bits = 16 KiB of LDS per wave).
-      // The partition table may grow up to the size of the postings themselves for it.
-      gs = 16384;
-      db->sparse = true;
-      budget = std::max<uint64_t>(256ull << 20, db->n_postings * 4);
-    }
-    while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
-    gsize = (uint32_t)gs;
-    if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
-    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 16) gsize = 1u << v; }
-  }
-  const uint32_t np = nseq ? (uint32_t)(((uint64_t)nseq - 1) / gsize + 1) : 1;
-  DBCHK(hipMalloc(&db->d_part, (size_t)slots * (np + 1) * sizeof(uint32_t)));
-  if ((rc = ugs_build_part(db->d_row_off, db->d_postings, slots, np, gsize, db->d_part, db->stream)) != UGS_OK) return fail(rc);
-  DBCHK(hipStreamSynchronize(db->stream));
+  db->nletters = nletters; db->seq_cap = nletters + 64; db->off_cap = (uint64_t)nseq + 1; db->post_cap = db->n_postings + 256; db->part_cap = 0;
+  db->v.nseq = nseq; db->v.slots = slots;
+  if ((rc = ugs_db_replan(db)) != UGS_OK) return fail(rc);
 #undef DBCHK
   UgsDbView &v = db->v;
-  v.seqs = db->d_seqs; v.offs = db->d_offs; v.nseq = nseq; v.slots = slots; v.row_off = db->d_row_off;
-  v.postings = db->d_postings; v.part = db->d_part; v.np = np; v.gsize = gsize; v.tab = db->d_tab;
-  v.word_len = p->word_len; v.alpha = alpha; v.big = nseq > p->big ? 1 : 0; v.bump_pct = p->bump_pct;
+  v.tab = db->d_tab;
+  v.word_len = p->word_len; v.alpha = alpha; v.bump_pct = p->bump_pct;
   v.hsp_w = p->hsp_word_len; v.hsp_words = (int)hspw64;
   v.xdrop2 = (int)floor(2.0 * (double)p->xdrop_nw);
   // alnheuristics.cpp:26-62 (float arithmetic as in the reference)
@@ -427,8 +395,6 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
   v.align_flags = p->align_flags; v.termid = p->termid; v.termidd = p->termidd;
   if (p->align_flags & UGS_A_FULLDP) v.band = 1 << 20;          // every diagonal: ViterbiFastMem (globalalignmem.cpp:148-152)
-  db->hbm_bytes = nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
-                  (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
   if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
   if (p->local) {   // x-drop tables (the ones ugs_xdrop_batch uses) and the constants of LocalAligner / XDropAlignMem
     int8_t xsub2[1024]; uint8_t xcls[256];
@@ -829,7 +795,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
 }
 
 // sort.h:85-117 QuickSortOrderRecurse<float, Desc=true> (HitMgr::Sort, hitmgr.cpp:477-483)
-static void qs_order_desc(const float *V, int left, int right, unsigned *Order)
+void ugs_qs_order_desc(const float *V, int left, int right, unsigned *Order)
 {
   int i = left, j = right;
   float pivot = V[Order[(left + right) / 2]];
@@ -838,8 +804,8 @@ static void qs_order_desc(const float *V, int left, int right, unsigned *Order)
     while (V[Order[j]] < pivot) j--;
     if (i <= j) { std::swap(Order[i], Order[j]); i++; j--; }
   }
-  if (left < j) qs_order_desc(V, left, j, Order);
-  if (i < right) qs_order_desc(V, i, right, Order);
+  if (left < j) ugs_qs_order_desc(V, left, j, Order);
+  if (i < right) ugs_qs_order_desc(V, i, right, Order);
 }
 
 // HitMgr::Sort (hitmgr.cpp:477-483) on a hit table grouped by query: each query's hits in the order of the reference's
@@ -854,7 +820,7 @@ extern "C" int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uin
     if (n > 1) {
       tmp.assign(hits + k, hits + k + n); sc.resize(n); ord.resize(n);
       for (uint32_t i = 0; i < n; ++i) { sc[i] = local ? tmp[i].raw_score : (float)(tmp[i].aln_len == 0 ? 0.0 : (double)tmp[i].ids / (double)tmp[i].aln_len); ord[i] = i; }
-      qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
+      ugs_qs_order_desc(sc.data(), 0, (int)n - 1, ord.data());
       for (uint32_t i = 0; i < n; ++i) hits[k + i] = tmp[ord[i]];
     }
     k += n;

@@ -1,0 +1,63 @@
+// ugs_host.h - handle structs shared by the host translation units (ugs_host.cpp, ugs_cluster.cpp).  Internal.
+#pragma once
+#include "ugs_dev.h"
+#include <vector>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+#define RCCHK(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
+
+static const size_t LDS_MAX = 160 * 1024;
+
+struct ugs_db {
+  ugs_params p;
+  int device;
+  hipStream_t stream;
+  int num_cu;
+  UgsDbView v;
+  // owned device memory
+  uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
+  uint32_t *d_step; UgsTables *d_tab;
+  std::vector<uint32_t> step;       // host copy: step[Nu]
+  uint64_t n_postings, hbm_bytes;
+  uint32_t max_row, max_tlen;
+  // usearch_local
+  int8_t *d_xsub2; uint8_t *d_xcls;
+  UgsLocalView lv;
+  // pair filters / -abskew
+  uint32_t *d_tkey, *d_tsize; bool have_tkey, have_tsize;
+  bool sparse;                      // sparse dictionary (protein): short index rows
+  // capacities (elements) of the growable arrays and the letter count: ugs_db_append grows the DB in place
+  uint64_t nletters, seq_cap, off_cap, post_cap, part_cap;
+};
+
+struct ugs_batch {
+  ugs_db *db;
+  uint32_t max_queries; uint64_t max_letters;
+  uint32_t nq, max_qlen, K, nstrand;
+  UgsBatchView v;
+  uint8_t *d_qseqs; uint64_t *d_qoffs;
+  uint32_t *d_qn, *d_qoff; ugs_hit *d_compact; void *d_scan_tmp; size_t scan_tmp_bytes;
+  uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
+  ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
+  uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
+  // usearch_local
+  uint32_t hit_slots;               // hit table entries per unit
+  int2 *d_qthr; uint8_t *d_ltb; uint2 *d_lrow; uint32_t *d_lruns;
+  uint64_t ltb_alloc, lrow_alloc, lruns_alloc;
+  UgsLocalView lv; int lgrid, lwpb; size_t llds;
+  uint32_t *d_qkey, *d_qsize; bool have_qkey, have_qsize;
+  unsigned long long *d_cigar_used, *d_ctr;
+  uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
+  int rank_grid_alloc, align_waves_alloc;
+  UgsRankLaunch rl; UgsAlignLaunch al;
+  hipEvent_t ev0, ev0s, ev1, ev2;
+  bool searched, synced;
+  unsigned long long ctr[UGS_CTR_N];
+  unsigned long long cigar_used_host;
+  uint64_t q_letters;
+};
+
+
+// internal entry points of ugs_host.cpp used by the cluster_fast driver
+int ugs_db_replan(ugs_db *db);                    // partition size / table + Big latch after the index changed
+void ugs_qs_order_desc(const float *V, int left, int right, unsigned *Order);

@@ -1005,6 +1005,20 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
       if (lane == 0) {
         sh->M = m; sh->next_value = nv; sh->min_value = nv / 2;
         sh->nev = 0; sh->fill_limit = KEY_INF;
+        if (bv.cl_ev) {
+          // cluster_fast (ugs_cluster.cpp): the greedy loop's host side merges this unit's walk with the centroids founded
+          // inside the same batch, which can move the CountSort cut-off (countsort.cpp:13-24) either way.  So the candidates
+          // are chosen WITHOUT the MinValue cut-off here, and the strict prefix maxima of the scan (count, first position) -
+          // all the cut-off depends on - go to the host, which applies the cut-off of the merged scan.
+          sh->min_value = 0;
+          unsigned long long sufmin = KEY_INF;
+          uint32_t ne = 0;
+          for (uint32_t c = m; c >= 1; --c) {
+            const unsigned long long f = s_fp[c];
+            if (f != KEY_INF && f < sufmin) { if (ne < UGS_CL_EV) bv.cl_ev[(uint64_t)unit * UGS_CL_EV + ne] = ((uint64_t)c << POS_BITS) | f; ++ne; sufmin = f; }
+          }
+          bv.cl_info[(uint64_t)unit * 4 + 0] = m; bv.cl_info[(uint64_t)unit * 4 + 1] = nv; bv.cl_info[(uint64_t)unit * 4 + 2] = ne;
+        }
         if (small_path && m && db.bump_pct != 0) {
           // strict prefix maxima in ascending-target order = counts c whose first position
           // precedes the first position of every larger count (udbusortedsearcher.cpp:230-267)
@@ -1136,6 +1150,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
           if (me < ncl && rank < K) {
             bv.cand[(uint64_t)unit * K + rank] = key_target(mykey);
             bv.cand_cnt[(uint64_t)unit * K + rank] = key_count(mykey);
+            if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + rank] = mykey;
             if (rank + 1 == nout) sh->last_key = mykey;
           }
           if (tid == 0) { sh->n_sel = nout; sh->exhausted = ncl < K ? 1u : 0u; }
@@ -1188,6 +1203,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
             if (lane == 0) {
               bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
               bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
+              if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + nsel] = best;
             }
             mlast = best; mfirst = false; last = best; ++nsel;
           }
@@ -1273,6 +1289,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
           if (me < ncl && rank < want) {
             bv.cand[(uint64_t)unit * K + nsel + rank] = key_target(mykey);
             bv.cand_cnt[(uint64_t)unit * K + nsel + rank] = key_count(mykey);
+            if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + nsel + rank] = mykey;
             if (rank + 1 == nout) sh->last_key = mykey;
           }
           __syncthreads();
@@ -1292,6 +1309,7 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
           if (tid == 0) {
             bv.cand[(uint64_t)unit * K + nsel] = key_target(best);
             bv.cand_cnt[(uint64_t)unit * K + nsel] = key_count(best);
+            if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + nsel] = best;
           }
           last = best; ++nsel;
         }
