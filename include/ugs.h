@@ -471,6 +471,9 @@ typedef struct ugs_cluster_stats {
   uint64_t pairs_frozen;     /* pair alignments of the frozen-index walks                                 */
   uint64_t postings;         /* algorithmic postings of the frozen-index scans            */
   float    ms_rank, ms_align; /* summed device time of the frozen-index stages                            */
+  /* host wall-clock seconds by stage: dereplication, frozen search (upload .. sync), in-batch counts (+ batch index),
+   * device -> host copies, the two input-order passes, the pair stage, growing the index */
+  float    s_derep, s_search, s_inbatch, s_d2h, s_replay, s_pairs, s_append, s_total;
 } ugs_cluster_stats;
 int ugs_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq, int device, ugs_cluster **out);
 void ugs_cluster_destroy(ugs_cluster *c);

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts():
     assert C.sizeof(Params) == 192
     assert HIT_DTYPE.itemsize == 80
-    assert C.sizeof(ClusterStats) == 72
+    assert C.sizeof(ClusterStats) == 104
     p = capi.params(is_nucleo=True, id=0.97)
     assert (p.word_len, p.max_accepts, p.max_rejects, p.big, p.band, p.hsp_word_len) == (8, 1, 32, 100000, 16, 5)
     assert p.id_accept == float(np.float32(0.97))     # options are stored as float (opts.cpp:265)

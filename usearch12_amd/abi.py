@@ -63,7 +63,8 @@ class ClusterStats(C.Structure):
     _fields_ = [("batches", C.c_uint32), ("batches_cut", C.c_uint32), ("max_batch", C.c_uint32), ("reserved_", C.c_uint32),
                 ("queries_redone", C.c_uint64), ("inbatch_entries", C.c_uint64), ("pairs_in_batch", C.c_uint64),
                 ("hits_in_batch", C.c_uint64), ("pairs_frozen", C.c_uint64), ("postings", C.c_uint64),
-                ("ms_rank", C.c_float), ("ms_align", C.c_float)]
+                ("ms_rank", C.c_float), ("ms_align", C.c_float)] + \
+               [(n, C.c_float) for n in ("s_derep", "s_search", "s_inbatch", "s_d2h", "s_replay", "s_pairs", "s_append", "s_total")]
 
 
 class UdbInfo(C.Structure):

@@ -30,6 +30,9 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <chrono>
+
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int ugs_index_merge(const uint64_t *old_off, const uint32_t *old_post, const uint64_t *delta_off, const uint32_t *delta_post,
                     uint32_t slots, uint32_t base_target, uint64_t *new_off, uint32_t *new_post, uint64_t n_total,
@@ -324,7 +327,9 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
   for (uint32_t i = 0; i <= nseq; ++i) C->offs[i] = offs[i] - offs[0];
   const char *S = C->seqs.data(); const uint64_t *O = C->offs.data();
   const bool revcomp = p.strand_both && p.is_nucleo;
+  const double t_start = now_s();
   const uint32_t nu = derep_full(S, O, nseq, revcomp, C->seq_unique, C->uniq_seed);
+  C->st.s_derep = (float)(now_s() - t_start);
   C->n_unique = nu;
   C->uniq_size.assign(nu, 0);
   for (uint32_t i = 0; i < nseq; ++i) ++C->uniq_size[C->seq_unique[i]];
@@ -372,6 +377,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
     }
     B = std::min(B, Bmax); B = std::min(B, nu - next);
     // ---- upload the batch (the uniques' seed sequences, as read) and search the frozen index
+    double tq = now_s();
     stage.clear(); stage_off.assign(1, 0);
     for (uint32_t k = 0; k < B; ++k) {
       const uint32_t si = C->uniq_seed[next + k];
@@ -379,12 +385,15 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
       stage_off.push_back(stage.size());
     }
     RCCHK(ugs_batch_upload(b, stage.data(), stage_off.data(), B));
+    if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: n0 %u B %u stage+upload %.4f s\n", C->st.batches, n0, B, now_s() - tq);
     const uint32_t units = B * ns;
     b->v.cand_key = (uint64_t *)d_ckey.p; b->v.cl_ev = (uint64_t *)d_clev.p; b->v.cl_info = (uint32_t *)d_clinfo.p; b->v.walk_n = (uint32_t *)d_walk.p;
     b->v.unit_map = nullptr;
     RCCHK(ugs_batch_search(b));
     RCCHK(ugs_batch_sync(b));
+    if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: search done %.4f s\n", C->st.batches, now_s() - tq);
     const bool small_path = !db->v.big;
+    C->st.s_search += (float)(now_s() - tq); tq = now_s();
     // ---- the batch's own index and the in-batch word counts (count, scan, write)
     uint64_t *d_brow = nullptr; uint32_t *d_bpost = nullptr; uint64_t n_bpost = 0; uint32_t bmax = 0;
     RCCHK(ugs_build_index(db->d_tab, b->d_qseqs, b->d_qoffs, B, stage.size(), p.word_len, db->v.alpha, db->v.slots, &d_brow, &d_bpost, &n_bpost, &bmax, st));
@@ -404,6 +413,8 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
       RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, (const uint32_t *)d_entoff.p, (uint2 *)d_ent.p, st));
       HIPCHK(hipMemcpyAsync(H.ent.data(), d_ent.p, n_ent * 8, hipMemcpyDeviceToHost, st));
     }
+    HIPCHK(hipStreamSynchronize(st));
+    C->st.s_inbatch += (float)(now_s() - tq); tq = now_s();
     // ---- what the frozen search found
     H.cand_key.resize((size_t)units * K); H.cand.resize((size_t)units * K); H.cand_n.resize(units); H.walk_n.resize(units); H.hit_n.resize(units);
     H.cl_info.resize((size_t)units * 4); H.cl_ev.resize((size_t)units * UGS_CL_EV); H.fhits.resize(units);
@@ -417,6 +428,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
     HIPCHK(hipMemcpyAsync(H.fhits.data(), b->d_hits, (size_t)units * sizeof(ugs_hit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     H.pair_out.assign(n_ent, 0); H.pair_hit.assign(n_ent, 0);
+    C->st.s_d2h += (float)(now_s() - tq); tq = now_s();
 
     // ---- pass 1 (input order): queries no earlier query of the batch can influence are final at once; for the others
     // every pair that may matter is listed for the device
@@ -448,6 +460,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
         }
       }
     }
+    C->st.s_replay += (float)(now_s() - tq); tq = now_s();
     // ---- the pair stage: k_align over explicit (query strand, in-batch target) lists; targets are the batch's own letters
     const uint32_t npu = (uint32_t)pmap.size();
     H.phits.clear();
@@ -527,6 +540,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
     H.pool.resize(b->cigar_used_host);
     if (b->cigar_used_host) HIPCHK(hipMemcpy(H.pool.data(), b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost));
 
+    C->st.s_pairs += (float)(now_s() - tq); tq = now_s();
     // ---- pass 2 (input order): every earlier query of the batch is decided when a query is replayed
     for (uint32_t q = 0; q < B; ++q) if (status[q] == ST_MAYBE) status[q] = ST_UNKNOWN;
     cidx.assign(B, 0);
@@ -584,7 +598,9 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
       done = q + 1;
     }
     if (done == 0) { ugs_set_error("cluster_fast made no progress (internal error)"); return UGS_E_HIP; }
+    C->st.s_replay += (float)(now_s() - tq); tq = now_s();
     if (nc_batch) RCCHK(ugs_db_append(db, app_seq.data(), app_off.data(), nc_batch));
+    C->st.s_append += (float)(now_s() - tq);
     ++C->st.batches; C->st.pairs_in_batch += n_pairs; C->st.inbatch_entries += n_ent; C->st.queries_redone += B - done;
     C->st.max_batch = std::max<uint32_t>(C->st.max_batch, B);
     ugs_batch_stats bs;
@@ -593,6 +609,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
     B_prev = B; pairs_prev = n_pairs;
   }
   C->n_clusters = nc;
+  C->st.s_total = (float)(now_s() - t_start);
   G.c = nullptr;
   *out = C;
   return UGS_OK;

@@ -621,9 +621,13 @@ static int plan_launch(ugs_batch *b)
   // a target with count c is emitted c times (deduplicated at selection): bounded by the postings read
   uint64_t ecap = std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20) + (uint64_t)db->v.np * 4 * b->K + 64;
   if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
+    // (a database that grows - cluster_fast - asks for a little more with every batch: over-allocate then, a multi-GB
+    // hipMalloc per batch costs more than the batch's kernels)
+    const uint64_t want = ecap * (uint64_t)b->rl.grid, cap = b->d_emit ? want + want / 2 : want;
     if (b->d_emit) HIPCHK(hipFree(b->d_emit));
-    HIPCHK(hipMalloc(&b->d_emit, ecap * (uint64_t)b->rl.grid * 8));
-    b->emit_cap_alloc = ecap * (uint64_t)b->rl.grid;
+    b->d_emit = nullptr;
+    HIPCHK(hipMalloc(&b->d_emit, cap * 8));
+    b->emit_cap_alloc = cap;
   }
   b->v.emit_cap = ecap;
   {   // sampled rows per unit (k_rank_setup -> k_rank)
