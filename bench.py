@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py - usearch_global hot path on MI355X (BASELINE.json metric: query-seqs/s).
 
-One "step" = one pass of the hot path (ranking + alignment kernels + hit-table fetch) over one
-batch of synthetic queries already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]
-(C2): 1M x 250 nt queries vs a 1M-sequence DB, -id 0.97, -strand plus, all other options at the
-reference defaults.  For N>1 every rank holds a replica of the DB index in its own HBM and its
-own shard of 1M queries (weak scaling); the only exchange is one RCCL gather of the
-device-resident hit tables to rank 0 per step.
+One "step" = one pass of the hot path over one batch of synthetic queries: H2D upload of the batch, ranking +
+alignment kernels, hit table back on the host.  The upload of step i+1's batch is issued while step i's kernels
+run (two batches in flight, a copy stream per batch), and every step searches a batch that differs from the one
+before it; both are inside the timed region.
+
+  N = 1  BASELINE.json configs[1] (C2): 1M x 250 nt queries vs a 1M-sequence DB, -id 0.97, -strand plus, reference
+         defaults - the configuration the metric is quoted on.
+  N > 1  BASELINE.json configs[3] (C4): 10M x 250 nt queries split into N contiguous shards vs a 5M-sequence DB whose
+         index is replicated in every GPU's HBM (strong scaling); the only exchange is one RCCL gather of
+         the device-resident hit tables to rank 0 per step.  (A 5M-sequence index makes every query read 5x the
+         postings of C2: compare the N > 1 lines with each other, or with `--gpus 1 --workload C4`.)
+`python bench.py --gpus N` starts its N ranks itself (torch.distributed.run on 127.0.0.1) when it is not already
+running under a launcher, and refuses to run when the launcher's world size differs from --gpus.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -75,48 +82,111 @@ def cpu_baseline(kind, db, qs, ident, sample_q, threads):
                       (sample.n, db.n, threads)}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def make_query_sets(synth, seed, db, n, length, nsets):
+    """`nsets` different batches of n queries each, built in chunks of <= 1M (bounds the generator's temporaries)"""
+    import numpy as _np
+    sets = []
+    for k in range(nsets):
+        parts = []
+        done = 0
+        while done < n:
+            m = min(1_000_000, n - done)
+            parts.append(synth.make_queries(seed + 7919 * k + 104729 * (done // 1_000_000), db, m, length))
+            done += m
+        if len(parts) == 1:
+            sets.append(parts[0])
+        else:
+            seqs = _np.concatenate([q.seqs for q in parts])
+            offs = [parts[0].offs]
+            base = int(parts[0].offs[-1])
+            for q in parts[1:]:
+                offs.append(q.offs[1:] + _np.uint64(base))
+                base += int(q.offs[-1])
+            sets.append(synth.SeqSet(seqs, _np.concatenate(offs), lambda i: "q%d" % i))
+    return sets
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--db", type=int, default=1_000_000, help="DB sequences (C2 = 1M)")
-    ap.add_argument("--queries", type=int, default=1_000_000, help="queries per GPU per step (C2 = 1M)")
+    ap.add_argument("--workload", choices=["auto", "C2", "C4"], default="auto", help="auto: C2 at --gpus 1, C4 above")
+    ap.add_argument("--db", type=int, default=0, help="DB sequences (default: the workload's)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step over all GPUs (default: the workload's)")
     ap.add_argument("--length", type=int, default=250)
     ap.add_argument("--id", type=float, default=0.97)
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU sample (0 = auto)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, "
+                         "tables travel through the host) - not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to report a mislabelled line" % (args.gpus, world))
     dist = None
     torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if args.backend == "gloo" else "cuda"
 
     from usearch12_amd import capi, synth, multigpu
-    from usearch12_amd.abi import HIT_DTYPE
 
-    # ---- synthetic C2 workload (seed 2); rank r gets its own query shard against the replicated DB
+    workload = args.workload if args.workload != "auto" else ("C2" if world == 1 else "C4")
+    seed = 2 if workload == "C2" else 4
+    db_n = args.db or (1_000_000 if workload == "C2" else 5_000_000)
+    total_q = args.queries or (1_000_000 if workload == "C2" else 10_000_000)
+    lo, hi = multigpu.shard_range(total_q, world, rank)            # contiguous shard of this rank
+    shard_n = hi - lo
+
+    # ---- synthetic workload; the DB is the same on every rank (replicated index), the queries are the rank's shard.
+    # Two different batches alternate from step to step.
     t0 = time.time()
-    db = synth.make_db(2, args.db, args.length)
-    qs = synth.make_queries(2 + 1000 * rank, db, args.queries, args.length)
+    db = synth.make_db(seed, db_n, args.length)
+    qsets = make_query_sets(synth, seed + 1000 * rank, db, shard_n, args.length, 2)
     t_gen = time.time() - t0
 
     p = capi.params(is_nucleo=True, id=args.id)
     t0 = time.time()
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=local_rank)
     t_index = time.time() - t0
-    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    max_letters = max(int(q.offs[-1]) for q in qsets)
+    bats = [capi.UgsBatch(gdb, shard_n, max_letters) for _ in range(2)]
+    for q in qsets:                                                 # page-locked once: uploads are then true async DMA
+        capi._chk(capi.lib().ugs_host_register(q.seqs.ctypes.data, q.seqs.nbytes))
     t0 = time.time()
-    bat.upload(qs.seqs, qs.offs)      # H2D happens here, outside the timed region
+    bats[0].upload(qsets[0].seqs, qsets[0].offs)                    # the first batch of the pipeline
+    bats[0].search(); bats[0].sync()                                # (also sizes the scratch buffers)
     t_upload = time.time() - t0
 
     def barrier():
@@ -124,47 +194,68 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    t_parts = {"search_sync": 0.0, "fetch": 0.0}
+    t_parts = {"search_sync": 0.0, "fetch": 0.0, "gather": 0.0, "upload_issue": 0.0}
+    state = {"i": 0}
 
     def step():
+        i = state["i"]
+        state["i"] = i + 1
+        cur, nxt = bats[i % 2], bats[(i + 1) % 2]
         ta = time.time()
-        bat.search()
-        bat.sync()
+        cur.search()                                                # enqueue: waits (on the GPU) for cur's upload
+        tu = time.time()
+        nxt.upload(qsets[(i + 1) % 2].seqs, qsets[(i + 1) % 2].offs)   # next step's batch travels while cur's kernels run
+        t_parts["upload_issue"] += time.time() - tu
+        cur.sync()
         tb = time.time()
         t_parts["search_sync"] += tb - ta
         if dist is None:
-            out = bat.fetch(reuse=True)     # result buffers owned by the batch, page-locked once (a streaming caller's setup)
+            out = cur.fetch(reuse=True)     # result buffers owned by the batch, page-locked once (a streaming caller's setup)
             t_parts["fetch"] += time.time() - tb
-            return out
+            return out, cur
         # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)
-        (ph, bh), (pn, bn), (pc, bc) = bat.device_results(query_base=rank * qs.n)   # compacted + global query ids on device
+        (ph, bh), (pn, bn), (pc, bc) = cur.device_results(query_base=lo)   # compacted + global query ids on device
         t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
         t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
         t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
+        if cdev == "cpu":
+            t_h, t_n, t_c = t_h.cpu(), t_n.cpu(), t_c.cpu()
         got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
+        t_parts["gather"] += time.time() - tb
         if rank == 0:
-            return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3])
-        return None
+            return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3]), cur
+        return None, cur
 
+    # the pipeline is primed so that step 0 finds its batch uploaded
+    bats[0].upload(qsets[0].seqs, qsets[0].offs)
     for _ in range(args.warmup):
         step()
+    for k in t_parts:
+        t_parts[k] = 0.0
     barrier()
     t0 = time.time()
     stats = []
     out = None
     for _ in range(args.steps):
-        out = step()
-        stats.append(bat.stats())
+        out, cur = step()
+        stats.append(cur.stats())
     barrier()
     elapsed = time.time() - t0
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        mine = torch.tensor([float(np.mean([s["ms_rank"] for s in stats])), float(np.mean([s["ms_align"] for s in stats])),
+                             float(np.mean([s["ms_rank_setup"] for s in stats])), 1000.0 * t_parts["gather"] / max(args.steps, 1),
+                             1000.0 * t_parts["search_sync"] / max(args.steps, 1), float(shard_n)], device=cdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(zip(("ms_rank", "ms_align", "ms_rank_setup", "ms_gather", "ms_search_sync", "queries"), [float(x) for x in t.tolist()])) for t in allr]
 
     steps = max(args.steps, 1)
-    total_q = qs.n * world * steps
-    value = total_q / elapsed
+    value = total_q * steps / elapsed
+    qs = qsets[0]
 
     if rank == 0:
         st = stats[-1]
@@ -181,7 +272,8 @@ def main():
         # HBM traffic per launch from the PMC passes of the same command (profiles/*_pmc.json, FETCH_SIZE
         # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
         traffic = None
-        for pmc_name in ("r01k_pmc.json", "r01j_pmc.json", "r01i_pmc.json", "r01h_pmc.json", "r01g_pmc.json", "r01f_pmc.json", "r01_pmc.json"):       # newest PMC pass first
+        pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True)   # newest round first
+        for pmc_name in pmcs:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
                 if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
@@ -190,24 +282,25 @@ def main():
             except (OSError, ValueError):
                 pass
         achieved = b_dom / (ms_dom * 1e-3) / 1e9
-        if dist is None:
-            hits, nh, pool = out
-            n_hits = int(len(hits))
-        else:
-            n_hits = int(len(out[0]))
+        n_hits = int(len(out[0]))
         threads = os.cpu_count() or 1
         sample_q = args.cpu_sample or max(2000, min(qs.n, 1500 * threads))
         # the CPU baseline is a single-GPU-run item (rank 0 at N=1): the other ranks of a multi-GPU run would only wait for it
-        cb = cpu_baseline(args.cpu_baseline if world == 1 else "none", db, qs, args.id, sample_q, threads)
+        cb = cpu_baseline(args.cpu_baseline if (world == 1 and workload == "C2") else "none", db, qs, args.id, sample_q, threads)
+        if workload == "C2":
+            wl = ("C2: usearch_global %d x %d nt queries vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
+                  "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one" %
+                  (total_q, args.length, db.n, args.id))
+        else:
+            wl = ("C4: usearch_global %d x %d nt queries in %d contiguous shard(s) vs a %d-seq DB replicated per GPU, -id %.2f "
+                  "-strand plus, reference defaults; one RCCL gather of the hit tables to rank 0 per step" %
+                  (total_q, args.length, world, db.n, args.id))
         line = {
-            "metric": "query-seqs/s usearch_global -id 0.97 (search phase, queries resident in HBM -> hit table on host)",
-            "value": value, "unit": "query-seqs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+            "metric": "query-seqs/s usearch_global -id 0.97 (search phase: query batch on the host -> hit table on the host)",
+            "value": value, "unit": "query-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None, "dtype": "u8/u32 (int32 half-unit DP scores)", "data": "synthetic",
-            "config": {"workload": "C2: usearch_global %d x %d nt queries per GPU vs %d-seq DB, -id %.2f -strand plus, "
-                                   "reference defaults (maxaccepts 1, maxrejects 32, Big ranking path)" %
-                                   (qs.n, args.length, db.n, args.id),
-                       "queries_per_gpu": qs.n, "db_seqs": db.n, "seq_len": args.length,
+            "config": {"workload": wl, "queries_per_step": total_q, "queries_per_gpu": shard_n, "db_seqs": db.n, "seq_len": args.length,
                        "parallelism": "query shards, DB replicated per GPU" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -225,9 +318,12 @@ def main():
                        "postings_per_query": st["postings"] / max(qs.n, 1),
                        "pairs_aligned_per_query": st["pairs_aligned"] / max(qs.n, 1),
                        "dp_gcells_per_s": st["dp_cells"] / max(ms_align * 1e-3, 1e-9) / 1e9,
-                       "host_ms_search_sync": 1000.0 * t_parts["search_sync"] / (args.steps + args.warmup),
-                       "host_ms_fetch": 1000.0 * t_parts["fetch"] / (args.steps + args.warmup),
-                       "index_build_s": t_index, "upload_s": t_upload, "gen_s": t_gen,
+                       "host_ms_search_sync": 1000.0 * t_parts["search_sync"] / steps,
+                       "host_ms_upload_issue": 1000.0 * t_parts["upload_issue"] / steps,
+                       "host_ms_fetch": 1000.0 * t_parts["fetch"] / steps,
+                       "host_ms_gather": 1000.0 * t_parts["gather"] / steps,
+                       "per_rank": per_rank,
+                       "index_build_s": t_index, "first_upload_search_s": t_upload, "gen_s": t_gen,
                        "db_hbm_bytes": gdb.stats()["hbm_bytes"],
                        "gpu_over_cpu": (value / world / cb["value"]) if cb else None},
         }

@@ -254,6 +254,8 @@ int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uint32_t nq, i
  * cand[(q*nstrand + s)*k + j] = target index, cnt[...] = word count, n[q*nstrand+s] = entries.
  */
 int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap);
+/* k of this batch: max_accepts + max_rejects - 1, plus the spare candidates kept for -selfid on the small path (<= 64) */
+int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
 
 /*
  * Device-resident, query-grouped results of the last synced search (valid until the next search

@@ -11,13 +11,13 @@ import numpy as np
 from .abi import FILTER_BITS, PAIR_BITS, UdbInfo, Params, HIT_DTYPE, BatchStats, ClusterStats, as_u8, XdropParams, XDROP_JOB_DTYPE, XDROP_HSP_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libugs.so")
+LIB_PATH = os.environ.get("UGS_LIB") or os.path.join(HERE, "libugs.so")     # UGS_LIB: a tuning build (tools/build_variant.sh)
 _lib = None
 
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -61,6 +61,7 @@ def lib():
         L.ugs_batch_fetch.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
         L.ugs_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
         L.ugs_batch_get_candidates.argtypes = [vp, vp, vp, vp, u32]
+        L.ugs_batch_candidate_k.argtypes = [vp, C.POINTER(u32)]
         L.ugs_batch_device_results.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -195,8 +196,14 @@ class UgsDB:
         cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
         pool = np.zeros(cig_cap, dtype=np.uint32)
         used = C.c_uint64(0)
-        _chk(lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
-                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
+        rc = lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
+                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+        if rc == -5 and used.value > cig_cap:                     # UGS_E_CAPACITY: retry with the run pool the library asked for
+            cig_cap = int(used.value) + 1024
+            pool = np.zeros(cig_cap, dtype=np.uint32)
+            rc = lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
+                                        nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+        _chk(rc)
         nh = nh[:nq]
         return hits[:int(nh.sum())], nh, pool[:used.value]
 
@@ -226,6 +233,7 @@ class UgsBatch:
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         self.nq = len(qoffs) - 1
         self.nletters = int(qoffs[-1] - qoffs[0])
+        self._up = qseqs            # the copy is asynchronous: the letters must stay alive until the next sync
         _chk(lib().ugs_batch_upload(self.h, qseqs.ctypes.data, qoffs.ctypes.data, self.nq))
 
     def set_pair_keys(self, label_key=None, size=None):
@@ -251,7 +259,12 @@ class UgsBatch:
             nh = np.zeros(self.nq + 1, dtype=np.uint32)
             pool = np.zeros(cig_cap, dtype=np.uint32)
             used = C.c_uint64(0)
-            _chk(lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used)))
+            rc = lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+            if rc == -5 and used.value > cig_cap:                 # UGS_E_CAPACITY: the library reports the run pool it needs
+                cig_cap = int(used.value) + 1024
+                pool = np.zeros(cig_cap, dtype=np.uint32)
+                rc = lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+            _chk(rc)
             nh = nh[:self.nq]
             return hits[:int(nh.sum())], nh, pool[:used.value]
         bufs = getattr(self, "_out", None)
@@ -302,7 +315,9 @@ class UgsBatch:
 
     def candidates(self):
         p = self.db.p
-        K = p.max_accepts + p.max_rejects - 1
+        k = C.c_uint32(0)                # the library may keep more than max_accepts+max_rejects-1 (-selfid on the small path)
+        _chk(lib().ugs_batch_candidate_k(self.h, C.byref(k)))
+        K = k.value
         units = self.nq * (2 if p.strand_both else 1)
         cand = np.zeros((max(units, 1), K), dtype=np.uint32)
         cnt = np.zeros((max(units, 1), K), dtype=np.uint32)

@@ -496,6 +496,9 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev2) (void)hipEventDestroy(b->ev2);
+  if (b->ev_up) (void)hipEventDestroy(b->ev_up);
+  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+  if (b->h_rel) (void)hipHostFree(b->h_rel);
   delete b;
 }
 
@@ -533,6 +536,9 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cigar_used, 8));
   BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
+  BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  BCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  BCHK(hipHostMalloc((void **)&b->h_rel, ((size_t)max_queries + 1) * 8, hipHostMallocDefault));
 #undef BCHK
   (void)rc;
   *out = b;
@@ -604,7 +610,7 @@ static int plan_launch(ugs_batch *b)
   const size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;      // + 64 dummy words per wave
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
-  (void)bits;   // (no LDS copy of the partition-table rows any more: the fast path uses scalar loads)
+  (void)bits;   // (no LDS copy of the partition-table rows: the fast path reads them with scalar loads)
   const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
@@ -691,10 +697,13 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
     if (L > maxl) maxl = (uint32_t)L;
   }
   b->nq = nq; b->max_qlen = maxl; b->q_letters = qoffs[nq] - qoffs[0];
-  std::vector<uint64_t> rel((size_t)nq + 1);
-  for (uint32_t i = 0; i <= nq; ++i) rel[i] = qoffs[i] - qoffs[0];
-  if (b->q_letters) HIPCHK(hipMemcpyAsync(b->d_qseqs, qseqs + qoffs[0], b->q_letters, hipMemcpyHostToDevice, db->stream));
-  HIPCHK(hipMemcpyAsync(b->d_qoffs, rel.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, db->stream));
+  // The copies run on the batch's own stream and are not waited for here: ugs_batch_search orders the kernels behind
+  // them with an event.  (The caller's letters must stay untouched until the next ugs_batch_sync of this batch; from
+  // page-locked memory - ugs_host_register - the copy then overlaps whatever another batch is running.)
+  HIPCHK(hipEventSynchronize(b->ev_up));                       // h_rel may still feed the previous upload
+  for (uint32_t i = 0; i <= nq; ++i) b->h_rel[i] = qoffs[i] - qoffs[0];
+  if (b->q_letters) HIPCHK(hipMemcpyAsync(b->d_qseqs, qseqs + qoffs[0], b->q_letters, hipMemcpyHostToDevice, b->copy_stream));
+  HIPCHK(hipMemcpyAsync(b->d_qoffs, b->h_rel, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, b->copy_stream));
   if (db->p.local && nq) {
     // the two e-value gates of LocalAligner::AlignPos as integer score thresholds (half-units), per query length:
     //   ungapped: Score < (float)GetMinUngappedRawScore(QL) rejects            (localmulti.cpp:15, localaligner.cpp:163-168)
@@ -715,9 +724,10 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
       }
       thr[i] = m;
     }
-    HIPCHK(hipMemcpyAsync(b->d_qthr, thr.data(), (size_t)nq * sizeof(int2), hipMemcpyHostToDevice, db->stream));
+    HIPCHK(hipMemcpyAsync(b->d_qthr, thr.data(), (size_t)nq * sizeof(int2), hipMemcpyHostToDevice, b->copy_stream));
+    HIPCHK(hipStreamSynchronize(b->copy_stream));              // (thr is a local)
   }
-  HIPCHK(hipStreamSynchronize(db->stream));
+  HIPCHK(hipEventRecord(b->ev_up, b->copy_stream));
   RCCHK(plan_launch(b));
   UgsBatchView &v = b->v;
   v.qseqs = b->d_qseqs; v.qoffs = b->d_qoffs; v.nq = nq; v.nstrand = b->nstrand; v.K = b->K; v.max_qlen = maxl;
@@ -752,6 +762,7 @@ extern "C" int ugs_batch_search(ugs_batch *b)
     }
   }
   b->v.K = b->K;
+  HIPCHK(hipStreamWaitEvent(db->stream, b->ev_up, 0));          // the batch's letters and offsets have arrived
   HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
@@ -885,6 +896,13 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
             b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]),
     fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu, bits %d ns_max %u gsize %u np %u | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
             b->rl.bits, b->rl.ns_max, b->db->v.gsize, b->db->v.np, b->al.grid, b->al.wpb, b->al.lds);
+  return UGS_OK;
+}
+
+extern "C" int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k)
+{
+  if (!b || !k) return UGS_E_ARG;
+  *k = b->K;
   return UGS_OK;
 }
 

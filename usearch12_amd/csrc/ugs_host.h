@@ -51,6 +51,9 @@ struct ugs_batch {
   int rank_grid_alloc, align_waves_alloc;
   UgsRankLaunch rl; UgsAlignLaunch al;
   hipEvent_t ev0, ev0s, ev1, ev2;
+  // upload path: H2D copies go through the batch's own copy stream; the search waits for ev_up on the handle's stream,
+  // so the upload of one batch overlaps the kernels of another (h_rel: page-locked staging of the relative offsets)
+  hipStream_t copy_stream; hipEvent_t ev_up; uint64_t *h_rel;
   bool searched, synced;
   unsigned long long ctr[UGS_CTR_N];
   unsigned long long cigar_used_host;

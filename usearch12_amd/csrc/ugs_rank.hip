@@ -488,7 +488,7 @@ __device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R,
 }
 
 template <int NR>
-__device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> &B, uint32_t p, unsigned long long &cache1)
+__device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
 {
   const int lane = s.lane;
   uint32_t *tbl = s.tbl;
@@ -523,7 +523,6 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   uint32_t old[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[r], ~(15u << (sh[r] & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const uint32_t c1hi = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
   uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
   uint32_t cnt = 0;          // rows in which this lane holds a first touch with count >= 2
 #pragma unroll
@@ -531,13 +530,14 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
     // v_bfe_u32 takes the offset mod 32, so the unmasked shift (x << 2) serves directly
     c[r] = (uint32_t)lane < B.len[r] ? __builtin_amdgcn_ubfe(old[r], sh[r], 4u) : 0u;
     cnt += c[r] >= 2u ? 1u : 0u;
-    if (s.small_path || (uint32_t)r <= c1hi) {      // uniform: can this row still lower fp[1]?
+    if (s.small_path || (uint32_t)r <= c1row) {     // scalar test (c1row = row of the cached fp[1], kept in an SGPR): can this row still lower fp[1]?
       const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
       const bool f1 = c[r] == 1 && pos < cache1;
       if (__ballot(f1)) {
         if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         cache1 = s.s_fp[1];
+        c1row = __builtin_amdgcn_readfirstlane((uint32_t)(cache1 >> 32));
       }
     }
   }
@@ -587,6 +587,7 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
     R.base[r] = s.postings + ((cptr64)(uintptr_t)s.row_off)[slot];
   }
   unsigned long long cache1 = KEY_INF;          // register copy of fp[1] (a stale-high filter)
+  uint32_t c1row = 0xffffffffu;                 // its row, kept in an SGPR
   uint32_t p0 = s.wave;
   if (p0 >= s.np) return;
   const uint32_t last = s.np - 1;
@@ -595,11 +596,11 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
     issue_batch<NR>(s, R, p1 < last ? p1 : last, B);
-    process_batch<NR>(s, A, p0, cache1);
+    process_batch<NR>(s, A, p0, cache1, c1row);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
     issue_batch<NR>(s, R, p2 < last ? p2 : last, A);
-    process_batch<NR>(s, B, p1, cache1);
+    process_batch<NR>(s, B, p1, cache1, c1row);
     if (p2 >= s.np) break;
     p0 = p2;
   }
@@ -915,7 +916,10 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
 // FAST8: dense indexes (nucleotide) take scan_fast8 for 8-bit tables; sparse dictionaries (protein) keep the generic code,
 // which flattens their short sub-rows - again an instantiation of its own, so that neither pays for the other's registers
 template <bool SMALL, bool BATCH, bool FAST8>
-__global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
+#ifndef UGS_RANK_WGS
+#define UGS_RANK_WGS 4
+#endif
+__global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -963,19 +967,10 @@ __global__ __launch_bounds__(256, 4) void k_rank(UgsDbView db, UgsBatchView bv, 
     __syncthreads();
     // ---- the scan; counter width by the largest possible count (= ns)
     const int cb0 = ns <= 15 ? 4 : (ns <= 255 ? 8 : 16);
-    const bool use_part_cache = false;      // (the fast path reads the partition table with scalar loads)
-    if (use_part_cache) {
-      const uint32_t npp = db.np + 1;
-      for (uint32_t r = wave; r < ns; r += wpb) {
-        const uint32_t *src = db.part + (uint64_t)s_slots[r] * npp;
-        for (uint32_t pp = lane; pp < npp; pp += 64) s_part[r * npp + pp] = src[pp];
-      }
-      __syncthreads();
-    }
     ScanCtx sc;
     sc.pq = nullptr;
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
-    sc.s_part = use_part_cache ? s_part : nullptr;
+    sc.s_part = nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
     sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.s_ebuf = s_ebuf; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;

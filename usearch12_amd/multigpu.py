@@ -28,8 +28,7 @@ def gather_tables(dist, torch, t_hits, t_n, t_pool, rank, world, dst=0):
     dist.gather(sizes, all_sizes, dst=dst)
 
     def pad(t, n):
-        if t.numel() == n:
-            return t.contiguous()
+        # always a torch-owned staging copy: the inputs alias the library's device buffers, which the next search rewrites
         out = torch.zeros(n, dtype=t.dtype, device=dev)
         out[:t.numel()] = t
         return out
@@ -41,6 +40,8 @@ def gather_tables(dist, torch, t_hits, t_n, t_pool, rank, world, dst=0):
         dist.gather(tp, lst, dst=dst)
         outs.append(lst)
     if rank != dst:
+        if t_hits.is_cuda:
+            torch.cuda.synchronize()                                # the sends have left the staging copies
         return None
     sz = torch.stack(all_sizes).cpu().numpy()                       # [world, 3]
     res = []
