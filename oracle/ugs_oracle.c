@@ -1087,6 +1087,8 @@ static float viterbi_band(Work *w, const byte *A, unsigned LA, const byte *B, un
 static float viterbi_main_diag(Work *w, const byte *A, unsigned LA, const byte *B, unsigned LB,
                                unsigned BandRadius, const AlnPen *AP, char *out)
 {
+  /* -band 0: GlobalAlignBandMem / AlignHSPMem call ViterbiFastMem instead (globalalignmem.cpp:105-108,118-119) = every diagonal */
+  if (BandRadius == 0) return viterbi_band(w, A, LA, B, LB, 1, LA + LB - 1, AP, out);
   unsigned DiagLo = LA < LB ? LA : LB;
   unsigned DiagHi = LA > LB ? LA : LB;
   if (DiagLo > BandRadius) DiagLo -= BandRadius; else DiagLo = 1;
@@ -1111,7 +1113,6 @@ static void align_hole(Work *w, unsigned Loi, unsigned Loj, unsigned Leni, unsig
   L.LOpenB = LeftB ? AP->LOpenB : AP->OpenB;   L.LExtB = LeftB ? AP->LExtB : AP->ExtB;
   L.ROpenA = RightA ? AP->ROpenA : AP->OpenA;  L.RExtA = RightA ? AP->RExtA : AP->ExtA;
   L.ROpenB = RightB ? AP->ROpenB : AP->OpenB;  L.RExtB = RightB ? AP->RExtB : AP->ExtB;
-  /* BandRadius==0 would be the full DP (viterbifastmem.cpp); not reachable at -band 16 */
   viterbi_main_diag(w, w->A + Loi, Leni, w->B + Loj, Lenj, db->BandRadius, &L, out);
 }
 

@@ -60,6 +60,12 @@ CASES = {
     # -termid / -termidd: the walk also ends on the identity of the hits collected so far (both strands share them)
     "hard_termid":  dict(gen="hard", seed=38, n_fam=250, fam=8, q_n=900, aa=False, id=0.8, strand="both", big=100, maxaccepts=6, maxrejects=16, termid=0.93),
     "hard_termidd": dict(gen="hard", seed=39, n_fam=250, fam=8, q_n=900, aa=False, id=0.8, strand="both", maxaccepts=6, maxrejects=16, termidd=0.04),
+    # -band 0: every hole (and a pair without HSPs under -gaforce) goes through the unbanded ViterbiFastMem (globalalignmem.cpp:105-108,118-119)
+    "hard_band0":  dict(gen="hard", seed=40, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", big=100, lmin=20, lmax=300, maxaccepts=2, maxrejects=8, band=0, gaforce=1),
+    "hard_band0_aa": dict(gen="hard", seed=41, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, lmin=30, lmax=250, band=0),
+    # maxaccepts 0 / maxrejects 0 = unlimited (terminator.cpp:40-45,91-97): the walk ends on the other limit or at the end of the list
+    "hard_acc0":   dict(gen="hard", seed=42, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", big=100, lmin=20, lmax=300, maxaccepts=0, maxrejects=6),
+    "hard_rej0":   dict(gen="hard", seed=43, n_fam=7, fam=8, q_n=600, aa=False, id=0.9, strand="plus", lmin=100, lmax=300, maxaccepts=2, maxrejects=0),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
@@ -93,7 +99,7 @@ def ref_cmd(c, qfa, dbfa, prefix):
            "-uc", prefix + ".uc", "-threads", "1"]
     if not c["aa"]:
         cmd += ["-strand", c["strand"]]
-    for opt in ("big", "maxaccepts", "maxrejects") + FILTER_OPTS:
+    for opt in ("big", "maxaccepts", "maxrejects", "band") + FILTER_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
     for opt in ("termid", "termidd"):

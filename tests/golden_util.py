@@ -44,6 +44,8 @@ def params_kw(c):
         kw["max_accepts"] = c["maxaccepts"]
     if "maxrejects" in c:
         kw["max_rejects"] = c["maxrejects"]
+    if "band" in c:
+        kw["band"] = c["band"]
     if c.get("fulldp") or c.get("gaforce"):
         kw["align_flags"] = (1 if c.get("fulldp") else 0) | (2 if c.get("gaforce") else 0)
     if c.get("hardmask"):

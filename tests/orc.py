@@ -159,7 +159,7 @@ class OrcDB:
         qseqs = as_u8(qseqs)
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         nq = len(qoffs) - 1
-        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) * (64 if self.p.local else 1) + 1
+        cap = nq * (self.p.max_accepts or 64) * (2 if self.p.strand_both else 1) * (64 if self.p.local else 1) + 1
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         nh = np.zeros(nq + 1, dtype=np.uint32)
         cig_cap = (int(qoffs[-1]) * 2 + 64 * nq + 1024) * (8 if self.p.local else 1)

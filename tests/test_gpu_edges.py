@@ -77,3 +77,23 @@ def test_fetch_capacity_error_reports_demand():
     assert rc == -5 and used.value > 4
     h, n, p = bat.fetch()
     assert len(p) == used.value
+
+
+def test_unlimited_rejects_fail_loudly_when_the_list_is_longer_than_the_device_keeps():
+    """maxrejects 0 on a database where walks run past 64 candidates: UGS_E_ENVELOPE at sync, never a shortened walk"""
+    db, qs = synth.make_hard(77, 60, 8, 200)
+    p = capi.params(is_nucleo=True, id=0.99, max_accepts=1, max_rejects=0)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    with pytest.raises(capi.UgsError) as e:
+        gdb.search(qs.seqs, qs.offs)
+    assert e.value.code == -6
+
+
+def test_options_outside_the_envelope_are_refused_at_create():
+    db = synth.make_db(5, 200, 120)
+    for kw in (dict(local_evalue=1e-3, self=True),               # pair filters exist for usearch_global only
+               dict(local_evalue=1e-3, max_accepts=0),          # open walks too
+               dict(max_accepts=40, max_rejects=40),             # more than 64 candidates per strand
+               dict(band=-1)):
+        with pytest.raises(capi.UgsError):
+            capi.UgsDB(capi.params(is_nucleo=True, id=0.9, **kw), db.seqs, db.offs, device=0)

@@ -190,7 +190,7 @@ class UgsDB:
             out = bat.fetch()
             bat.close()
             return out
-        cap = nq * max(1, self.p.max_accepts) * (2 if self.p.strand_both else 1) * (self.p.max_hsps if self.p.local else 1) + 1
+        cap = nq * (self.p.max_accepts or 64) * (2 if self.p.strand_both else 1) * (self.p.max_hsps if self.p.local else 1) + 1
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         nh = np.zeros(nq + 1, dtype=np.uint32)
         cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
@@ -252,7 +252,7 @@ class UgsBatch:
         """Hits of the last synced search -> (hits, nhits_per_query, run pool).  reuse=True fills result buffers owned by
         this batch (page-locked once, valid until the next fetch) instead of fresh arrays - what a streaming caller does."""
         p = self.db.p
-        cap = self.nq * max(1, p.max_accepts) * (2 if p.strand_both else 1) * (p.max_hsps if p.local else 1) + 1
+        cap = self.nq * (p.max_accepts or 64) * (2 if p.strand_both else 1) * (p.max_hsps if p.local else 1) + 1
         cig_cap = self.nletters * 2 + 64 * self.nq + 1024
         if not reuse:
             hits = np.zeros(cap, dtype=HIT_DTYPE)

@@ -754,6 +754,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     c.LA = LA;
     const uint32_t ncand = bv.cand_n[unit];
     uint32_t nvis = 0;
+    bool walk_ended = false;          // the terminator ended the walk (not the end of the list)
     uint32_t nacc = 0, nrej = 0;
     if (ncand) {
       for (uint32_t p = lane; p < LA; p += 64) {
@@ -826,9 +827,9 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
           wave_sync();
           if (!db.big) continue;
           if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
-                                   ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) break;
+                                   ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) { walk_ended = true; break; }
           ++nrej;
-          if (nrej == max_rej) break;
+          if (nrej == max_rej) { walk_ended = true; break; }
           continue;
         }
       }
@@ -952,15 +953,18 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       if constexpr (PAIR) if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
                                                     ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) {
         if (accept) ++nacc;
+        walk_ended = true;
         break;
       }
       if (accept) ++nacc; else ++nrej;
-      if (nacc == max_acc) break;
-      if (nrej == max_rej) { if constexpr (PAIR) { if (!(db.align_flags & UGS_A_NOTERM)) break; } else break; }
+      if (nacc == max_acc) { walk_ended = true; break; }
+      if (nrej == max_rej) { if constexpr (PAIR) { if (!(db.align_flags & UGS_A_NOTERM)) { walk_ended = true; break; } } else break; }
       wave_sync();
     }
     // small path with pair filters: passed-over pairs do not count, so the walk may want more candidates than were kept
     if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
+    // unlimited maxaccepts / maxrejects: a walk that ran through a FULL candidate list without meeting its limit may have more to visit
+    if constexpr (PAIR) if ((db.align_flags & UGS_A_OPENWALK) && nvis == ncand && ncand == K && !walk_ended && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
     if (lane == 0) { bv.hit_n[unit] = nacc; if (bv.walk_n) bv.walk_n[unit] = nvis; }
     wave_sync();
     if constexpr (PAIR) if (--strands_left) { ++unit; goto next_strand; }

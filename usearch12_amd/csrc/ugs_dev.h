@@ -103,6 +103,7 @@ struct UgsBatchView {
 };
 #define UGS_CL_EV 16
 #define UGS_A_NOTERM 0x100u  // internal align flag: rejects never end a walk (the in-batch pair stage of cluster_fast)
+#define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited): a walk that reaches the end of a full candidate list is an error
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
        UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_N };  // T*: phase clocks (profiling)

@@ -301,17 +301,22 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     ugs_set_error("device %d not available (%d devices); there is no CPU fallback", device, ndev);
     return UGS_E_NODEVICE;
   }
-  if (p->max_accepts <= 0 || p->max_rejects <= 0 || p->max_accepts + p->max_rejects - 1 > UGS_KMAX) {
-    ugs_set_error("max_accepts/max_rejects must be > 0 and max_accepts+max_rejects-1 <= %d", UGS_KMAX);
+  // 0 = unlimited (terminator.cpp:40-45,91-97 test "m_MaxAccepts > 0 && ..."): the walk then ends only on the other limit
+  // or at the end of the candidate list; the device keeps UGS_KMAX candidates per strand and a walk that would need more
+  // fails loudly at ugs_batch_sync (never a silently shortened walk)
+  const bool open_walk = p->max_accepts == 0 || p->max_rejects == 0;
+  if (p->max_accepts < 0 || p->max_rejects < 0 || (!open_walk && p->max_accepts + p->max_rejects - 1 > UGS_KMAX) || p->max_accepts > UGS_KMAX) {
+    ugs_set_error("max_accepts/max_rejects must be >= 0 (0 = unlimited) and max_accepts+max_rejects-1 <= %d", UGS_KMAX);
     return UGS_E_ENVELOPE;
   }
+  if (open_walk && p->local) { ugs_set_error("unlimited maxaccepts/maxrejects are implemented for usearch_global only"); return UGS_E_ENVELOPE; }
   const int alpha = p->is_nucleo ? 4 : 20;
   uint64_t slots64 = 1;
   for (int i = 0; i < p->word_len; ++i) { slots64 *= alpha; if (slots64 > (1ull << 28)) break; }
   uint64_t hspw64 = 1;
   for (int i = 0; i < p->hsp_word_len; ++i) { hspw64 *= alpha; if (hspw64 > 65536) break; }
-  if (p->word_len < 1 || slots64 > (1ull << 28) || p->hsp_word_len < 1 || hspw64 > 65536 || p->band < 1) {
-    ugs_set_error("unsupported word_len/hsp_word_len/band (band 0 = full DP is not implemented)"); return UGS_E_ENVELOPE;
+  if (p->word_len < 1 || slots64 > (1ull << 28) || p->hsp_word_len < 1 || hspw64 > 65536 || p->band < 0) {
+    ugs_set_error("unsupported word_len/hsp_word_len/band"); return UGS_E_ENVELOPE;
   }
   if (p->strand_both && !p->is_nucleo) { ugs_set_error("strand_both needs a nucleotide search"); return UGS_E_ARG; }
   if (p->local && p->align_flags) { ugs_set_error("-fulldp / -gaforce belong to the global aligner"); return UGS_E_ARG; }
@@ -390,11 +395,14 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.filter_mask = p->filter_mask; v.maxid = p->maxid; v.query_cov = p->query_cov; v.max_query_cov = p->max_query_cov;
   v.target_cov = p->target_cov; v.max_target_cov = p->max_target_cov;
   v.mincols = p->mincols; v.maxgaps = p->maxgaps; v.maxdiffs = p->maxdiffs; v.mindiffs = p->mindiffs;
-  v.max_accepts = p->max_accepts; v.max_rejects = p->max_rejects; v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
+  v.max_accepts = p->max_accepts ? p->max_accepts : UGS_KMAX; v.max_rejects = p->max_rejects ? p->max_rejects : 0x7fffffff;
+  v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
   v.pair_mask = p->pair_mask; v.min_sizeratio = p->min_sizeratio; v.minqt = p->minqt; v.maxqt = p->maxqt; v.minsl = p->minsl; v.maxsl = p->maxsl;
   v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
-  v.align_flags = p->align_flags; v.termid = p->termid; v.termidd = p->termidd;
-  if (p->align_flags & UGS_A_FULLDP) v.band = 1 << 20;          // every diagonal: ViterbiFastMem (globalalignmem.cpp:148-152)
+  v.align_flags = p->align_flags | (open_walk ? UGS_A_OPENWALK : 0u); v.termid = p->termid; v.termidd = p->termidd;
+  // every diagonal = ViterbiFastMem: -fulldp (globalalignmem.cpp:148-152) and -band 0 (:105-108,118-119: every hole, and a whole pair
+  // without HSPs, goes through the unbanded aligner)
+  if ((p->align_flags & UGS_A_FULLDP) || p->band == 0) v.band = 1 << 20;
   if ((rc = db_step_table(db, 4096)) != UGS_OK) return fail(rc);
   if (p->local) {   // x-drop tables (the ones ugs_xdrop_batch uses) and the constants of LocalAligner / XDropAlignMem
     int8_t xsub2[1024]; uint8_t xcls[256];
@@ -510,12 +518,12 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   memset(b, 0, sizeof(*b));
   b->db = db; b->max_queries = max_queries; b->max_letters = max_letters;
   b->nstrand = db->p.strand_both ? 2 : 1;
-  b->K = (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
+  b->K = (db->p.max_accepts == 0 || db->p.max_rejects == 0) ? (uint32_t)UGS_KMAX : (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
   // small path + pair filters: passed-over pairs are not counted (searcher.cpp:63-67), the walk can go deeper
   // (only -selfid is left to the aligner on that path: the other pair filters are applied where candidates are chosen)
   if ((db->p.pair_mask & UGS_P_SELFID) && !db->v.big) b->K = std::min<uint32_t>(UGS_KMAX, b->K + 32);
   const uint64_t units = (uint64_t)max_queries * b->nstrand;
-  b->hit_slots = (uint32_t)db->p.max_accepts * (db->p.local ? db->p.max_hsps : 1u);
+  b->hit_slots = (uint32_t)db->v.max_accepts * (db->p.local ? db->p.max_hsps : 1u);
   int rc = UGS_OK;
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); ugs_batch_destroy(b); return UGS_E_HIP; } } while (0)
   BCHK(hipMalloc(&b->d_qseqs, max_letters ? max_letters : 16));
@@ -525,7 +533,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
   BCHK(hipMalloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
   BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
-  b->cigar_cap = units * db->p.max_accepts * 12 + 4096;
+  b->cigar_cap = units * std::max(db->p.max_accepts, 1) * 12 + 4096;
   if (db->p.local) BCHK(hipMalloc(&b->d_qthr, std::max<uint64_t>(max_queries, 1) * sizeof(int2)));
   BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
   BCHK(hipMalloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
@@ -667,7 +675,7 @@ static int plan_launch(ugs_batch *b)
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
   b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
   const int waves = b->al.grid * awpb;
-  const uint64_t band_eff = (p.align_flags & UGS_A_FULLDP) ? std::max(b->max_qlen, db->max_tlen) : (uint64_t)p.band;
+  const uint64_t band_eff = ((p.align_flags & UGS_A_FULLDP) || p.band == 0) ? std::max(b->max_qlen, db->max_tlen) : (uint64_t)p.band;
   const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * band_eff + 4) + 63) & ~63ull;
   const uint32_t runs_stride = 2 * (b->max_qlen + db->max_tlen + 4);
   if (!b->d_tb || tb_stride * waves > b->tb_alloc) {
@@ -790,7 +798,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
         ugs_set_error("more than max_hsps = %u HSPs on one accepted target; raise ugs_params.max_hsps", db->p.max_hsps);
         return UGS_E_CAPACITY;
       }
-      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots 64=a small-path walk with pair filters wanted more than 64 candidates)", b->ctr[UGS_CTR_ERR]);
+      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots 64=a walk wanted more than the 64 candidates kept per strand: -selfid on the small path, or unlimited maxaccepts/maxrejects)", b->ctr[UGS_CTR_ERR]);
       return UGS_E_ENVELOPE;
     }
     if (b->cigar_used_host <= b->cigar_cap) { b->synced = true; return UGS_OK; }
