@@ -90,3 +90,30 @@ def test_db_append_equals_building_at_once():
     for f in h0.dtype.names:
         if f != "cigar_off":
             assert np.array_equal(h0[f], h1[f]), f
+
+
+def test_c3_full_size_properties_and_prefix_parity():
+    """BASELINE config C3 at its literal size (5M x 300 nt reads, 50k species, -id 0.97): size-independent properties of the
+    whole result, and the clustering of the first 30k reads (a prefix of the same loop) compared with the oracle's serial loop"""
+    r = synth.make_reads(3, 5_000_000, n_species=50_000)
+    res = _cluster(dict(id=0.97, strand="plus"), r)
+    assert int(res.cluster_size.sum()) == r.n                                   # every read in exactly one cluster
+    assert np.array_equal(res.uniq_cluster[res.centroid_uniq], np.arange(res.n_clusters, dtype=np.uint32))
+    assert np.all(np.diff(res.centroid_uniq.astype(np.int64)) > 0)              # clusters are numbered in the order they were founded
+    founders = np.zeros(res.n_unique, bool); founders[res.centroid_uniq] = True
+    assert np.array_equal(res.uniq_nhits == 0, founders)                        # a unique founds a cluster iff it has no hit
+    h = res.hits
+    assert len(h) == int((res.uniq_nhits > 0).sum()) and np.all(h["target"] < res.n_clusters)
+    assert (h["ids"] / np.maximum(h["aln_len"], 1)).min() >= float(np.float32(0.97)) - 1e-12
+    assert np.all(res.centroid_uniq[h["target"]] < h["query"])                  # a member's centroid was founded before it
+    assert np.array_equal(res.uniq_cluster[h["query"]], h["target"])
+    assert res.stats.batches_cut == 0 and res.stats.queries_redone < 1000
+    # species are far apart (random roots): no cluster mixes species
+    sp_of_cluster = r.species[res.uniq_seed[res.centroid_uniq]]
+    assert np.array_equal(r.species[res.uniq_seed], sp_of_cluster[res.uniq_cluster])
+    res.close()
+    n = 30_000
+    s = r.slice(0, n)
+    g = _cluster(dict(id=0.97, strand="plus"), s)
+    o = orc.cluster_fast(orc.cluster_params(0.97), s.seqs, s.offs)
+    _same(g, o)

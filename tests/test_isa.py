@@ -1,0 +1,40 @@
+"""Pins a property of the emitted gfx950 code the ranking kernel's fast paths depend on (ugs_rank.hip process_batch,
+scan_fast8): the ordered clear-with-return of a partition's counters (ds_and_rtn_b32) is only issued after every counter
+increment of the partition (ds_add_u32) has COMPLETED - an `s_waitcnt lgkmcnt(0)` stands between the two batches in every
+basic block that holds both.  Compiles the kernel to assembly (hipcc cross-compiles without a GPU)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "usearch12_amd", "csrc", "ugs_rank.hip")
+OUT = "/tmp/ugs_rank_isa_%d.s" % int(os.path.getmtime(SRC))
+
+
+def _isa():
+    if not os.path.exists(OUT):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip",
+                               "--cuda-device-only", "-S", SRC, "-o", OUT], stderr=subprocess.DEVNULL)
+    return open(OUT).read().split("\n")
+
+
+def test_counter_clears_wait_for_the_adds_of_their_batch():
+    pending_add = False            # an LDS add of this basic block may still be in flight
+    n_rtn = n_guarded = 0
+    for ln in _isa():
+        t = ln.strip()
+        if not t or t.startswith(";"):
+            continue
+        if re.match(r"^[.\w$]+:", t) or t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+            pending_add = False
+            continue
+        if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+            if pending_add:
+                n_guarded += 1
+            pending_add = False
+        elif t.startswith("ds_add_u32") and not t.startswith("ds_add_rtn"):
+            pending_add = True
+        elif t.startswith("ds_and_rtn_b32"):
+            n_rtn += 1
+            assert not pending_add, "ds_and_rtn_b32 issued while adds of its batch may be in flight"
+    assert n_rtn >= 11 * 6 and n_guarded >= 6       # the fast paths are there (three row widths x ping-pong per instantiation)

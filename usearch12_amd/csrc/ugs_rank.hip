@@ -516,7 +516,13 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[r], 1u << (sh[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");       // order only: the LDS unit executes one wave's operations in program order
+  // The clears below must find the final counts: every add of the batch has completed before the first clear issues
+  // (explicit wait; it costs nothing measurable - the wave would wait for the clears' return values a few instructions
+  // later anyway - and the result no longer rests on the order in which the LDS unit executes a wave's atomics).
+  // tests/test_isa.py checks the emitted code for the wait.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  asm volatile("" ::: "memory");
   // ordered clears with return: LDS executes a wave's atomics in program order, so only the first
   // row that holds a target still sees its counter set and gets the target's final count back;
   // later rows of the same target read 0.
@@ -741,6 +747,7 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the count pass has completed before the ordered clears start
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
