@@ -117,3 +117,17 @@ def test_c3_full_size_properties_and_prefix_parity():
     g = _cluster(dict(id=0.97, strand="plus"), s)
     o = orc.cluster_fast(orc.cluster_params(0.97), s.seqs, s.offs)
     _same(g, o)
+
+
+def test_cli_cluster_fast_writes_the_reference_files(tmp_path):
+    """the C++ driver end to end: FASTA in, -uc and -centroids out, byte-identical to the reference's files"""
+    import subprocess
+    c, r, uc, cen = G.load_cluster("cl_both")
+    fa = str(tmp_path / "r.fa")
+    r.write_fasta(fa)
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
+    subprocess.check_call([cli, "-cluster_fast", fa, "-id", str(c["id"]), "-strand", c["strand"], "-big", str(c["big"]), "-uc", ucp,
+                           "-centroids", cp], stderr=subprocess.DEVNULL)
+    assert open(ucp).read() == uc
+    assert open(cp).read() == cen

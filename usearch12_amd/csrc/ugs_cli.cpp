@@ -4,6 +4,7 @@
 //   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
+//   ugs_cli -cluster_fast reads.fa -id 0.97 [-strand both] -uc c.uc -centroids c.fa   (clusterfast.cpp:81-138)
 //   ugs_cli -usearch_local q.fa -db db.fa|db.udb -evalue 1e-6 [-id ..] -strand plus|both -blast6out f
 //   ugs_cli -closed_ref reads.fa -db ref.fa -strand plus|both -tabbedout f
 //   ugs_cli -otutab reads.fa -otus otus.fa|-zotus ..|-db .. [-otutabout f] [-mapout f] [+ the usearch_global outputs]
@@ -296,6 +297,7 @@ int main(int argc, char **argv)
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
   std::string tabbedout, trimpath, matchedfqpath, notmatchedfqpath; bool closedref_cmd = false;
   std::string biomout;
+  std::string clusterfast, centroidspath;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -306,6 +308,7 @@ int main(int argc, char **argv)
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
+    else if (a == "-cluster_fast") clusterfast = val(); else if (a == "-centroids") centroidspath = val();
     else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
     else if (a == "-closed_ref") { qpath = val(); closedref_cmd = true; } else if (a == "-tabbedout") tabbedout = val();
     else if (a == "-biomout") biomout = val();
@@ -350,6 +353,34 @@ int main(int argc, char **argv)
     else if (a == "-dbtype") { std::string v = val(); dbtype = (v == "nt"); }
     else if (a == "-threads" || a == "-quiet") { if (a == "-threads") val(); }   // accepted, meaningless here
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+  }
+  if (!clusterfast.empty()) {                               // cmd_cluster_fast clusterfast.cpp:81-138 (-sort unset: input order)
+    if (id < 0) { fprintf(stderr, "Must specify -id\n"); return 1; }                        // makeclustersearcher.cpp:30-31
+    SeqSet in;
+    { FastaReader r(clusterfast.c_str()); while (r.read(in, 1u << 20)) {} }
+    if (in.size() == 0) { fprintf(stderr, "No sequences in input file\n"); return 1; }      // clusterfast.cpp:91-92
+    if (!guess_nucleo(in)) { fprintf(stderr, "cluster_fast: amino acid input is not supported by this build\n"); return 1; }
+    ugs_params p;
+    ugs_params_init(&p, 1, id);
+    ugs_params_set_cluster(&p);
+    if (!strand.empty()) {                                                                   // StrandOptToRevComp(false, false) clusterfast.cpp:18-36
+      if (strand == "both") p.strand_both = 1; else if (strand != "plus") { fprintf(stderr, "Invalid -strand\n"); return 1; }
+    }
+    if (maxacc >= 0) p.max_accepts = maxacc;
+    if (maxrej >= 0) p.max_rejects = maxrej;
+    if (big >= 0) p.big = (uint32_t)big;
+    ugs_cluster *c = nullptr;
+    if (ugs_cluster_fast(&p, in.letters.data(), in.offs.data(), (uint32_t)in.size(), device, &c) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    std::string labels;
+    for (const std::string &l : in.labels) { labels += l; labels.push_back('\0'); }
+    int rc = 0;
+    if (!ucpath.empty() && ugs_cluster_write_uc(c, labels.data(), ucpath.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); rc = 1; }
+    if (!centroidspath.empty() && ugs_cluster_write_centroids(c, labels.data(), centroidspath.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); rc = 1; }
+    uint32_t nu = 0, nc = 0;
+    ugs_cluster_counts(c, &nu, &nc, nullptr, nullptr);
+    fprintf(stderr, "%zu seqs, %u uniques, %u clusters\n", in.size(), nu, nc);
+    ugs_cluster_destroy(c);
+    return rc;
   }
   if (!makeudb.empty()) {                                   // cmd_makeudb_usearch makeudb.cpp:27-66
     if (outpath.empty()) { fprintf(stderr, "-makeudb_usearch needs -output\n"); return 1; }
