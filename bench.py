@@ -272,15 +272,34 @@ def main():
         # HBM traffic per launch from the PMC passes of the same command (profiles/*_pmc.json, FETCH_SIZE
         # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
         traffic = None
+        mix = {}
         pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True)   # newest round first
         for pmc_name in pmcs:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
                 if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
                     traffic = pm["traffic_bytes_per_launch"][dom]
+                    mix = pm.get("instruction_mix_per_launch", {})
                     break
             except (OSError, ValueError):
                 pass
+
+        def issue_roofline(kernel, ms):
+            """VALU-issue ceiling of an integer/LDS kernel: wave-level VALU instructions of one launch (SQ_INSTS_VALU, PMC pass of
+            this command in profiles/) over the live kernel time, against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU op
+            (MI355X_MICROARCH.md).  The instruction count is a property of the code and the workload, not of the run."""
+            m = mix.get(kernel)
+            if not m or "SQ_INSTS_VALU" not in m:
+                return None
+            peak = 256 * 4 * 2.4e9 / 2
+            ach = m["SQ_INSTS_VALU"] / (ms * 1e-3)
+            out = {"bound": "valu-issue", "valu_insts_per_launch": m["SQ_INSTS_VALU"], "achieved_Ginst_s": ach / 1e9, "peak_Ginst_s": peak / 1e9,
+                   "frac": ach / peak}
+            if "SQ_INSTS_LDS" in m:
+                out["lds_insts_per_launch"] = m["SQ_INSTS_LDS"]
+            if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_INST_ANY" in m:
+                out["wave_time_waiting_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+            return out
         achieved = b_dom / (ms_dom * 1e-3) / 1e9
         n_hits = int(len(out[0]))
         threads = os.cpu_count() or 1
@@ -308,11 +327,14 @@ def main():
                          "bytes_per_query": b_dom / max(qs.n, 1)},
             "roofline_per_kernel": {
                 "k_rank": {"bound": "hbm", "algorithmic_bytes_per_launch": b_rank, "kernel_ms": ms_rank,
-                           "achieved_GBps": b_rank / (ms_rank * 1e-3) / 1e9, "frac": b_rank / (ms_rank * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "achieved_GBps": b_rank / (ms_rank * 1e-3) / 1e9, "frac": b_rank / (ms_rank * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "issue_roofline": issue_roofline("k_rank", ms_rank)},
                 "k_rank_setup": {"bound": "latency (dependent loads, one wavefront per query)", "kernel_ms": ms_setup},
-                "k_align": {"bound": "integer ALU / LDS (not a bandwidth kernel)", "algorithmic_bytes_per_launch": b_align,
+                "k_align": {"bound": "valu-issue (integer ALU / LDS, not a bandwidth kernel)", "algorithmic_bytes_per_launch": b_align,
                             "kernel_ms": ms_align, "achieved_GBps": b_align / (ms_align * 1e-3) / 1e9,
-                            "pair_alignments_per_s": st["pairs_aligned"] / (ms_align * 1e-3)}},
+                            "pair_alignments_per_s": st["pairs_aligned"] / (ms_align * 1e-3),
+                            "valu_per_pair": (mix["k_align"]["SQ_INSTS_VALU"] / max(st["pairs_aligned"], 1)) if "k_align" in mix else None,
+                            "issue_roofline": issue_roofline("k_align", ms_align)}},
             "cpu_baseline": cb,
             "detail": {"ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),

@@ -13,13 +13,13 @@ python - "$tag" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
 files = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
-acc = collections.defaultdict(float)
+acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in files:
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if not k.startswith(("k_rank", "k_align")):
             continue
-        acc[(k, row["Counter_Name"])] += float(row["Counter_Value"])
-for (k, c), v in sorted(acc.items()):
-    print("%-14s %-28s %.6g" % (k, c, v))
+        acc[(k, row["Counter_Name"])] += float(row["Counter_Value"]); n[(k, row["Counter_Name"])] += 1
+for (k, c), v in sorted(acc.items()):          # per launch (bench.py launches each kernel once per step plus once while priming)
+    print("%-14s %-28s %.6g  (mean of %d launches)" % (k, c, v / n[(k, c)], n[(k, c)]))
 PY
