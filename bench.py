@@ -203,16 +203,25 @@ def main():
         cur, nxt = bats[i % 2], bats[(i + 1) % 2]
         ta = time.time()
         cur.search()                                                # enqueue: waits (on the GPU) for cur's upload
+        out = None
+        if dist is None and state.get("pending") is not None:
+            # the previous step's hit table travels to the host while this step's kernels run (result buffers owned by the
+            # batch, page-locked once: a streaming caller's setup); the last table is drained before the clock stops.
+            # (the two batches alternate: the previous step's batch is the one the next upload goes into, so fetch first)
+            tf = time.time()
+            out = state["pending"].fetch(reuse=True)
+            t_parts["fetch"] += time.time() - tf
         tu = time.time()
         nxt.upload(qsets[(i + 1) % 2].seqs, qsets[(i + 1) % 2].offs)   # next step's batch travels while cur's kernels run
         t_parts["upload_issue"] += time.time() - tu
+        if dist is None:
+            cur.sync()
+            t_parts["search_sync"] += time.time() - ta
+            state["pending"] = cur
+            return out, cur
         cur.sync()
         tb = time.time()
         t_parts["search_sync"] += tb - ta
-        if dist is None:
-            out = cur.fetch(reuse=True)     # result buffers owned by the batch, page-locked once (a streaming caller's setup)
-            t_parts["fetch"] += time.time() - tb
-            return out, cur
         # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)
         (ph, bh), (pn, bn), (pc, bc) = cur.device_results(query_base=lo)   # compacted + global query ids on device
         t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
@@ -230,6 +239,9 @@ def main():
     bats[0].upload(qsets[0].seqs, qsets[0].offs)
     for _ in range(args.warmup):
         step()
+    if dist is None and state.get("pending") is not None:
+        state["pending"].fetch(reuse=True)
+        state["pending"] = None
     for k in t_parts:
         t_parts[k] = 0.0
     barrier()
@@ -239,6 +251,10 @@ def main():
     for _ in range(args.steps):
         out, cur = step()
         stats.append(cur.stats())
+    if dist is None:                                            # drain: the last step's hit table
+        tf = time.time()
+        out = state["pending"].fetch(reuse=True)
+        t_parts["fetch"] += time.time() - tf
     barrier()
     elapsed = time.time() - t0
     per_rank = None

@@ -542,6 +542,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   b->scan_tmp_bytes = ugs_compact_tmp_bytes(max_queries);
   BCHK(hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes));
   BCHK(hipMalloc(&b->d_cigar_used, 8));
+  BCHK(hipMemset(b->d_cigar_used, 0, 8));
   BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
@@ -777,10 +778,14 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipEventRecord(b->ev1, db->stream));
   const bool dbg = getenv("UGS_DEBUG_SYNC") != nullptr;             // fault isolation: finish each stage before the next
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] ranking stage done\n"); }
-  if (b->nq) RCCHK(enqueue_align(b));
+  if (b->nq) RCCHK(enqueue_align(b)); else HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
   HIPCHK(hipEventRecord(b->ev2, db->stream));
+  // hits grouped by query on the device right behind the alignment stage (count, scan, gather): ugs_batch_fetch is then
+  // nothing but copies, which overlap the kernels of whatever batch runs next
+  if (b->nq) RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
+                                    b->scan_tmp_bytes, 0, db->stream));
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
-  b->searched = true; b->synced = false;
+  b->searched = true; b->synced = false; b->compact_base = 0;
   return UGS_OK;
 }
 
@@ -812,6 +817,8 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     HIPCHK(hipMemcpyAsync(b->d_ctr, &keep, 8, hipMemcpyHostToDevice, db->stream));
     RCCHK(enqueue_align(b));
     HIPCHK(hipEventRecord(b->ev2, db->stream));
+    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
+                           b->scan_tmp_bytes, 0, db->stream));
   }
   ugs_set_error("path pool overflow persisted");
   return UGS_E_CAPACITY;
@@ -858,25 +865,32 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
   const uint32_t nq = b->nq, ns = b->nstrand, ma = b->hit_slots;
+  // (the search has been synced: grouping and the copies run on the batch's own stream, so that they overlap whatever
+  // another batch has running on the handle's stream)
+  hipStream_t cs = b->copy_stream;
   if (cigar_used) *cigar_used = 0;
   if (nq == 0) return UGS_OK;
-  // group by query on the device (count, exclusive scan, gather), then three plain D2H copies
-  RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                         b->scan_tmp_bytes, 0, db->stream));
+  // (grouped by query on the device by ugs_batch_search; a ugs_batch_device_results call in between regroups with its
+  // own query base, so regroup then)
+  if (b->compact_base != 0) {
+    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp, b->scan_tmp_bytes, 0, cs));
+    b->compact_base = 0;
+  }
+  (void)ns; (void)ma;
   uint32_t last_off = 0, last_n = 0;
-  HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
-  HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
-  HIPCHK(hipMemcpyAsync(nhits_per_query, b->d_qn, (size_t)nq * 4, hipMemcpyDeviceToHost, db->stream));
-  HIPCHK(hipStreamSynchronize(db->stream));
+  HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipMemcpyAsync(nhits_per_query, b->d_qn, (size_t)nq * 4, hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipStreamSynchronize(cs));
   const uint64_t total = (uint64_t)last_off + last_n;
   if (total > hits_cap || b->cigar_used_host > cigar_cap) {
     if (cigar_used) *cigar_used = b->cigar_used_host;            // the demand, so that the caller can size the run pool
     ugs_set_error("output buffers too small (%llu hits, %llu runs)", (unsigned long long)total, (unsigned long long)b->cigar_used_host);
     return UGS_E_CAPACITY;
   }
-  if (total) HIPCHK(hipMemcpyAsync(hits, b->d_compact, total * sizeof(ugs_hit), hipMemcpyDeviceToHost, db->stream));
-  if (b->cigar_used_host) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost, db->stream));
-  HIPCHK(hipStreamSynchronize(db->stream));
+  if (total) HIPCHK(hipMemcpyAsync(hits, b->d_compact, total * sizeof(ugs_hit), hipMemcpyDeviceToHost, cs));
+  if (b->cigar_used_host) HIPCHK(hipMemcpyAsync(cigar_pool, b->d_cigar, b->cigar_used_host * 4, hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipStreamSynchronize(cs));
   if (cigar_used) *cigar_used = b->cigar_used_host;
   // HitMgr::Sort for the (rare) queries with several hits; cigar_off keeps pointing into the pool as copied
   if (ma > 1 || ns > 1) return ugs_hits_sort(hits, nhits_per_query, nq, db->p.local);
@@ -1034,11 +1048,12 @@ extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void 
   uint64_t total = 0;
   if (nq) {
     RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                           b->scan_tmp_bytes, query_base, db->stream));
+                           b->scan_tmp_bytes, query_base, b->copy_stream));
+    b->compact_base = query_base;
     uint32_t last_off = 0, last_n = 0;
-    HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
-    HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, db->stream));
-    HIPCHK(hipStreamSynchronize(db->stream));
+    HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, b->copy_stream));
+    HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, b->copy_stream));
+    HIPCHK(hipStreamSynchronize(b->copy_stream));
     total = (uint64_t)last_off + last_n;
   }
   if (d_hits) *d_hits = b->d_compact;
