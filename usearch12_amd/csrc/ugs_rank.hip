@@ -83,6 +83,7 @@ struct RankShared {
   uint64_t red[8];
   uint32_t wsum[8];
   uint32_t ncl, qcut, pad2, pad3;
+  uint32_t wn[8];            // emitted entries per wave (each wave fills its own segment of the candidate buffer)
   uint32_t hist[256];        // emitted entries per (count, first row) class: hist[c*16 + i], 4-bit fast path only
 };
 
@@ -118,16 +119,18 @@ struct ScanCtx {
   const uint32_t *s_slots; const uint32_t *s_part; uint32_t *tbl; unsigned long long *s_fp; RankShared *sh;
   uint32_t *hist;            // non-null: count emitted entries per (count,row) class
   uint64_t *ebuf; uint64_t ecap;
-  uint64_t *s_ebuf;          // the first UGS_ELDS emitted keys of a unit stay in LDS (the usual case), the rest go to ebuf
+  uint64_t *s_ebuf;          // this wave's LDS segment: its first `elw` emitted keys of a unit (the usual case), the rest go to ebuf
+  uint32_t *wn;              // this wave's emitted-entry count (a register of the kernel: slots are handed out without an atomic)
+  uint32_t elw; uint64_t ecapw;   // entries of the LDS segment / of this wave's share of the HBM buffer
   uint32_t ns, np, gsize, tbl_words;
   int wave, wpb, lane; bool small_path;
 };
 
 #define UGS_ELDS 1024u
-__device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)
+__device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)     // idx: position in this wave's segment
 {
-  if (idx < UGS_ELDS) s.s_ebuf[idx] = key;
-  else if (idx < s.ecap) s.ebuf[idx] = key;
+  if (idx < s.elw) s.s_ebuf[idx] = key;
+  else if (idx - s.elw < s.ecapw) s.ebuf[idx - s.elw] = key;
 }
 
 // emit the lanes with e==true (at most `take` of them, in lane order) into the WG's candidate buffer
@@ -139,9 +142,8 @@ __device__ __forceinline__ void emit_lanes(const ScanCtx &s, bool e, uint32_t ta
   const uint32_t take = n < take_cap ? n : take_cap;
   if (!take) return;
   const uint32_t rank = __popcll(m & ((1ull << s.lane) - 1ull));
-  uint32_t base = 0;
-  if (s.lane == 0) base = atomicAdd(&s.sh->emit_n, take);
-  base = __builtin_amdgcn_readfirstlane(base);
+  const uint32_t base = *s.wn;
+  *s.wn = base + take;
   if (e && rank < take) put_key(s, (uint64_t)base + rank, key);
 }
 
@@ -170,8 +172,8 @@ __device__ __forceinline__ void extract_one(const ScanCtx &s, bool on, uint32_t 
 {
   const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)i << 32) | t);
   if (!FILL) {
-    if (on && c) { if (pos < s.s_fp[c]) atomicMin(&s.s_fp[c], (unsigned long long)pos); }
-    if (on && c >= 2 && s.hist) atomicAdd(&s.hist[c * 16 + i], 1u);
+    // (first positions and class sizes of the count >= 2 entries are derived from the emitted keys after the scan)
+    if (on && c == 1) { if (pos < s.s_fp[1]) atomicMin(&s.s_fp[1], (unsigned long long)pos); }
     emit_lanes(s, on && c >= 2, 0xffffffffu, make_key(c, pos));
   } else {
     const bool e = on && c == 1 && pos < fill_limit && !(s.pq && pair_reject(*s.pq, t));
@@ -304,9 +306,8 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
       const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
       if (total && quota_left) {
         const uint32_t take = quota_left < total ? quota_left : total;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s.sh->emit_n, take);
-        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t base = *s.wn;
+        *s.wn = base + take;
         uint32_t rr = incl - mine;
         for (uint32_t e2 = 0; e2 < EPW; ++e2) {
           const uint32_t cc = (word >> (e2 * CB)) & Tbl<CB>::MASK;
@@ -554,14 +555,11 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   if (__ballot(cnt != 0)) {
     const uint32_t incl = wave_incl_sum_u32(cnt);
     const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&s.sh->emit_n, total);
-    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t base = *s.wn;                                  // the wave's own segment: no atomic, no round trip
+    *s.wn = base + total;
     uint32_t o = base + incl - cnt;
     auto emit = [&](uint32_t csel, uint32_t vsel, uint32_t rsel) {
       const uint64_t pos = s.small_path ? (uint64_t)vsel : (((uint64_t)rsel << 32) | vsel);
-      atomicMin(&s.s_fp[csel], (unsigned long long)pos);          // fire-and-forget LDS atomics
-      if (s.hist) atomicAdd(&s.hist[csel * 16 + rsel], 1u);
       put_key(s, o, make_key(csel, pos));
       ++o;
     };
@@ -731,15 +729,13 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
           if (__ballot(cnt != 0)) {
             const uint32_t incl = wave_incl_sum_u32(cnt);
             const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s.sh->emit_n, total);
-            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t base = *s.wn;
+            *s.wn = base + total;
             uint32_t o = base + incl - cnt;
 #pragma unroll
             for (int u = 0; u < NR; ++u)
               if (c[u] >= 2u) {
                 const uint64_t pos = s.small_path ? (uint64_t)v[u] : (((uint64_t)rix[u] << 32) | v[u]);
-                atomicMin(&s.s_fp[c[u]], (unsigned long long)pos);
                 put_key(s, o, make_key(c[u], pos));
                 ++o;
               }
@@ -979,7 +975,11 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     sc.row_off = db.row_off; sc.part = db.part; sc.postings = db.postings; sc.s_slots = s_slots; sc.tbl = tbl;
     sc.s_part = nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
-    sc.s_fp = s_fp; sc.sh = sh; sc.ebuf = ebuf; sc.ecap = ecap; sc.s_ebuf = s_ebuf; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
+    sc.s_fp = s_fp; sc.sh = sh; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
+    sc.elw = UGS_ELDS / (uint32_t)wpb; sc.ecapw = ecap / (uint64_t)wpb;
+    sc.s_ebuf = s_ebuf + (size_t)wave * sc.elw; sc.ebuf = ebuf + (uint64_t)wave * sc.ecapw;
+    uint32_t wave_n = 0;
+    sc.wn = &wave_n;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
@@ -988,9 +988,33 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
     const unsigned long long tk2w = clock64();
+    if (lane == 0) sh->wn[wave] = wave_n;
     __threadfence_block();
     __syncthreads();
     const unsigned long long tk2 = clock64();
+    // ---- the emitted entries: wave w's segment holds wn[w] keys; entry k of the unit = segment w, place k - woff[w]
+    const uint32_t elw = sc.elw; const uint64_t ecapw = sc.ecapw;
+    uint32_t woff1 = 0, woff2 = 0, woff3 = 0, n_emit = 0;
+    auto read_counts = [&]() {
+      const uint32_t n0 = sh->wn[0], n1 = wpb > 1 ? sh->wn[1] : 0u, n2 = wpb > 2 ? sh->wn[2] : 0u, n3 = wpb > 3 ? sh->wn[3] : 0u;
+      woff1 = n0; woff2 = n0 + n1; woff3 = n0 + n1 + n2; n_emit = n0 + n1 + n2 + n3;
+    };
+    read_counts();
+    auto load_key = [&](uint32_t k) -> uint64_t {
+      const uint32_t w = (uint32_t)(k >= woff1) + (uint32_t)(k >= woff2) + (uint32_t)(k >= woff3);
+      const uint32_t i = k - (w == 0 ? 0u : w == 1 ? woff1 : w == 2 ? woff2 : woff3);
+      return i < elw ? s_ebuf[(size_t)w * elw + i] : ebuf[(uint64_t)w * ecapw + (i - elw)];
+    };
+    {   // first position per count value and, on the 4-bit Big path, the (count, first row) class sizes - from the keys
+      // (count >= 2 entries only; fp[1] is maintained by the scan)
+      for (uint32_t k = tid; k < n_emit; k += nthr) {
+        const uint64_t key = load_key(k);
+        const uint32_t cc = key_count(key);
+        atomicMin(&s_fp[cc], (unsigned long long)(key & POS_MASK));
+        if (sc.hist) atomicAdd(&sh->hist[cc * 16 + ((uint32_t)(key >> 32) & 0xfu)], 1u);
+      }
+      __syncthreads();
+    }
 
     // ---- cut-offs.  NextValue = running max just before the max last increased, in scan
     // (first-touch / ascending-target) order  == max{c < M : fp[c] < fp[M]}  (countsort.cpp:13-24,114-126)
@@ -1076,7 +1100,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     };
 
     for (int phase = 0; phase < 2; ++phase) {
-      const uint32_t N = sh->emit_n < ecap ? sh->emit_n : (uint32_t)ecap;
+      const uint32_t N = n_emit;
       // select the K smallest kept keys by repeated min above the previous one
       uint32_t nsel = sh->n_sel;
       uint64_t last = sh->last_key;
@@ -1113,7 +1137,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
           const uint32_t k = k0 + tid;
           uint64_t key = 0; bool take = false;
           if (k < N) {
-            key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
+            key = load_key(k);
             const uint32_t cc = key_count(key), ii = (uint32_t)(key >> 32) & 0xfffu;
             take = cc >= cmin && ((Mx - cc) * 16 + ii) <= qcut;
           }
@@ -1171,7 +1195,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
           for (int e = 0; e < SELQ; ++e) {
             const uint32_t k = (lane + e * 64) * wpb + wave;
             uint64_t key = KEY_INF;
-            if (k < N) { key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k]; if (!kept(key) || !((nsel == 0 && last == 0) || key > last)) key = KEY_INF; }
+            if (k < N) { key = load_key(k); if (!kept(key) || !((nsel == 0 && last == 0) || key > last)) key = KEY_INF; }
             ent[e] = key;
           }
           uint64_t llast = 0; bool lfirst = true;
@@ -1228,7 +1252,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
           __syncthreads();
           const uint64_t pref = sh->red[0], pmask = sh->red[1];
           for (uint32_t k = tid; k < N; k += nthr) {
-            const uint64_t key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
+            const uint64_t key = load_key(k);
             if ((key & pmask) == pref && eligible(key)) atomicAdd(&sh->hist[(uint32_t)(key >> shift) & 255u], 1u);
           }
           __syncthreads();
@@ -1259,7 +1283,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
           for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
             const uint32_t k = k0 + tid;
             uint64_t key = 0; bool take = false;
-            if (k < N) { key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k]; take = (key & pmask) <= pref && eligible(key); }
+            if (k < N) { key = load_key(k); take = (key & pmask) <= pref && eligible(key); }
             const uint64_t mk = __ballot(take);
             if (mk) {
               uint32_t base = 0;
@@ -1303,7 +1327,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
         while (nsel < K) {
           uint64_t best = KEY_INF;
           for (uint32_t k = tid; k < N; k += nthr) {
-            const uint64_t key = k < UGS_ELDS ? s_ebuf[k] : ebuf[k];
+            const uint64_t key = load_key(k);
             if (((nsel == 0 && last == 0) || key > last) && key < best && kept(key)) best = key;
           }
           best = block_min_u64(best, sh, wave, wpb, lane);
@@ -1327,13 +1351,15 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
       scan_dispatch<true, BATCH, FAST8>(sc, cb, need, fill_limit);
+      if (lane == 0) sh->wn[wave] = wave_n;
       __threadfence_block();
       __syncthreads();
+      read_counts();
     }
     tacc0 += tk1 - tk0; tacc1 += tk2w - tk1; tacc2 += tk2 - tk2w; tacc3 += clock64() - tk2;
     if (tid == 0) {
       bv.cand_n[unit] = sh->n_sel;
-      if (sh->emit_n > ecap) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
+      for (int w2 = 0; w2 < wpb; ++w2) if ((uint64_t)sh->wn[w2] > (uint64_t)elw + ecapw) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
       sh->pad1 = next_unit;
     }
     __syncthreads();
