@@ -31,6 +31,7 @@
 #include <unordered_map>
 #include <vector>
 #include <chrono>
+#include <thread>
 
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -94,18 +95,23 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
                            &d_dpost, &n_dpost, &dmax, st);
   if (rc != UGS_OK) { (void)hipFree(d_rel); (void)hipFree(d_drow); (void)hipFree(d_dpost); return rc; }
   const uint64_t total = db->n_postings + n_dpost;
-  uint64_t *d_noff = nullptr; uint32_t *d_npost = nullptr, *d_max = nullptr;
-  const uint64_t pcap = total + total / 2 + 4096;
-  HIPCHK(hipMalloc(&d_noff, ((size_t)db->v.slots + 1) * 8));
-  HIPCHK(hipMalloc(&d_npost, (pcap + 256) * 4));
+  // the merged index goes into the handle's spare arrays, which then change places with the live ones (a multi-GB
+  // hipMalloc / hipFree per append would cost more than the merge)
+  uint32_t *d_max = nullptr;
+  if (!db->d_row_off2) HIPCHK(hipMalloc(&db->d_row_off2, ((size_t)db->v.slots + 1) * 8));
+  if (!db->d_postings2 || total + 256 > db->post_cap2) {
+    if (db->d_postings2) HIPCHK(hipFree(db->d_postings2));
+    db->d_postings2 = nullptr;
+    db->post_cap2 = total + total / 2 + 4096 + 256;
+    HIPCHK(hipMalloc(&db->d_postings2, db->post_cap2 * 4));
+  }
   HIPCHK(hipMalloc(&d_max, 4));
-  rc = ugs_index_merge(db->d_row_off, db->d_postings, d_drow, d_dpost, db->v.slots, old_n, d_noff, d_npost, total, d_max, st);
+  rc = ugs_index_merge(db->d_row_off, db->d_postings, d_drow, d_dpost, db->v.slots, old_n, db->d_row_off2, db->d_postings2, total, d_max, st);
   if (rc == UGS_OK && hipMemcpyAsync(&db->max_row, d_max, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = UGS_E_HIP;
   if (hipStreamSynchronize(st) != hipSuccess) rc = UGS_E_HIP;
   (void)hipFree(d_rel); (void)hipFree(d_drow); (void)hipFree(d_dpost); (void)hipFree(d_max);
-  if (rc != UGS_OK) { (void)hipFree(d_noff); (void)hipFree(d_npost); ugs_set_error("index append failed"); return rc; }
-  HIPCHK(hipFree(db->d_row_off)); HIPCHK(hipFree(db->d_postings));
-  db->d_row_off = d_noff; db->d_postings = d_npost; db->post_cap = pcap + 256;
+  if (rc != UGS_OK) { ugs_set_error("index append failed"); return rc; }
+  std::swap(db->d_row_off, db->d_row_off2); std::swap(db->d_postings, db->d_postings2); std::swap(db->post_cap, db->post_cap2);
   db->n_postings = total; db->nletters += add; db->max_tlen = maxl;
   db->v.nseq = old_n + n;
   return ugs_db_replan(db);
@@ -154,11 +160,30 @@ uint32_t derep_full(const char *seqs, const uint64_t *offs, uint32_t nseq, bool 
   const uint64_t slots = (uint64_t)nseq * 2 + 7;
   std::vector<uint32_t> tab(slots, 0xffffffffu);
   seq_unique.assign(nseq, 0); uniq_seed.clear();
+  // the hashes are independent of each other: computed by a few host threads; the grouping itself stays in input order
+  std::vector<uint32_t> hv(nseq);
+  {
+    unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (nseq < 100000) nt = 1;
+    auto work = [&](unsigned t) {
+      const uint32_t lo = (uint32_t)((uint64_t)nseq * t / nt), hi = (uint32_t)((uint64_t)nseq * (t + 1) / nt);
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint8_t *q = (const uint8_t *)seqs + offs[i];
+        const uint32_t L = (uint32_t)(offs[i + 1] - offs[i]);
+        uint32_t h = seq_hash(q, L, false);
+        if (revcomp) h = std::min(h, seq_hash(q, L, true));
+        hv[i] = h;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
   for (uint32_t i = 0; i < nseq; ++i) {
     const uint8_t *q = (const uint8_t *)seqs + offs[i];
     const uint32_t L = (uint32_t)(offs[i + 1] - offs[i]);
-    uint32_t h = seq_hash(q, L, false);
-    if (revcomp) h = std::min(h, seq_hash(q, L, true));
+    const uint32_t h = hv[i];
     uint64_t k = h % slots;
     for (;;) {
       const uint32_t u = tab[k];

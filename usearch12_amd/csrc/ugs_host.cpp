@@ -227,6 +227,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   if (!db) return;
   (void)hipSetDevice(db->device);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
+  (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
   (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls); (void)hipFree(db->d_tkey); (void)hipFree(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
   delete db;
@@ -341,6 +342,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
+  db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0;
   db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
   memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;
