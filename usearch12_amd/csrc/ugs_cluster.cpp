@@ -368,6 +368,7 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
   RCCHK(ugs_db_create(&p, "", &zero, 0, device, &G.db));
   ugs_db *db = G.db;
   db->max_tlen = maxlen; db->v.max_tlen = maxlen;           // every centroid is one of the input sequences: plan the kernels for the longest
+  if (maxlen >= (uint32_t)p.word_len + 255u) db->gsize_limit = 2048;   // > 255 query words: 16-bit counters on the small path
   uint32_t Bmax = 16384;
   if (const char *e = getenv("UGS_CLUSTER_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) Bmax = (uint32_t)v; }
   Bmax = std::min<uint32_t>(Bmax, std::max<uint32_t>(nu, 1));
@@ -629,7 +630,8 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
     ++C->st.batches; C->st.pairs_in_batch += n_pairs; C->st.inbatch_entries += n_ent; C->st.queries_redone += B - done;
     C->st.max_batch = std::max<uint32_t>(C->st.max_batch, B);
     ugs_batch_stats bs;
-    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { C->st.ms_rank += bs.ms_rank + bs.ms_rank_setup; C->st.ms_align += bs.ms_align; C->st.postings += bs.postings; C->st.pairs_frozen += bs.pairs_aligned; }
+    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: n0 %u B %u done %u path %s ms_setup %.3f ms_rank %.3f ms_align %.3f pairs %llu\n", C->st.batches, n0, B, done, small_path ? "small" : "big", bs.ms_rank_setup, bs.ms_rank, bs.ms_align, (unsigned long long)n_pairs);
+      C->st.ms_rank += bs.ms_rank + bs.ms_rank_setup; C->st.ms_align += bs.ms_align; C->st.postings += bs.postings; C->st.pairs_frozen += bs.pairs_aligned; }
     next += done;
     B_prev = B; pairs_prev = n_pairs;
   }

@@ -272,6 +272,9 @@ int ugs_db_replan(ugs_db *db)
     }
     while (gs < 65536 && (uint64_t)slots * ((uint64_t)nseq / gs + 2) * 4 > budget) gs += 1024;
     gsize = (uint32_t)gs;
+    // (queries with more than 255 words need 16-bit counters on the small path: partitions are then kept small enough for
+    // four workgroups per CU, and their short sub-rows take the flattened scan - 2.4x on cluster_fast's small-path phase)
+    if (db->gsize_limit && nseq <= db->p.big && gsize > db->gsize_limit) gsize = db->gsize_limit;
     if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
     if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 16) gsize = 1u << v; }
   }
@@ -342,7 +345,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
-  db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0;
+  db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0; db->gsize_limit = 0;
   db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
   memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;

@@ -28,6 +28,7 @@ struct ugs_db {
   bool sparse;                      // sparse dictionary (protein): short index rows
   // capacities (elements) of the growable arrays and the letter count: ugs_db_append grows the DB in place
   uint64_t nletters, seq_cap, off_cap, post_cap, part_cap;
+  uint32_t gsize_limit;             // small ranking path only: cap on the partition size (0 = none), see ugs_cluster.cpp
   uint64_t *d_row_off2; uint32_t *d_postings2; uint64_t post_cap2;   // spare index arrays (ugs_db_append merges into them, then swaps)
 };
 
