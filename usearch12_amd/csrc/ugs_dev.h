@@ -124,7 +124,7 @@ struct UgsLocalView {
 };
 
 // launch descriptors computed on the host
-struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; int fast8; };
+struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; int fast8; int longrows; };
 struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; uint32_t seed_cap; };
 
 // kernels' host-callable launchers (defined in the .hip files)

@@ -635,6 +635,9 @@ static int plan_launch(ugs_batch *b)
   per_cu = std::max(1, std::min(per_cu, 8));
   if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
   b->rl.fast8 = bits >= 8 && !db->sparse;
+  // very long index rows (the longest row 16x the average or more: an abundant family of sequences shares its words):
+  // sub-rows longer than a wavefront are then common and get their own path (ugs_rank.hip range_long)
+  b->rl.longrows = (uint64_t)db->max_row * db->v.slots > 16ull * std::max<uint64_t>(db->n_postings, 1) && db->max_row > 64u * db->v.np;
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well

@@ -408,6 +408,68 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// One whole partition whose sub-rows may be (much) longer than a wavefront - the rows of the words an abundant family of
+// database sequences shares (skewed databases: cluster_fast's centroids, amplicon references).  Rows in scan order, 256
+// postings per trip (a 16-byte load per lane: 4 consecutive postings) with the next trip's load already in flight; pass 1
+// counts, pass 2 reads and clears each counter at once, so only the first touch of a target sees its count.
+// (Only the LONG instantiations of the ranking kernel call it: inlined into the register-resident fast path it costs that
+// path 3 % through register allocation even when it never runs, and out of line the call ABI costs far more.)
+template <int CB>
+__device__ __forceinline__ void range_long(const ScanCtx &s, uint32_t p, uint32_t base_t)
+{
+  typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+  const int lane = s.lane;
+  const uint32_t ns = s.ns;
+  uint32_t *tbl = s.tbl;
+  unsigned long long cache1 = s.s_fp[1];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+      uint64_t a = 0, b = 0;
+      if (i0 + lane < ns) row_bounds(s, s.s_slots[i0 + lane], p, false, base_t, 0, a, b);
+      uint64_t rows = __ballot(b > a);
+      while (rows) {
+        const uint32_t r = (uint32_t)__ffsll((long long)rows) - 1;
+        rows &= rows - 1;
+        const uint64_t ra = shfl64(a, r), rbb = shfl64(b, r);
+        const uint32_t row = i0 + r;
+        const uint32_t *src = s.postings + ra;
+        const uint32_t n = (uint32_t)(rbb - ra);
+        // (the array is padded: a 16-byte load may run past the row's end, those lanes are masked by index)
+        u32x4 nxt;
+        __builtin_memcpy(&nxt, src + (uint32_t)lane * 4u, 16);          // 4-byte aligned 16-byte load
+        for (uint32_t k0 = 0; k0 < n; k0 += 256) {
+          const u32x4 cur = nxt;
+          if (k0 + 256 < n) __builtin_memcpy(&nxt, src + k0 + 256u + (uint32_t)lane * 4u, 16);
+          const uint32_t i = k0 + (uint32_t)lane * 4u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool on = i + j < n;
+            const uint32_t t = cur[j];
+            if (pass == 0) { if (on) Tbl<CB>::inc(tbl, t - base_t); }
+            else {
+              uint32_t c = 0;
+              if (on) {
+                const uint32_t x = t - base_t, sh = (x * CB) & 31u;
+                c = (atomicAnd(&tbl[(x * CB) >> 5], ~(Tbl<CB>::MASK << sh)) >> sh) & Tbl<CB>::MASK;     // count, cleared at once
+              }
+              const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)row << 32) | t);
+              const bool f1 = c == 1 && pos < cache1;
+              if (__ballot(f1)) {
+                if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                cache1 = s.s_fp[1];
+              }
+              emit_lanes(s, c >= 2, 0xffffffffu, make_key(c, pos));
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // every add has completed before the clears start
+  }
+}
+
 template <int CB, bool FILL, bool BATCH = false, bool FLATPF = false>
 __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, uint64_t fill_limit)
 {
@@ -488,7 +550,7 @@ __device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R,
   B.tail = mx > 64;
 }
 
-template <int NR>
+template <int NR, bool LONG>
 __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
 {
   const int lane = s.lane;
@@ -496,7 +558,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   const uint32_t base_t = p * s.gsize;
   if (B.tail) {
     // a sub-row longer than a wavefront (rare at the chosen partition size): generic, row-ordered
-    range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
+    if constexpr (LONG) range_long<4>(s, p, base_t); else range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
     return;
   }
   // Branch-free: lanes without a posting in row r aim at a private dummy word behind the table
@@ -580,7 +642,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> 
   }
 }
 
-template <int NR>
+template <int NR, bool LONG>
 __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
 {
   Rows<NR> R;
@@ -600,11 +662,11 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
     issue_batch<NR>(s, R, p1 < last ? p1 : last, B);
-    process_batch<NR>(s, A, p0, cache1, c1row);
+    process_batch<NR, LONG>(s, A, p0, cache1, c1row);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
     issue_batch<NR>(s, R, p2 < last ? p2 : last, A);
-    process_batch<NR>(s, B, p1, cache1, c1row);
+    process_batch<NR, LONG>(s, B, p1, cache1, c1row);
     if (p2 >= s.np) break;
     p0 = p2;
   }
@@ -617,7 +679,7 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
 // rows); a row's load address is made wave-uniform with three readlanes.  Rows are handled NR at a time: NR loads in
 // flight, NR branch-free LDS atomics.  The postings are read twice (count, then ordered clear + extract); the second
 // read hits the L2.  A partition with a sub-row longer than a wavefront goes through the generic code.
-template <int NR>
+template <int NR, bool LONG>
 __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
 {
   typedef uint32_t __attribute__((address_space(3))) *lds32;
@@ -647,6 +709,7 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
     }
     // a sub-row longer than a wavefront, or sparse sub-rows (protein indexes: a handful of postings per row and
     // partition - the generic code flattens those row-major into full instructions): not this path's case
+    if constexpr (LONG) if (tail) { range_long<8>(s, p, base_t); cache1 = s.s_fp[1]; continue; }
     if (tail || tot < 32u * nrows) { range_generic<8, false, true>(s, p, false, base_t, 0, 0, 0); continue; }
     for (int pass = 0; pass < 2; ++pass) {
       for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
@@ -749,16 +812,16 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <bool FILL, bool BATCH, bool FAST8>
+template <bool FILL, bool BATCH, bool FAST8, bool LONG>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
   if (cb == 4) {
     if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
-      if (s.ns <= 8) scan_fast4<8>(s); else if (s.ns <= 11) scan_fast4<11>(s); else scan_fast4<12>(s);
+      if (s.ns <= 8) scan_fast4<8, LONG>(s); else if (s.ns <= 11) scan_fast4<11, LONG>(s); else scan_fast4<12, LONG>(s);
     }
     else scan_generic<4, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
   } else if (cb == 8) {
-    if (!FILL && FAST8 && s.tbl_words * 4 >= s.gsize) scan_fast8<8>(s);
+    if (!FILL && FAST8 && s.tbl_words * 4 >= s.gsize) scan_fast8<8, LONG>(s);
     else scan_generic<8, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
   }
   else scan_generic<16, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
@@ -918,7 +981,9 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
 // for every unit; their row loops keep four loads in flight.  The 4-bit launches keep the code the hot path was tuned with.
 // FAST8: dense indexes (nucleotide) take scan_fast8 for 8-bit tables; sparse dictionaries (protein) keep the generic code,
 // which flattens their short sub-rows - again an instantiation of its own, so that neither pays for the other's registers
-template <bool SMALL, bool BATCH, bool FAST8>
+// LONG: databases with very long index rows (an abundant family shares its words) - the partitions whose sub-rows exceed a
+// wavefront then go through range_long; again an instantiation of its own (see range_long)
+template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #ifndef UGS_RANK_WGS
 #define UGS_RANK_WGS 4
 #endif
@@ -983,7 +1048,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
-    scan_dispatch<false, BATCH, FAST8>(sc, cb, 0, 0);
+    scan_dispatch<false, BATCH, FAST8, LONG>(sc, cb, 0, 0);
     // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
@@ -1350,7 +1415,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
       const uint32_t need = K - nsel;
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
-      scan_dispatch<true, BATCH, FAST8>(sc, cb, need, fill_limit);
+      scan_dispatch<true, BATCH, FAST8, LONG>(sc, cb, need, fill_limit);
       if (lane == 0) sh->wn[wave] = wave_n;
       __threadfence_block();
       __syncthreads();
@@ -1376,8 +1441,8 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds)
 {
   int n = 0;
   // (both instantiations have the same register budget; the Big one is asked)
-  if (hipFuncSetAttribute((const void *)k_rank<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
+  if (hipFuncSetAttribute((const void *)k_rank<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false, false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
@@ -1415,8 +1480,14 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
   const int mode = L.bits == 4 ? 0 : (L.fast8 ? 2 : 1);
-  const void *fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false> : (const void *)k_rank<false, true, true>)
-                          : (mode == 0 ? (const void *)k_rank<true, false, false> : mode == 1 ? (const void *)k_rank<true, true, false> : (const void *)k_rank<true, true, true>);
+  const void *fn;
+  if (L.longrows) {
+    fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
+                : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
+  } else {
+    fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, false>)
+                : (mode == 0 ? (const void *)k_rank<true, false, false, false> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, false>);
+  }
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
