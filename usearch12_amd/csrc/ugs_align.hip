@@ -47,6 +47,8 @@ struct WaveCtx {
   // LDS
   uint8_t *A, *B;             // class codes of query / target letters (identity tests)
   uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
+  uint32_t *A2, *Ai, *B2, *Bi; // nt: the score codes packed 2 bits per letter (16 letters per word) and, in the same layout, one bit per
+                              // letter that is not A/C/G/T/U (bit 2k of its word); two zero words in front, three behind
   uint16_t *wstart;           // per HSP word: first index in qsort (12 bits) | min(count,8) << 12 (0 = absent), or null
   uint32_t *seeds; uint32_t seed_cap; uint32_t union_words;   // seed list of the current pair: bpos << 16 | apos, in reference order
   bool nt;
@@ -218,6 +220,94 @@ __device__ __forceinline__ uint64_t nzbytes(uint64_t x)
   return (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;
 }
 
+// nt score codes (bytes, 0..3 = A,C,G,T/U, 4 = other) -> 2 bits per letter + "other" bits in the same layout
+__device__ __forceinline__ void pack_codes(const uint8_t *codes, uint32_t L, uint32_t *w2, uint32_t *wi, int lane)
+{
+  const uint32_t nw = (L + 15) >> 4;
+  for (uint32_t k = lane; k < nw + 3; k += 64) {
+    uint32_t v = 0, iv = 0;
+    if (k < nw) {
+      const uint4 d4 = *(const uint4 *)(codes + 16 * k);             // (the code arrays are 16-byte aligned and padded)
+      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t lo = d[q] & 0x03030303u, hi = (d[q] >> 2) & 0x01010101u;
+        v |= ((lo | (lo >> 6) | (lo >> 12) | (lo >> 18)) & 0xffu) << (8 * q);
+        iv |= ((hi | (hi >> 6) | (hi >> 12) | (hi >> 18)) & 0x55u) << (8 * q);
+      }
+    }
+    w2[k] = v; wi[k] = iv;
+  }
+  if (lane < 2) { w2[-1 - lane] = 0; wi[-1 - lane] = 0; }
+}
+// 32 letters starting at letter `pos` (may be negative down to -32) of a packed array, 2 bits each
+__device__ __forceinline__ uint64_t read32l(const uint32_t *w, int pos)
+{
+  const int k = pos >> 4;
+  const uint32_t sh = ((uint32_t)pos & 15u) * 2u;
+  const uint32_t w0 = w[k], w1 = w[k + 1], w2 = w[k + 2];
+  return ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+}
+
+// The nt extension on packed letters: 32 letter pairs per LDS round trip; inside a block the walk goes from one
+// non-matching pair to the next (a run of matches is consumed at once: the score rises through it, so its best is its end
+// and the x-drop test cannot fire inside it).  Same results as the byte-wise walk of ungappedblast.cpp:91-178.
+__device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int mm2, int X, uint32_t LA, uint32_t LB,
+                                                 uint32_t &a1, uint32_t &b1, uint32_t &a2, uint32_t &b2, int &score, int &best,
+                                                 uint32_t &bestb1, uint32_t &bestb2)
+{
+  const uint64_t EVEN = 0x5555555555555555ull;
+  {
+    uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+    bool stop = false;
+    while (rem && !stop) {
+      const uint32_t n = rem < 32 ? rem : 32;
+      const uint64_t x = read32l(c.A2, (int)a2 + 1) ^ read32l(c.B2, (int)b2 + 1);
+      const uint64_t inv = read32l(c.Ai, (int)a2 + 1) | read32l(c.Bi, (int)b2 + 1);
+      uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
+      if (n < 32) bad |= 1ull << (2 * n);                          // sentinel behind the last pair of the block
+      uint32_t pos = 0;
+      for (;;) {
+        const uint64_t b = bad >> (2 * pos);
+        const uint32_t run = b ? (uint32_t)(__ffsll((long long)b) - 1) >> 1 : 32u - pos;
+        if (run) { score += (int)run * m2; pos += run; if (score > best) { best = score; bestb2 = b2 + pos; } }
+        if (pos >= n) break;
+        score += ((inv >> (2 * pos)) & 1ull) ? 0 : mm2;            // a pair with a non-ACGT letter scores 0 (setnucmx.cpp)
+        ++pos;
+        if (score > best) { best = score; bestb2 = b2 + pos; }
+        else if (best - score > X) { stop = true; break; }
+        if (pos >= n) break;
+      }
+      a2 += n; b2 += n; rem -= n;
+    }
+  }
+  score = best;
+  {
+    uint32_t rem = b1 < a1 ? b1 : a1;
+    bool stop = false;
+    while (rem && !stop) {
+      const uint32_t n = rem < 32 ? rem : 32;
+      const uint64_t x = read32l(c.A2, (int)a1 - 32) ^ read32l(c.B2, (int)b1 - 32);     // pair 31 = position -1
+      const uint64_t inv = read32l(c.Ai, (int)a1 - 32) | read32l(c.Bi, (int)b1 - 32);
+      uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
+      if (n < 32) bad |= 1ull << (2 * (31 - n));                   // sentinel in front of the first pair of the block
+      uint32_t pos = 0;                                            // pairs consumed, from the top
+      for (;;) {
+        const uint64_t b = bad << (2 * pos);
+        const uint32_t run = b ? (uint32_t)__clzll((long long)b) >> 1 : 32u - pos;
+        if (run) { score += (int)run * m2; pos += run; if (score > best) { best = score; bestb1 = b1 - pos; } }
+        if (pos >= n) break;
+        score += ((inv >> (2 * (31 - pos))) & 1ull) ? 0 : mm2;
+        ++pos;
+        if (score > best) { best = score; bestb1 = b1 - pos; }
+        else if (best - score > X) { stop = true; break; }
+        if (pos >= n) break;
+      }
+      a1 -= n; b1 -= n; rem -= n;
+    }
+  }
+}
+
 // One seed of UngappedBlast (ungappedblast.cpp:62-180): seed score, x-drop extension right then
 // left, acceptance test.  nt: byte-SWAR - a run of matching letters is consumed per step (a match
 // always raises the score, so inside a run the best is the run's end and the x-drop test cannot
@@ -236,50 +326,7 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
   if (NT) {
-    {
-      uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
-      while (rem) {
-        const uint32_t n = rem < 8 ? rem : 8;
-        const uint64_t A8 = load8(c.As, (int)a2 + 1), B8 = load8(c.Bs, (int)b2 + 1);
-        uint64_t bad = nzbytes(A8 ^ B8) | nzbytes((A8 | B8) & 0x0404040404040404ull);
-        if (n < 8) bad |= 0x8080808080808080ull << (8 * n);
-        const uint32_t run = bad ? (uint32_t)(__ffsll((long long)bad) - 1) >> 3 : 8u;   // leading matches (<= n)
-        if (run) {
-          score += (int)run * m2; a2 += run; b2 += run; rem -= run;
-          if (score > best) { best = score; bestb2 = b2; }
-        }
-        if (run < n) {                                   // the next pair is a mismatch or a non-ACGT letter
-          const uint32_t a = (uint32_t)(A8 >> (8 * run)) & 0xffu, b = (uint32_t)(B8 >> (8 * run)) & 0xffu;
-          score += sscore<true>(c, m2, mm2, a, b);
-          ++a2; ++b2; --rem;
-          if (score > best) { best = score; bestb2 = b2; }
-          else if (best - score > X) break;
-        }
-      }
-    }
-    score = best;
-    {
-      uint32_t rem = b1 < a1 ? b1 : a1;
-      while (rem) {
-        const uint32_t n = rem < 8 ? rem : 8;
-        const uint64_t A8 = load8(c.As, (int)a1 - 8), B8 = load8(c.Bs, (int)b1 - 8);      // byte 7 = position -1
-        uint64_t bad = nzbytes(A8 ^ B8) | nzbytes((A8 | B8) & 0x0404040404040404ull);
-        if (n < 8) bad |= 0x8080808080808080ull >> (8 * n);
-        const uint32_t run = bad ? (uint32_t)__clzll((long long)bad) >> 3 : 8u;          // matches counted from the top byte
-        if (run) {
-          score += (int)run * m2; a1 -= run; b1 -= run; rem -= run;
-          if (score > best) { best = score; bestb1 = b1; }
-        }
-        if (run < n) {
-          const uint32_t sh = 8 * (7 - run);
-          const uint32_t a = (uint32_t)(A8 >> sh) & 0xffu, b = (uint32_t)(B8 >> sh) & 0xffu;
-          score += sscore<true>(c, m2, mm2, a, b);
-          --a1; --b1; --rem;
-          if (score > best) { best = score; bestb1 = b1; }
-          else if (best - score > X) break;
-        }
-      }
-    }
+    extend_nt_packed(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
   } else {
     {
       uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
@@ -689,6 +736,11 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
   c.B = wb + off; off += maxt;
   c.As = wb + off + 16; off += maxq + 32;
   c.Bs = wb + off + 16; off += maxt + 32;
+  {
+    const size_t wa = (((size_t)maxq / 16 + 6) * 4 + 15) & ~(size_t)15, wt = (((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15;
+    c.A2 = (uint32_t *)(wb + off) + 2; off += wa; c.Ai = (uint32_t *)(wb + off) + 2; off += wa;
+    c.B2 = (uint32_t *)(wb + off) + 2; off += wt; c.Bi = (uint32_t *)(wb + off) + 2; off += wt;
+  }
   c.nwords = (uint32_t)db.hsp_words;
   c.wstart = nullptr;
   if (db.hsp_words <= 1024 && bv.max_qlen < 4096) { c.wstart = (uint16_t *)(wb + off); off += ((size_t)db.hsp_words * 2 + 15) & ~(size_t)15; }
@@ -763,6 +815,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
         c.A[p] = cl; c.As[p] = s_sc[cl & 31];
       }
       wave_sync();
+      if (c.nt) pack_codes(c.As, LA, c.A2, c.Ai, lane);
       build_query_words(c, db.hsp_w, db.alpha);
     }
     ta0 += clock64() - tq;
@@ -803,6 +856,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
       if (k + 1 < ncand) prefetch(k + 1);
       wave_sync();
+      if (c.nt) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
       if constexpr (PAIR) if (db.pair_mask) {
         // Accepter::RejectPair accepter.cpp:140-197.  Big path: the pair is a reject for the terminator
         // (udbusortedsearcherbig.cpp:118-127); small path: it is passed over without a trace (searcher.cpp:63-67)

@@ -672,7 +672,8 @@ static int plan_launch(ugs_batch *b)
   // sorted query words, run buffers, small-hole traceback, HSPs + chain, union{seed list | DP rows + chainer scratch}
   const size_t u_region = std::max<size_t>((size_t)seed_cap * 4, std::max<size_t>(2 * ((size_t)maxt + 8) * 4, (size_t)hsp_cap * 28));
   const bool always_counting = wstart_b != 0 && (uint64_t)maxq * 3 / 2 + 16 <= u_region / 4;
-  const size_t wave_lds = (32 + ((size_t)maxq + maxt) + ((size_t)maxq + maxt + 64) + wstart_b + (size_t)(always_counting ? maxq : q2) * 4 +
+  const size_t packed_b = 2 * ((((size_t)maxq / 16 + 6) * 4 + 15) & ~(size_t)15) + 2 * ((((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15);   // 2-bit letters
+  const size_t wave_lds = (32 + ((size_t)maxq + maxt) + ((size_t)maxq + maxt + 64) + packed_b + wstart_b + (size_t)(always_counting ? maxq : q2) * 4 +
                            2 * 32 * 4 + 1024 + (size_t)hsp_cap * (16 + 4) + u_region + 15 + 16) & ~(size_t)15;
   int awpb = 4;
   while (awpb > 1 && 2112 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
