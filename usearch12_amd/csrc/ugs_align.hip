@@ -111,6 +111,14 @@ __device__ __forceinline__ bool is_global_hsp(uint32_t ALo, uint32_t BLo, uint32
   return true;
 }
 
+// nt HSP-finder word of w letters at `pos`, read from the packed letters: the same letters as the reference's rolling word
+// (hspfinder.cpp:226-270, invalid letter -> 0) in little-endian digit order - query table and target look-ups both use it
+__device__ __forceinline__ uint32_t nt_word(const uint32_t *w2, uint32_t pos, int w)
+{
+  const uint32_t k = pos >> 4;
+  return __builtin_amdgcn_alignbit(w2[k + 1], w2[k], (pos & 15u) * 2u) & ((1u << (2 * w)) - 1u);
+}
+
 // Query side of HSPFinder::SetA: words for every position (invalid letter -> 0), sorted by
 // (word, pos) so a word's first MaxReps positions are contiguous and ascending.
 __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
@@ -129,7 +137,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     for (uint32_t k = lane; k < (nwords + 1) / 2; k += 64) ((uint32_t *)c.wstart)[k] = 0;
     for (uint32_t p = lane; p < ((nwA + 3) & ~3u); p += 64) {
       uint32_t word = 0xffffffffu;
-      if (p < nwA) { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; }
+      if (p < nwA) { if (c.nt) word = nt_word(c.A2, p, w); else { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; } }
       tw[p] = word;
     }
     lds_sync();
@@ -167,7 +175,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     uint32_t key = 0xffffffffu;
     if (p < c.nwA) {
       uint32_t word = 0;
-      for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31];
+      if (c.nt) word = nt_word(c.A2, p, w); else for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31];
       key = (word << 16) | p;
     }
     c.qsort[p] = key;
@@ -397,7 +405,8 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
         uint32_t lo = 0, cnt = 0;
         if (bpos < nwB) {
           uint32_t word = 0;
-          for (int k = 0; k < w; ++k) word = word * db.alpha + (NT ? (c.Bs[bpos + k] & 3u) * (c.Bs[bpos + k] < 4) : c.s_hl[c.B[bpos + k] & 31]);
+          if (NT) word = nt_word(c.B2, bpos, w);
+          else for (int k = 0; k < w; ++k) word = word * db.alpha + c.s_hl[c.B[bpos + k] & 31];
           if (c.wstart) { const uint32_t e = c.wstart[word]; lo = e & 0xfffu; cnt = e >> 12; }
           else {
             const uint32_t want = word << 16;
