@@ -329,7 +329,13 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   const uint32_t LA = c.LA, LB = c.LB;
   const int X = db.xdrop2;
   int score = 0;
-  for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
+  if (NT) {
+    // the two words are equal, so no pair of the seed is a mismatch: every pair scores a match unless one of its letters is not
+    // A/C/G/T/U (both then carry the letter 0 in the word and the pair scores 0, setnucmx.cpp:11-99)
+    const uint32_t ninv = (uint32_t)__popc((nt_word(c.Ai, apos, w) | nt_word(c.Bi, bpos, w)));
+    score = ((int)w - (int)ninv) * m2;
+  } else
+    for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
   int best = score;
   uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
