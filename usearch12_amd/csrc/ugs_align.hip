@@ -862,16 +862,28 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
       c.LB = LB;
+      const bool pack_direct = c.nt && LB <= 1024;             // nt: a lane's 4 letters are one byte of the packed arrays
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
-        if (o < LB)
-          for (uint32_t b = 0; b < 4 && o + b < LB; ++b) { const uint8_t cl = s_cls[(pre[e] >> (8 * b)) & 0xffu]; c.B[o + b] = cl; c.Bs[o + b] = s_sc[cl & 31]; }
+        if (o < LB) {
+          uint32_t p2 = 0, pi = 0, cls4 = 0;
+#pragma unroll
+          for (uint32_t b = 0; b < 4; ++b) {
+            const uint8_t cl = s_cls[(pre[e] >> (8 * b)) & 0xffu];
+            const uint32_t sc = s_sc[cl & 31];
+            cls4 |= (uint32_t)cl << (8 * b);
+            p2 |= (sc & 3u) << (2 * b); pi |= (sc >> 2) << (2 * b);
+            if (!pack_direct && o + b < LB) c.Bs[o + b] = (uint8_t)sc;
+          }
+          *(uint32_t *)(c.B + o) = cls4;                          // (classes behind the last letter are never read)
+          if (pack_direct) { ((uint8_t *)c.B2)[o >> 2] = (uint8_t)p2; ((uint8_t *)c.Bi)[o >> 2] = (uint8_t)pi; }
+        }
       }
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
       if (k + 1 < ncand) prefetch(k + 1);
       wave_sync();
-      if (c.nt) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
+      if (c.nt && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
       if constexpr (PAIR) if (db.pair_mask) {
         // Accepter::RejectPair accepter.cpp:140-197.  Big path: the pair is a reject for the terminator
         // (udbusortedsearcherbig.cpp:118-127); small path: it is passed over without a trace (searcher.cpp:63-67)
