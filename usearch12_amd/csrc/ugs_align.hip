@@ -141,15 +141,30 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       tw[p] = word;
     }
     lds_sync();
-    for (uint32_t p = lane; p < nwA; p += 64) {
-      const uint32_t wd = tw[p];
+    for (uint32_t p = lane; p < nwA; p += 64)
+      atomicAdd(&((uint32_t *)c.wstart)[tw[p] >> 1], 1u << ((tw[p] & 1u) * 16));   // 16-bit counters, two per LDS word
+    lds_sync();
+    // only the positions of words that occur more than once need a rank (about a fifth of a random query): they are listed
+    // densely first, so that the O(L) rank scans fill whole wavefronts
+    uint32_t *dup = c.qsort;                               // (free until the final scatter)
+    uint32_t ndup = 0;
+    for (uint32_t p0 = 0; p0 < nwA; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      const bool need = p < nwA && c.wstart[tw[p < nwA ? p : 0]] > 1;
+      if (p < nwA) tr[p] = 0;
+      const uint64_t m = __ballot(need);
+      if (need) dup[ndup + __popcll(m & ((1ull << lane) - 1ull))] = p;
+      ndup += (uint32_t)__popcll(m);
+    }
+    lds_sync();
+    for (uint32_t i = lane; i < ndup; i += 64) {
+      const uint32_t p = dup[i], wd = tw[p];
       const uint4 *v4 = (const uint4 *)tw;
       uint32_t rank = 0;
       const uint32_t nq4 = p >> 2;
       for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += (x.x == wd) + (x.y == wd) + (x.z == wd) + (x.w == wd); }
       for (uint32_t q = nq4 << 2; q < p; ++q) rank += tw[q] == wd;
       tr[p] = (uint16_t)rank;
-      atomicAdd(&((uint32_t *)c.wstart)[wd >> 1], 1u << ((wd & 1u) * 16));     // 16-bit counters, two per LDS word
     }
     lds_sync();
     {   // exclusive prefix sum of the counts: each lane owns a contiguous block of words
