@@ -888,9 +888,11 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
   const uint32_t maxq = (bv.max_qlen + 15u) & ~15u;
   uint8_t *s_udb = smem;
-  unsigned char *wb = smem + 256 + (size_t)wave * ((size_t)maxq * 6);
+  unsigned char *wb = smem + 256 + (size_t)wave * ((size_t)maxq * 8 + 2048);
   uint32_t *s_words = (uint32_t *)wb;
   uint8_t *s_q = wb + (size_t)maxq * 4, *s_first = s_q + maxq;
+  uint16_t *s_dup = (uint16_t *)(s_first + maxq);                 // positions whose word may have occurred before
+  uint32_t *s_hc = (uint32_t *)(wb + (size_t)maxq * 8);            // hash counts
   const UgsTables *tab = db.tab;
   for (int k = tid; k < 256; k += blockDim.x) s_udb[k] = tab->udb_letter[k];
   __syncthreads();
@@ -925,26 +927,44 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
       s_words[p] = w;
     }
     __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
-    // ---- first occurrences: any earlier position with the same word?  (128-bit LDS reads, no early exit)
-    uint32_t Nu = 0;
+    // ---- first occurrences: any earlier position with the same word?  A 1024-bucket hash count tells most positions apart at
+    // once (a word alone in its bucket occurs once); only the others are compared with the earlier positions (128-bit LDS
+    // reads), and those are listed densely first so that the scans fill whole wavefronts
+    for (uint32_t k = lane; k < 512; k += 64) s_hc[k] = 0;                      // 1024 16-bit counters
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    for (uint32_t p = lane; p < L; p += 64) {
+      const uint32_t w = s_words[p];
+      if (w != UGS_BAD_WORD) { const uint32_t h = (w ^ (w >> 10)) & 1023u; atomicAdd(&s_hc[h >> 1], 1u << ((h & 1u) * 16)); }
+    }
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    uint32_t ndup = 0;
     for (uint32_t p0 = 0; p0 < L; p0 += 64) {
       const uint32_t p = p0 + lane;
-      bool first = false;
+      bool need = false;
       if (p < L) {
         const uint32_t w = s_words[p];
-        first = (w != UGS_BAD_WORD);
-        if (first) {
-          const uint4 *v4 = (const uint4 *)s_words;
-          const uint32_t nq4 = p >> 2;
-          bool dupf = false;
-          for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
-          for (uint32_t q = nq4 << 2; q < p; ++q) dupf = dupf | (s_words[q] == w);
-          first = !dupf;
-        }
-        s_first[p] = first ? 1 : 0;
+        const uint32_t h = (w ^ (w >> 10)) & 1023u;
+        const bool valid = w != UGS_BAD_WORD;
+        need = valid && ((s_hc[h >> 1] >> ((h & 1u) * 16)) & 0xffffu) > 1u;
+        s_first[p] = valid ? 1 : 0;                                               // (corrected below for the listed ones)
       }
-      Nu += (uint32_t)__popcll(__ballot(first));
+      const uint64_t m = __ballot(need);
+      if (need) s_dup[ndup + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
+      ndup += (uint32_t)__popcll(m);
     }
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    for (uint32_t i = lane; i < ndup; i += 64) {
+      const uint32_t p = s_dup[i], w = s_words[p];
+      const uint4 *v4 = (const uint4 *)s_words;
+      const uint32_t nq4 = p >> 2;
+      bool dupf = false;
+      for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
+      for (uint32_t q = nq4 << 2; q < p; ++q) dupf = dupf | (s_words[q] == w);
+      if (dupf) s_first[p] = 0;
+    }
+    __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    uint32_t Nu = 0;
+    for (uint32_t p0 = 0; p0 < L; p0 += 64) Nu += (uint32_t)__popcll(__ballot(p0 + lane < L && s_first[p0 + lane]));
     uint32_t step = 1;
     if (!small_path) step = db.step_tab[Nu < db.step_n ? Nu : db.step_n - 1];
     const uint32_t ns_q = Nu == 0 ? 0 : (Nu + step - 1) / step;
@@ -1467,7 +1487,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   dim3 grid(L.grid), block(64 * L.wpb);
   {   // stage 1: sampled rows of every unit (one wavefront per unit, as many workgroups as fit)
     const uint32_t units = b.nq * b.nstrand, maxq = (b.max_qlen + 15u) & ~15u;
-    const size_t slds = 256 + 4 * (size_t)maxq * 6;
+    const size_t slds = 256 + 4 * ((size_t)maxq * 8 + 2048);
     if (slds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_rank_setup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
     int per_cu = 0, ncu = 0, dev = 0;
     HIPCHK(hipGetDevice(&dev));
