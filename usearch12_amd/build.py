@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
     cli_src = os.path.join(CSRC, "ugs_cli.cpp")
     if force or _mtime(CLI) < max(_mtime(cli_src), _mtime(LIB)):
-        cmd = ["hipcc", "-O2", "-std=c++17", "-o", CLI, cli_src, "-L" + HERE, "-lugs", "-Wl,-rpath,$ORIGIN"]
+        cmd = ["hipcc", "-O2", "-std=c++17", "-pthread", "-o", CLI, cli_src, "-L" + HERE, "-lugs", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

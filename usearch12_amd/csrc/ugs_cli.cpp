@@ -24,6 +24,12 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <thread>
 
 struct SeqSet {                       // SeqDB (seqdb.h:29-52) flattened: labels + concatenated letters
   std::vector<std::string> labels;
@@ -68,7 +74,12 @@ class FastaReader {
       std::string label = line_.substr(1);
       const size_t start = out.letters.size();
       while ((have_ = next_line()) && !(line_.size() && line_[0] == '>'))
-        for (unsigned char c : line_) if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) out.letters.push_back((char)c);
+        {   // (almost every line is letters only: one check, one append)
+          bool pure = true;
+          for (unsigned char c : line_) pure &= (unsigned char)((c | 0x20) - 'a') < 26;
+          if (pure) out.letters.append(line_);
+          else for (unsigned char c : line_) if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) out.letters.push_back((char)c);
+        }
       if (out.letters.size() == start) continue;                 // empty sequence: skipped (with a warning in the reference)
       out.labels.push_back(label); out.offs.push_back(out.letters.size()); ++n;
     }
@@ -105,13 +116,77 @@ class FastaReader {
   FILE *f_; std::string line_; bool have_; bool fastq_ = false;
 };
 
+// Whole-file FASTA parse by several threads (same rules as FastaReader): the file is cut at record starts into one piece per
+// thread, every piece is parsed into its own SeqSet, the pieces are concatenated in order.  FASTQ and tiny files take the
+// serial reader.
+static void parse_fasta_piece(const char *p, const char *e, SeqSet &out)
+{
+  while (p < e) {
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+    const char *le = nl ? nl : e;
+    if (le == p || (le == p + 1 && *p == '\r')) { p = nl ? nl + 1 : e; continue; }       // blank line
+    if (*p != '>') { fprintf(stderr, "bad FASTA: expected '>'\n"); exit(1); }
+    std::string label(p + 1, le);
+    if (label.find('\r') != std::string::npos) label.erase(std::remove(label.begin(), label.end(), '\r'), label.end());
+    p = nl ? nl + 1 : e;
+    const size_t start = out.letters.size();
+    while (p < e && *p != '>') {
+      nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+      le = nl ? nl : e;
+      bool pure = true;
+      for (const char *c = p; c < le; ++c) pure &= (unsigned char)(((unsigned char)*c | 0x20) - 'a') < 26;
+      if (pure) out.letters.append(p, le);
+      else for (const char *c = p; c < le; ++c) if ((*c >= 'A' && *c <= 'Z') || (*c >= 'a' && *c <= 'z')) out.letters.push_back(*c);
+      p = nl ? nl + 1 : e;
+    }
+    if (out.letters.size() == start) continue;                  // empty sequence: skipped
+    out.labels.push_back(std::move(label)); out.offs.push_back(out.letters.size());
+  }
+}
+static bool parse_fasta_parallel(const char *path, SeqSet &out)
+{
+  FILE *f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(1); }
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (sz < (8 << 20)) { fclose(f); return false; }
+  std::vector<char> buf((size_t)sz);
+  if (fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fprintf(stderr, "read error on %s\n", path); exit(1); }
+  fclose(f);
+  if (buf[0] != '>') return false;                                  // FASTQ (or garbage): the serial reader decides
+  const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  std::vector<const char *> cut(nt + 1);
+  const char *b = buf.data(), *e = b + sz;
+  cut[0] = b; cut[nt] = e;
+  for (unsigned t = 1; t < nt; ++t) {
+    const char *p = b + (size_t)sz * t / nt;
+    while (p < e && !(p[0] == '\n' && p + 1 < e && p[1] == '>')) ++p;   // the next record start
+    cut[t] = p < e ? p + 1 : e;
+  }
+  std::vector<SeqSet> part(nt);
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { parse_fasta_piece(cut[t], cut[t + 1], part[t]); });
+  parse_fasta_piece(cut[0], cut[1], part[0]);
+  for (auto &x : th) x.join();
+  size_t nl = 0, ns = 0;
+  for (const SeqSet &q : part) { nl += q.letters.size(); ns += q.size(); }
+  out.letters.reserve(out.letters.size() + nl); out.labels.reserve(out.labels.size() + ns); out.offs.reserve(out.offs.size() + ns);
+  for (SeqSet &q : part) {
+    const uint64_t base = out.letters.size();
+    out.letters += q.letters;
+    for (size_t i = 0; i < q.size(); ++i) { out.labels.push_back(std::move(q.labels[i])); out.offs.push_back(base + q.offs[i + 1]); }
+  }
+  return true;
+}
+
 // Searcher (searcher.h:21-96) as a batch object over one ugs_db
 class Searcher {
  public:
   Searcher(const ugs_params &p, const SeqSet &db, int device) : p_(p) {
     if (ugs_db_create(&p_, db.letters.data(), db.offs.data(), (uint32_t)db.size(), device, &db_) != UGS_OK) die("ugs_db_create");
   }
-  ~Searcher() { ugs_db_destroy(db_); }
+  ~Searcher() { if (b_) ugs_batch_destroy(b_); ugs_db_destroy(db_); }
   const ugs_db *handle() const { return db_; }
   bool pair_keys() const { return p_.pair_mask != 0 || (p_.filter_mask & UGS_F_ABSKEW) != 0; }
   // labels as integer keys (equal labels <=> equal keys) and ;size= annotations (label.cpp:152-161) for the pair filters
@@ -134,7 +209,7 @@ class Searcher {
     const uint32_t nq = (uint32_t)q.size();
     hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) * (p_.local ? p_.max_hsps : 1) + 1);
     nhits.assign(nq + 1, 0);
-    pool.resize(q.letters.size() * 2 + 64 * (size_t)nq + 1024);
+    pool.resize(24 * (size_t)nq + 4096);                      // grown to the library's demand when a batch needs more (UGS_E_CAPACITY)
     uint64_t used = 0;
     if (pair_keys()) {                                       // staged calls: the one-shot entry point has no room for per-query keys
       std::vector<uint32_t> k, z;
@@ -151,18 +226,47 @@ class Searcher {
       if (rc != UGS_OK) die("search with pair filters");
       return;
     }
-    int rc = ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+    // one batch object serves every batch of the run (its device buffers are sized once, for the largest batch seen)
+    if (!b_ || nq > bq_ || q.letters.size() > bl_) {
+      if (b_) ugs_batch_destroy(b_);
+      bq_ = std::max<uint32_t>(nq, bq_); bl_ = std::max<uint64_t>(q.letters.size(), bl_);
+      if (ugs_batch_create(db_, bq_, bl_, &b_) != UGS_OK) die("ugs_batch_create");
+    }
+    int rc = ugs_batch_upload(b_, q.letters.data(), q.offs.data(), nq);
+    if (rc == UGS_OK) rc = ugs_batch_search(b_);
+    if (rc == UGS_OK) rc = ugs_batch_sync(b_);
+    if (rc == UGS_OK) rc = ugs_batch_fetch(b_, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
     if (rc == UGS_E_CAPACITY && used > pool.size()) {        // the demand comes back in `used`
       pool.resize(used + 1024);
-      rc = ugs_search_batch(db_, q.letters.data(), q.offs.data(), nq, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+      rc = ugs_batch_fetch(b_, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
     }
-    if (rc != UGS_OK) die("ugs_search_batch");
+    if (rc != UGS_OK) die("search");
   }
  private:
   [[noreturn]] static void die(const char *what) { fprintf(stderr, "%s: %s\n", what, ugs_last_error()); exit(1); }
   ugs_params p_; ugs_db *db_ = nullptr;
+  ugs_batch *b_ = nullptr; uint32_t bq_ = 0; uint64_t bl_ = 0;
   std::unordered_map<std::string, uint32_t> label_ids_;
 };
+
+// Stages of the driver run as threads (FASTA parsing | GPU search | text formatting) joined by small queues, so that a run
+// costs about its slowest stage instead of the sum (the reference overlaps them with its worker threads, search.cpp:121-128)
+template <class T> class Channel {
+ public:
+  explicit Channel(size_t cap) : cap_(cap) {}
+  void push(T v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push(std::move(v)); cv_.notify_all(); }
+  bool pop(T &v) {          // false: closed and drained
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    v = std::move(q_.front()); q_.pop(); cv_.notify_all();
+    return true;
+  }
+  void close() { std::lock_guard<std::mutex> l(m_); closed_ = true; cv_.notify_all(); }
+ private:
+  std::mutex m_; std::condition_variable cv_; std::queue<T> q_; size_t cap_; bool closed_ = false;
+};
+struct SearchResult { std::unique_ptr<SeqSet> q; std::vector<ugs_hit> hits; std::vector<uint32_t> nhits, pool; };
 
 // the optional sinks of one search (OutputSink::OpenOutputFiles outputsink.cpp:60-130, DBHitSink dbhitsink.cpp)
 struct Outputs {
@@ -193,6 +297,7 @@ static void output_query(Outputs &O, const ugs_params &p, const SeqSet &q, const
   const char *qs = q.letters.data() + q.offs[qi], *qlab = q.labels[qi].c_str();
   auto put_to = [&](FILE *f, int len) {
     if (len < 0) { fprintf(stderr, "%s\n", ugs_last_error()); exit(1); }
+    if ((size_t)len >= line.size()) { fprintf(stderr, "output line too long\n"); exit(1); }
     if (f && len > 0) fputs(line.data(), f);
   };
   auto put = [&](FILE *f, int len) {
@@ -292,8 +397,13 @@ static bool guess_nucleo(const SeqSet &db)     // SeqDB::GetIsNucleo samples 100
   return n > 0 && nt * 10 >= n * 9;
 }
 
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char **argv)
 {
+  const double t_start = now_s();
+  const bool prof = getenv("UGS_CLI_PROFILE") != nullptr;
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
   std::string tabbedout, trimpath, matchedfqpath, notmatchedfqpath; bool closedref_cmd = false;
   std::string biomout;
@@ -303,7 +413,7 @@ int main(int argc, char **argv)
   Outputs O;
   bool hardmask = false;
   bool local_cmd = false; double evalue = -1; double xdrop_u = -1, xdrop_g = -1, ka_dbsize = -1; long maxhsps = -1, hspw = -1;
-  double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 20; int dbtype = -1;
+  double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 18; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
@@ -397,12 +507,26 @@ int main(int argc, char **argv)
     return 0;
   }
   if (qpath.empty() || dbpath.empty()) { fprintf(stderr, "usage: ugs_cli -usearch_global q.fa -db db.fa -id 0.97 -strand plus -blast6out o.b6 -uc o.uc\n"); return 1; }
+  // stage 1: the query file is parsed by its own thread, batch by batch, from the start (while the DB is read and indexed)
+  // (the thread owns what it touches - path, batch size, the channel - so that an early error exit of main is harmless)
+  auto parsed_ptr = std::make_shared<Channel<std::unique_ptr<SeqSet>>>(3);
+  Channel<std::unique_ptr<SeqSet>> &parsed = *parsed_ptr;
+  std::thread([parsed_ptr, qpath, batch] {
+    FastaReader qr(qpath.c_str());
+    for (;;) {
+      std::unique_ptr<SeqSet> q(new SeqSet);
+      if (!qr.read(*q, batch)) break;
+      parsed_ptr->push(std::move(q));
+    }
+    parsed_ptr->close();
+  }).detach();
   SeqSet db;
   bool from_udb = false, udb_nucleo = true; uint32_t udb_word = 0;
   if (is_udb_file(dbpath.c_str())) {
     if (!load_udb(dbpath.c_str(), db, udb_nucleo, udb_word)) return 1;
     from_udb = true;
-  } else { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
+  } else if (!parse_fasta_parallel(dbpath.c_str(), db)) { FastaReader r(dbpath.c_str()); while (r.read(db, 1u << 20)) {} }
+  if (prof) fprintf(stderr, "[cli] db parsed %.3f s\n", now_s() - t_start);
   const bool nucleo = from_udb ? udb_nucleo : (dbtype >= 0 ? dbtype != 0 : guess_nucleo(db));
   if (otutab_cmd) {                                                   // cmd_otutab searchcmd.cpp:20-40 (oset_*d: only if not given)
     if (id < 0) id = 0.97;
@@ -418,6 +542,7 @@ int main(int argc, char **argv)
     if (maxrej < 0) maxrej = 16;
   }
   if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
+  if (id < 0 && !local_cmd) { fprintf(stderr, "--id not set\n"); return 1; }                                         // udbusortedsearcher.cpp:100-101
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
   p.id_set = id >= 0;
@@ -461,6 +586,7 @@ int main(int argc, char **argv)
   if (otutab_cmd) { O.otutab = ugs_otutab_create(); O.map = open_out(mapout); }
   if (closedref_cmd) { O.closedref = ugs_closedref_create(); O.tabbed = open_out(tabbedout); }
   Searcher searcher(p, db, device);
+  if (prof) fprintf(stderr, "[cli] db on device %.3f s\n", now_s() - t_start);
   if (searcher.pair_keys()) searcher.SetDbKeys(db);
   std::string masked;
   if (O.user || O.aln || O.pairs || O.qseg || O.tseg || !dbmatchedpath.empty() || !dbnotmatchedpath.empty()) {
@@ -469,19 +595,80 @@ int main(int argc, char **argv)
     O.db_masked = masked.data();
     O.db_hit_counts.assign(db.size(), 0);
   }
-  FastaReader qr(qpath.c_str());
-  std::vector<ugs_hit> hits; std::vector<uint32_t> nhits, pool;
   size_t total = 0, with_hit = 0;
-  for (;;) {
-    SeqSet q;
-    if (!qr.read(q, batch)) break;
-    searcher.Search(q, hits, nhits, pool);
-    size_t k = 0;
-    for (uint32_t qi = 0; qi < q.size(); ++qi) {
-      output_query(O, p, q, db, qi, hits.data() + k, nhits[qi], pool.data());
-      k += nhits[qi]; with_hit += nhits[qi] > 0;
+  {
+    Channel<SearchResult> results(2);
+    std::thread writer([&] {                                         // stage 3: the sinks, in query order
+      SearchResult r;
+      // the usual outputs (-blast6out / -uc only, global hits) are formatted by several threads, each over a contiguous
+      // range of queries into its own buffers, and written out in range order; everything else takes the general loop
+      const bool plain = !p.local && !O.user && !O.aln && !O.pairs && !O.qseg && !O.tseg && !O.trim && !O.matched && !O.notmatched &&
+                         !O.matchedfq && !O.notmatchedfq && !O.otutab && !O.closedref && O.db_hit_counts.empty() && !O.output_no_hits &&
+                         !O.top_hit_only && !O.top_hits_only && O.maxhits == 0;
+      while (results.pop(r)) {
+        if (plain) {
+          const uint32_t nq = (uint32_t)r.q->size();
+          const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+          std::vector<size_t> hoff((size_t)nq + 1, 0);
+          for (uint32_t qi = 0; qi < nq; ++qi) hoff[qi + 1] = hoff[qi] + r.nhits[qi];
+          std::vector<std::string> sb6(nt), suc(nt);
+          std::vector<size_t> nwith(nt, 0);
+          auto work = [&](unsigned t) {
+            std::vector<char> line(1 << 16);
+            const uint32_t lo = (uint32_t)((uint64_t)nq * t / nt), hi = (uint32_t)((uint64_t)nq * (t + 1) / nt);
+            for (uint32_t qi = lo; qi < hi; ++qi) {
+              const char *qlab = r.q->labels[qi].c_str();
+              const uint32_t n = r.nhits[qi];
+              if (n == 0) {
+                if (O.uc) { const int len = ugs_format_uc_nohit((uint32_t)(r.q->offs[qi + 1] - r.q->offs[qi]), qlab, line.data(), (int)line.size()); suc[t].append(line.data(), (size_t)len); }
+                continue;
+              }
+              ++nwith[t];
+              for (uint32_t j = 0; j < n; ++j) {
+                const ugs_hit *h = &r.hits[hoff[qi] + j];
+                const char *tl = db.labels[h->target].c_str();
+                if (O.b6) { const int len = ugs_format_blast6(h, qlab, tl, line.data(), (int)line.size()); if (len < 0 || (size_t)len >= line.size()) { fprintf(stderr, "output line too long\n"); exit(1); } sb6[t].append(line.data(), (size_t)len); }
+                if (O.uc) {
+                  int len = ugs_format_uc_hit(h, r.pool.data(), p.is_nucleo, qlab, tl, line.data(), (int)line.size());
+                  if (len >= (int)line.size()) { line.resize((size_t)len + 16); len = ugs_format_uc_hit(h, r.pool.data(), p.is_nucleo, qlab, tl, line.data(), (int)line.size()); }
+                  suc[t].append(line.data(), (size_t)len);
+                }
+              }
+            }
+          };
+          std::vector<std::thread> th;
+          for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+          work(0);
+          for (auto &x : th) x.join();
+          for (unsigned t = 0; t < nt; ++t) {
+            if (O.b6 && !sb6[t].empty()) fwrite(sb6[t].data(), 1, sb6[t].size(), O.b6);
+            if (O.uc && !suc[t].empty()) fwrite(suc[t].data(), 1, suc[t].size(), O.uc);
+            with_hit += nwith[t];
+          }
+          total += nq;
+          continue;
+        }
+        size_t k = 0;
+        for (uint32_t qi = 0; qi < r.q->size(); ++qi) {
+          output_query(O, p, *r.q, db, qi, r.hits.data() + k, r.nhits[qi], r.pool.data());
+          k += r.nhits[qi]; with_hit += r.nhits[qi] > 0;
+        }
+        total += r.q->size();
+      }
+    });
+    for (;;) {                                                        // stage 2: the GPU
+      std::unique_ptr<SeqSet> q;
+      if (!parsed.pop(q)) break;
+      SearchResult r;
+      if (prof) fprintf(stderr, "[cli] batch popped %.3f s\n", now_s() - t_start);
+      searcher.Search(*q, r.hits, r.nhits, r.pool);
+      if (prof) fprintf(stderr, "[cli] batch searched %.3f s\n", now_s() - t_start);
+      r.q = std::move(q);
+      results.push(std::move(r));
     }
-    total += q.size();
+    results.close();
+    writer.join();
+    if (prof) fprintf(stderr, "[cli] written %.3f s\n", now_s() - t_start);
   }
   for (FILE *f : {O.b6, O.uc, O.user, O.matched, O.notmatched, O.map, O.aln, O.pairs, O.qseg, O.tseg, O.tabbed, O.trim, O.matchedfq, O.notmatchedfq}) if (f) fclose(f);
   if (O.closedref) ugs_closedref_destroy(O.closedref);
