@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UGS_ABI_VERSION 4   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
+#define UGS_ABI_VERSION 5   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
                              * (ugs_params.local..., ugs_hit.raw_score/flags); 4: ugs_db_append, cluster_fast (ugs_cluster_*) */
 
 /* error codes */
@@ -478,6 +478,18 @@ typedef struct ugs_cluster_stats {
   float    s_derep, s_search, s_inbatch, s_d2h, s_replay, s_pairs, s_append, s_total;
 } ugs_cluster_stats;
 int ugs_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq, int device, ugs_cluster **out);
+/* The same with -sort length | size (GetSeqOrder clusterfast.cpp:37-79: the uniques are searched by decreasing seed length or
+ * summed size= annotation - default 1, read whether or not -sizein is set, derepresult.cpp:211-225 - in QuickSortOrderDesc's
+ * order) and -sizein (cluster sizes sum the annotations, ClusterSink::GetSize clustersink.cpp:119-150; a label without one fails
+ * with UGS_E_ARG like the reference's "Missing size= in").  size_in[nseq] = ugs_label_size of every input label, may be NULL
+ * when neither is used.  The uniques are then numbered in processing order (uniq_seed, uniq_*, hits.query follow it). */
+#define UGS_SORT_NONE   0
+#define UGS_SORT_LENGTH 1
+#define UGS_SORT_SIZE   2
+int ugs_cluster_fast_sorted(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq, int sort_mode,
+                            const uint32_t *size_in, int sizein, int device, ugs_cluster **out);
+/* GetSizeFromLabel label.cpp:152-161: (unsigned) atoi after the first ";size=", 0xffffffff = no annotation */
+uint32_t ugs_label_size(const char *label);
 void ugs_cluster_destroy(ugs_cluster *c);
 int ugs_cluster_counts(const ugs_cluster *c, uint32_t *n_unique, uint32_t *n_clusters, uint64_t *n_hits, uint64_t *cigar_runs);
 int ugs_cluster_get(const ugs_cluster *c, uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *uniq_cluster, uint32_t *uniq_nhits,
@@ -488,6 +500,11 @@ int ugs_cluster_get_stats(const ugs_cluster *c, ugs_cluster_stats *st);
  * labels: the nseq input labels, NUL-terminated, concatenated in input order. */
 int ugs_cluster_write_uc(const ugs_cluster *c, const char *labels, const char *path);
 int ugs_cluster_write_centroids(const ugs_cluster *c, const char *labels, const char *path);
+/* + MakeCentroidLabel clustersink.cpp:219-243: UGS_SIZEIN | UGS_SIZEOUT strip the size= annotation, UGS_SIZEOUT appends
+ * ";size=<cluster size>;"; -minsize ends the file at the first smaller cluster (clustersink.cpp:275-277) */
+#define UGS_SIZEIN  1
+#define UGS_SIZEOUT 2
+int ugs_cluster_write_centroids_sized(const ugs_cluster *c, const char *labels, const char *path, int size_flags, uint32_t minsize);
 
 /* Page-lock / unlock a caller-owned host buffer (hipHostRegister): result buffers that are reused from batch to batch
  * are then filled by direct DMA instead of through the runtime's staging copies.  Optional; any host pointer works

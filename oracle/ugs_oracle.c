@@ -1867,6 +1867,22 @@ int orc_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs
                      uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
                      uint64_t *n_hits, uint64_t *cigar_used)
 {
+  return orc_cluster_fast_sorted(p, seqs, offs, nseq, 0, NULL, 0, seq_unique, uniq_seed, n_unique, uniq_cluster, uniq_nhits, centroid_uniq,
+                                 cluster_size, n_clusters, hits, hits_cap, cigar_pool, cigar_cap, n_hits, cigar_used);
+}
+
+/* -sort length | size (GetSeqOrder clusterfast.cpp:37-79: QuickSortOrderDesc over the uniques' seed lengths / DerepResult::GetSumSizeIn
+ * derepresult.cpp:211-225, which reads ;size= with default 1 whether or not -sizein is set) and -sizein (ClusterSink::GetSize
+ * clustersink.cpp:119-150: cluster sizes sum the annotations, a label without one is fatal).  size_in[nseq]: the ;size= value
+ * of every input label (GetSizeFromLabel label.cpp:152-161), UINT32_MAX = none.  The uniques are renumbered in processing
+ * order (= ClusterFast's loop order clusterfast.cpp:113-123), so uniq_seed / uniq_* / hits.query all follow it. */
+int orc_cluster_fast_sorted(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                     int sort_mode, const uint32_t *size_in, int sizein,
+                     uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *n_unique,
+                     uint32_t *uniq_cluster, uint32_t *uniq_nhits, uint32_t *centroid_uniq, uint32_t *cluster_size,
+                     uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
+                     uint64_t *n_hits, uint64_t *cigar_used)
+{
   uint64_t zero = 0;
   orc_db *db = NULL;
   int rc = orc_db_create(p, "", &zero, 0, &db);
@@ -1879,8 +1895,23 @@ int orc_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs
   const int revcomp = p->strand_both && p->is_nucleo;
   const uint32_t nu = orc_derep_full(seqs, offs, nseq, revcomp, seq_unique, uniq_seed);
   *n_unique = nu;
-  uint32_t *usize = (uint32_t *)calloc(nu ? nu : 1, 4);          /* ClusterSink::GetSize without -sizein: member count */
-  for (uint32_t i = 0; i < nseq; ++i) ++usize[seq_unique[i]];
+  if (sizein) {
+    if (!size_in) { orc_db_destroy(db); return UGS_E_ARG; }
+    for (uint32_t i = 0; i < nseq; ++i) if (size_in[i] == UINT32_MAX) { orc_db_destroy(db); return UGS_E_ARG; }   /* "Missing size= in >..." */
+  }
+  if (sort_mode == 1 || sort_mode == 2) {
+    uint32_t *v = (uint32_t *)calloc(nu ? nu : 1, 4), *ord = (uint32_t *)calloc(nu ? nu : 1, 4), *rank = (uint32_t *)calloc(nu ? nu : 1, 4);
+    uint32_t *seed2 = (uint32_t *)calloc(nu ? nu : 1, 4);
+    if (sort_mode == 1) for (uint32_t u = 0; u < nu; ++u) v[u] = (uint32_t)(offs[uniq_seed[u] + 1] - offs[uniq_seed[u]]);
+    else for (uint32_t i = 0; i < nseq; ++i) v[seq_unique[i]] += (size_in && size_in[i] != UINT32_MAX) ? size_in[i] : 1;
+    orc_order_desc_u32(v, nu, ord);
+    for (uint32_t k = 0; k < nu; ++k) { rank[ord[k]] = k; seed2[k] = uniq_seed[ord[k]]; }
+    for (uint32_t i = 0; i < nseq; ++i) seq_unique[i] = rank[seq_unique[i]];
+    memcpy(uniq_seed, seed2, (size_t)nu * 4);
+    free(v); free(ord); free(rank); free(seed2);
+  } else if (sort_mode != 0) { orc_db_destroy(db); return UGS_E_ARG; }
+  uint32_t *usize = (uint32_t *)calloc(nu ? nu : 1, 4);          /* ClusterSink::GetSize: member count, or the summed annotations */
+  for (uint32_t i = 0; i < nseq; ++i) usize[seq_unique[i]] += sizein ? size_in[i] : 1;
   Work *w = work_new_cap(db, nu);
   byte *stampw = (byte *)calloc(db->slots, 1);
   HitBuf hb; memset(&hb, 0, sizeof(hb));

@@ -96,6 +96,13 @@ int orc_cluster_fast(const ugs_params *p, const char *seqs, const uint64_t *offs
                      uint32_t *uniq_cluster, uint32_t *uniq_nhits, uint32_t *centroid_uniq, uint32_t *cluster_size,
                      uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
                      uint64_t *n_hits, uint64_t *cigar_used);
+/* + -sort (0 unset, 1 length, 2 size), -sizein; size_in[nseq] = ;size= of every label, UINT32_MAX = none (may be NULL) */
+int orc_cluster_fast_sorted(const ugs_params *p, const char *seqs, const uint64_t *offs, uint32_t nseq,
+                     int sort_mode, const uint32_t *size_in, int sizein,
+                     uint32_t *seq_unique, uint32_t *uniq_seed, uint32_t *n_unique,
+                     uint32_t *uniq_cluster, uint32_t *uniq_nhits, uint32_t *centroid_uniq, uint32_t *cluster_size,
+                     uint32_t *n_clusters, ugs_hit *hits, uint64_t hits_cap, uint32_t *cigar_pool, uint64_t cigar_cap,
+                     uint64_t *n_hits, uint64_t *cigar_used);
 
 void orc_params_init(ugs_params *p, int is_nucleo, double id);
 /* switch a parameter block to usearch_local (searcher.cpp:28-50, localmulti.cpp, localaligner.cpp, estats.cpp);

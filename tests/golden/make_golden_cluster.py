@@ -31,7 +31,37 @@ CASES = {
     "cl_hard":   dict(gen="hard", seed=45, n=4000, id=0.95, strand="both", big=300),
     # one dominant species: long chains of centroids founded inside one batch of the device loop
     "cl_skew":   dict(gen="reads", seed=46, n=6000, species=3, dup=0.0, id=0.97, strand="plus", big=400),
+    # -sort length (GetSeqOrder clusterfast.cpp:37-79): variable read lengths with many ties, QuickSortOrderDesc's tie order
+    "cl_sortlen": dict(gen="hard", seed=47, n=3000, id=0.95, strand="plus", big=300, sort="length"),
+    "cl_sortlen2": dict(gen="reads", seed=48, n=5000, species=40, dup=0.05, id=0.97, strand="both", big=200, sort="length", indel=0.004),
+    # ;size= annotations on two thirds of the labels: -sort size reads them with default 1, -sizeout strips and re-appends
+    "cl_sortsize": dict(gen="reads", seed=49, n=5000, species=40, dup=0.05, id=0.97, strand="plus", big=250, sort="size", sizes=0.66, sizeout=1),
+    # every label annotated: -sizein sums them into the cluster sizes (C records, centroid order), -sizeout, -minsize
+    "cl_sizein": dict(gen="reads", seed=50, n=5000, species=40, dup=0.05, id=0.97, strand="plus", big=250, sort="size", sizes=1.0, sizein=1,
+                      sizeout=1, minsize=3),
+    "cl_sizein_nosort": dict(gen="reads", seed=51, n=3000, species=30, dup=0.05, id=0.97, strand="both", sizes=1.0, sizein=1),
 }
+
+
+def with_sizes(r, seed, frac):
+    """append ;size=N; (or ;size=N without the closing separator, or in the middle of other annotations) to a fraction of the labels"""
+    import numpy as np
+    rng = np.random.default_rng(seed + 1000)
+    pick = rng.random(r.n) < frac
+    val = np.where(rng.random(r.n) < 0.6, rng.integers(1, 4, r.n), rng.integers(1, 400, r.n))
+    style = rng.integers(0, 3, r.n)
+    base = r._label_fn
+
+    def lab(i):
+        l = base(i)
+        if not pick[i]:
+            return l
+        if style[i] == 0:
+            return "%s;size=%d;" % (l, val[i])
+        if style[i] == 1:
+            return "%s;size=%d" % (l, val[i])
+        return "%s;sample=s%d;size=%d;tax=x;" % (l, i % 7, val[i])
+    return synth.SeqSet(r.seqs, r.offs, lab)
 
 
 def make_reads(c):
@@ -42,6 +72,8 @@ def make_reads(c):
         _, r = synth.make_hard(c["seed"], 200, 6, c["n"], lmin=120, lmax=400)
     if c["strand"] == "both":
         r = synth.revcomp_some(c["seed"], r)
+    if c.get("sizes"):
+        r = with_sizes(r, c["seed"], c["sizes"])
     return r
 
 
@@ -49,6 +81,8 @@ def digest(ss):
     h = hashlib.sha256()
     h.update(ss.offs.tobytes())
     h.update(ss.seqs.tobytes())
+    if getattr(ss, "_label_fn", None) is not None and ss.n and ";size=" in "".join(ss.label(i) for i in range(min(ss.n, 64))):
+        h.update("\n".join(ss.labels()).encode())
     return h.hexdigest()
 
 
@@ -73,6 +107,13 @@ def main():
             cmd = [REF, "-cluster_fast", fa, "-id", str(c["id"]), "-uc", uc, "-centroids", cen, "-threads", "1", "-strand", c["strand"]]
             if "big" in c:
                 cmd += ["-big", str(c["big"])]
+            if c.get("sort"):
+                cmd += ["-sort", c["sort"]]
+            for flag in ("sizein", "sizeout"):
+                if c.get(flag):
+                    cmd += ["-" + flag]
+            if c.get("minsize"):
+                cmd += ["-minsize", str(c["minsize"])]
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             uct = open(uc, "rb").read()
             gz_write(os.path.join(HERE, name + ".uc.gz"), uct)

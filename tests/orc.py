@@ -281,13 +281,30 @@ class ClusterResult:
     pass
 
 
-def cluster_fast(p, seqs, offs):
+SORT_MODES = {None: 0, "": 0, "length": 1, "size": 2}
+
+
+def label_sizes(labels):
+    """GetSizeFromLabel (label.cpp:152-161) per label: (unsigned) atoi after the first ";size=", 0xffffffff = no annotation"""
+    import re
+    out = np.full(len(labels), 0xFFFFFFFF, np.uint32)
+    for i, l in enumerate(labels):
+        k = l.find(";size=")
+        if k >= 0:
+            m = re.match(r"\s*[+-]?\d+", l[k + 6:])
+            out[i] = (int(m.group(0)) if m else 0) & 0xFFFFFFFF
+    return out
+
+
+def cluster_fast(p, seqs, offs, sort=None, size_in=None, sizein=False):
     L = lib()
     seqs = as_u8(seqs)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = len(offs) - 1
-    L.orc_cluster_fast.restype = C.c_int
-    L.orc_cluster_fast.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 2 + \
+    if size_in is not None:
+        size_in = np.ascontiguousarray(size_in, dtype=np.uint32)
+    L.orc_cluster_fast_sorted.restype = C.c_int
+    L.orc_cluster_fast_sorted.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 2 + \
         [C.POINTER(C.c_uint32)] + [C.c_void_p] * 4 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     r = ClusterResult()
@@ -297,7 +314,8 @@ def cluster_fast(p, seqs, offs):
     nu, nc, nh, cu = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
     hits = np.zeros(2 * n + 1, HIT_DTYPE)
     pool = np.zeros(int(offs[-1]) // 2 + 64 * n + 1024, np.uint32)
-    rc = L.orc_cluster_fast(C.byref(p), _vp(seqs), _vp(offs), n, _vp(r.seq_unique), _vp(r.uniq_seed), C.byref(nu),
+    rc = L.orc_cluster_fast_sorted(C.byref(p), _vp(seqs), _vp(offs), n, SORT_MODES[sort], _vp(size_in) if size_in is not None else None,
+                                   int(bool(sizein)), _vp(r.seq_unique), _vp(r.uniq_seed), C.byref(nu),
                             _vp(r.uniq_cluster), _vp(r.uniq_nhits), _vp(r.centroid_uniq), _vp(r.cluster_size), C.byref(nc),
                             _vp(hits), len(hits), _vp(pool), len(pool), C.byref(nh), C.byref(cu))
     assert rc == 0, rc
@@ -347,13 +365,39 @@ def cluster_uc_text(r, labels, seqlens, is_nucleo=True):
     return "".join(out)
 
 
-def cluster_centroids_text(r, labels, ss):
-    """-centroids: centroids by decreasing cluster size (QuickSortOrderDesc, clustersink.cpp:262-289), 80-column FASTA"""
+def strip_size(label):
+    """StripSize = StripAnnot(Label, "size=") label.cpp:46-71"""
+    if "size=" not in label:
+        return label
+    fields = label.split(";")                       # Split(myutils.cpp:1588-1607): no field after a trailing separator
+    if fields[-1] == "":
+        fields.pop()
+    new = "".join(f + ";" for f in fields if not f.startswith("size="))
+    return new[:-1] if "=" not in new else new
+
+
+def append_size(label, size):
+    """AppendSize -> Psasc (myutils.cpp:824-839)"""
+    if label and not label.endswith(";"):
+        label += ";"
+    return label + "size=%u;" % size
+
+
+def cluster_centroids_text(r, labels, ss, sizein=False, sizeout=False, minsize=0):
+    """-centroids: centroids by decreasing cluster size (QuickSortOrderDesc, clustersink.cpp:262-289), 80-column FASTA;
+    labels per MakeCentroidLabel clustersink.cpp:219-243"""
     order = order_desc_u32(r.cluster_size)
     out = []
     for c in order:
+        if int(r.cluster_size[int(c)]) < minsize:
+            break
         i = int(r.uniq_seed[int(r.centroid_uniq[int(c)])])
         s = ss.seq(i).decode()
-        out.append(">%s\n" % labels[i])
+        lab = labels[i]
+        if sizein or sizeout:
+            lab = strip_size(lab)
+        if sizeout:
+            lab = append_size(lab, int(r.cluster_size[int(c)]))
+        out.append(">%s\n" % lab)
         out.extend(s[k:k + 80] + "\n" for k in range(0, len(s), 80))
     return "".join(out)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(capi.EXPORTS) == names
-    assert L.ugs_abi_version() == 4
+    assert L.ugs_abi_version() == 5
 
 
 def test_struct_layouts():

@@ -21,7 +21,7 @@ def _cluster(c, r, batch=None):
     if batch:
         os.environ["UGS_CLUSTER_BATCH"] = str(batch)
     try:
-        return capi.UgsCluster(p, r.seqs, r.offs)
+        return capi.UgsCluster(p, r.seqs, r.offs, sort=c.get("sort"), labels=r.labels(), sizein=c.get("sizein", 0))
     finally:
         os.environ.pop("UGS_CLUSTER_BATCH", None)
         if old is not None:
@@ -37,7 +37,7 @@ def test_gpu_cluster_fast_files_identical_to_reference(name, batch, tmp_path):
     labels = r.labels()
     ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
     res.write_uc(labels, ucp)
-    res.write_centroids(labels, cp)
+    res.write_centroids(labels, cp, sizein=c.get("sizein", 0), sizeout=c.get("sizeout", 0), minsize=c.get("minsize", 0))
     assert open(ucp).read() == uc
     assert open(cp).read() == cen
 
@@ -119,15 +119,24 @@ def test_c3_full_size_properties_and_prefix_parity():
     _same(g, o)
 
 
-def test_cli_cluster_fast_writes_the_reference_files(tmp_path):
+@pytest.mark.parametrize("name", ["cl_both", "cl_sizein", "cl_sortlen2"])
+def test_cli_cluster_fast_writes_the_reference_files(name, tmp_path):
     """the C++ driver end to end: FASTA in, -uc and -centroids out, byte-identical to the reference's files"""
     import subprocess
-    c, r, uc, cen = G.load_cluster("cl_both")
+    c, r, uc, cen = G.load_cluster(name)
     fa = str(tmp_path / "r.fa")
     r.write_fasta(fa)
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
     ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
-    subprocess.check_call([cli, "-cluster_fast", fa, "-id", str(c["id"]), "-strand", c["strand"], "-big", str(c["big"]), "-uc", ucp,
-                           "-centroids", cp], stderr=subprocess.DEVNULL)
+    extra = (["-sort", c["sort"]] if c.get("sort") else []) + [f for f in ("-sizein", "-sizeout") if c.get(f[1:])] + \
+        (["-minsize", str(c["minsize"])] if c.get("minsize") else [])
+    subprocess.check_call([cli, "-cluster_fast", fa, "-id", str(c["id"]), "-strand", c["strand"], "-big", str(c.get("big", 100000)), "-uc", ucp,
+                           "-centroids", cp] + extra, stderr=subprocess.DEVNULL)
     assert open(ucp).read() == uc
     assert open(cp).read() == cen
+
+
+def test_sizein_without_annotation_is_refused():
+    r = synth.make_reads(5, 200, n_species=5)
+    with pytest.raises(capi.UgsError):
+        capi.UgsCluster(capi.cluster_params(0.97), r.seqs, r.offs, labels=r.labels(), sizein=True)

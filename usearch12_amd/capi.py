@@ -28,6 +28,7 @@ EXPORTS = [
     "ugs_otutab_create", "ugs_otutab_destroy", "ugs_otutab_add", "ugs_otutab_write", "ugs_otutab_write_biom", "ugs_otutab_totals",
     "ugs_db_append", "ugs_params_set_cluster", "ugs_cluster_fast", "ugs_cluster_destroy", "ugs_cluster_counts", "ugs_cluster_get",
     "ugs_cluster_get_stats", "ugs_cluster_write_uc", "ugs_cluster_write_centroids",
+    "ugs_cluster_fast_sorted", "ugs_label_size", "ugs_cluster_write_centroids_sized",
 ]
 
 
@@ -93,6 +94,10 @@ def lib():
         L.ugs_cluster_get_stats.argtypes = [vp, C.POINTER(ClusterStats)]
         L.ugs_cluster_write_uc.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.ugs_cluster_write_centroids.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.ugs_cluster_fast_sorted.argtypes = [C.POINTER(Params), vp, vp, u32, i32, vp, i32, i32, C.POINTER(vp)]
+        L.ugs_label_size.argtypes = [C.c_char_p]
+        L.ugs_label_size.restype = u32
+        L.ugs_cluster_write_centroids_sized.argtypes = [vp, C.c_char_p, C.c_char_p, i32, u32]
         _lib = L
     return _lib
 
@@ -402,13 +407,20 @@ def cluster_params(id=0.97, strand_both=False, **kw):
 class UgsCluster:
     """ugs_cluster_fast on `device`; fields as the C-ABI returns them (see include/ugs.h)"""
 
-    def __init__(self, p, seqs, offs, device=0):
+    SORT = {None: 0, "": 0, "length": 1, "size": 2}
+
+    def __init__(self, p, seqs, offs, device=0, sort=None, labels=None, sizein=False):
+        """sort: None | "length" | "size" (-sort); labels: the input labels (their size= annotations feed -sort size / -sizein)"""
         L = lib()
         seqs = as_u8(seqs)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         n = len(offs) - 1
         self.h = C.c_void_p()
-        _chk(L.ugs_cluster_fast(C.byref(p), seqs.ctypes.data, offs.ctypes.data, n, device, C.byref(self.h)))
+        size_in = None
+        if labels is not None:
+            size_in = np.array([L.ugs_label_size(l.encode()) for l in labels], dtype=np.uint32)
+        _chk(L.ugs_cluster_fast_sorted(C.byref(p), seqs.ctypes.data, offs.ctypes.data, n, self.SORT[sort],
+                                       size_in.ctypes.data if size_in is not None else None, int(bool(sizein)), device, C.byref(self.h)))
         nu, nc, nh, nr = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
         _chk(L.ugs_cluster_counts(self.h, C.byref(nu), C.byref(nc), C.byref(nh), C.byref(nr)))
         self.n_unique, self.n_clusters = nu.value, nc.value
@@ -425,8 +437,9 @@ class UgsCluster:
     def write_uc(self, labels, path):
         _chk(lib().ugs_cluster_write_uc(self.h, b"".join(l.encode() + b"\0" for l in labels), path.encode()))
 
-    def write_centroids(self, labels, path):
-        _chk(lib().ugs_cluster_write_centroids(self.h, b"".join(l.encode() + b"\0" for l in labels), path.encode()))
+    def write_centroids(self, labels, path, sizein=False, sizeout=False, minsize=0):
+        _chk(lib().ugs_cluster_write_centroids_sized(self.h, b"".join(l.encode() + b"\0" for l in labels), path.encode(),
+                                                     (1 if sizein else 0) | (2 if sizeout else 0), minsize))
 
     def close(self):
         if self.h:

@@ -4,7 +4,7 @@
 //   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
-//   ugs_cli -cluster_fast reads.fa -id 0.97 [-strand both] -uc c.uc -centroids c.fa   (clusterfast.cpp:81-138)
+//   ugs_cli -cluster_fast reads.fa -id 0.97 [-strand both] [-sort length|size] [-sizein] [-sizeout] [-minsize n] -uc c.uc -centroids c.fa   (clusterfast.cpp:37-138)
 //   ugs_cli -usearch_local q.fa -db db.fa|db.udb -evalue 1e-6 [-id ..] -strand plus|both -blast6out f
 //   ugs_cli -closed_ref reads.fa -db ref.fa -strand plus|both -tabbedout f
 //   ugs_cli -otutab reads.fa -otus otus.fa|-zotus ..|-db .. [-otutabout f] [-mapout f] [+ the usearch_global outputs]
@@ -407,7 +407,7 @@ int main(int argc, char **argv)
   std::string qpath, dbpath, b6path, ucpath, strand, makeudb, outpath, userpath, matchedpath, notmatchedpath, dbmatchedpath, dbnotmatchedpath;
   std::string tabbedout, trimpath, matchedfqpath, notmatchedfqpath; bool closedref_cmd = false;
   std::string biomout;
-  std::string clusterfast, centroidspath;
+  std::string clusterfast, centroidspath, sortname; bool sizein = false, sizeout = false; long minsize = 0;
   std::string otutabout, mapout, alnpath, pairspath, qsegpath, tsegpath; bool otutab_cmd = false; long stepwords = -1;
   ugs_params filt; memset(&filt, 0, sizeof filt);                     // only the filter fields are used
   Outputs O;
@@ -419,6 +419,8 @@ int main(int argc, char **argv)
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
     if (a == "-makeudb_usearch") makeudb = val(); else if (a == "-output") outpath = val();
     else if (a == "-cluster_fast") clusterfast = val(); else if (a == "-centroids") centroidspath = val();
+    else if (a == "-sort") sortname = val(); else if (a == "-sizein") sizein = true; else if (a == "-sizeout") sizeout = true;
+    else if (a == "-minsize") minsize = atol(val());
     else if (a == "-otutab") { qpath = val(); otutab_cmd = true; } else if (a == "-otus" || a == "-zotus") dbpath = val();
     else if (a == "-closed_ref") { qpath = val(); closedref_cmd = true; } else if (a == "-tabbedout") tabbedout = val();
     else if (a == "-biomout") biomout = val();
@@ -479,13 +481,19 @@ int main(int argc, char **argv)
     if (maxacc >= 0) p.max_accepts = maxacc;
     if (maxrej >= 0) p.max_rejects = maxrej;
     if (big >= 0) p.big = (uint32_t)big;
+    int sort_mode = UGS_SORT_NONE;                                                           // GetSeqOrder clusterfast.cpp:37-66
+    if (sortname == "length") sort_mode = UGS_SORT_LENGTH; else if (sortname == "size") sort_mode = UGS_SORT_SIZE;
+    else if (sortname == "other") { fprintf(stderr, "-cluster_fast does not support -sort other, use -cluster_smallmem\n"); return 1; }
+    else if (!sortname.empty() && sortname != "user") { fprintf(stderr, "Invalid sort name %s\n", sortname.c_str()); return 1; }
+    std::vector<uint32_t> size_in(in.size());
+    for (size_t i = 0; i < in.size(); ++i) size_in[i] = ugs_label_size(in.labels[i].c_str());
     ugs_cluster *c = nullptr;
-    if (ugs_cluster_fast(&p, in.letters.data(), in.offs.data(), (uint32_t)in.size(), device, &c) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
+    if (ugs_cluster_fast_sorted(&p, in.letters.data(), in.offs.data(), (uint32_t)in.size(), sort_mode, size_in.data(), sizein, device, &c) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); return 1; }
     std::string labels;
     for (const std::string &l : in.labels) { labels += l; labels.push_back('\0'); }
     int rc = 0;
     if (!ucpath.empty() && ugs_cluster_write_uc(c, labels.data(), ucpath.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); rc = 1; }
-    if (!centroidspath.empty() && ugs_cluster_write_centroids(c, labels.data(), centroidspath.c_str()) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); rc = 1; }
+    if (!centroidspath.empty() && ugs_cluster_write_centroids_sized(c, labels.data(), centroidspath.c_str(), (sizein ? UGS_SIZEIN : 0) | (sizeout ? UGS_SIZEOUT : 0), (uint32_t)std::max(0l, minsize)) != UGS_OK) { fprintf(stderr, "%s\n", ugs_last_error()); rc = 1; }
     uint32_t nu = 0, nc = 0;
     ugs_cluster_counts(c, &nu, &nc, nullptr, nullptr);
     fprintf(stderr, "%zu seqs, %u uniques, %u clusters\n", in.size(), nu, nc);

@@ -336,7 +336,25 @@ extern "C" void ugs_cluster_destroy(ugs_cluster *c) { delete c; }
 
 extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const uint64_t *offs, uint32_t nseq, int device, ugs_cluster **out)
 {
+  return ugs_cluster_fast_sorted(pp, seqs, offs, nseq, UGS_SORT_NONE, nullptr, 0, device, out);
+}
+
+// GetSizeFromLabel label.cpp:152-161
+extern "C" uint32_t ugs_label_size(const char *label)
+{
+  const char *z = label ? strstr(label, ";size=") : nullptr;
+  return z ? (uint32_t)atoi(z + 6) : 0xffffffffu;
+}
+
+extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, const uint64_t *offs, uint32_t nseq, int sort_mode,
+                                       const uint32_t *size_in, int sizein, int device, ugs_cluster **out)
+{
   if (!pp || !offs || !out || (nseq && !seqs)) { ugs_set_error("null argument"); return UGS_E_ARG; }
+  if (sort_mode != UGS_SORT_NONE && sort_mode != UGS_SORT_LENGTH && sort_mode != UGS_SORT_SIZE) { ugs_set_error("Invalid sort name"); return UGS_E_ARG; }   // clusterfast.cpp:65-66
+  if (sizein) {                                                                                    // GetSizeFromLabel(Label, UINT_MAX) label.cpp:158-159
+    if (!size_in) { ugs_set_error("-sizein needs the labels' size= values"); return UGS_E_ARG; }
+    for (uint32_t i = 0; i < nseq; ++i) if (size_in[i] == 0xffffffffu) { ugs_set_error("Missing size= in the label of input sequence %u", i); return UGS_E_ARG; }
+  }
   if (!pp->id_set) { ugs_set_error("Must specify -id"); return UGS_E_ARG; }                     // makeclustersearcher.cpp:30-31
   if (pp->max_accepts != 1 || pp->dbmask != 2 || pp->local || pp->pair_mask || pp->align_flags || (pp->filter_mask & UGS_F_ABSKEW)) {
     ugs_set_error("cluster_fast: use ugs_params_set_cluster (one accept per strand, letters as read); pair filters / -fulldp / -termid are not supported here");
@@ -356,8 +374,20 @@ extern "C" int ugs_cluster_fast(const ugs_params *pp, const char *seqs, const ui
   const uint32_t nu = derep_full(S, O, nseq, revcomp, C->seq_unique, C->uniq_seed);
   C->st.s_derep = (float)(now_s() - t_start);
   C->n_unique = nu;
+  if (sort_mode != UGS_SORT_NONE && nu) {
+    // GetSeqOrder clusterfast.cpp:37-79: QuickSortOrderDesc over the seeds' lengths or DerepResult::GetSumSizeIn (size= with default 1,
+    // whether or not -sizein is set: derepresult.cpp:211-225); the uniques are renumbered in that order = the loop order :113-123
+    std::vector<uint32_t> v(nu, 0), order(nu), rank(nu), seed2(nu);
+    if (sort_mode == UGS_SORT_LENGTH) for (uint32_t u = 0; u < nu; ++u) v[u] = (uint32_t)(O[C->uniq_seed[u] + 1] - O[C->uniq_seed[u]]);
+    else for (uint32_t i = 0; i < nseq; ++i) v[C->seq_unique[i]] += (size_in && size_in[i] != 0xffffffffu) ? size_in[i] : 1;
+    for (uint32_t u = 0; u < nu; ++u) order[u] = u;
+    qs_order_desc_u(v.data(), 0, (int)nu - 1, order.data());
+    for (uint32_t k = 0; k < nu; ++k) { rank[order[k]] = k; seed2[k] = C->uniq_seed[order[k]]; }
+    for (uint32_t i = 0; i < nseq; ++i) C->seq_unique[i] = rank[C->seq_unique[i]];
+    C->uniq_seed.swap(seed2);
+  }
   C->uniq_size.assign(nu, 0);
-  for (uint32_t i = 0; i < nseq; ++i) ++C->uniq_size[C->seq_unique[i]];
+  for (uint32_t i = 0; i < nseq; ++i) C->uniq_size[C->seq_unique[i]] += sizein ? size_in[i] : 1;     // ClusterSink::GetSize clustersink.cpp:119-150
   C->uniq_cluster.assign(nu, 0); C->uniq_nhits.assign(nu, 0); C->uniq_hit_off.assign((size_t)nu + 1, 0);
   uint32_t maxlen = 0;
   for (uint32_t u = 0; u < nu; ++u) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(O[C->uniq_seed[u] + 1] - O[C->uniq_seed[u]]));
@@ -728,6 +758,31 @@ extern "C" int ugs_cluster_write_uc(const ugs_cluster *c, const char *labels, co
 // reference's QuickSortOrderDesc, 80 columns (SeqToFasta seqdb.cpp:62-90)
 extern "C" int ugs_cluster_write_centroids(const ugs_cluster *c, const char *labels, const char *path)
 {
+  return ugs_cluster_write_centroids_sized(c, labels, path, 0, 0);
+}
+
+// StripSize = StripAnnot(Label, "size=") label.cpp:46-71 over Split(';') myutils.cpp:1588-1607
+static void strip_size(std::string &label)
+{
+  if (label.find("size=") == std::string::npos) return;
+  std::string out, field;
+  auto put = [&](const std::string &f) { if (f.compare(0, 5, "size=") != 0) { out += f; out += ';'; } };
+  for (char ch : label) { if (ch == ';') { put(field); field.clear(); } else field.push_back(ch); }
+  if (!field.empty()) put(field);
+  if (out.find('=') == std::string::npos && !out.empty()) out.pop_back();
+  label.swap(out);
+}
+
+// AppendSize -> Psasc myutils.cpp:824-839
+static void append_size(std::string &label, uint32_t size)
+{
+  if (!label.empty() && label.back() != ';') label += ';';
+  label += "size=" + std::to_string(size) + ";";
+}
+
+// + MakeCentroidLabel clustersink.cpp:219-243 (-sizein | -sizeout strip size=, -sizeout appends the cluster size) and -minsize (:275-277)
+extern "C" int ugs_cluster_write_centroids_sized(const ugs_cluster *c, const char *labels, const char *path, int size_flags, uint32_t minsize)
+{
   if (!c || !labels || !path) { ugs_set_error("null argument"); return UGS_E_ARG; }
   std::vector<const char *> lab;
   split_labels(labels, c->nseq, lab);
@@ -741,8 +796,12 @@ extern "C" int ugs_cluster_write_centroids(const ugs_cluster *c, const char *lab
     const uint32_t si = c->uniq_seed[c->centroid_uniq[order[k]]];
     const char *s = c->seqs.data() + c->offs[si];
     const uint32_t L = (uint32_t)(c->offs[si + 1] - c->offs[si]);
+    if (c->cluster_size[order[k]] < minsize) break;
     if (L == 0) continue;
-    ok = ok && fprintf(f, ">%s\n", lab[si]) >= 0;
+    std::string label = lab[si];
+    if (size_flags & (UGS_SIZEIN | UGS_SIZEOUT)) strip_size(label);
+    if (size_flags & UGS_SIZEOUT) append_size(label, c->cluster_size[order[k]]);
+    ok = ok && fprintf(f, ">%s\n", label.c_str()) >= 0;
     for (uint32_t from = 0; from < L && ok; from += 80) {
       const uint32_t n = std::min<uint32_t>(80, L - from);
       ok = ok && fwrite(s + from, 1, n, f) == n && fputc('\n', f) != EOF;
