@@ -14,8 +14,8 @@ from usearch12_amd.abi import Params, HIT_DTYPE, ClusterStats
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "ugs.h")).read()
+def _declared(header="ugs.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ugs_[a-z0-9_]+)\s*\(", txt)))
 
@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
     assert sorted(capi.EXPORTS) == names
     assert L.ugs_abi_version() == 5
+
+
+def test_rccl_library_exports_every_symbol_of_ugs_comm_h():
+    names = _declared("ugs_comm.h")
+    assert sorted(capi.COMM_EXPORTS) == names
+    L = capi.lib_rccl()                       # loads without a GPU: librccl is only called by the entry points
+    for n in names:
+        assert hasattr(L, n), n
 
 
 def test_struct_layouts():

@@ -1,0 +1,90 @@
+"""include/ugs_comm.h on a GPU: the gather of device-resident hit tables to one rank.
+ * RCCL transport with the world a single-GPU box allows (1 rank): ncclCommInitRank from a unique id and ncclCommInitAll;
+ * loopback transport with 2 and 3 ranks on one device (RCCL refuses two ranks per GPU): sizes exchange, placement in rank
+   order, query ids, path-offset rebasing, HitMgr::Sort on the destination - everything except the RCCL calls themselves.
+The gathered tables must equal what one ugs_batch_fetch over all queries returns."""
+import threading
+
+import numpy as np
+import pytest
+
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(both=True):
+    db = synth.make_db(31, 3000, 220)
+    qs = synth.make_queries(31, db, 900, 220)
+    if both:
+        qs = synth.revcomp_some(31, qs)
+    p = capi.params(is_nucleo=True, id=0.9, max_accepts=3, max_rejects=16, strand_both=1 if both else 0)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    return gdb, qs, bat.fetch()
+
+
+def _runs(h, pool):
+    return [tuple(pool[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["cigar_len"])]) for r in h]
+
+
+def _same(got, want):
+    (h, n, p), (h0, n0, p0) = got, want
+    assert np.array_equal(n, n0)
+    assert len(h) == len(h0)
+    for f in h.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(h[f], h0[f]), f
+    assert _runs(h, p) == _runs(h0, p0)
+
+
+def _shard_batches(gdb, qs, world):
+    out = []
+    for r in range(world):
+        lo, hi = (qs.n * r) // world, (qs.n * (r + 1)) // world
+        if r == 1:
+            hi = lo                                        # an empty shard in the middle: the rank still takes part
+        sub = qs.slice(lo, hi)
+        b = capi.UgsBatch(gdb, max(1, sub.n), max(1, int(sub.offs[-1])))
+        b.upload(sub.seqs, sub.offs); b.search(); b.sync()
+        out.append((lo, hi, b))
+    return out
+
+
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, 2)])
+def test_loopback_gather_equals_one_fetch(world, dst):
+    gdb, qs, want = _setup()
+    shards = _shard_batches(gdb, qs, world)
+    keep = np.concatenate([np.arange(lo, hi) for lo, hi, _ in shards]) if shards else np.zeros(0, int)
+    comms = capi.UgsComm.init_loopback(world, 0)
+    res, err = [None] * world, []
+
+    def run(r):
+        try:
+            res[r] = comms[r].gather(shards[r][2], shards[r][0], dst=dst)
+        except Exception as e:                               # a failing rank must not leave the others in the barrier
+            err.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(120) for t in th]
+    assert not err, err
+    assert all(res[r] is None for r in range(world) if r != dst)
+    h0, n0, p0 = want
+    # the reference table restricted to the queries that were sharded (rank 1's shard is empty)
+    mask = np.isin(h0["query"], keep)
+    _same(res[dst], (h0[mask], n0[keep], p0))
+    [c.close() for c in comms]
+
+
+def test_rccl_world_of_one_from_unique_id_and_init_all():
+    gdb, qs, want = _setup(both=False)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    c = capi.UgsComm.init_rank(capi.UgsComm.unique_id(), 0, 1, 0)
+    _same(c.gather(bat, 0), want)
+    got = c.gather(bat, 0, hits_cap=len(want[0]) + 8, nq_cap=qs.n, pool_cap=len(want[2]) + 64)     # roomy buffers: one call
+    _same(got, want)
+    c.close()
+    (c2,) = capi.UgsComm.init_all([0])
+    _same(c2.gather(bat, 0), want)
+    c2.close()

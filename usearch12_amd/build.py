@@ -5,9 +5,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
+LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
 SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
 DEPS = SOURCES + ["ugs_dev.h", "ugs_host.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 
 
@@ -31,9 +33,22 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    g_src, g_obj = os.path.join(CSRC, "ugs_gather.cpp"), os.path.join(CSRC, "ugs_gather.o")
+    g_new = max(newest, _mtime(g_src), _mtime(os.path.join(HERE, "..", "include", "ugs_comm.h")))
+    if force or _mtime(g_obj) < g_new:
+        cmd = ["hipcc"] + FLAGS + ["-c", g_src, "-o", g_obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if force or _mtime(LIB_RCCL) < max(_mtime(g_obj), _mtime(LIB)):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_RCCL, g_obj, "-L" + HERE, "-lugs",
+               "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     cli_src = os.path.join(CSRC, "ugs_cli.cpp")
-    if force or _mtime(CLI) < max(_mtime(cli_src), _mtime(LIB)):
-        cmd = ["hipcc", "-O2", "-std=c++17", "-pthread", "-o", CLI, cli_src, "-L" + HERE, "-lugs", "-Wl,-rpath,$ORIGIN"]
+    if force or _mtime(CLI) < max(_mtime(cli_src), _mtime(LIB), _mtime(LIB_RCCL)):
+        cmd = ["hipcc", "-O2", "-std=c++17", "-pthread", "-o", CLI, cli_src, "-L" + HERE, "-lugs_rccl", "-lugs", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

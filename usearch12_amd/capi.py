@@ -451,3 +451,86 @@ class UgsCluster:
             self.close()
         except Exception:
             pass
+
+
+# ---- include/ugs_comm.h: the RCCL gather of device-resident hit tables (libugs_rccl.so)
+LIB_RCCL_PATH = os.path.join(HERE, "libugs_rccl.so")
+_lib_rccl = None
+COMM_EXPORTS = ["ugs_comm_unique_id", "ugs_comm_init_rank", "ugs_comm_init_all", "ugs_comm_init_loopback", "ugs_comm_destroy",
+                "ugs_comm_rank", "ugs_comm_world", "ugs_gather_results", "ugs_gather_refetch", "ugs_gather_last_times"]
+
+
+def lib_rccl():
+    global _lib_rccl
+    if _lib_rccl is None:
+        lib()                                                   # libugs.so first: libugs_rccl.so resolves its symbols against it
+        if not os.path.exists(LIB_RCCL_PATH):
+            raise ImportError("usearch12_amd/libugs_rccl.so is missing - run __graft_entry__.build()")
+        L = C.CDLL(LIB_RCCL_PATH, mode=C.RTLD_GLOBAL)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.ugs_comm_unique_id.argtypes = [C.c_char_p]
+        L.ugs_comm_init_rank.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+        L.ugs_comm_init_all.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+        L.ugs_comm_init_loopback.argtypes = [i32, i32, C.POINTER(vp)]
+        L.ugs_comm_destroy.argtypes = [vp]
+        L.ugs_comm_destroy.restype = None
+        L.ugs_comm_rank.argtypes = [vp]
+        L.ugs_comm_world.argtypes = [vp]
+        L.ugs_gather_results.argtypes = [vp, vp, u32, i32, vp, u64, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.ugs_gather_refetch.argtypes = [vp, vp, u64, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.ugs_gather_last_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib_rccl = L
+    return _lib_rccl
+
+
+class UgsComm:
+    """one rank's communicator (include/ugs_comm.h)"""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _chk(lib_rccl().ugs_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid, rank, world, device):
+        h = C.c_void_p()
+        _chk(lib_rccl().ugs_comm_init_rank(uid, rank, world, device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def init_all(cls, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        hs = (C.c_void_p * len(devices))()
+        _chk(lib_rccl().ugs_comm_init_all(len(devices), arr, hs))
+        return [cls(h) for h in hs]
+
+    @classmethod
+    def init_loopback(cls, world, device=0):
+        hs = (C.c_void_p * world)()
+        _chk(lib_rccl().ugs_comm_init_loopback(world, device, hs))
+        return [cls(h) for h in hs]
+
+    def gather(self, batch, query_base, dst=0, hits_cap=0, nq_cap=0, pool_cap=0):
+        """collective; on dst returns (hits, nhits_per_query, pool), elsewhere None.  Capacities 0: sized by a first call's demand."""
+        L = lib_rccl()
+        nh, nq, nr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        hits = np.zeros(max(1, hits_cap), HIT_DTYPE); cnt = np.zeros(max(1, nq_cap), np.uint32); pool = np.zeros(max(1, pool_cap), np.uint32)
+        rc = L.ugs_gather_results(self.h, batch.h, query_base, dst, hits.ctypes.data, hits_cap, cnt.ctypes.data, nq_cap, pool.ctypes.data, pool_cap,
+                                  C.byref(nh), C.byref(nq), C.byref(nr))
+        if rc == -5:                                            # UGS_E_CAPACITY on dst: the exchange is done, fetch again with room
+            hits = np.zeros(max(1, nh.value), HIT_DTYPE); cnt = np.zeros(max(1, nq.value), np.uint32); pool = np.zeros(max(1, nr.value), np.uint32)
+            rc = L.ugs_gather_refetch(self.h, hits.ctypes.data, len(hits), cnt.ctypes.data, len(cnt), pool.ctypes.data, len(pool),
+                                      C.byref(nh), C.byref(nq), C.byref(nr))
+        _chk(rc)
+        if L.ugs_comm_rank(self.h) != dst:
+            return None
+        return hits[:nh.value], cnt[:nq.value], pool[:nr.value]
+
+    def close(self):
+        if self.h:
+            lib_rccl().ugs_comm_destroy(self.h)
+            self.h = C.c_void_p()
