@@ -88,3 +88,28 @@ def test_rccl_world_of_one_from_unique_id_and_init_all():
     (c2,) = capi.UgsComm.init_all([0])
     _same(c2.gather(bat, 0), want)
     c2.close()
+
+
+@pytest.mark.parametrize("name", ["hard_both", "hard_aa", "hard_acc0"])
+def test_cli_gather_path_text_identical_to_reference(name, tmp_path):
+    """ugs_cli's multi-GPU stage (-gpus N: one host thread per device, the rounds' hit tables gathered to rank 0 over RCCL) with the
+    one device a test box has: UGS_CLI_FORCE_GATHER sends -gpus 1 through it.  Several rounds (-batch 300); byte-identical files."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import golden_util as G
+    c, db, qs, b6, uc = G.load(name)
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    db.write_fasta(dbfa); qs.write_fasta(qfa)
+    cmd = [cli, "-usearch_global", qfa, "-db", dbfa, "-id", str(c["id"]), "-blast6out", str(tmp_path / "o.b6"), "-uc", str(tmp_path / "o.uc"),
+           "-batch", "300", "-gpus", "1"]
+    if not c["aa"]:
+        cmd += ["-strand", c["strand"]]
+    for opt in ("big", "maxaccepts", "maxrejects"):
+        if opt in c:
+            cmd += ["-" + opt, str(c[opt])]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL, env=dict(os.environ, UGS_CLI_FORCE_GATHER="1"))
+    assert open(tmp_path / "o.b6").read() == b6
+    assert open(tmp_path / "o.uc").read() == uc

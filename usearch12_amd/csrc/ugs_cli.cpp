@@ -16,6 +16,7 @@
 // The mirror of the reference's object surface is deliberately thin: Searcher::Search(batch),
 // HitMgr (hit grouping, done inside ugs_batch_fetch) and OutputSink (the text writers).
 #include "../../include/ugs.h"
+#include "../../include/ugs_comm.h"
 
 #include <cctype>
 #include <cstdio>
@@ -204,6 +205,20 @@ class Searcher {
     std::vector<uint32_t> k, z;
     keys_of(db, k, z);
     if (ugs_db_set_pair_keys(db_, k.data(), z.data()) != UGS_OK) die("ugs_db_set_pair_keys");
+  }
+  // upload + search + sync, results left on the device (multi-GPU: they are gathered with ugs_gather_results); q may be empty
+  ugs_batch *SearchOnDevice(const SeqSet &q) {
+    const uint32_t nq = (uint32_t)q.size();
+    if (!b_ || nq > bq_ || q.letters.size() > bl_) {
+      if (b_) ugs_batch_destroy(b_);
+      bq_ = std::max<uint32_t>(std::max<uint32_t>(nq, 1), bq_); bl_ = std::max<uint64_t>(std::max<uint64_t>(q.letters.size(), 1), bl_);
+      if (ugs_batch_create(db_, bq_, bl_, &b_) != UGS_OK) die("ugs_batch_create");
+    }
+    int rc = ugs_batch_upload(b_, q.letters.data(), q.offs.data(), nq);
+    if (rc == UGS_OK) rc = ugs_batch_search(b_);
+    if (rc == UGS_OK) rc = ugs_batch_sync(b_);
+    if (rc != UGS_OK) die("search");
+    return b_;
   }
   void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
     const uint32_t nq = (uint32_t)q.size();
@@ -413,6 +428,7 @@ int main(int argc, char **argv)
   Outputs O;
   bool hardmask = false;
   bool local_cmd = false; double evalue = -1; double xdrop_u = -1, xdrop_g = -1, ka_dbsize = -1; long maxhsps = -1, hspw = -1;
+  int ngpus = 1;                                                     // -gpus N: devices device .. device+N-1, one host thread each
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 18; int dbtype = -1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -431,7 +447,7 @@ int main(int argc, char **argv)
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
-    else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
+    else if (a == "-big") big = atol(val()); else if (a == "-device") device = atoi(val()); else if (a == "-gpus") ngpus = atoi(val()); else if (a == "-batch") batch = (size_t)atol(val());
     else if (a == "-maxid") { filt.maxid = (float)atof(val()); filt.filter_mask |= UGS_F_MAXID; }
     else if (a == "-mincols") { filt.mincols = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MINCOLS; }
     else if (a == "-maxgaps") { filt.maxgaps = (uint32_t)atol(val()); filt.filter_mask |= UGS_F_MAXGAPS; }
@@ -664,6 +680,66 @@ int main(int argc, char **argv)
         total += r.q->size();
       }
     });
+    if (ngpus > 1 || getenv("UGS_CLI_FORCE_GATHER")) {            // (the variable sends a single-GPU run through the gather path: tests)
+      // stage 2 on N GPUs: the index is replicated, every round hands N consecutive query batches to the N devices
+      // (one host thread each), and the only exchange is the gather of the round's device-resident hit tables to rank 0 over
+      // RCCL (include/ugs_comm.h), which arrive in rank order = query order and go to the sinks as one result
+      if (searcher.pair_keys()) { fprintf(stderr, "-gpus: pair filters / -abskew are single-GPU options here\n"); exit(1); }
+      std::vector<std::unique_ptr<Searcher>> reps((size_t)ngpus);
+      {
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngpus; ++g) th.emplace_back([&, g] { reps[(size_t)g].reset(new Searcher(p, db, device + g)); });
+        for (auto &x : th) x.join();
+      }
+      std::vector<int> devs((size_t)ngpus);
+      for (int g = 0; g < ngpus; ++g) devs[(size_t)g] = device + g;
+      std::vector<ugs_comm *> comms((size_t)ngpus, nullptr);
+      if (ugs_comm_init_all(ngpus, devs.data(), comms.data()) != UGS_OK) { fprintf(stderr, "ugs_comm_init_all: %s\n", ugs_last_error()); exit(1); }
+      const SeqSet empty;
+      for (bool more = true; more;) {
+        std::vector<std::unique_ptr<SeqSet>> qs((size_t)ngpus);
+        int got = 0;
+        for (; got < ngpus; ++got) if (!parsed.pop(qs[(size_t)got])) { more = false; break; }
+        if (got == 0) break;
+        std::vector<uint32_t> base((size_t)ngpus + 1, 0);
+        for (int g = 0; g < ngpus; ++g) base[(size_t)g + 1] = base[(size_t)g] + (qs[(size_t)g] ? (uint32_t)qs[(size_t)g]->size() : 0u);
+        const uint32_t nq = base[(size_t)ngpus];
+        SearchResult r;
+        r.hits.resize((size_t)nq * p.max_accepts * (p.strand_both ? 2 : 1) * (p.local ? p.max_hsps : 1) + 1);
+        r.nhits.assign((size_t)nq + 1, 0);
+        r.pool.resize(24 * (size_t)nq + 4096);
+        std::vector<int> rcs((size_t)ngpus, UGS_OK);
+        auto rank_work = [&](int g) {
+          Searcher &S = g == 0 ? searcher : *reps[(size_t)g];
+          ugs_batch *b = S.SearchOnDevice(qs[(size_t)g] ? *qs[(size_t)g] : empty);
+          uint64_t nh = 0, nqt = 0, used = 0;
+          int rc = ugs_gather_results(comms[(size_t)g], b, base[(size_t)g], 0, g == 0 ? r.hits.data() : nullptr, g == 0 ? r.hits.size() : 0,
+                                      g == 0 ? r.nhits.data() : nullptr, g == 0 ? r.nhits.size() : 0, g == 0 ? r.pool.data() : nullptr,
+                                      g == 0 ? r.pool.size() : 0, &nh, &nqt, &used);
+          if (g == 0 && rc == UGS_E_CAPACITY) {               // the exchange is complete: only the host copy is repeated with room
+            r.hits.resize(nh + 1); r.nhits.resize(nqt + 1); r.pool.resize(used + 1024);
+            rc = ugs_gather_refetch(comms[0], r.hits.data(), r.hits.size(), r.nhits.data(), r.nhits.size(), r.pool.data(), r.pool.size(), &nh, &nqt, &used);
+          }
+          if (rc != UGS_OK) fprintf(stderr, "gather (rank %d): %s\n", g, ugs_last_error());      // (the message is per thread)
+          rcs[(size_t)g] = rc;
+        };
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngpus; ++g) th.emplace_back(rank_work, g);
+        rank_work(0);
+        for (auto &x : th) x.join();
+        for (int g = 0; g < ngpus; ++g) if (rcs[(size_t)g] != UGS_OK) exit(1);
+        // the round's queries as one set, in rank order
+        r.q = std::move(qs[0]);
+        for (int g = 1; g < got; ++g) {
+          SeqSet &d = *r.q; const SeqSet &a = *qs[(size_t)g];
+          const uint64_t off0 = d.letters.size();
+          d.letters += a.letters; d.quals += a.quals;
+          for (size_t i = 0; i < a.size(); ++i) { d.labels.push_back(a.labels[i]); d.offs.push_back(off0 + a.offs[i + 1]); }
+        }
+        results.push(std::move(r));
+      }
+      for (ugs_comm *c : comms) ugs_comm_destroy(c);
+    } else
     for (;;) {                                                        // stage 2: the GPU
       std::unique_ptr<SeqSet> q;
       if (!parsed.pop(q)) break;
