@@ -46,7 +46,11 @@ def check(name, db, qs, aa, ident, n_oracle, **kw):
             ok = ok and np.array_equal(pool[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])],
                                        opool[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])])
     out = dict(config=name, ok=bool(ok), db_seqs=db.n, queries=qs.n, hits=int(len(hits)), queries_per_s=round(qs.n / (best["ms_total"] * 1e-3)),
-               ms_rank=round(best["ms_rank"], 2), ms_align=round(best["ms_align"], 2), index_build_s=round(t_build, 2),
+               ms_rank=round(best["ms_rank"], 2), ms_align=round(best["ms_align"], 2), ms_rank_setup=round(best["ms_rank_setup"], 2),
+               postings_per_query=round(best["postings"] / max(1, qs.n)),
+               rank_algorithmic_GBps=round((4.0 * best["postings"] + best["query_letters"]) / (best["ms_rank"] * 1e-3) / 1e9, 1),
+               rank_frac_of_hbm_peak=round((4.0 * best["postings"] + best["query_letters"]) / (best["ms_rank"] * 1e-3) / 8e12, 4),
+               pairs_aligned=int(best["pairs_aligned"]), index_build_s=round(t_build, 2),
                oracle_checked_queries=n_oracle, oracle_index_build_s=round(t_obuild, 1), oracle_search_s=round(t2 - t1 - t_obuild, 1))
     print(json.dumps(out), flush=True)
     return ok
@@ -61,6 +65,7 @@ if "C4" in which:
     db = synth.make_db(4, 5_000_000, 250); qs = synth.make_queries(4, db, 500_000, 250)
     ok &= check("C4 shard: 500k x 250nt vs 5M", db, qs, False, 0.97, 20_000)
 if "C5" in which:
-    db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 200_000, 300, aa=True)
-    ok &= check("C5 200k x 300aa vs 2M", db, qs, True, 0.8, 10_000)
+    nq5 = 1_000_000 if "full" in which else 200_000
+    db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, nq5, 300, aa=True)
+    ok &= check("C5 %dk x 300aa vs 2M" % (nq5 // 1000), db, qs, True, 0.8, 10_000)
 print("ALL OK" if ok else "FAILED")

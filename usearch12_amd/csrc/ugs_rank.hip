@@ -1432,6 +1432,39 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
       // fewer than K candidates with count >= 2: append count-1 targets in scan order if the
       // cut-offs keep them (MinValue <= 1; small path additionally position < first MinU bump)
       if (min_value > 1 || sh->M == 0) break;
+      if constexpr (!SMALL) {
+        // Big path: the count-1 targets in first-touch order are the postings of row 0 in ascending target order, then those of
+        // row 1 that no earlier row holds, ...  A target has count 1 exactly when it is not one of the count >= 2 targets, and
+        // those are all selected already (the list is exhausted and MinValue <= 1 keeps every one of them): fewer than K, one per
+        // lane.  So the fill is a walk over the first few postings of the first row(s) against that list - no second scan.
+        if (wave == 0) {
+          const uint32_t mine = (uint32_t)lane < nsel ? bv.cand[(uint64_t)unit * K + lane] : 0xffffffffu;
+          uint32_t filled = nsel;
+          for (uint32_t r = 0; r < ns && filled < K; ++r) {
+            const uint32_t slot = s_slots[r];
+            const uint64_t ra = db.row_off[slot], rb = db.row_off[slot + 1];
+            for (uint64_t k0 = ra; k0 < rb && filled < K; k0 += 64) {
+              const bool on = k0 + (uint64_t)lane < rb;
+              const uint32_t t = on ? db.postings[k0 + lane] : 0u;
+              bool in_set = false;
+              for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+              const bool e = on && !in_set;
+              const uint64_t m = __ballot(e);
+              const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              if (e && filled + rank < K) {
+                bv.cand[(uint64_t)unit * K + filled + rank] = t;
+                bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u;
+                if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + filled + rank] = make_key(1, ((uint64_t)r << 32) | t);
+              }
+              const uint32_t n = (uint32_t)__popcll(m);
+              filled = filled + n < K ? filled + n : K;
+            }
+          }
+          if (lane == 0) sh->n_sel = filled;
+        }
+        __syncthreads();
+        break;
+      }
       const uint32_t need = K - nsel;
       const uint64_t fill_limit = sh->fill_limit;
       __syncthreads();
