@@ -228,6 +228,50 @@ __device__ __forceinline__ void range_generic(const ScanCtx &s, uint32_t p, bool
   uint32_t *tbl = s.tbl;
   const uint32_t *postings = s.postings;
   uint32_t quota_left = need;
+  if constexpr (FLATPF && !FILL) {
+    // sparse rows, at most 64 of them, and the whole range holds at most two instructions' worth of postings (the usual case
+    // of a protein index): bounds, flattening and postings are fetched ONCE and serve the count pass and the extract pass
+    if (ns <= 64) {
+      uint64_t a = 0, b = 0;
+      if (have_ab) { a = a_in; b = b_in; }
+      else if ((uint32_t)lane < ns) row_bounds(s, s.s_slots[lane], p, split, base_t, hi_t, a, b);
+      const uint64_t rows = __ballot(b > a);
+      if (!rows) return;
+      FlatRows fr;
+      if (flat_rows_setup(fr, a, b, rows) && fr.T <= 128) {
+        uint32_t row[2] = {0, 0}, t[2] = {0, 0}; bool on[2]; uint64_t k0, k1;
+        on[0] = flat_rows_at(fr, (uint32_t)lane, row[0], k0);
+        on[1] = fr.T > 64 && flat_rows_at(fr, 64 + (uint32_t)lane, row[1], k1);
+        t[0] = on[0] ? postings[k0] : 0u; t[1] = on[1] ? postings[k1] : 0u;
+        if (on[0]) Tbl<CB>::inc(tbl, t[0] - base_t);
+        if (on[1]) Tbl<CB>::inc(tbl, t[1] - base_t);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && fr.T <= 64) break;
+          const bool o2 = on[h];
+          const uint32_t t2 = t[h];
+          const uint32_t c2 = o2 ? Tbl<CB>::get(tbl, t2 - base_t) : 0u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+          // an instruction spans several rows: a target held by two of its lanes (count >= 2) is reported by the lower lane = the
+          // earlier row only, as the row-by-row walk would
+          bool dup = false;
+          uint64_t m = __ballot(o2 && c2 >= 2);
+          while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t2, L);
+            const bool same = o2 && lane > L && t2 == tL;
+            dup = dup || same;
+            m &= ~(__ballot(same) | (1ull << L));
+          }
+          extract_one<CB, FILL>(s, o2 && !dup, t2, base_t, row[h], c2, quota_left, fill_limit);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        return;
+      }
+    }
+  }
   for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
     uint64_t a = 0, b = 0;
     if (have_ab) { a = a_in; b = b_in; }                       // (ns <= 64: the caller tracks each row's cursor)
@@ -501,6 +545,22 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
         if (!__ballot(cur > a)) continue;                        // no sampled row has a posting in this range
         range_generic<CB, FILL, BATCH, FLATPF>(s, p, split, base_t, hi_t, need, fill_limit, true, a, cur);
       }
+    }
+    return;
+  }
+  if (!split && s.ns <= 64) {
+    // at most one row per lane and the table spans the partition: the lane keeps its row's start and reads the NEXT partition's
+    // sub-row bounds while the current partition is counted (one global round trip per partition less, twice: both passes)
+    uint64_t rb = 0; const uint32_t *pp = s.part;
+    if ((uint32_t)s.lane < s.ns) { const uint32_t slot = s.s_slots[s.lane]; rb = s.row_off[slot]; pp = s.part + (uint64_t)slot * (s.np + 1); }
+    uint32_t lo = 0, hi = 0;
+    if ((uint32_t)s.lane < s.ns && (uint32_t)s.wave < s.np) { lo = pp[s.wave]; hi = pp[s.wave + 1]; }
+    for (uint32_t p = s.wave; p < s.np; p += s.wpb) {
+      const uint32_t pn = p + s.wpb;
+      uint32_t nlo = 0, nhi = 0;
+      if ((uint32_t)s.lane < s.ns && pn < s.np) { nlo = pp[pn]; nhi = pp[pn + 1]; }
+      range_generic<CB, FILL, BATCH, FLATPF>(s, p, false, p * s.gsize, 0, need, fill_limit, true, rb + lo, rb + hi);
+      lo = nlo; hi = nhi;
     }
     return;
   }
