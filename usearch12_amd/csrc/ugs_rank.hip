@@ -549,16 +549,84 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
     return;
   }
   if (!split && s.ns <= 64) {
-    // at most one row per lane and the table spans the partition: the lane keeps its row's start and reads the NEXT partition's
-    // sub-row bounds while the current partition is counted (one global round trip per partition less, twice: both passes)
+    // at most one row per lane and the table spans the partition: the lane keeps its row's start and reads the sub-row bounds of
+    // the partitions ahead while the current one is counted (one global round trip per partition less, twice: both passes)
     uint64_t rb = 0; const uint32_t *pp = s.part;
-    if ((uint32_t)s.lane < s.ns) { const uint32_t slot = s.s_slots[s.lane]; rb = s.row_off[slot]; pp = s.part + (uint64_t)slot * (s.np + 1); }
+    const bool rowlane = (uint32_t)s.lane < s.ns;
+    if (rowlane) { const uint32_t slot = s.s_slots[s.lane]; rb = s.row_off[slot]; pp = s.part + (uint64_t)slot * (s.np + 1); }
+    if constexpr (FLATPF && !FILL) {
+      // sparse rows (protein index): a partition's postings - the sub-rows of all rows flattened row-major, usually fewer than
+      // 128 - are located and REQUESTED one partition ahead, so that a partition costs no exposed global round trip at all
+      // (bounds two ahead, postings one ahead, both passes on registers)
+      struct Ahead { uint64_t a, b; FlatRows fr; bool flat, on[2]; uint32_t row[2], t[2]; };
+      auto prepare = [&](uint32_t lo, uint32_t hi, Ahead &A) {
+        A.a = rb + lo; A.b = rb + hi;
+        const uint64_t rows = __ballot(A.b > A.a);
+        A.flat = flat_rows_setup(A.fr, A.a, A.b, rows) && A.fr.T <= 128;
+        A.on[0] = A.on[1] = false; A.t[0] = A.t[1] = 0; A.row[0] = A.row[1] = 0;
+        if (A.flat) {
+          uint64_t k0 = 0, k1 = 0;
+          A.on[0] = flat_rows_at(A.fr, (uint32_t)s.lane, A.row[0], k0);
+          A.on[1] = A.fr.T > 64 && flat_rows_at(A.fr, 64 + (uint32_t)s.lane, A.row[1], k1);
+          A.t[0] = A.on[0] ? s.postings[k0] : 0u; A.t[1] = A.on[1] ? s.postings[k1] : 0u;
+        }
+      };
+      uint32_t quota_left = 0;
+      const uint32_t p0 = s.wave, p1 = p0 + s.wpb;
+      if (p0 >= s.np) return;
+      uint32_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
+      if (rowlane) { lo = pp[p0]; hi = pp[p0 + 1]; if (p1 < s.np) { lo1 = pp[p1]; hi1 = pp[p1 + 1]; } }
+      Ahead cur, nxt;
+      prepare(lo, hi, cur);
+      for (uint32_t p = p0; p < s.np; p += s.wpb) {
+        const uint32_t pn = p + s.wpb, pnn = pn + s.wpb;
+        // everything requested so far has landed (the current partition's postings have been in flight for a whole trip): the
+        // requests issued next are then the only ones outstanding and nothing below waits for them
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
+        uint32_t lo2 = 0, hi2 = 0;
+        if (rowlane && pnn < s.np) { lo2 = pp[pnn]; hi2 = pp[pnn + 1]; }
+        if (pn < s.np) prepare(lo1, hi1, nxt);
+        const uint32_t base_t = p * s.gsize;
+        if (!cur.flat) {
+          if (__ballot(cur.b > cur.a)) range_generic<CB, FILL, BATCH, FLATPF>(s, p, false, base_t, 0, need, fill_limit, true, cur.a, cur.b);
+        } else {
+          uint32_t *tbl = s.tbl;
+          if (cur.on[0]) Tbl<CB>::inc(tbl, cur.t[0] - base_t);
+          if (cur.on[1]) Tbl<CB>::inc(tbl, cur.t[1] - base_t);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && cur.fr.T <= 64) break;
+            const bool o2 = cur.on[h];
+            const uint32_t t2 = cur.t[h];
+            const uint32_t c2 = o2 ? Tbl<CB>::get(tbl, t2 - base_t) : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (o2 && c2) Tbl<CB>::clear(tbl, t2 - base_t);
+            // an instruction spans several rows: a target held by two of its lanes (count >= 2) is reported by the lower lane =
+            // the earlier row only, as the row-by-row walk would
+            bool dup = false;
+            uint64_t m = __ballot(o2 && c2 >= 2);
+            while (m) {
+              const int L = __ffsll((long long)m) - 1;
+              const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t2, L);
+              const bool same = o2 && s.lane > L && t2 == tL;
+              dup = dup || same;
+              m &= ~(__ballot(same) | (1ull << L));
+            }
+            extract_one<CB, FILL>(s, o2 && !dup, t2, base_t, cur.row[h], c2, quota_left, fill_limit);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        cur = nxt; lo1 = lo2; hi1 = hi2;
+      }
+      return;
+    }
     uint32_t lo = 0, hi = 0;
-    if ((uint32_t)s.lane < s.ns && (uint32_t)s.wave < s.np) { lo = pp[s.wave]; hi = pp[s.wave + 1]; }
+    if (rowlane && (uint32_t)s.wave < s.np) { lo = pp[s.wave]; hi = pp[s.wave + 1]; }
     for (uint32_t p = s.wave; p < s.np; p += s.wpb) {
       const uint32_t pn = p + s.wpb;
       uint32_t nlo = 0, nhi = 0;
-      if ((uint32_t)s.lane < s.ns && pn < s.np) { nlo = pp[pn]; nhi = pp[pn + 1]; }
+      if (rowlane && pn < s.np) { nlo = pp[pn]; nhi = pp[pn + 1]; }
       range_generic<CB, FILL, BATCH, FLATPF>(s, p, false, p * s.gsize, 0, need, fill_limit, true, rb + lo, rb + hi);
       lo = nlo; hi = nhi;
     }
