@@ -548,7 +548,8 @@ __device__ __forceinline__ void scan_generic(const ScanCtx &s, uint32_t need, ui
     }
     return;
   }
-  if (!split && s.ns <= 64) {
+  // (not in the dense 8-bit kernels - BATCH without FLATPF: there it is a rare path and goes without)
+  if constexpr (FLATPF || !BATCH) if (!split && s.ns <= 64) {
     // at most one row per lane and the table spans the partition: the lane keeps its row's start and reads the sub-row bounds of
     // the partitions ahead while the current one is counted (one global round trip per partition less, twice: both passes)
     uint64_t rb = 0; const uint32_t *pp = s.part;
@@ -1123,6 +1124,39 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
 }
 
+// Big path, fewer than K targets with count >= 2 and MinValue <= 1: the count-1 targets in first-touch order are the postings of
+// row 0 in ascending target order, then those of row 1 that no earlier row holds, ...  A target has count 1 exactly when it is not
+// one of the count >= 2 targets, and those are all selected already (cand[0 .. nsel), one per lane).  So the fill is a walk over
+// the first few postings of the first row(s) against that list - no second scan.  One wave; returns the new number of candidates.
+// (Out of line on purpose: it runs once per unit at most, and inlined its registers cost the scan loops of every instantiation.)
+__device__ __attribute__((noinline)) uint32_t big_path_fill(const uint64_t *row_off, const uint32_t *postings, const uint32_t *s_slots, uint32_t ns,
+                                                            uint32_t *cand, uint32_t *cand_cnt, uint64_t *cand_key, uint32_t K, uint32_t nsel, int lane)
+{
+  const uint32_t mine = (uint32_t)lane < nsel ? cand[lane] : 0xffffffffu;
+  uint32_t filled = nsel;
+  for (uint32_t r = 0; r < ns && filled < K; ++r) {
+    const uint32_t slot = s_slots[r];
+    const uint64_t ra = row_off[slot], rb = row_off[slot + 1];
+    for (uint64_t k0 = ra; k0 < rb && filled < K; k0 += 64) {
+      const bool on = k0 + (uint64_t)lane < rb;
+      const uint32_t t = on ? postings[k0 + lane] : 0u;
+      bool in_set = false;
+      for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+      const bool e = on && !in_set;
+      const uint64_t m = __ballot(e);
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (e && filled + rank < K) {
+        cand[filled + rank] = t;
+        cand_cnt[filled + rank] = 1u;
+        if (cand_key) cand_key[filled + rank] = make_key(1, ((uint64_t)r << 32) | t);
+      }
+      const uint32_t n = (uint32_t)__popcll(m);
+      filled = filled + n < K ? filled + n : K;
+    }
+  }
+  return filled;
+}
+
 // SMALL: the database is at or below -big (small ranking path) - a per-database constant, so the two rankers are two
 // instantiations and each carries only its own branches through the hot loop
 // BATCH: launches whose tables are wider than 4 bits (16-255 sampled rows: mid-identity searches) walk the generic path
@@ -1560,34 +1594,14 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
       // fewer than K candidates with count >= 2: append count-1 targets in scan order if the
       // cut-offs keep them (MinValue <= 1; small path additionally position < first MinU bump)
       if (min_value > 1 || sh->M == 0) break;
-      if constexpr (!SMALL) {
+      if constexpr (!SMALL && !FAST8) {       // (the FAST8 kernels - mid-identity nt - all but never come here and keep the scan: with this code compiled in their scan_fast8 loop spills, 171 -> 190 ms)
         // Big path: the count-1 targets in first-touch order are the postings of row 0 in ascending target order, then those of
         // row 1 that no earlier row holds, ...  A target has count 1 exactly when it is not one of the count >= 2 targets, and
         // those are all selected already (the list is exhausted and MinValue <= 1 keeps every one of them): fewer than K, one per
         // lane.  So the fill is a walk over the first few postings of the first row(s) against that list - no second scan.
         if (wave == 0) {
-          const uint32_t mine = (uint32_t)lane < nsel ? bv.cand[(uint64_t)unit * K + lane] : 0xffffffffu;
-          uint32_t filled = nsel;
-          for (uint32_t r = 0; r < ns && filled < K; ++r) {
-            const uint32_t slot = s_slots[r];
-            const uint64_t ra = db.row_off[slot], rb = db.row_off[slot + 1];
-            for (uint64_t k0 = ra; k0 < rb && filled < K; k0 += 64) {
-              const bool on = k0 + (uint64_t)lane < rb;
-              const uint32_t t = on ? db.postings[k0 + lane] : 0u;
-              bool in_set = false;
-              for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
-              const bool e = on && !in_set;
-              const uint64_t m = __ballot(e);
-              const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              if (e && filled + rank < K) {
-                bv.cand[(uint64_t)unit * K + filled + rank] = t;
-                bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u;
-                if (bv.cand_key) bv.cand_key[(uint64_t)unit * K + filled + rank] = make_key(1, ((uint64_t)r << 32) | t);
-              }
-              const uint32_t n = (uint32_t)__popcll(m);
-              filled = filled + n < K ? filled + n : K;
-            }
-          }
+          const uint32_t filled = big_path_fill(db.row_off, db.postings, s_slots, ns, bv.cand + (uint64_t)unit * K, bv.cand_cnt + (uint64_t)unit * K,
+                                                bv.cand_key ? bv.cand_key + (uint64_t)unit * K : nullptr, K, nsel, lane);
           if (lane == 0) sh->n_sel = filled;
         }
         __syncthreads();
