@@ -67,7 +67,8 @@ def cpu_baseline(kind, db, qs, ident, sample_q, threads):
             t_full = run(qfa)
         t_search = max(t_full - t_load, 1e-3)
         return {"value": sample.n / t_search, "unit": "query-seqs/s", "cores": threads, "kind": "reference",
-                "sample": "%d of the same C2 queries vs the full %d-seq DB, unmodified usearch12 -threads %d; "
+                "sample": "%d of the same C2 queries vs the full %d-seq DB, unmodified usearch12 sources -threads %d "
+                          "(built by oracle/build_ref.sh with g++ -O3 -march=x86-64-v2, not the reference Makefile's -march=native); "
                           "search wall = full run %.1fs minus a 1-query run %.1fs (DB load+index)" %
                           (sample.n, db.n, threads, t_full, t_load)}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
