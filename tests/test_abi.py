@@ -74,3 +74,13 @@ def test_no_cpu_fallback():
     assert e.value.code == -2          # UGS_E_NODEVICE
     with pytest.raises(capi.UgsError):
         capi.UgsDB(capi.params(), seqs, offs, device=-1)   # "-1 = CPU" does not exist here
+
+
+def test_cli_refuses_what_the_device_path_does_not_implement():
+    """-quicksort (udbusortedsearcher.cpp:192-198: an unstable quicksort over every touched target instead of CountSort) has no
+    field in the ABI and no device path: the driver refuses it (and any other unknown option) instead of ignoring it"""
+    import subprocess
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
+    for opt in ("-quicksort", "-nosuchoption"):
+        r = subprocess.run([cli, "-usearch_global", "/nonexistent.fa", "-db", "/nonexistent2.fa", "-id", "0.97", opt], capture_output=True, text=True)
+        assert r.returncode != 0 and "unknown option" in r.stderr
