@@ -422,6 +422,39 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       // ---- list seeds until the list is comfortably full or the target is exhausted
       if (idx >= count) { idx = 0; count = 0; }
       while (scan < nwB && count + 64 * UGS_MAXREPS <= c.seed_cap) {
+        if (NT && c.wstart && nwB - scan > 64u) {
+          // four instructions' worth of target positions at once: the word and table look-ups of all four are in flight together
+          // and two prefix sums over packed 16-bit counts place them (a lane's count is <= MaxReps, a chunk's total <= 512)
+          uint32_t bp[4], lo4[4], cn[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bp[e] = scan + (uint32_t)e * 64u + (uint32_t)lane;
+            lo4[e] = 0; cn[e] = 0;
+          }
+          uint32_t wd[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wd[e] = bp[e] < nwB ? nt_word(c.B2, bp[e], w) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (bp[e] < nwB) { const uint32_t en = c.wstart[wd[e]]; lo4[e] = en & 0xfffu; cn[e] = en >> 12; }
+          const uint32_t c01 = cn[0] | (cn[1] << 16), c23 = cn[2] | (cn[3] << 16);
+          const uint32_t i01 = wave_incl_sum_u32(c01), i23 = wave_incl_sum_u32(c23);
+          const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, 63);
+          const uint32_t tot[4] = {t01 & 0xffffu, t01 >> 16, t23 & 0xffffu, t23 >> 16};
+          const uint32_t total4 = tot[0] + tot[1] + tot[2] + tot[3];
+          if (count + total4 <= c.seed_cap) {
+            const uint32_t inc[4] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
+            uint32_t base = count;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t off = base + inc[e] - cn[e];
+              for (uint32_t r = 0; r < cn[e]; ++r) c.seeds[off + r] = (bp[e] << 16) | (c.qsort[lo4[e] + r] & 0xffffu);
+              base += tot[e];
+            }
+            count += total4;
+            scan += 256;
+            continue;
+          }
+        }
         const uint32_t bpos = scan + lane;
         uint32_t lo = 0, cnt = 0;
         if (bpos < nwB) {
