@@ -414,6 +414,15 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
   const int m2 = c.s_sub2[0], mm2 = c.s_sub2[2];      // nt: 2*score(A,A), 2*score(A,C)
   const uint32_t LB = c.LB;
   uint32_t nh = 0;
+  // is_global_hsp (hspfinder.cpp:594-636) depends on the seed's diagonal d = apos - bpos only (ALo - BLo = d, AR - BR = LA - LB - d):
+  // a seed outside [dlo, dhi] can never be accepted, and an extension that is not accepted leaves no trace in the reference's
+  // loop (ungappedblast.cpp:62-180) - such seeds are not even listed
+  int dlo, dhi;
+  {
+    const int LAi = (int)c.LA, LBi = (int)LB;
+    if (LAi <= LBi) { const int mg = LAi / 4 + 1; dlo = LAi - LBi - mg; dhi = mg; }
+    else { const int mg = LBi / 4 + 1; dlo = -mg; dhi = mg + LAi - LBi; }
+  }
   if (LB >= 2u * w && c.nwA > 0) {
     const uint32_t nwB = LB - w + 1;
     uint32_t scan = 0;          // next target position whose seeds are not listed yet
@@ -436,6 +445,13 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
           for (int e = 0; e < 4; ++e) wd[e] = bp[e] < nwB ? nt_word(c.B2, bp[e], w) : 0u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (bp[e] < nwB) { const uint32_t en = c.wstart[wd[e]]; lo4[e] = en & 0xfffu; cn[e] = en >> 12; }
+          uint32_t okm[4];                                   // the query positions of the word (<= MaxReps) whose diagonal can be accepted
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            okm[e] = 0;
+            for (uint32_t r = 0; r < cn[e]; ++r) { const int d = (int)(c.qsort[lo4[e] + r] & 0xffffu) - (int)bp[e]; okm[e] |= (d >= dlo && d <= dhi ? 1u : 0u) << r; }
+            cn[e] = (uint32_t)__popc(okm[e]);
+          }
           const uint32_t c01 = cn[0] | (cn[1] << 16), c23 = cn[2] | (cn[3] << 16);
           const uint32_t i01 = wave_incl_sum_u32(c01), i23 = wave_incl_sum_u32(c23);
           const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, 63);
@@ -446,8 +462,8 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
             uint32_t base = count;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const uint32_t off = base + inc[e] - cn[e];
-              for (uint32_t r = 0; r < cn[e]; ++r) c.seeds[off + r] = (bp[e] << 16) | (c.qsort[lo4[e] + r] & 0xffffu);
+              uint32_t off = base + inc[e] - cn[e];
+              for (uint32_t m = okm[e]; m; m &= m - 1) { const uint32_t r = (uint32_t)__ffs((int)m) - 1u; c.seeds[off++] = (bp[e] << 16) | (c.qsort[lo4[e] + r] & 0xffffu); }
               base += tot[e];
             }
             count += total4;
@@ -469,10 +485,13 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
             while (cnt < UGS_MAXREPS && lo + cnt < c.nwA && (c.qsort[lo + cnt] >> 16) == word) ++cnt;
           }
         }
+        uint32_t okm1 = 0;
+        for (uint32_t r = 0; r < cnt; ++r) { const int d = (int)(c.qsort[lo + r] & 0xffffu) - (int)bpos; okm1 |= (d >= dlo && d <= dhi ? 1u : 0u) << r; }
+        cnt = (uint32_t)__popc(okm1);
         const uint32_t incl = wave_incl_sum_u32(cnt);
         const uint32_t total = __builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t off = count + incl - cnt;
-        for (uint32_t r = 0; r < cnt; ++r) c.seeds[off + r] = (bpos << 16) | (c.qsort[lo + r] & 0xffffu);
+        uint32_t off = count + incl - cnt;
+        for (uint32_t m = okm1; m; m &= m - 1) { const uint32_t r = (uint32_t)__ffs((int)m) - 1u; c.seeds[off++] = (bpos << 16) | (c.qsort[lo + r] & 0xffffu); }
         count += total;
         scan += 64;
       }
