@@ -63,6 +63,7 @@ struct WaveCtx {
   uint8_t *tb; uint32_t *runs; uint32_t runs_cap;
   uint8_t *lds_tb; uint32_t *lds_runs; uint32_t *lds_rt;   // LDS fast copies: small traceback matrices, first LRUNS runs
   uint32_t LA, LB, nwA, nA2, hsp_cap, nwords;
+  bool a_inv, b_inv;          // nt: the query / the target holds a letter that is not A/C/G/T/U (wave-uniform)
   int lane;
 };
 
@@ -275,6 +276,7 @@ __device__ __forceinline__ uint64_t read32l(const uint32_t *w, int pos)
 // The nt extension on packed letters: 32 letter pairs per LDS round trip; inside a block the walk goes from one
 // non-matching pair to the next (a run of matches is consumed at once: the score rises through it, so its best is its end
 // and the x-drop test cannot fire inside it).  Same results as the byte-wise walk of ungappedblast.cpp:91-178.
+template <bool INV>          // INV = false: neither sequence holds a non-ACGTU letter, the "other letter" planes are not read
 __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int mm2, int X, uint32_t LA, uint32_t LB,
                                                  uint32_t &a1, uint32_t &b1, uint32_t &a2, uint32_t &b2, int &score, int &best,
                                                  uint32_t &bestb1, uint32_t &bestb2)
@@ -286,7 +288,7 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
     while (rem && !stop) {
       const uint32_t n = rem < 32 ? rem : 32;
       const uint64_t x = read32l(c.A2, (int)a2 + 1) ^ read32l(c.B2, (int)b2 + 1);
-      const uint64_t inv = read32l(c.Ai, (int)a2 + 1) | read32l(c.Bi, (int)b2 + 1);
+      const uint64_t inv = INV ? (read32l(c.Ai, (int)a2 + 1) | read32l(c.Bi, (int)b2 + 1)) : 0ull;
       uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
       if (n < 32) bad |= 1ull << (2 * n);                          // sentinel behind the last pair of the block
       uint32_t pos = 0;
@@ -295,7 +297,7 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
         const uint32_t run = b ? (uint32_t)(__ffsll((long long)b) - 1) >> 1 : 32u - pos;
         if (run) { score += (int)run * m2; pos += run; if (score > best) { best = score; bestb2 = b2 + pos; } }
         if (pos >= n) break;
-        score += ((inv >> (2 * pos)) & 1ull) ? 0 : mm2;            // a pair with a non-ACGT letter scores 0 (setnucmx.cpp)
+        score += (INV && ((inv >> (2 * pos)) & 1ull)) ? 0 : mm2;   // a pair with a non-ACGT letter scores 0 (setnucmx.cpp)
         ++pos;
         if (score > best) { best = score; bestb2 = b2 + pos; }
         else if (best - score > X) { stop = true; break; }
@@ -311,7 +313,7 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
     while (rem && !stop) {
       const uint32_t n = rem < 32 ? rem : 32;
       const uint64_t x = read32l(c.A2, (int)a1 - 32) ^ read32l(c.B2, (int)b1 - 32);     // pair 31 = position -1
-      const uint64_t inv = read32l(c.Ai, (int)a1 - 32) | read32l(c.Bi, (int)b1 - 32);
+      const uint64_t inv = INV ? (read32l(c.Ai, (int)a1 - 32) | read32l(c.Bi, (int)b1 - 32)) : 0ull;
       uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
       if (n < 32) bad |= 1ull << (2 * (31 - n));                   // sentinel in front of the first pair of the block
       uint32_t pos = 0;                                            // pairs consumed, from the top
@@ -320,7 +322,7 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
         const uint32_t run = b ? (uint32_t)__clzll((long long)b) >> 1 : 32u - pos;
         if (run) { score += (int)run * m2; pos += run; if (score > best) { best = score; bestb1 = b1 - pos; } }
         if (pos >= n) break;
-        score += ((inv >> (2 * (31 - pos))) & 1ull) ? 0 : mm2;
+        score += (INV && ((inv >> (2 * (31 - pos))) & 1ull)) ? 0 : mm2;
         ++pos;
         if (score > best) { best = score; bestb1 = b1 - pos; }
         else if (best - score > X) { stop = true; break; }
@@ -347,7 +349,7 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   if (NT) {
     // the two words are equal, so no pair of the seed is a mismatch: every pair scores a match unless one of its letters is not
     // A/C/G/T/U (both then carry the letter 0 in the word and the pair scores 0, setnucmx.cpp:11-99)
-    const uint32_t ninv = (uint32_t)__popc((nt_word(c.Ai, apos, w) | nt_word(c.Bi, bpos, w)));
+    const uint32_t ninv = (c.a_inv || c.b_inv) ? (uint32_t)__popc((nt_word(c.Ai, apos, w) | nt_word(c.Bi, bpos, w))) : 0u;
     score = ((int)w - (int)ninv) * m2;
   } else
     for (int k = 0; k < w; ++k) score += sscore<NT>(c, m2, mm2, c.As[apos + k], c.Bs[bpos + k]);
@@ -355,7 +357,8 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
   if (NT) {
-    extend_nt_packed(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+    if (c.a_inv || c.b_inv) extend_nt_packed<true>(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+    else extend_nt_packed<false>(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
   } else {
     {
       uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
   c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_tb = wb + off; off += LTB;
   c.nt = db.is_nucleo != 0;
+  c.a_inv = false; c.b_inv = false;
   // union region: the seed list lives only inside UngappedBlast, the chainer scratch only inside the chainer, the DP
   // rows only in the holes after it
   const size_t uo = std::max(2 * ((size_t)maxt + 8) * 4, (size_t)hsp_cap * 7 * 4);
@@ -897,7 +901,12 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
         c.A[p] = cl; c.As[p] = s_sc[cl & 31];
       }
       wave_sync();
-      if (c.nt) pack_codes(c.As, LA, c.A2, c.Ai, lane);
+      if (c.nt) {
+        pack_codes(c.As, LA, c.A2, c.Ai, lane);
+        bool any = false;
+        for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;
+        c.a_inv = __ballot(any) != 0;
+      }
       build_query_words(c, db.hsp_w, db.alpha);
     }
     ta0 += clock64() - tq;
@@ -930,6 +939,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
       c.LB = LB;
       const bool pack_direct = c.nt && LB <= 1024;             // nt: a lane's 4 letters are one byte of the packed arrays
+      bool anyb = false;                                       // a target letter that is not A/C/G/T/U
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
@@ -941,13 +951,15 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
             const uint32_t sc = s_sc[cl & 31];
             cls4 |= (uint32_t)cl << (8 * b);
             p2 |= (sc & 3u) << (2 * b); pi |= (sc >> 2) << (2 * b);
+            anyb = anyb || (sc > 3u && o + b < LB);
             if (!pack_direct && o + b < LB) c.Bs[o + b] = (uint8_t)sc;
           }
           *(uint32_t *)(c.B + o) = cls4;                          // (classes behind the last letter are never read)
           if (pack_direct) { ((uint8_t *)c.B2)[o >> 2] = (uint8_t)p2; ((uint8_t *)c.Bi)[o >> 2] = (uint8_t)pi; }
         }
       }
-      for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; c.B[p] = cl; c.Bs[p] = s_sc[cl & 31]; }
+      for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; const uint8_t sc = s_sc[cl & 31]; c.B[p] = cl; c.Bs[p] = sc; anyb = anyb || sc > 3; }
+      c.b_inv = c.nt && __ballot(anyb) != 0;
       if (k + 1 < ncand) prefetch(k + 1);
       wave_sync();
       if (c.nt && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
