@@ -787,6 +787,12 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
 
 // PAIR: the pair filters, -abskew, -fulldp and -gaforce are compiled into an instantiation of their own, so that the usual launch keeps the
 // code (and register allocation) it was tuned with
+// phase clocks (UGS_PHASE_CLOCKS report): reading the clock waits for every outstanding LDS / scalar-memory operation of the wave,
+// four times per pair - compiled in only for tuning builds (-DUGS_ALIGN_CLOCKS=1)
+#ifndef UGS_ALIGN_CLOCKS
+#define UGS_ALIGN_CLOCKS 0
+#endif
+#define ACLK() (UGS_ALIGN_CLOCKS ? clock64() : 0ull)
 template <bool PAIR>
 __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     }
     if (unit >= units) break;
   next_strand:
-    tq = clock64();
+    tq = ACLK();
     uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     if constexpr (PAIR) if (bv.unit_map) { const uint32_t m = bv.unit_map[unit]; qi = m >> 1; strand = m & 1u; }
     const uint64_t qo = bv.qoffs[qi];
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       }
       build_query_words(c, db.hsp_w, db.alpha);
     }
-    ta0 += clock64() - tq;
+    ta0 += ACLK() - tq;
     // one lane per candidate: id, offset and length fetched once for the whole unit
     uint32_t ct = 0, clen = 0; uint64_t cto = 0;
     if ((uint32_t)lane < ncand) {
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
     };
     if (ncand) prefetch(0);
     for (uint32_t k = 0; k < ncand; ++k) {
-      tq = clock64();
+      tq = ACLK();
       nvis = k + 1;
       const uint32_t t = (uint32_t)rl((int)ct, (int)k);
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
@@ -998,14 +1004,14 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
       if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
       if (MinHSPLength < 16) MinHSPLength = 16;
-      ta1 += clock64() - tq; tq = clock64();
+      ta1 += ACLK() - tq; tq = ACLK();
       // -fulldp: no HSPs at all, the whole pair is one unbanded hole (globalalignmem.cpp:148-152); -gaforce: FailIfNoHSPs = false
       const bool fulldp = PAIR ? (db.align_flags & UGS_A_FULLDP) != 0 : false;
       const bool force_all = PAIR ? (db.align_flags & (UGS_A_FULLDP | UGS_A_GAFORCE)) != 0 : false;
       if (!fulldp) {
         if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
       }
-      ta2 += clock64() - tq; tq = clock64();
+      ta2 += ACLK() - tq; tq = ACLK();
       if (lane == 0) { if (fulldp) c.ws->nchain = 0; else chain_lane0(c); }
       wave_sync();
       const uint32_t nchain = c.ws->nchain;
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
           }
         }
       }
-      ta3 += clock64() - tq;
+      ta3 += ACLK() - tq;
       // Terminator::Terminate (terminator.cpp:64-100)
       if constexpr (PAIR) if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
                                                     ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) {
