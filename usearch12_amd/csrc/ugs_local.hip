@@ -22,6 +22,12 @@
 #include "ugs_xdrop_dev.h"
 #include <algorithm>
 
+// phase clocks: tuning builds only (-DUGS_ALIGN_CLOCKS=1; see ugs_align.hip)
+#ifndef UGS_ALIGN_CLOCKS
+#define UGS_ALIGN_CLOCKS 0
+#endif
+#define ACLK() (UGS_ALIGN_CLOCKS ? clock64() : 0ull)
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
 namespace {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
         uint32_t fLoi = 0xffffffffu, fLoj = 0, fLen = 0;   // last anchor whose gapped extension was not kept
         while (curT < TWC) {
           // ---- list the seeds of target positions [curT, tend) in walk order: position ascending, then query position
-          tq = clock64();
+          tq = ACLK();
           uint32_t tend = min(curT + LOC_BT, TWC), nseeds = 0;
           for (uint32_t t0 = curT; t0 < tend; t0 += 64) {
             // lane = target position: its word's slice of the sorted query words is its seeds, already in query order
@@ -182,11 +188,11 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
           }
           if (tend == curT) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL); break; }   // one position overflowed the list
           wave_sync();
-          tl0 += clock64() - tq;
+          tl0 += ACLK() - tq;
           uint32_t cur = curT;
           for (uint32_t g0 = 0; g0 < nseeds && cur < tend; g0 += 64) {
             // ---- one seed per lane: ungapped x-drop both ways (localaligner.cpp:107-160) and the anchor (:11-58)
-            tq = clock64();
+            tq = ACLK();
             const uint32_t s = g0 + lane;
             const uint32_t sd = s < nseeds ? L.seeds[s] : 0;
             const uint32_t st = sd >> 16, sq = sd & 0xffffu;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
             }
             // ---- the survivors, in walk order
             uint64_t pm = __ballot(pass);
-            tl1 += clock64() - tq;
+            tl1 += ACLK() - tq;
             while (pm) {
               const int l = __ffsll((long long)pm) - 1;
               pm &= pm - 1;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               if (AncLen <= 1) continue;               // xdropalignmem.cpp:44-49: score 0
               if (AncLoi == fLoi && AncLoj == fLoj && AncLen == fLen) continue;   // same extension, same verdict
               // XDropAlignMem xdropalignmem.cpp:26-214
-              tq = clock64();
+              tq = ACLK();
               const uint32_t AncHii = AncLoi + AncLen - 1, AncHij = AncLoj + AncLen - 1;
               uint32_t bi = 0, bj = 0, fi = 0, fj = 0, nb = 0, nf = 0;
               bool ovf = false;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               for (int o = 32; o; o >>= 1) anc += __shfl_xor(anc, o);
               const int dupe = s_sub2[((int)L.Ax[AncLoi] << 5) | L.Bx[AncLoj]] + s_sub2[((int)L.Ax[AncHii] << 5) | L.Bx[AncHij]];
               const int score2 = bwd + fwd + anc - dupe;                                   // :176
-              tl2 += clock64() - tq; tq = clock64();
+              tl2 += ACLK() - tq; tq = ACLK();
               const uint32_t Loi = AncLoi + 1 - bi, Loj = AncLoj + 1 - bj;
               const uint32_t Leni = bi + fi + AncLen - 2, Lenj = bj + fj + AncLen - 2;
               bool keep = score2 > 0 && score2 >= thr.y;                                  // localaligner.cpp:193-205
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                 }
               }
               wave_sync();
-              tl3 += clock64() - tq;
+              tl3 += ACLK() - tq;
               // localmulti.cpp:104-110: the walk resumes behind the HSP
               const uint32_t NewT = Loj + Lenj;                                           // GetHij() + 1
               cur = NewT > tt ? NewT : tt + 1;
