@@ -1255,12 +1255,26 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     };
     {   // first position per count value and, on the 4-bit Big path, the (count, first row) class sizes - from the keys
       // (count >= 2 entries only; fp[1] is maintained by the scan)
-      for (uint32_t k = tid; k < n_emit; k += nthr) {
-        const uint64_t key = load_key(k);
+      auto pass_a = [&](uint64_t key) {
         const uint32_t cc = key_count(key);
-        atomicMin(&s_fp[cc], (unsigned long long)(key & POS_MASK));
+        // (nearly every key has count 2: a plain read first - after the first few keys hardly any position is still below the
+        // minimum, and the atomics on that one word no longer queue up)
+        const unsigned long long pos = (unsigned long long)(key & POS_MASK);
+        if (pos < *(volatile unsigned long long *)&s_fp[cc]) atomicMin(&s_fp[cc], pos);
         if (sc.hist) atomicAdd(&sh->hist[cc * 16 + ((uint32_t)(key >> 32) & 0xfu)], 1u);
-      }
+      };
+      if constexpr (BATCH) {
+        // mid-identity launches emit ~10 k keys per unit, most of them in the HBM part of the buffer: four loads in flight per
+        // thread instead of one (eight: the scan_fast8 loop of the same kernel spills, 162 -> 185 ms) (a loop over single loads waits out the memory latency once per key)
+        for (uint32_t k0 = tid; k0 < n_emit; k0 += 4 * nthr) {
+          uint64_t kk[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + (uint32_t)u * nthr; kk[u] = k < n_emit ? load_key(k) : KEY_INF; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (kk[u] != KEY_INF) pass_a(kk[u]);
+        }
+      } else
+        for (uint32_t k = tid; k < n_emit; k += nthr) pass_a(load_key(k));
       __syncthreads();
     }
 
@@ -1499,9 +1513,13 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
           for (uint32_t k = tid; k < 256; k += nthr) sh->hist[k] = 0;
           __syncthreads();
           const uint64_t pref = sh->red[0], pmask = sh->red[1];
-          for (uint32_t k = tid; k < N; k += nthr) {
-            const uint64_t key = load_key(k);
-            if ((key & pmask) == pref && eligible(key)) atomicAdd(&sh->hist[(uint32_t)(key >> shift) & 255u], 1u);
+          for (uint32_t k0 = tid; k0 < N; k0 += 4 * nthr) {       // four keys in flight per thread
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + (uint32_t)u * nthr; kk[u] = k < N ? load_key(k) : KEY_INF; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (kk[u] != KEY_INF && (kk[u] & pmask) == pref && eligible(kk[u])) atomicAdd(&sh->hist[(uint32_t)(kk[u] >> shift) & 255u], 1u);
           }
           __syncthreads();
           if (wave == 0) {
@@ -1528,17 +1546,22 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
         }
         {
           const uint64_t pref = sh->red[0], pmask = sh->red[1];
-          for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
-            const uint32_t k = k0 + tid;
-            uint64_t key = 0; bool take = false;
-            if (k < N) { key = load_key(k); take = (key & pmask) <= pref && eligible(key); }
-            const uint64_t mk = __ballot(take);
-            if (mk) {
-              uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(&sh->ncl, (uint32_t)__popcll(mk));
-              base = __builtin_amdgcn_readfirstlane(base);
-              const uint32_t slot = base + __popcll(mk & ((1ull << lane) - 1ull));
-              if (take && slot < 4 * UGS_KMAX) s_wsel[slot] = key;
+          for (uint32_t k0 = 0; k0 < N; k0 += 4 * nthr) {
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + (uint32_t)u * nthr + tid; kk[u] = k < N ? load_key(k) : KEY_INF; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint64_t key = kk[u];
+              const bool take = key != KEY_INF && (key & pmask) <= pref && eligible(key);
+              const uint64_t mk = __ballot(take);
+              if (mk) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sh->ncl, (uint32_t)__popcll(mk));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+                if (take && slot < 4 * UGS_KMAX) s_wsel[slot] = key;
+              }
             }
           }
           __syncthreads();
