@@ -637,7 +637,12 @@ static int plan_launch(ugs_batch *b)
   b->rl.fast8 = bits >= 8 && !db->sparse;
   // very long index rows (the longest row 16x the average or more: an abundant family of sequences shares its words):
   // sub-rows longer than a wavefront are then common and get their own path (ugs_rank.hip range_long)
-  b->rl.longrows = (uint64_t)db->max_row * db->v.slots > 16ull * std::max<uint64_t>(db->n_postings, 1) && db->max_row > 64u * db->v.np;
+  // LONG instantiations (sub-rows longer than a wavefront are handled from the batch's registers + extra chunks instead of the generic
+  // row-by-row walk): whenever the longest index row averages more than 56 postings per partition, i.e. tails are common for the
+  // queries that hold its word (uniform data stays below: C2 3.9 k vs 5.0 k, C4 19 k vs 25 k; cluster_fast's centroid index passes
+  // it as soon as an abundant species has a few hundred centroids).  UGS_LONGROWS=0/1 overrides (tuning).
+  b->rl.longrows = db->max_row > 56u * db->v.np;
+  if (const char *e = getenv("UGS_LONGROWS")) b->rl.longrows = atoi(e) != 0;
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well

@@ -679,15 +679,67 @@ __device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R,
   B.tail = mx > 64;
 }
 
+// A partition of the 4-bit path in which some sub-row is longer than a wavefront (skewed databases: the words an abundant family
+// shares - cluster_fast's centroids).  The first 64 postings of every row are in registers already (the batch); only the rows
+// that are longer fetch their remaining postings, 256 per trip.  Pass 1 counts, pass 2 reads and clears each counter at once in
+// ROW ORDER (a row's chunks together), so only the first touch of a target - its lowest row - sees the count.  Replaces a
+// walk of ALL rows from memory, twice, which waited out a load latency per row and pass (LONG instantiations only).
+template <int NR>
+__device__ __forceinline__ void tail_mixed(const ScanCtx &s, const Rows<NR> &R, const Batch<NR> &B, uint32_t p, uint32_t base_t)
+{
+  typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+  const int lane = s.lane;
+  uint32_t *tbl = s.tbl;
+  unsigned long long cache1 = s.s_fp[1];
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t len = B.len[r];
+      if (len == 0) continue;
+      auto one = [&](bool on, uint32_t t) {
+        if (pass == 0) { if (on) Tbl<4>::inc(tbl, t - base_t); }
+        else {
+          uint32_t c = 0;
+          if (on) { const uint32_t x = t - base_t, sh = (x * 4u) & 31u; c = (atomicAnd(&tbl[(x * 4u) >> 5], ~(15u << sh)) >> sh) & 15u; }
+          const uint64_t pos = s.small_path ? (uint64_t)t : (((uint64_t)r << 32) | t);
+          const bool f1 = c == 1 && pos < cache1;
+          if (__ballot(f1)) {
+            if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            cache1 = s.s_fp[1];
+          }
+          emit_lanes(s, c >= 2, 0xffffffffu, make_key(c, pos));
+        }
+      };
+      one((uint32_t)lane < len, B.v[r]);
+      if (len > 64) {
+        cptr32 pp = (cptr32)(uintptr_t)s.part + (uint64_t)R.slot[r] * (s.np + 1) + p;     // (uniform: scalar load)
+        const uint32_t *src = R.base[r] + pp[0];
+        u32x4 nxt;
+        __builtin_memcpy(&nxt, src + 64u + (uint32_t)lane * 4u, 16);       // (the array is padded: loads past the row's end are masked by index)
+        for (uint32_t k0 = 64; k0 < len; k0 += 256) {
+          const u32x4 cur = nxt;
+          if (k0 + 256 < len) __builtin_memcpy(&nxt, src + k0 + 256u + (uint32_t)lane * 4u, 16);
+          const uint32_t i = k0 + (uint32_t)lane * 4u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) one(i + j < len, cur[j]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // every add has completed before the clears start
+  }
+}
+
 template <int NR, bool LONG>
-__device__ __forceinline__ void process_batch(const ScanCtx &s, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
+__device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &R, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
 {
   const int lane = s.lane;
   uint32_t *tbl = s.tbl;
   const uint32_t base_t = p * s.gsize;
   if (B.tail) {
     // a sub-row longer than a wavefront (rare at the chosen partition size): generic, row-ordered
-    if constexpr (LONG) range_long<4>(s, p, base_t); else range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
+    if constexpr (LONG) tail_mixed<NR>(s, R, B, p, base_t); else range_generic<4, false>(s, p, false, base_t, 0, 0, 0);
     return;
   }
   // Branch-free: lanes without a posting in row r aim at a private dummy word behind the table
@@ -791,11 +843,11 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
     issue_batch<NR>(s, R, p1 < last ? p1 : last, B);
-    process_batch<NR, LONG>(s, A, p0, cache1, c1row);
+    process_batch<NR, LONG>(s, R, A, p0, cache1, c1row);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
     issue_batch<NR>(s, R, p2 < last ? p2 : last, A);
-    process_batch<NR, LONG>(s, B, p1, cache1, c1row);
+    process_batch<NR, LONG>(s, R, B, p1, cache1, c1row);
     if (p2 >= s.np) break;
     p0 = p2;
   }
@@ -1263,7 +1315,8 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
         if (pos < *(volatile unsigned long long *)&s_fp[cc]) atomicMin(&s_fp[cc], pos);
         if (sc.hist) atomicAdd(&sh->hist[cc * 16 + ((uint32_t)(key >> 32) & 0xfu)], 1u);
       };
-      if constexpr (BATCH) {
+      if constexpr (BATCH || LONG) {
+        // (LONG: skewed databases emit as many)
         // mid-identity launches emit ~10 k keys per unit, most of them in the HBM part of the buffer: four loads in flight per
         // thread instead of one (eight: the scan_fast8 loop of the same kernel spills, 162 -> 185 ms) (a loop over single loads waits out the memory latency once per key)
         for (uint32_t k0 = tid; k0 < n_emit; k0 += 4 * nthr) {
@@ -1395,11 +1448,9 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
         __syncthreads();
         const uint32_t qcut = sh->qcut;
         // gather every kept entry whose class is not after the cut class
-        for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
-          const uint32_t k = k0 + tid;
-          uint64_t key = 0; bool take = false;
-          if (k < N) {
-            key = load_key(k);
+        auto gather_one = [&](uint64_t key, bool valid) {
+          bool take = false;
+          if (valid) {
             const uint32_t cc = key_count(key), ii = (uint32_t)(key >> 32) & 0xfffu;
             take = cc >= cmin && ((Mx - cc) * 16 + ii) <= qcut;
           }
@@ -1411,7 +1462,20 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
             const uint32_t slot = base + __popcll(mk & ((1ull << lane) - 1ull));
             if (take && slot < 4 * UGS_KMAX) s_wsel[slot] = key;
           }
-        }
+        };
+        if constexpr (LONG) {
+          for (uint32_t k0 = 0; k0 < N; k0 += 4 * nthr) {       // four key loads in flight per thread
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t k = k0 + (uint32_t)u * nthr + tid; kk[u] = k < N ? load_key(k) : KEY_INF; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gather_one(kk[u], kk[u] != KEY_INF);
+          }
+        } else
+          for (uint32_t k0 = 0; k0 < N; k0 += nthr) {
+            const uint32_t k = k0 + tid;
+            gather_one(k < N ? load_key(k) : 0, k < N);
+          }
         __syncthreads();
         const uint32_t ncl = sh->ncl;
         if (ncl <= 64u * (uint32_t)wpb && ncl <= 4 * UGS_KMAX) {
@@ -1499,7 +1563,9 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
         }
         __syncthreads();
         nsel = sh->n_sel; last = sh->last_key; exhausted = sh->exhausted != 0;
-      } else if (BATCH) {
+      } else if (BATCH || LONG) {
+        // (LONG: a skewed database - cluster_fast's centroids - emits ~10 k keys per unit as well; without this branch the
+        // fallback below makes K passes over them)
         // ---- many emitted entries (mid-identity searches: ~1 % of the database shares two of 40 sampled words): radix
         // select.  Byte by byte from the top of the key, a 256-bin histogram of the entries still in the running for
         // the K-th place narrows the class that holds it; when the entries below the class plus the class itself fit
