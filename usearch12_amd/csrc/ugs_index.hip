@@ -13,7 +13,11 @@
 // Method: one 64-bit key (word << 32 | target) per sequence position, device radix sort,
 // adjacent-unique; sort order == (word asc, target asc) == the reference's sequential insert order.
 #include <cstring>
+#include <algorithm>
 #include "ugs_dev.h"
+#ifndef RCCHK
+#define RCCHK(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
+#endif
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -125,6 +129,34 @@ __global__ void k_max_row(const uint64_t *row_off, uint32_t slots, uint32_t *max
   if ((threadIdx.x & 63) == 0 && v) atomicMax(max_row, v);
 }
 
+// Temporaries of ugs_build_index: cluster_fast builds two small indexes per batch (the batch's own and the new centroids'), and
+// eight hipMalloc / hipFree pairs per build cost more than the kernels.  Buffers up to 64 MB are kept per host thread and device
+// and reused; larger ones (a whole database) are allocated and released as before.
+namespace {
+struct Scratch {
+  void *p = nullptr; size_t cap = 0; int dev = -1;
+  ~Scratch() { /* released with the process: the device may be gone when thread-locals are destroyed */ }
+};
+constexpr size_t SCRATCH_KEEP = 64ull << 20;
+thread_local Scratch g_scratch[5];
+int scratch_get(int i, size_t bytes, void **out, bool *cached)
+{
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (bytes > SCRATCH_KEEP) { *cached = false; HIPCHK(hipMalloc(out, bytes)); return UGS_OK; }
+  Scratch &sc = g_scratch[i];
+  if (sc.dev != dev || sc.cap < bytes) {
+    if (sc.p && sc.dev == dev) HIPCHK(hipFree(sc.p));
+    sc.p = nullptr; sc.cap = 0; sc.dev = dev;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&sc.p, want));
+    sc.cap = want;
+  }
+  *cached = true; *out = sc.p;
+  return UGS_OK;
+}
+}  // namespace
+
 int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq,
                     uint64_t nletters, int word_len, int alpha, uint32_t slots, uint64_t **d_row_off_out,
                     uint32_t **d_postings_out, uint64_t *n_postings, uint32_t *max_row, hipStream_t st)
@@ -139,10 +171,11 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
     return UGS_OK;
   }
   uint64_t *keys = nullptr, *keys2 = nullptr; unsigned long long *d_count = nullptr; void *tmp = nullptr; uint32_t *d_max = nullptr;
-  HIPCHK(hipMalloc(&keys, nletters * sizeof(uint64_t)));
-  HIPCHK(hipMalloc(&keys2, nletters * sizeof(uint64_t)));
-  HIPCHK(hipMalloc(&d_count, sizeof(unsigned long long)));
-  HIPCHK(hipMalloc(&d_max, sizeof(uint32_t)));
+  bool c_keys = false, c_keys2 = false, c_cnt = false, c_tmp = false;
+  RCCHK(scratch_get(0, nletters * sizeof(uint64_t), (void **)&keys, &c_keys));
+  RCCHK(scratch_get(1, nletters * sizeof(uint64_t), (void **)&keys2, &c_keys2));
+  RCCHK(scratch_get(2, 64, (void **)&d_count, &c_cnt));           // the counter and, 16 bytes on, the row maximum
+  d_max = (uint32_t *)((char *)d_count + 16);
   HIPCHK(hipMemsetAsync(d_max, 0, sizeof(uint32_t), st));
   {
     uint64_t threads = (uint64_t)nseq * 64;
@@ -152,13 +185,11 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   }
   unsigned wordbits = 1; while ((1ull << wordbits) <= slots) ++wordbits;   // values 0..slots
   size_t tmp_bytes = 0;
-  HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
-  HIPCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-  HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
-  HIPCHK(hipFree(tmp)); tmp = nullptr;
   size_t tmp2 = 0;
+  HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
   HIPCHK(rocprim::unique(nullptr, tmp2, keys2, keys, d_count, (size_t)nletters, rocprim::equal_to<uint64_t>(), st));
-  HIPCHK(hipMalloc(&tmp, tmp2 ? tmp2 : 16));
+  RCCHK(scratch_get(3, std::max<size_t>(std::max(tmp_bytes, tmp2), 16), &tmp, &c_tmp));     // one buffer serves both primitives (stream order)
+  HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)nletters, 0u, 32u + wordbits, st));
   HIPCHK(rocprim::unique(tmp, tmp2, keys2, keys, d_count, (size_t)nletters, rocprim::equal_to<uint64_t>(), st));
   unsigned long long nuniq = 0;
   HIPCHK(hipMemcpyAsync(&nuniq, d_count, sizeof(nuniq), hipMemcpyDeviceToHost, st));
@@ -178,7 +209,10 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(max_row, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipFree(tmp)); HIPCHK(hipFree(keys)); HIPCHK(hipFree(keys2)); HIPCHK(hipFree(d_count)); HIPCHK(hipFree(d_max));
+  if (!c_tmp) HIPCHK(hipFree(tmp));
+  if (!c_keys) HIPCHK(hipFree(keys));
+  if (!c_keys2) HIPCHK(hipFree(keys2));
+  if (!c_cnt) HIPCHK(hipFree(d_count));
   *d_postings_out = postings;
   *n_postings = np_host;
   return UGS_OK;
