@@ -1180,8 +1180,8 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
 // row 0 in ascending target order, then those of row 1 that no earlier row holds, ...  A target has count 1 exactly when it is not
 // one of the count >= 2 targets, and those are all selected already (cand[0 .. nsel), one per lane).  So the fill is a walk over
 // the first few postings of the first row(s) against that list - no second scan.  One wave; returns the new number of candidates.
-// (Inlined: a call in the kernel means a stack frame, and with it the launch's scratch demand passes the size above which the
-// runtime allocates scratch per dispatch - milliseconds per launch.  The dense 8-bit kernels do not use it, see the call.)
+// (Inlined like every helper of this kernel: out-of-line functions cost it dearly, see scan_generic's history in DESIGN.md.  The dense
+// 8-bit kernels do not use it, see the call.)
 __device__ __forceinline__ uint32_t big_path_fill(const uint64_t *row_off, const uint32_t *postings, const uint32_t *s_slots, uint32_t ns,
                                                             uint32_t *cand, uint32_t *cand_cnt, uint64_t *cand_key, uint32_t K, uint32_t nsel, int lane)
 {
