@@ -206,21 +206,25 @@ extern "C" int ugs_gather_results(ugs_comm *c, ugs_batch *b, uint32_t query_base
     HIPCHK(hipStreamSynchronize(c->st));
     c->loop->barrier();                         // the sources stay untouched until dst has copied them
   } else {
+    // (an error inside the group is remembered and reported after ncclGroupEnd: the group is never left open)
     NCCLCHK(ncclGroupStart());
-    for (int k = 0; k < 3; ++k) {
+    ncclResult_t gerr = ncclSuccess; hipError_t herr = hipSuccess;
+    for (int k = 0; k < 3 && gerr == ncclSuccess && herr == hipSuccess; ++k) {
       if (R == dst) {
         uint64_t off = 0;
-        for (int r = 0; r < W; ++r) {
+        for (int r = 0; r < W && gerr == ncclSuccess && herr == hipSuccess; ++r) {
           const uint64_t n = c->all[(size_t)r * 3 + k];
           if (n) {
-            if (r == R) HIPCHK(hipMemcpyAsync((char *)c->d_stage[k] + off, src[k], n, hipMemcpyDeviceToDevice, c->st));
-            else NCCLCHK(ncclRecv((char *)c->d_stage[k] + off, n, ncclUint8, r, c->nccl, c->st));
+            if (r == R) herr = hipMemcpyAsync((char *)c->d_stage[k] + off, src[k], n, hipMemcpyDeviceToDevice, c->st);
+            else gerr = ncclRecv((char *)c->d_stage[k] + off, n, ncclUint8, r, c->nccl, c->st);
           }
           off += n;
         }
-      } else if (my[k]) NCCLCHK(ncclSend(src[k], my[k], ncclUint8, dst, c->nccl, c->st));
+      } else if (my[k]) gerr = ncclSend(src[k], my[k], ncclUint8, dst, c->nccl, c->st);
     }
-    NCCLCHK(ncclGroupEnd());
+    const ncclResult_t eerr = ncclGroupEnd();
+    if (herr != hipSuccess) { ugs_set_error("gather: device copy failed: %s", hipGetErrorString(herr)); return UGS_E_HIP; }
+    if (gerr != ncclSuccess || eerr != ncclSuccess) { ugs_set_error("gather: RCCL exchange failed: %s", ncclGetErrorString(gerr != ncclSuccess ? gerr : eerr)); return UGS_E_HIP; }
     HIPCHK(hipStreamSynchronize(c->st));
   }
   c->s_exchange = now_s() - t0;
