@@ -16,3 +16,20 @@ try:
     import torch  # noqa: F401,E402
 except Exception:  # torch is optional for the CPU-only tests
     pass
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _heap_guard(request):
+    """GPU tests only: host heap canaries around every test (tests/heapguard.py)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import heapguard
+    g = request.session.__dict__.setdefault("_ugs_heap_guard", heapguard.HeapGuard())
+    yield
+    bad = g.check()
+    g.plant()
+    assert not bad, "host heap memory changed behind the process's back during this test (size, offset, byte): %r" % (bad[:8],)

@@ -224,3 +224,26 @@ def test_cli_usearch_local_userout_identical_to_reference(tmp_path):
             subprocess.check_call(cmd[:cmd.index("-userout")] + ["-blast6out", b6p, "-" + flag] + cmd[cmd.index("-uc") + 2:], stderr=subprocess.DEVNULL)
             got = open(b6p, "rb").read()
             assert got.count(b"\n") == u[flag + "_lines"] and hashlib.sha256(got).hexdigest() == u[flag + "_sha256"], (name, flag)
+
+
+def test_gpu_local_same_search_fifty_times():
+    """Determinism of k_local (it runs the same device code as k_xdrop for the gapped extension): one golden
+    usearch_local search 50 times in one process, hit records and paths byte for byte equal to the first run, which
+    equals the oracle."""
+    c, db, qs, b6 = G.load_local("loc_nt_both")
+    p = capi.params(is_nucleo=True, **G.local_params_kw(c))
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
+
+    def key(hits, nh, pool):
+        parts = [nh.tobytes()] + [hits[f].tobytes() for f in hits.dtype.names if f != "cigar_off"]
+        parts += [pool[int(h["cigar_off"]):int(h["cigar_off"]) + int(h["cigar_len"])].tobytes() for h in hits]
+        return b"".join(parts)
+    first = None
+    for it in range(50):
+        r = gdb.search(qs.seqs, qs.offs)
+        if first is None:
+            first = key(*r)
+            odb = orc.OrcDB(orc.params(is_nucleo=True, **G.local_params_kw(c)), db.seqs, db.offs)
+            _same_records(*r, *odb.search(qs.seqs, qs.offs, nthreads=4))
+        else:
+            assert key(*r) == first, "run %d differs from run 0" % it

@@ -138,3 +138,34 @@ def test_xdrop_non_default_scoring(aa, x, pk):
         if g != want:
             bad.append((mode, len(a), len(b), anc, g[:5], want[:5]))
     assert not bad, (len(bad), bad[:5])
+
+
+def _raw_batch(cases, is_nucleo, x):
+    jobs = np.zeros(len(cases), XDROP_JOB_DTYPE)
+    for k, (mode, a, b, anc) in enumerate(cases):
+        jobs[k] = (k, k, anc[0], anc[1], anc[2], mode)
+    return capi.xdrop_params(is_nucleo, xdrop=x), pack([c[1] for c in cases]), pack([c[2] for c in cases]), jobs
+
+
+@pytest.mark.parametrize("aa,x,seed", [(False, 200.0, 5), (True, 60.0, 4)])
+def test_xdrop_same_batch_fifty_times(aa, x, seed):
+    """Determinism: the batch that was red in GPUTEST_r02 (seed 5, X = 200: windows of several
+    64-column chunks, long tracebacks) through k_xdrop 50 times in one process - every run's device output (HSP
+    records and the run pool, compared as raw bytes) equals the first run's, and the first equals the oracle."""
+    cases = _random_batch(seed, aa, 1500, 5, 900)
+    p, A, B, jobs = _raw_batch(cases, not aa, x)
+    first = None
+    for it in range(50):
+        hsps, pool = capi.xdrop_batch(p, A, B, jobs)
+        raw = (hsps.tobytes(), pool.tobytes())
+        if first is None:
+            first = raw
+            op = orc.xdrop_params(not aa, x)
+            for (mode, a, b, anc), h in zip(cases, hsps):
+                o = orc.xdrop_job(op, a, b, mode, anc)
+                want = o[:6] if mode != XDROP_FWD else (o[0], 0, 0, o[3], o[4], o[5])
+                got = (float(h["score"]), int(h["loi"]), int(h["loj"]), int(h["leni"]), int(h["lenj"]),
+                       path_text(pool, h["path_off"], h["path_len"]))
+                assert got == want, (mode, len(a), len(b), anc, got[:5], want[:5])
+        else:
+            assert raw == first, "run %d differs from run 0" % it

@@ -38,3 +38,34 @@ def test_counter_clears_wait_for_the_adds_of_their_batch():
             n_rtn += 1
             assert not pending_add, "ds_and_rtn_b32 issued while adds of its batch may be in flight"
     assert n_rtn >= 11 * 6 and n_guarded >= 6       # the fast paths are there (three row widths x ping-pong per instantiation)
+
+
+def _isa_of(name):
+    src = os.path.join(ROOT, "usearch12_amd", "csrc", name)
+    dep = os.path.join(ROOT, "usearch12_amd", "csrc", "ugs_xdrop_dev.h")
+    out = "/tmp/%s_isa_%d_%d.s" % (name, int(os.path.getmtime(src)), int(os.path.getmtime(dep)))
+    if not os.path.exists(out):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip",
+                               "--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernel_body(isa, name):
+    m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % name, isa, re.S | re.M)
+    assert m, name
+    return m.group(2)
+
+
+def test_xdrop_cross_lane_traffic_is_explicit():
+    """k_xdrop / k_local hand traceback bytes, row windows and run lists from one lane to another through HBM scratch.
+    Pinned on the emitted code (ugs_xdrop_dev.h, UGS_XD_SYNC): the readers are agent-scope loads (sc1: never served by a
+    line the CU's L1 kept from an earlier job), and the path merge of k_xdrop has no read-modify-write on the arena
+    (round 2 zero-filled it with plain stores and merged with atomics behind a fence that waits for no store)."""
+    x = _kernel_body(_isa_of("ugs_xdrop.hip"), "k_xdrop")
+    assert len(re.findall(r"global_load_ubyte [^\n]* sc1", x)) >= 3         # traceback bytes (three states)
+    assert len(re.findall(r"global_load_dwordx2 [^\n]* sc1", x)) >= 3       # row windows
+    assert len(re.findall(r"global_load_dword [^\n]* sc1", x)) >= 2         # run lists
+    atom = re.findall(r"global_atomic_\w+[^\n]*", x)
+    assert all("_x2" in a or " sc0" in a for a in atom), atom                # job counter (returning), arena offset / cell counter (64-bit): no 32-bit adds into the arena
+    lo = _kernel_body(_isa_of("ugs_local.hip"), "k_local")
+    assert len(re.findall(r"global_load_ubyte [^\n]* sc1", lo)) >= 3

@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                   if (clen2 && (r & 3u) == cop) clen2 += r >> 2;
                   else { if (clen2) mruns[nm++] = (clen2 << 2) | cop; cop = r & 3u; clen2 = r >> 2; }
                 };
-                for (uint32_t x = 0; x < nb; ++x) put(runsB[nb - 1 - x]);
+                for (uint32_t x = 0; x < nb; ++x) put(xl32(&runsB[nb - 1 - x]));
                 if (AncLen > 2) put((AncLen - 2) << 2);
-                for (uint32_t x = 0; x < nf; ++x) put(runsF[x]);
+                for (uint32_t x = 0; x < nf; ++x) put(xl32(&runsF[x]));
                 if (clen2) mruns[nm++] = (clen2 << 2) | cop;
               }
               nm = (uint32_t)__builtin_amdgcn_readfirstlane((int)nm);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               // ---- AlignResult::FillLo on the run list (arscorer.cpp:201-296)
               uint32_t qpos = Loi, tpos = Loj, ids = 0, mcols = 0, gaps = 0, opens = 0, cols = 0, lastop = 0;
               for (uint32_t r = 0; r < nm; ++r) {
-                const uint32_t run = mruns[r], op = run & 3u, len = run >> 2;
+                const uint32_t run = xl32(&mruns[r]), op = run & 3u, len = run >> 2;
                 if (op == 0) {
                   for (uint32_t x0 = 0; x0 < len; x0 += 64) {
                     const uint32_t x = x0 + lane;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                   if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nm);
                   coff = rl64(coff, 0);
                   if (coff + nm <= bv.cigar_cap)
-                    for (uint32_t r = lane; r < nm; r += 64) bv.cigar_pool[coff + r] = mruns[r];
+                    for (uint32_t r = lane; r < nm; r += 64) bv.cigar_pool[coff + r] = xl32(&mruns[r]);
                   if (lane == 0) {
                     ugs_hit *h = &bv.hits[(uint64_t)unit * lv.hit_slots + nhit];
                     h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = cols;

@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void k_xdrop(XdView v)
         // path = reverse(backward side) + M x mid + forward side, adjacent equal ops merged
         const uint32_t nm = mid ? 1u : 0u, n = nb + nm + nf;
         auto elem = [&](uint32_t k) -> uint32_t {
-          if (k < nb) return runsB[nb - 1 - k];
+          if (k < nb) return xl32(&runsB[nb - 1 - k]);
           if (k < nb + nm) return mid << 2;
-          return runsF[k - nb - nm];
+          return xl32(&runsF[k - nb - nm]);
         };
         for (uint32_t k0 = 0; k0 < n; k0 += 64) {
           const uint32_t k = k0 + lane;
@@ -115,17 +115,25 @@ __global__ __launch_bounds__(256) void k_xdrop(XdView v)
               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
         if (off + nheads > v.arena_cap) st = ST_ARENA;
         else {
+          // merged run = segment of equal ops; the LAST element of a segment writes it (one plain store per output
+          // word, no read-modify-write): length = running sum at the tail - running sum before the segment's head,
+          // the head found by ballot inside the chunk or carried in a scalar from the chunks before
           uint32_t *out = v.arena + off;
-          for (uint32_t k = lane; k < nheads; k += 64) out[k] = 0;
-          wave_sync();
-          uint32_t before = 0;
+          uint32_t before = 0, sbase = 0, seg_start = 0;
           for (uint32_t k0 = 0; k0 < n; k0 += 64) {
             const uint32_t k = k0 + lane;
             const uint32_t r = k < n ? elem(k) : 0;
             const bool head = k < n && (k == 0 || ((r ^ elem(k - 1)) & 3u));
+            const bool tail = k < n && (k + 1 == n || ((r ^ elem(k + 1)) & 3u));
+            const uint32_t len = r >> 2;
+            const uint32_t S = sbase + wave_incl_sum(len), Sx = S - len;
             const uint64_t hm = __ballot(head);
-            const uint32_t idx = before + (uint32_t)__popcll(hm & ((2ull << lane) - 1)) - 1;
-            if (k < n) atomicAdd(&out[idx], head ? r : (r & ~3u));
+            const uint64_t below = hm & ((2ull << lane) - 1);
+            const uint32_t sp = (uint32_t)__shfl((int)Sx, below ? hibit(below) : 0);
+            const uint32_t start = below ? sp : seg_start;
+            if (tail) out[before + (uint32_t)__popcll(below) - 1] = ((S - start) << 2) | (r & 3u);
+            if (hm) seg_start = (uint32_t)rl((int)Sx, hibit(hm));
+            sbase = (uint32_t)rl((int)S, 63);
             before += (uint32_t)__popcll(hm);
           }
         }
@@ -165,16 +173,48 @@ __global__ void k_xd_lens(const ugs_xdrop_hsp *hsps, uint32_t njobs, uint64_t *l
 thread_local float g_last_ms = 0.0f;
 thread_local uint64_t g_last_cells = 0;
 
+// UGS_XD_HOSTMODE (A/B builds, tools/build_xd_variant.sh): which of the call's stream / two events are created and
+// destroyed per call.  0 = all three per call (rounds 1-2), 1 = none (product: kept per host thread and device),
+// 3 = stream per call, events kept, 4 = events per call, stream kept.
+#ifndef UGS_XD_HOSTMODE
+#define UGS_XD_HOSTMODE 1
+#endif
+struct XdHostCtx { int dev = -1; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; };
+thread_local XdHostCtx g_ctx[8];
+
 struct DevBufs {
   std::vector<void *> ptrs;
   hipStream_t st = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool own_st = false, own_ev = false;
   ~DevBufs()
   {
     for (void *p : ptrs) (void)hipFree(p);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (st) (void)hipStreamDestroy(st);
+    if (own_ev && e0) (void)hipEventDestroy(e0);
+    if (own_ev && e1) (void)hipEventDestroy(e1);
+    if (own_st && st) (void)hipStreamDestroy(st);
+  }
+  hipError_t open(int device)
+  {
+    XdHostCtx *c = nullptr;
+    for (auto &x : g_ctx) if (x.dev == device) c = &x;
+    if (!c) for (auto &x : g_ctx) if (x.dev < 0) { c = &x; x.dev = device; break; }
+    const bool keep_st = c && (UGS_XD_HOSTMODE == 1 || UGS_XD_HOSTMODE == 4), keep_ev = c && (UGS_XD_HOSTMODE == 1 || UGS_XD_HOSTMODE == 3);
+    hipError_t e;
+    if (keep_st) {
+      if (!c->st && (e = hipStreamCreate(&c->st)) != hipSuccess) return e;
+      st = c->st;
+    } else { if ((e = hipStreamCreate(&st)) != hipSuccess) return e; own_st = true; }
+    if (keep_ev) {
+      if (!c->e0 && (e = hipEventCreate(&c->e0)) != hipSuccess) return e;
+      if (!c->e1 && (e = hipEventCreate(&c->e1)) != hipSuccess) return e;
+      e0 = c->e0; e1 = c->e1;
+    } else {
+      own_ev = true;
+      if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+      if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+    }
+    return hipSuccess;
   }
   template <class T> hipError_t alloc(T **p, size_t n)
   {
@@ -275,8 +315,7 @@ extern "C" int ugs_xdrop_batch(int device, const ugs_xdrop_params *p,
 
   XCHK(hipSetDevice(device));
   DevBufs d;
-  XCHK(hipStreamCreate(&d.st));
-  XCHK(hipEventCreate(&d.e0)); XCHK(hipEventCreate(&d.e1));
+  XCHK(d.open(device));
   hipDeviceProp_t prop;
   XCHK(hipGetDeviceProperties(&prop, device));
 

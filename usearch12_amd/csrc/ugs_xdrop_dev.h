@@ -36,8 +36,30 @@ struct XdWave {
   uint8_t *tb; uint2 *rowinfo;
 };
 
+// Cross-lane traffic through HBM scratch (traceback bytes, row windows, run lists: one lane stores, another lane of
+// the SAME wave loads).  UGS_XD_SYNC=1 (product): the writer side waits for its stores to be acknowledged by L2
+// (s_waitcnt vmcnt(0) - a workgroup-scope fence emits no such wait on gfx950, it trusts the CU's L1 to be coherent
+// with the CU's own stores) and the reader side uses agent-scope loads (sc1: served by L2, never by a line the
+// CU's L1 still holds from an earlier job).  UGS_XD_SYNC=0 is the round-1/2 behaviour, kept for A/B runs only.
+#ifndef UGS_XD_SYNC
+#define UGS_XD_SYNC 1
+#endif
 __device__ __forceinline__ void lds_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#if UGS_XD_SYNC
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ uint8_t xl8(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t xl32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint2 xl64(const uint2 *p)
+{
+  const unsigned long long x = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint2((uint32_t)x, (uint32_t)(x >> 32));
+}
+#else
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ uint8_t xl8(const uint8_t *p) { return *p; }
+__device__ __forceinline__ uint32_t xl32(const uint32_t *p) { return *p; }
+__device__ __forceinline__ uint2 xl64(const uint2 *p) { return *p; }
+#endif
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -56,6 +78,18 @@ __device__ __forceinline__ int wave_incl_max(int v)
 }
 __device__ __forceinline__ int wave_max(int v) { return rl(wave_incl_max(v), 63); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~(uint32_t)wave_max((int)(~v ^ 0x80000000u)) ^ 0x80000000u; }
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t u)
+{
+  int v = (int)u, x;
+  x = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v += x;
+  x = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v += x;
+  x = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v += x;
+  x = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v += x;
+  const int t0 = rl(v, 15), t1 = t0 + rl(v, 31), t2 = t1 + rl(v, 47);
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  return (uint32_t)(v + (row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t1 : t2))));
+}
 // value of lane-1 (lane 0 gets `first`)
 __device__ __forceinline__ int shift_up1(int v, int first, int lane)
 {
@@ -68,10 +102,10 @@ __device__ __forceinline__ int hibit(uint64_t m) { return 63 - __clzll((long lon
 __device__ __forceinline__ uint8_t tbget(const XdWave &w, uint32_t lastrow, uint32_t r, uint32_t c)
 {
   if (r < 1 || r > lastrow) return 0;
-  const uint2 ri = w.rowinfo[r];
+  const uint2 ri = xl64(&w.rowinfo[r]);
   const uint32_t jlo = ri.y & 0xffffu, width = ri.y >> 16;
   if (c < jlo || c - jlo >= width) return 0;
-  return w.tb[ri.x + (c - jlo)];
+  return xl8(&w.tb[ri.x + (c - jlo)]);
 }
 
 // XDropFwdFastMem on A[0], A[sa], ... / B[0], B[sb], ...  (sa = sb = -1 walks backwards).
@@ -90,6 +124,13 @@ __device__ __forceinline__ int xd_extend(const XdView &v, XdWave &w, const uint8
     wave_sync();
     return s00;
   }
+#if defined(UGS_XD_POISON)
+  // debugging build: whatever this call reads without having written it shows up as a wrong answer
+  for (unsigned long long k = lane; k < v.tb_cap && k < (2ull << 20); k += 64) w.tb[k] = 0xff;
+  for (uint32_t k = lane; k < LA + 1; k += 64) w.rowinfo[k] = make_uint2(0xffffffffu, 0xffffffffu);
+  for (uint32_t k = lane; k < LB + 4; k += 64) { w.M0[k] = 0x3f3f3f3f; w.M1[k] = 0x3f3f3f3f; w.D[k] = 0x3f3f3f3f; w.Bc[k] = 0x1f; }
+  wave_sync();
+#endif
   for (uint32_t j = lane; j < LB; j += 64) w.Bc[j] = w.cls[B[(long)j * sb]];
   int *Mcur = w.M0, *Mnxt = w.M1, *D = w.D;
   if (lane == 0) { Mcur[1] = s00; D[1] = NEG; }
@@ -235,7 +276,7 @@ __device__ __forceinline__ int xd_extend(const XdView &v, XdWave &w, const uint8
   {                                                          // traceback order is inward; store outward
     const uint32_t n = nruns - n0;
     for (uint32_t k = lane; k < n / 2; k += 64) {
-      const uint32_t x = runs[n0 + k], y = runs[n0 + n - 1 - k];
+      const uint32_t x = xl32(&runs[n0 + k]), y = xl32(&runs[n0 + n - 1 - k]);
       runs[n0 + k] = y; runs[n0 + n - 1 - k] = x;
     }
   }
