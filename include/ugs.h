@@ -28,7 +28,9 @@ extern "C" {
 #endif
 
 #define UGS_ABI_VERSION 5   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
-                             * (ugs_params.local..., ugs_hit.raw_score/flags); 4: ugs_db_append, cluster_fast (ugs_cluster_*) */
+                             * (ugs_params.local..., ugs_hit.raw_score/flags); 4: ugs_db_append, cluster_fast (ugs_cluster_*);
+                             * 5: ugs_batch_upload is asynchronous (lifetime rule at its declaration), max_accepts / max_rejects 0 =
+                             * unlimited, band 0 = unbanded, ugs_comm.h (RCCL gather) */
 
 /* error codes */
 #define UGS_OK            0
@@ -217,6 +219,14 @@ int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *qoffs, uint3
  */
 int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_letters, ugs_batch **out);
 void ugs_batch_destroy(ugs_batch *b);
+/* ugs_batch_upload is ASYNCHRONOUS since ABI 5: it validates, enqueues the H2D copies on the batch's own copy stream and
+ * returns; ugs_batch_search orders its kernels behind them with an event.  Rules for the caller:
+ *   - qseqs[qoffs[0] .. qoffs[nq]) must stay allocated and unmodified until the next ugs_batch_sync (or ugs_batch_destroy)
+ *     of this batch returns; qoffs itself is consumed before the call returns.  From page-locked memory
+ *     (ugs_host_register) the copy overlaps other batches' kernels; from pageable memory the runtime stages it.
+ *   - uploading into a batch whose previous search has not been synced is allowed: the copies queue behind that
+ *     search on the device (its inputs are not overwritten under it), but its RESULTS are then lost - fetch first.
+ * ugs_search_batch (the one-call form above) keeps the synchronous contract: it returns with everything consumed. */
 int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t *qoffs, uint32_t nq);
 int ugs_batch_search(ugs_batch *b);
 int ugs_batch_sync(ugs_batch *b);

@@ -45,6 +45,10 @@ int ugs_comm_world(const ugs_comm *c);
  * On the other ranks the output pointers are not touched (may be NULL) and the counts come back 0.
  * UGS_E_CAPACITY on dst when a buffer is too small (the three demands are then in n_hits / nq_total / cigar_used); the
  * collective itself has completed on every rank in that case, so nobody hangs: call ugs_gather_refetch with larger buffers.
+ * A rank that fails before the transfer (its batch has no synced search, dst cannot allocate its staging buffers) does not
+ * strand its peers: every rank always takes part in two small status exchanges, and when any rank reported a failure ALL
+ * ranks return an error (the failing rank its own code, the others UGS_E_HIP naming that rank) without moving a table.
+ * Only a failure of the RCCL / HIP calls of the exchange itself leaves the communicator unusable.
  */
 int ugs_gather_results(ugs_comm *c, ugs_batch *b, uint32_t query_base, int dst,
                        ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query, uint64_t nq_cap,

@@ -66,6 +66,9 @@ CASES = {
     # maxaccepts 0 / maxrejects 0 = unlimited (terminator.cpp:40-45,91-97): the walk ends on the other limit or at the end of the list
     "hard_acc0":   dict(gen="hard", seed=42, n_fam=250, fam=6, q_n=900, aa=False, id=0.9, strand="both", big=100, lmin=20, lmax=300, maxaccepts=0, maxrejects=6),
     "hard_rej0":   dict(gen="hard", seed=43, n_fam=7, fam=8, q_n=600, aa=False, id=0.9, strand="plus", lmin=100, lmax=300, maxaccepts=2, maxrejects=0),
+    # no -id at all: ranking parameters of id 0.5, no identity filter, no error (accepter.cpp:35, makedbsearcher.cpp:195)
+    "hard_noid":   dict(gen="hard", seed=44, n_fam=250, fam=6, q_n=900, aa=False, id=None, strand="both", big=100, lmin=20, lmax=300, maxaccepts=3, maxrejects=8),
+    "hard_noid_s": dict(gen="hard", seed=45, n_fam=200, fam=6, q_n=700, aa=False, id=None, strand="plus", lmin=60, lmax=300),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
@@ -95,8 +98,8 @@ def digest(ss):
 
 
 def ref_cmd(c, qfa, dbfa, prefix):
-    cmd = [REF, "-usearch_global", qfa, "-db", dbfa, "-id", str(c["id"]), "-blast6out", prefix + ".b6",
-           "-uc", prefix + ".uc", "-threads", "1"]
+    cmd = [REF, "-usearch_global", qfa, "-db", dbfa] + (["-id", str(c["id"])] if c["id"] is not None else []) + \
+          ["-blast6out", prefix + ".b6", "-uc", prefix + ".uc", "-threads", "1"]
     if not c["aa"]:
         cmd += ["-strand", c["strand"]]
     for opt in ("big", "maxaccepts", "maxrejects", "band") + FILTER_OPTS:

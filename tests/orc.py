@@ -98,6 +98,8 @@ def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
     lib().orc_params_init(C.byref(p), 1 if is_nucleo else 0, float(0.5 if id is None else id))
     if local_evalue is not None:
         lib().orc_params_set_local(C.byref(p), float(local_evalue), 0 if id is None else 1)
+    elif id is None:                    # usearch_global without -id: ranking as for 0.5, no identity filter (accepter.cpp:35)
+        p.id_set = 0
     for k, v in kw.items():
         if k in PAIR_BITS:              # pair filters of Accepter::RejectPair (-self, -minqt ...): flag or value + bit
             if v is not None and v is not False:

@@ -140,3 +140,34 @@ def test_sizein_without_annotation_is_refused():
     r = synth.make_reads(5, 200, n_species=5)
     with pytest.raises(capi.UgsError):
         capi.UgsCluster(capi.cluster_params(0.97), r.seqs, r.offs, labels=r.labels(), sizein=True)
+
+
+def test_c3_model_across_the_natural_latch_equals_the_reference_files(tmp_path):
+    """the Big phase of cluster_fast pinned to the reference at the DEFAULT -big 100000.  700 000 reads of
+    the C3 model found 149 104 centroids, so the last third of the run searches a database beyond the small -> Big latch
+    (udbusortedsearcher.cpp:39-58) and appends to it (clusterfast.cpp:120-129).  The unmodified reference's -uc and
+    -centroids files for this input (234 s at -threads 1; tests/golden/make_golden_cluster_big.py) are committed as sha256
+    digests; the device result is written by the product's writers and digested the same way."""
+    import hashlib
+    import json
+    m = json.load(open(os.path.join(G.GOLD, "cluster_big_manifest.json")))["cl_c3_natural_latch"]
+    r = synth.make_reads(m["seed"], m["n"], n_species=m["species"])
+    h = hashlib.sha256(); h.update(r.offs.tobytes()); h.update(r.seqs.tobytes())
+    assert h.hexdigest() == m["reads_sha256"], "generator drift"
+    res = _cluster(dict(id=m["id"], strand=m["strand"]), r)
+    assert res.n_clusters == m["n_clusters"] > 100_000
+    labels = r.labels()
+    ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
+    res.write_uc(labels, ucp)
+    res.write_centroids(labels, cp)
+
+    def sha(path):
+        d = hashlib.sha256()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                d.update(blk)
+        return d.hexdigest()
+    assert os.path.getsize(ucp) == m["uc_bytes"] and os.path.getsize(cp) == m["centroids_bytes"]
+    assert sha(ucp) == m["uc_sha256"]
+    assert sha(cp) == m["centroids_sha256"]
+    res.close()

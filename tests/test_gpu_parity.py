@@ -129,12 +129,13 @@ def test_cli_text_identical_to_reference(tmp_path):
     FASTA in, -blast6out / -uc out, byte-identical to the reference's files."""
     import subprocess
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
-    for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask", "hard_termid", "hard_termidd"):
+    for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask", "hard_termid", "hard_termidd",
+                 "hard_noid", "hard_noid_s"):
         c, db, qs, b6, uc = G.load(name)
         dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
-        cmd = [cli, "-usearch_global", qfa, "-db", dbfa, "-id", str(c["id"]), "-blast6out", str(tmp_path / "o.b6"),
-               "-uc", str(tmp_path / "o.uc"), "-batch", "500"]
+        cmd = [cli, "-usearch_global", qfa, "-db", dbfa] + (["-id", str(c["id"])] if c["id"] is not None else []) + \
+              ["-blast6out", str(tmp_path / "o.b6"), "-uc", str(tmp_path / "o.uc"), "-batch", "500"]
         if not c["aa"]:
             cmd += ["-strand", c["strand"]]
         for opt in ("big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:

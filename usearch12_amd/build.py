@@ -17,13 +17,29 @@ def _mtime(path):
     return os.path.getmtime(path) if os.path.exists(path) else 0.0
 
 
+def _deps(path, seen=None):
+    """the file and every project header it includes (transitively): a change rebuilds only the objects that see it"""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path, errors="replace").read(), re.M):
+        _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
+
+
+def _newest(src):
+    return max(_mtime(d) for d in _deps(src))
+
+
 def build(force=False, verbose=False):
-    newest = max(_mtime(os.path.join(CSRC, d)) for d in DEPS)
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _mtime(obj) < newest:
+        if force or _mtime(obj) < _newest(os.path.join(CSRC, src)):
             cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
@@ -34,8 +50,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     g_src, g_obj = os.path.join(CSRC, "ugs_gather.cpp"), os.path.join(CSRC, "ugs_gather.o")
-    g_new = max(newest, _mtime(g_src), _mtime(os.path.join(HERE, "..", "include", "ugs_comm.h")))
-    if force or _mtime(g_obj) < g_new:
+    if force or _mtime(g_obj) < _newest(g_src):
         cmd = ["hipcc"] + FLAGS + ["-c", g_src, "-o", g_obj]
         if verbose:
             print(" ".join(cmd))
@@ -47,7 +62,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     cli_src = os.path.join(CSRC, "ugs_cli.cpp")
-    if force or _mtime(CLI) < max(_mtime(cli_src), _mtime(LIB), _mtime(LIB_RCCL)):
+    if force or _mtime(CLI) < max(_newest(cli_src), _mtime(LIB), _mtime(LIB_RCCL)):
         cmd = ["hipcc", "-O2", "-std=c++17", "-pthread", "-o", CLI, cli_src, "-L" + HERE, "-lugs_rccl", "-lugs", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -115,6 +115,8 @@ def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):
         rc = lib().ugs_params_set_local(C.byref(p), float(local_evalue), 0 if id is None else 1)
         if rc != 0:
             raise UgsError(rc, last_error())
+    elif id is None:                    # usearch_global without -id: ranking as for 0.5, no identity filter (accepter.cpp:35)
+        p.id_set = 0
     for k, v in kw.items():
         if k in PAIR_BITS:              # pair filters of Accepter::RejectPair (-self, -minqt ...): flag or value + bit
             if v is not None and v is not False:

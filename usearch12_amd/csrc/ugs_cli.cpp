@@ -566,7 +566,8 @@ int main(int argc, char **argv)
     if (maxrej < 0) maxrej = 16;
   }
   if (nucleo && strand.empty()) { fprintf(stderr, "-strand plus|both required for a nucleotide db\n"); return 1; }   // search.cpp:23-34
-  if (id < 0 && !local_cmd) { fprintf(stderr, "--id not set\n"); return 1; }                                         // udbusortedsearcher.cpp:100-101
+  // no -id: the reference neither dies nor filters by identity - word counting runs with 0.5 (makedbsearcher.cpp:195), Accepter::IsAcceptLo
+  // tests the identity only when the option was given (accepter.cpp:35); golden runs hard_noid / hard_noid_s.  cluster_fast does die (above).
   ugs_params p;
   ugs_params_init(&p, nucleo, id < 0 ? 0.5 : id);
   p.id_set = id >= 0;

@@ -86,18 +86,20 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
   }
   if (add) HIPCHK(hipMemcpyAsync(db->d_seqs + db->nletters, seqs + offs[0], add, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(db->d_offs + old_n, abs_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
-  uint64_t *d_rel = nullptr;
-  HIPCHK(hipMalloc(&d_rel, ((size_t)n + 1) * 8));
-  HIPCHK(hipMemcpyAsync(d_rel, rel_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  struct Tmp {                                    // released on every way out, error returns included
+    uint64_t *rel = nullptr, *drow = nullptr; uint32_t *dpost = nullptr, *dmax = nullptr;
+    ~Tmp() { (void)hipFree(rel); (void)hipFree(drow); (void)hipFree(dpost); (void)hipFree(dmax); }
+  } t;
+  HIPCHK(hipMalloc(&t.rel, ((size_t)n + 1) * 8));
+  HIPCHK(hipMemcpyAsync(t.rel, rel_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
   // index of the new sequences on their own (targets 0..n-1), then row-wise append
-  uint64_t *d_drow = nullptr; uint32_t *d_dpost = nullptr; uint64_t n_dpost = 0; uint32_t dmax = 0;
-  int rc = ugs_build_index(db->d_tab, db->d_seqs + db->nletters, d_rel, n, add, db->p.word_len, db->v.alpha, db->v.slots, &d_drow,
-                           &d_dpost, &n_dpost, &dmax, st);
-  if (rc != UGS_OK) { (void)hipFree(d_rel); (void)hipFree(d_drow); (void)hipFree(d_dpost); return rc; }
+  uint64_t n_dpost = 0; uint32_t dmax = 0;
+  int rc = ugs_build_index(db->d_tab, db->d_seqs + db->nletters, t.rel, n, add, db->p.word_len, db->v.alpha, db->v.slots, &t.drow,
+                           &t.dpost, &n_dpost, &dmax, st);
+  if (rc != UGS_OK) { (void)hipStreamSynchronize(st); return rc; }
   const uint64_t total = db->n_postings + n_dpost;
   // the merged index goes into the handle's spare arrays, which then change places with the live ones (a multi-GB
   // hipMalloc / hipFree per append would cost more than the merge)
-  uint32_t *d_max = nullptr;
   if (!db->d_row_off2) HIPCHK(hipMalloc(&db->d_row_off2, ((size_t)db->v.slots + 1) * 8));
   if (!db->d_postings2 || total + 256 > db->post_cap2) {
     if (db->d_postings2) HIPCHK(hipFree(db->d_postings2));
@@ -105,11 +107,10 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
     db->post_cap2 = total + total / 2 + 4096 + 256;
     HIPCHK(hipMalloc(&db->d_postings2, db->post_cap2 * 4));
   }
-  HIPCHK(hipMalloc(&d_max, 4));
-  rc = ugs_index_merge(db->d_row_off, db->d_postings, d_drow, d_dpost, db->v.slots, old_n, db->d_row_off2, db->d_postings2, total, d_max, st);
-  if (rc == UGS_OK && hipMemcpyAsync(&db->max_row, d_max, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = UGS_E_HIP;
+  HIPCHK(hipMalloc(&t.dmax, 4));
+  rc = ugs_index_merge(db->d_row_off, db->d_postings, t.drow, t.dpost, db->v.slots, old_n, db->d_row_off2, db->d_postings2, total, t.dmax, st);
+  if (rc == UGS_OK && hipMemcpyAsync(&db->max_row, t.dmax, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = UGS_E_HIP;
   if (hipStreamSynchronize(st) != hipSuccess) rc = UGS_E_HIP;
-  (void)hipFree(d_rel); (void)hipFree(d_drow); (void)hipFree(d_dpost); (void)hipFree(d_max);
   if (rc != UGS_OK) { ugs_set_error("index append failed"); return rc; }
   std::swap(db->d_row_off, db->d_row_off2); std::swap(db->d_postings, db->d_postings2); std::swap(db->post_cap, db->post_cap2);
   db->n_postings = total; db->nletters += add; db->max_tlen = maxl;
@@ -743,6 +744,7 @@ extern "C" int ugs_cluster_write_uc(const ugs_cluster *c, const char *labels, co
         const char *ql = pass == 0 ? lab[seed] : lab[dup[u][pass - 1]];
         int n = ugs_format_uc_hit(&h, c->pool.data(), c->p.is_nucleo, ql, tl, buf.data(), (int)buf.size());
         if (n >= (int)buf.size()) { buf.resize((size_t)n + 16); n = ugs_format_uc_hit(&h, c->pool.data(), c->p.is_nucleo, ql, tl, buf.data(), (int)buf.size()); }
+        if (n < 0) { ok = false; break; }                          // formatter error: nothing sensible to write
         ok = ok && fwrite(buf.data(), 1, (size_t)n, f) == (size_t)n;
       }
     }

@@ -21,7 +21,7 @@ struct Loop {
   int world;
   std::mutex m; std::condition_variable cv; int arrived = 0; uint64_t gen = 0;
   std::vector<uint64_t> sizes; std::vector<const void *> ptrs;
-  explicit Loop(int w) : world(w), sizes((size_t)w * 3, 0), ptrs((size_t)w * 3, nullptr) {}
+  explicit Loop(int w) : world(w), sizes((size_t)w * 4, 0), ptrs((size_t)w * 3, nullptr) {}
   void barrier() {
     std::unique_lock<std::mutex> l(m);
     const uint64_t g = gen;
@@ -36,7 +36,8 @@ struct ugs_comm {
   ncclComm_t nccl = nullptr;
   std::shared_ptr<Loop> loop;
   hipStream_t st = nullptr;
-  uint64_t *d_my = nullptr, *d_all = nullptr;            // 3 sizes of this rank / of every rank (device, for ncclAllGather)
+  uint64_t *d_my = nullptr, *d_all = nullptr;            // 3 sizes + a status word of this rank / of every rank (device, for ncclAllGather)
+  std::vector<uint64_t> all4;                             // host copy of the last exchange: [world][4]
   void *d_stage[3] = {nullptr, nullptr, nullptr}; uint64_t stage_cap[3] = {0, 0, 0};     // dst: the gathered tables
   // the last gather (dst)
   std::vector<uint64_t> all;                              // [world][3] bytes of hits / counts / pool
@@ -48,9 +49,10 @@ static int comm_common_init(ugs_comm *c)
 {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&c->d_my, 3 * 8));
-  HIPCHK(hipMalloc(&c->d_all, (size_t)c->world * 3 * 8));
+  HIPCHK(hipMalloc(&c->d_my, 4 * 8));
+  HIPCHK(hipMalloc(&c->d_all, (size_t)c->world * 4 * 8));
   c->all.assign((size_t)c->world * 3, 0);
+  c->all4.assign((size_t)c->world * 4, 0);
   return UGS_OK;
 }
 
@@ -165,33 +167,56 @@ extern "C" int ugs_gather_results(ugs_comm *c, ugs_batch *b, uint32_t query_base
   if (nq_total) *nq_total = 0;
   if (cigar_used) *cigar_used = 0;
   void *src[3] = {nullptr, nullptr, nullptr};
-  uint64_t my[3] = {0, 0, 0};
-  RCCHK(ugs_batch_device_results(b, query_base, &src[0], &my[0], &src[1], &my[1], &src[2], &my[2]));
+  uint64_t my[4] = {0, 0, 0, 0};                            // three table sizes + this rank's status
+  // A rank that fails before the transfer must not leave its peers waiting in it: every rank always takes part in the two
+  // small exchanges below (sizes + status, then "dst has room"), and all ranks skip the transfer when any rank reported a failure.
+  const int rc_local = ugs_batch_device_results(b, query_base, &src[0], &my[0], &src[1], &my[1], &src[2], &my[2]);
+  if (rc_local != UGS_OK) { my[0] = my[1] = my[2] = 0; my[3] = (uint64_t)(uint32_t)(-rc_local); }
   const double t0 = now_s();
   const int W = c->world, R = c->rank;
-  // ---- everybody learns everybody's table sizes
-  if (c->loop) {
-    for (int k = 0; k < 3; ++k) { c->loop->sizes[(size_t)R * 3 + k] = my[k]; c->loop->ptrs[(size_t)R * 3 + k] = src[k]; }
-    c->loop->barrier();
-    c->all = c->loop->sizes;
-  } else {
-    HIPCHK(hipMemcpyAsync(c->d_my, my, 3 * 8, hipMemcpyHostToDevice, c->st));
-    NCCLCHK(ncclAllGather(c->d_my, c->d_all, 3, ncclUint64, c->nccl, c->st));
-    HIPCHK(hipMemcpyAsync(c->all.data(), c->d_all, (size_t)W * 3 * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-  }
-  // ---- dst: room for the concatenated tables
+  auto exchange = [&]() -> int {                             // my[0..3] of every rank -> c->all4 on every rank
+    if (c->loop) {
+      for (int k = 0; k < 4; ++k) c->loop->sizes[(size_t)R * 4 + k] = my[k];
+      for (int k = 0; k < 3; ++k) c->loop->ptrs[(size_t)R * 3 + k] = src[k];
+      c->loop->barrier();
+      c->all4 = c->loop->sizes;
+      c->loop->barrier();                                    // everybody has read the board before anybody posts again
+    } else {
+      HIPCHK(hipMemcpyAsync(c->d_my, my, 4 * 8, hipMemcpyHostToDevice, c->st));
+      NCCLCHK(ncclAllGather(c->d_my, c->d_all, 4, ncclUint64, c->nccl, c->st));
+      HIPCHK(hipMemcpyAsync(c->all4.data(), c->d_all, (size_t)W * 4 * 8, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(hipStreamSynchronize(c->st));
+    }
+    return UGS_OK;
+  };
+  auto failed_rank = [&]() -> int { for (int r = 0; r < W; ++r) if (c->all4[(size_t)r * 4 + 3]) return r; return -1; };
+  auto report = [&](int r, const char *where) -> int {
+    const int code = -(int)(uint32_t)c->all4[(size_t)r * 4 + 3];
+    if (r != R) ugs_set_error("gather: rank %d failed %s (code %d); no table was exchanged", r, where, code);
+    return r == R ? code : UGS_E_HIP;
+  };
+  // ---- everybody learns everybody's table sizes (and whether everybody has tables at all)
+  RCCHK(exchange());
+  c->have_last = false;
+  int bad = failed_rank();
+  if (bad >= 0) return report(bad, "before the exchange");
+  for (int r = 0; r < W; ++r) for (int k = 0; k < 3; ++k) c->all[(size_t)r * 3 + k] = c->all4[(size_t)r * 4 + k];
+  // ---- dst: room for the concatenated tables; its verdict travels in the second exchange
   uint64_t tot[3] = {0, 0, 0};
   for (int r = 0; r < W; ++r) for (int k = 0; k < 3; ++k) tot[k] += c->all[(size_t)r * 3 + k];
   if (R == dst)
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3 && !my[3]; ++k)
       if (tot[k] > c->stage_cap[k]) {
-        if (c->d_stage[k]) HIPCHK(hipFree(c->d_stage[k]));
+        if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
         c->d_stage[k] = nullptr; c->stage_cap[k] = 0;
         const uint64_t want = tot[k] + tot[k] / 4 + 4096;
-        HIPCHK(hipMalloc(&c->d_stage[k], want));
-        c->stage_cap[k] = want;
+        const hipError_t e = hipMalloc(&c->d_stage[k], want);
+        if (e != hipSuccess) { (void)hipGetLastError(); ugs_set_error("gather: %llu bytes of staging on rank %d: %s", (unsigned long long)want, R, hipGetErrorString(e)); my[3] = (uint64_t)(uint32_t)(-UGS_E_NOMEM); }
+        else c->stage_cap[k] = want;
       }
+  RCCHK(exchange());
+  bad = failed_rank();
+  if (bad >= 0) return report(bad, "allocating the staging buffers");
   // ---- the exchange: one grouped set of point-to-point transfers (rank r's table k lands behind the tables of ranks < r)
   if (c->loop) {
     if (R == dst)

@@ -510,6 +510,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev2) (void)hipEventDestroy(b->ev2);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
+  if (b->ev_done) (void)hipEventDestroy(b->ev_done);
   if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
   if (b->h_rel) (void)hipHostFree(b->h_rel);
   delete b;
@@ -551,6 +552,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  BCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   BCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
   BCHK(hipHostMalloc((void **)&b->h_rel, ((size_t)max_queries + 1) * 8, hipHostMallocDefault));
 #undef BCHK
@@ -724,6 +726,8 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   // them with an event.  (The caller's letters must stay untouched until the next ugs_batch_sync of this batch; from
   // page-locked memory - ugs_host_register - the copy then overlaps whatever another batch is running.)
   HIPCHK(hipEventSynchronize(b->ev_up));                       // h_rel may still feed the previous upload
+  // a search of this batch that was enqueued and not yet synced still reads d_qseqs / d_qoffs: the new copies queue behind it
+  if (b->searched && !b->synced) HIPCHK(hipStreamWaitEvent(b->copy_stream, b->ev_done, 0));
   for (uint32_t i = 0; i <= nq; ++i) b->h_rel[i] = qoffs[i] - qoffs[0];
   if (b->q_letters) HIPCHK(hipMemcpyAsync(b->d_qseqs, qseqs + qoffs[0], b->q_letters, hipMemcpyHostToDevice, b->copy_stream));
   HIPCHK(hipMemcpyAsync(b->d_qoffs, b->h_rel, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, b->copy_stream));
@@ -798,6 +802,7 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   // nothing but copies, which overlap the kernels of whatever batch runs next
   if (b->nq) RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
                                     b->scan_tmp_bytes, 0, db->stream));
+  HIPCHK(hipEventRecord(b->ev_done, db->stream));
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
   b->searched = true; b->synced = false; b->compact_base = 0;
   return UGS_OK;

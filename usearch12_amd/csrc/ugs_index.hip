@@ -146,7 +146,12 @@ int scratch_get(int i, size_t bytes, void **out, bool *cached)
   if (bytes > SCRATCH_KEEP) { *cached = false; HIPCHK(hipMalloc(out, bytes)); return UGS_OK; }
   Scratch &sc = g_scratch[i];
   if (sc.dev != dev || sc.cap < bytes) {
-    if (sc.p && sc.dev == dev) HIPCHK(hipFree(sc.p));
+    if (sc.p) {                                               // the old buffer may belong to the device this thread used before
+      if (sc.dev != dev) HIPCHK(hipSetDevice(sc.dev));
+      const hipError_t e = hipFree(sc.p);
+      if (sc.dev != dev) HIPCHK(hipSetDevice(dev));
+      HIPCHK(e);
+    }
     sc.p = nullptr; sc.cap = 0; sc.dev = dev;
     const size_t want = bytes + bytes / 4 + 4096;
     HIPCHK(hipMalloc(&sc.p, want));
