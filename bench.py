@@ -6,12 +6,16 @@ alignment kernels, hit table back on the host.  The upload of step i+1's batch i
 run (two batches in flight, a copy stream per batch), and every step searches a batch that differs from the one
 before it; both are inside the timed region.
 
-  N = 1  BASELINE.json configs[1] (C2): 1M x 250 nt queries vs a 1M-sequence DB, -id 0.97, -strand plus, reference
-         defaults - the configuration the metric is quoted on.
-  N > 1  BASELINE.json configs[3] (C4): 10M x 250 nt queries split into N contiguous shards vs a 5M-sequence DB whose
-         index is replicated in every GPU's HBM (strong scaling); the only exchange is one RCCL gather of
-         the device-resident hit tables to rank 0 per step.  (A 5M-sequence index makes every query read 5x the
-         postings of C2: compare the N > 1 lines with each other, or with `--gpus 1 --workload C4`.)
+  every N  BASELINE.json configs[1] (C2), the configuration the metric is quoted on: every GPU searches its own batch of
+         1M x 250 nt queries per step (N x 1M queries per step over the job: WEAK scaling) vs the 1M-sequence DB whose
+         index is replicated in every GPU's HBM, -id 0.97, -strand plus, reference defaults.  For N > 1 the query stream
+         is sharded one GPU per shard with no collective on the data path; the only exchange is one gather of the
+         device-resident hit tables to rank 0 per step - the product's own C++ gather (include/ugs_comm.h,
+         libugs_rccl.so: ncclAllGather of the sizes + grouped ncclSend/ncclRecv over xGMI) - issued for step i while the
+         kernels of step i+1 run.  The same workload at every N keeps the driver's per-N values comparable.
+  --workload C4  BASELINE.json configs[3]: 10M x 250 nt queries split into N contiguous shards vs a 5M-sequence DB
+         (STRONG scaling; a 5M-sequence index makes every query read 5x the postings of C2, so its lines compare with
+         `--gpus 1 --workload C4`, not with the C2 lines).
 `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run on 127.0.0.1) when it is not already
 running under a launcher, and refuses to run when the launcher's world size differs from --gpus.
 
@@ -92,27 +96,29 @@ def free_port():
     return port
 
 
-def make_query_sets(synth, seed, db, n, length, nsets):
-    """`nsets` different batches of n queries each, built in chunks of <= 1M (bounds the generator's temporaries)"""
+QCHUNK = 250_000
+
+
+def make_query_sets(synth, seed, db, lo, n, length, nsets):
+    """`nsets` different batches: queries [lo, lo + n) of a GLOBAL query stream per set.  The stream is generated in chunks of
+    QCHUNK queries seeded by (set, chunk index), so any sharding of it yields the same queries - a 2-rank run and a 1-rank run
+    of the same total search the same set (what the multi-rank test checks)."""
     import numpy as _np
     sets = []
     for k in range(nsets):
-        parts = []
-        done = 0
-        while done < n:
-            m = min(1_000_000, n - done)
-            parts.append(synth.make_queries(seed + 7919 * k + 104729 * (done // 1_000_000), db, m, length))
-            done += m
-        if len(parts) == 1:
-            sets.append(parts[0])
-        else:
-            seqs = _np.concatenate([q.seqs for q in parts])
-            offs = [parts[0].offs]
-            base = int(parts[0].offs[-1])
-            for q in parts[1:]:
-                offs.append(q.offs[1:] + _np.uint64(base))
-                base += int(q.offs[-1])
-            sets.append(synth.SeqSet(seqs, _np.concatenate(offs), lambda i: "q%d" % i))
+        seqs, lens = [], []
+        pos = lo
+        while pos < lo + n:
+            c = pos // QCHUNK
+            q = synth.make_queries(seed + 7919 * k + 104729 * c, db, QCHUNK, length)
+            a, b = pos - c * QCHUNK, min(lo + n, (c + 1) * QCHUNK) - c * QCHUNK
+            seqs.append(q.seqs[int(q.offs[a]):int(q.offs[b])])
+            lens.append(_np.diff(q.offs[a:b + 1].astype(_np.int64)))
+            pos = c * QCHUNK + b
+        ln = _np.concatenate(lens) if lens else _np.zeros(0, _np.int64)
+        offs = _np.zeros(len(ln) + 1, _np.uint64)
+        offs[1:] = _np.cumsum(ln).astype(_np.uint64)
+        sets.append(synth.SeqSet(_np.ascontiguousarray(_np.concatenate(seqs)) if seqs else _np.zeros(0, _np.uint8), offs, lambda i: "q%d" % i))
     return sets
 
 
@@ -121,9 +127,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["auto", "C2", "C4"], default="auto", help="auto: C2 at --gpus 1, C4 above")
+    ap.add_argument("--workload", choices=["auto", "C2", "C4"], default="auto", help="auto = C2 (weak scaling: 1M queries per GPU and step); "
+                    "C4 = 10M queries in N shards vs a 5M-sequence DB (strong scaling)")
+    ap.add_argument("--force-gather", action="store_true", help="--gpus 1 only: run the N > 1 step (C++ gather through a communicator "
+                    "of one rank) instead of the plain fetch - exercises that code on a one-GPU box")
     ap.add_argument("--db", type=int, default=0, help="DB sequences (default: the workload's)")
-    ap.add_argument("--queries", type=int, default=0, help="queries per step over all GPUs (default: the workload's)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step: per GPU for C2 (weak), over all GPUs for C4 (default: the workload's)")
     ap.add_argument("--length", type=int, default=250)
     ap.add_argument("--id", type=float, default=0.97)
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
@@ -163,18 +172,33 @@ def main():
 
     from usearch12_amd import capi, synth, multigpu
 
-    workload = args.workload if args.workload != "auto" else ("C2" if world == 1 else "C4")
+    workload = args.workload if args.workload != "auto" else "C2"
     seed = 2 if workload == "C2" else 4
     db_n = args.db or (1_000_000 if workload == "C2" else 5_000_000)
-    total_q = args.queries or (1_000_000 if workload == "C2" else 10_000_000)
-    lo, hi = multigpu.shard_range(total_q, world, rank)            # contiguous shard of this rank
-    shard_n = hi - lo
+    if workload == "C2":                                            # weak: every rank its own batch of the C2 size
+        shard_n = args.queries or 1_000_000
+        total_q = shard_n * world
+        lo = rank * shard_n
+    else:                                                           # strong: the C4 query set in contiguous shards
+        total_q = args.queries or 10_000_000
+        lo, hi = multigpu.shard_range(total_q, world, rank)
+        shard_n = hi - lo
 
-    # ---- synthetic workload; the DB is the same on every rank (replicated index), the queries are the rank's shard.
-    # Two different batches alternate from step to step.
+    # ---- synthetic workload; the DB is the same on every rank (replicated index): rank 0 generates it once and the other
+    # ranks of the node map the file.  The queries are the rank's shard; two different batches alternate from step to step.
     t0 = time.time()
-    db = synth.make_db(seed, db_n, args.length)
-    qsets = make_query_sets(synth, seed + 1000 * rank, db, shard_n, args.length, 2)
+    if world > 1:
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        tag = os.path.join(shm, "ugs_bench_db_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), seed, db_n, args.length))
+        if rank == 0:
+            db0 = synth.make_db(seed, db_n, args.length)
+            np.save(tag + "_seqs.npy", db0.seqs); np.save(tag + "_offs.npy", db0.offs)
+            del db0
+        dist.barrier()
+        db = synth.SeqSet(np.load(tag + "_seqs.npy", mmap_mode="r"), np.load(tag + "_offs.npy", mmap_mode="r"), lambda i: "t%d" % i)
+    else:
+        db = synth.make_db(seed, db_n, args.length)
+    qsets = make_query_sets(synth, seed, db, lo, shard_n, args.length, 2)
     t_gen = time.time() - t0
 
     p = capi.params(is_nucleo=True, id=args.id)
@@ -185,6 +209,29 @@ def main():
     bats = [capi.UgsBatch(gdb, shard_n, max_letters) for _ in range(2)]
     for q in qsets:                                                 # page-locked once: uploads are then true async DMA
         capi._chk(capi.lib().ugs_host_register(q.seqs.ctypes.data, q.seqs.nbytes))
+    if world > 1:
+        dist.barrier()                                              # every rank has built its index and its queries from the mapped file
+        if rank == 0:
+            os.remove(tag + "_seqs.npy"); os.remove(tag + "_offs.npy")
+    # ---- the exchange.  nccl backend (the measurement): the product's C++ gather over its own RCCL communicator; the id
+    # travels through torch.distributed, which is otherwise only the launcher's rendezvous, barrier and max-reduction.
+    # gloo backend (dry run on a box with fewer GPUs than ranks): torch.distributed gathers through the host.
+    comm = None
+    use_cpp_gather = (world > 1 and args.backend == "nccl") or (world == 1 and args.force_gather)
+    if use_cpp_gather:
+        ids = [capi.UgsComm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = capi.UgsComm.init_rank(ids[0], rank, world, local_rank)
+        for b in bats:
+            b.set_query_base(lo)                                    # the search's own grouping stamps global query ids
+    gbuf = None
+    if comm is not None and rank == 0:                              # rank 0's result buffers: page-locked once, reused every step
+        cap_h = total_q * (p.max_accepts or 64) + 1
+        from usearch12_amd.abi import HIT_DTYPE
+        gbuf = [np.zeros(cap_h, HIT_DTYPE), np.zeros(total_q + 1, np.uint32), np.zeros(24 * total_q + 4096, np.uint32)]
+        for a in gbuf:
+            capi._chk(capi.lib().ugs_host_register(a.ctypes.data, a.nbytes))
     t0 = time.time()
     bats[0].upload(qsets[0].seqs, qsets[0].offs)                    # the first batch of the pipeline
     bats[0].search(); bats[0].sync()                                # (also sizes the scratch buffers)
@@ -195,8 +242,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    t_parts = {"search_sync": 0.0, "fetch": 0.0, "gather": 0.0, "upload_issue": 0.0}
+    t_parts = {"search_sync": 0.0, "fetch": 0.0, "gather": 0.0, "upload_issue": 0.0, "sync_wait": 0.0, "gather_exchange": 0.0, "gather_d2h": 0.0}
     state = {"i": 0}
+
+    def collect(b):
+        """the hit table of a synced batch to the host: plain fetch (one GPU), the C++ gather to rank 0 (N ranks over RCCL),
+        or torch.distributed through the host (gloo dry run)"""
+        if comm is not None:
+            tg = time.time()
+            try:
+                got = comm.gather_into(b, lo, 0, *(gbuf if rank == 0 else (np.zeros(1, np.uint8),) * 3))
+            except capi.UgsError as e:                              # rank 0's run pool too small: the exchange itself is done on every
+                if e.code != -5 or rank != 0:                       # rank, so rank 0 alone grows its buffer and copies again
+                    raise
+                capi.lib().ugs_host_unregister(gbuf[2].ctypes.data)
+                gbuf[2] = np.zeros(int(comm.last_demand()[2] * 1.25) + 4096, np.uint32)
+                capi._chk(capi.lib().ugs_host_register(gbuf[2].ctypes.data, gbuf[2].nbytes))
+                got = comm.refetch_into(*gbuf)
+            t_parts["gather"] += time.time() - tg
+            ex, d2h = comm.last_times()
+            t_parts["gather_exchange"] += ex; t_parts["gather_d2h"] += d2h
+            return got
+        if dist is None:
+            tf = time.time()
+            out = b.fetch(reuse=True)
+            t_parts["fetch"] += time.time() - tf
+            return out
+        tg = time.time()
+        (ph, bh), (pn, bn), (pc, bc) = b.device_results(query_base=lo)   # compacted + global query ids on device
+        t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
+        t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
+        t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
+        if cdev == "cpu":
+            t_h, t_n, t_c = t_h.cpu(), t_n.cpu(), t_c.cpu()
+        got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
+        t_parts["gather"] += time.time() - tg
+        return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3]) if rank == 0 else None
 
     def step():
         i = state["i"]
@@ -205,43 +286,27 @@ def main():
         ta = time.time()
         cur.search()                                                # enqueue: waits (on the GPU) for cur's upload
         out = None
-        if dist is None and state.get("pending") is not None:
-            # the previous step's hit table travels to the host while this step's kernels run (result buffers owned by the
-            # batch, page-locked once: a streaming caller's setup); the last table is drained before the clock stops.
-            # (the two batches alternate: the previous step's batch is the one the next upload goes into, so fetch first)
-            tf = time.time()
-            out = state["pending"].fetch(reuse=True)
-            t_parts["fetch"] += time.time() - tf
+        if state.get("pending") is not None:
+            # the previous step's hit table travels (to the host; for N > 1 first GPU to GPU to rank 0) while this step's kernels
+            # run; the last table is drained before the clock stops.  (The two batches alternate: the previous step's batch is
+            # the one the next upload goes into, so collect first.)
+            out = collect(state["pending"])
         tu = time.time()
         nxt.upload(qsets[(i + 1) % 2].seqs, qsets[(i + 1) % 2].offs)   # next step's batch travels while cur's kernels run
-        t_parts["upload_issue"] += time.time() - tu
-        if dist is None:
-            cur.sync()
-            t_parts["search_sync"] += time.time() - ta
-            state["pending"] = cur
-            return out, cur
+        tw = time.time()
+        t_parts["upload_issue"] += tw - tu
         cur.sync()
-        tb = time.time()
-        t_parts["search_sync"] += tb - ta
-        # multi-GPU: gather the device-resident hit tables to rank 0 over RCCL/xGMI (the only exchange)
-        (ph, bh), (pn, bn), (pc, bc) = cur.device_results(query_base=lo)   # compacted + global query ids on device
-        t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
-        t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
-        t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
-        if cdev == "cpu":
-            t_h, t_n, t_c = t_h.cpu(), t_n.cpu(), t_c.cpu()
-        got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
-        t_parts["gather"] += time.time() - tb
-        if rank == 0:
-            return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3]), cur
-        return None, cur
+        t_parts["sync_wait"] += time.time() - tw                    # > 0: this step's kernels outlasted the previous table's journey
+        t_parts["search_sync"] += time.time() - ta
+        state["pending"] = cur
+        return out, cur
 
     # the pipeline is primed so that step 0 finds its batch uploaded
     bats[0].upload(qsets[0].seqs, qsets[0].offs)
     for _ in range(args.warmup):
         step()
-    if dist is None and state.get("pending") is not None:
-        state["pending"].fetch(reuse=True)
+    if state.get("pending") is not None:
+        collect(state["pending"])
         state["pending"] = None
     for k in t_parts:
         t_parts[k] = 0.0
@@ -252,10 +317,7 @@ def main():
     for _ in range(args.steps):
         out, cur = step()
         stats.append(cur.stats())
-    if dist is None:                                            # drain: the last step's hit table
-        tf = time.time()
-        out = state["pending"].fetch(reuse=True)
-        t_parts["fetch"] += time.time() - tf
+    out = collect(state["pending"])                             # drain: the last step's hit table
     barrier()
     elapsed = time.time() - t0
     per_rank = None
@@ -263,12 +325,17 @@ def main():
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ns = max(args.steps, 1)
         mine = torch.tensor([float(np.mean([s["ms_rank"] for s in stats])), float(np.mean([s["ms_align"] for s in stats])),
-                             float(np.mean([s["ms_rank_setup"] for s in stats])), 1000.0 * t_parts["gather"] / max(args.steps, 1),
-                             1000.0 * t_parts["search_sync"] / max(args.steps, 1), float(shard_n)], device=cdev, dtype=torch.float64)
+                             float(np.mean([s["ms_rank_setup"] for s in stats])), 1000.0 * t_parts["gather"] / (ns + 1),
+                             1000.0 * t_parts["gather_exchange"] / (ns + 1), 1000.0 * t_parts["gather_d2h"] / (ns + 1),
+                             1000.0 * t_parts["sync_wait"] / ns, 1000.0 * t_parts["search_sync"] / ns, float(shard_n)], device=cdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [dict(zip(("ms_rank", "ms_align", "ms_rank_setup", "ms_gather", "ms_search_sync", "queries"), [float(x) for x in t.tolist()])) for t in allr]
+        # ms_gather: host time inside one gather call (exchange over xGMI + rank 0's device-to-host copies); it runs beside the next
+        # step's kernels, ms_sync_wait_after = how long that step's kernels still ran when the gather had returned (0 = exposed)
+        per_rank = [dict(zip(("ms_rank", "ms_align", "ms_rank_setup", "ms_gather", "ms_gather_exchange", "ms_gather_d2h",
+                              "ms_sync_wait_after", "ms_step_host", "queries"), [float(x) for x in t.tolist()])) for t in allr]
 
     steps = max(args.steps, 1)
     value = total_q * steps / elapsed
@@ -290,12 +357,14 @@ def main():
         # KiB x2 gfx950 correction + WRITE_SIZE); only attached when the workload shape matches
         traffic = None
         mix = {}
+        traffic_source = None
         pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True)   # newest round first
         for pmc_name in pmcs:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
                 if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
                     traffic = pm["traffic_bytes_per_launch"][dom]
+                    traffic_source = "profiles/" + pmc_name + " (PMC passes of this command, not measured in this run)"
                     mix = pm.get("instruction_mix_per_launch", {})
                     break
             except (OSError, ValueError):
@@ -323,10 +392,12 @@ def main():
         sample_q = args.cpu_sample or max(2000, min(qs.n, 1500 * threads))
         # the CPU baseline is a single-GPU-run item (rank 0 at N=1): the other ranks of a multi-GPU run would only wait for it
         cb = cpu_baseline(args.cpu_baseline if (world == 1 and workload == "C2") else "none", db, qs, args.id, sample_q, threads)
+        how = ("ugs_gather_results (libugs_rccl.so: ncclAllGather of sizes + grouped ncclSend/ncclRecv), issued beside the next step's kernels"
+               if comm is not None else ("torch.distributed gloo through the host (dry run)" if dist is not None else "none (one GPU: plain fetch)"))
         if workload == "C2":
-            wl = ("C2: usearch_global %d x %d nt queries vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
-                  "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one" %
-                  (total_q, args.length, db.n, args.id))
+            wl = ("C2: usearch_global %d x %d nt queries per GPU and step vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
+                  "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one%s" %
+                  (shard_n, args.length, db.n, args.id, "" if world == 1 else "; %d GPUs = %d queries per step, DB replicated, one gather of the hit tables to rank 0 per step" % (world, total_q)))
         else:
             wl = ("C4: usearch_global %d x %d nt queries in %d contiguous shard(s) vs a %d-seq DB replicated per GPU, -id %.2f "
                   "-strand plus, reference defaults; one RCCL gather of the hit tables to rank 0 per step" %
@@ -334,12 +405,12 @@ def main():
         line = {
             "metric": "query-seqs/s usearch_global -id 0.97 (search phase: query batch on the host -> hit table on the host)",
             "value": value, "unit": "query-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak" if workload == "C2" else "strong",
             "vs_baseline": None, "dtype": "u8/u32 (int32 half-unit DP scores)", "data": "synthetic",
             "config": {"workload": wl, "queries_per_step": total_q, "queries_per_gpu": shard_n, "db_seqs": db.n, "seq_len": args.length,
-                       "parallelism": "query shards, DB replicated per GPU" if world > 1 else "single GPU"},
+                       "parallelism": "query shards, DB replicated per GPU" if world > 1 else "single GPU", "gather": how},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": b_dom, "kernel_ms": ms_dom,
                          "bytes_per_query": b_dom / max(qs.n, 1)},
             "roofline_per_kernel": {
@@ -360,13 +431,16 @@ def main():
                        "host_ms_search_sync": 1000.0 * t_parts["search_sync"] / steps,
                        "host_ms_upload_issue": 1000.0 * t_parts["upload_issue"] / steps,
                        "host_ms_fetch": 1000.0 * t_parts["fetch"] / steps,
-                       "host_ms_gather": 1000.0 * t_parts["gather"] / steps,
+                       "host_ms_gather": 1000.0 * t_parts["gather"] / (steps + 1),
+                       "host_ms_sync_wait_after_collect": 1000.0 * t_parts["sync_wait"] / steps,
                        "per_rank": per_rank,
                        "index_build_s": t_index, "first_upload_search_s": t_upload, "gen_s": t_gen,
                        "db_hbm_bytes": gdb.stats()["hbm_bytes"],
                        "gpu_over_cpu": (value / world / cb["value"]) if cb else None},
         }
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

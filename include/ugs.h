@@ -274,6 +274,11 @@ int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
  * For callers that move results GPU-to-GPU (the multi-GPU driver gathers them to rank 0 with RCCL
  * over xGMI) instead of fetching to the host.
  */
+/* A shard's offset into the global query numbering (multi-GPU: rank r's first query).  Set before ugs_batch_search, the
+ * search's own grouping stamps ugs_hit.query with it and ugs_batch_device_results(query_base = the same value) then hands the
+ * table over as it stands, with no regrouping pass between the search and the gather.  ugs_batch_fetch always returns
+ * batch-local query indexes.  Default 0. */
+int ugs_batch_set_query_base(ugs_batch *b, uint32_t query_base);
 int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void **d_hits, uint64_t *hits_bytes,
                              void **d_nhits, uint64_t *nhits_bytes, void **d_cigar, uint64_t *cigar_bytes);
 

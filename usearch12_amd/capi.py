@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -63,6 +63,7 @@ def lib():
         L.ugs_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
         L.ugs_batch_get_candidates.argtypes = [vp, vp, vp, vp, u32]
         L.ugs_batch_candidate_k.argtypes = [vp, C.POINTER(u32)]
+        L.ugs_batch_set_query_base.argtypes = [vp, u32]
         L.ugs_batch_device_results.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
                                                C.POINTER(vp), C.POINTER(u64)]
         L.ugs_format_blast6.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -311,6 +312,9 @@ class UgsBatch:
         _chk(lib().ugs_batch_get_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in BatchStats._fields_}
 
+    def set_query_base(self, base):
+        _chk(lib().ugs_batch_set_query_base(self.h, C.c_uint32(base)))
+
     def device_results(self, query_base=0):
         """(ptr, nbytes) of the device-resident compact hits (query ids offset by query_base),
         per-query hit counts and run pool."""
@@ -531,6 +535,35 @@ class UgsComm:
         if L.ugs_comm_rank(self.h) != dst:
             return None
         return hits[:nh.value], cnt[:nq.value], pool[:nr.value]
+
+    def gather_into(self, batch, query_base, dst, hits, cnt, pool):
+        """collective, into caller-owned (ideally page-locked: ugs_host_register) arrays that are reused from step to step;
+        on dst returns views (hits, nhits_per_query, pool) of them, elsewhere None.  UgsError(-5) when dst's arrays are too small."""
+        L = lib_rccl()
+        nh, nq, nr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = L.ugs_gather_results(self.h, batch.h, query_base, dst, hits.ctypes.data, len(hits), cnt.ctypes.data, len(cnt),
+                                  pool.ctypes.data, len(pool), C.byref(nh), C.byref(nq), C.byref(nr))
+        self._demand = (nh.value, nq.value, nr.value)
+        _chk(rc)
+        if L.ugs_comm_rank(self.h) != dst:
+            return None
+        return hits[:nh.value], cnt[:nq.value], pool[:nr.value]
+
+    def last_demand(self):
+        """(hits, queries, runs) the last gather wanted room for on dst (what UGS_E_CAPACITY reports)"""
+        return self._demand
+
+    def refetch_into(self, hits, cnt, pool):
+        """dst only, after UGS_E_CAPACITY: the tables of the last gather (still in dst's device staging buffers) once more"""
+        nh, nq, nr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _chk(lib_rccl().ugs_gather_refetch(self.h, hits.ctypes.data, len(hits), cnt.ctypes.data, len(cnt), pool.ctypes.data, len(pool),
+                                           C.byref(nh), C.byref(nq), C.byref(nr)))
+        return hits[:nh.value], cnt[:nq.value], pool[:nr.value]
+
+    def last_times(self):
+        a, b = C.c_double(0), C.c_double(0)
+        _chk(lib_rccl().ugs_gather_last_times(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def close(self):
         if self.h:

@@ -801,10 +801,10 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   // hits grouped by query on the device right behind the alignment stage (count, scan, gather): ugs_batch_fetch is then
   // nothing but copies, which overlap the kernels of whatever batch runs next
   if (b->nq) RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                                    b->scan_tmp_bytes, 0, db->stream));
+                                    b->scan_tmp_bytes, b->query_base, db->stream));
   HIPCHK(hipEventRecord(b->ev_done, db->stream));
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
-  b->searched = true; b->synced = false; b->compact_base = 0;
+  b->searched = true; b->synced = false; b->compact_base = b->query_base;
   return UGS_OK;
 }
 
@@ -837,7 +837,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     RCCHK(enqueue_align(b));
     HIPCHK(hipEventRecord(b->ev2, db->stream));
     RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                           b->scan_tmp_bytes, 0, db->stream));
+                           b->scan_tmp_bytes, b->query_base, db->stream));
   }
   ugs_set_error("path pool overflow persisted");
   return UGS_E_CAPACITY;
@@ -1057,6 +1057,13 @@ extern "C" int ugs_format_uc_nohit(uint32_t ql, const char *qlabel, char *buf, i
 // compact hits[n_hits] (ugs_hit, `query` offset by query_base), nhits_per_query[nq] (uint32) and the
 // run pool (uint32).  Hits of a query are in discovery order (strand 0 first); ugs_batch_fetch
 // additionally applies HitMgr::Sort to queries with several hits.
+extern "C" int ugs_batch_set_query_base(ugs_batch *b, uint32_t query_base)
+{
+  if (!b) return UGS_E_ARG;
+  b->query_base = query_base;
+  return UGS_OK;
+}
+
 extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void **d_hits, uint64_t *hits_bytes,
                                         void **d_nhits, uint64_t *nhits_bytes, void **d_cigar, uint64_t *cigar_bytes)
 {
@@ -1066,9 +1073,11 @@ extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void 
   const uint32_t nq = b->nq, ns = b->nstrand, ma = b->hit_slots;
   uint64_t total = 0;
   if (nq) {
-    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                           b->scan_tmp_bytes, query_base, b->copy_stream));
-    b->compact_base = query_base;
+    if (b->compact_base != query_base) {        // (a search already grouped the table with the batch's own base: ugs_batch_set_query_base)
+      RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
+                             b->scan_tmp_bytes, query_base, b->copy_stream));
+      b->compact_base = query_base;
+    }
     uint32_t last_off = 0, last_n = 0;
     HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (nq - 1), 4, hipMemcpyDeviceToHost, b->copy_stream));
     HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (nq - 1), 4, hipMemcpyDeviceToHost, b->copy_stream));

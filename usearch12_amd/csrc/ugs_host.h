@@ -56,7 +56,8 @@ struct ugs_batch {
   // upload path: H2D copies go through the batch's own copy stream; the search waits for ev_up on the handle's stream,
   // so the upload of one batch overlaps the kernels of another (h_rel: page-locked staging of the relative offsets)
   hipStream_t copy_stream; hipEvent_t ev_up, ev_done; uint64_t *h_rel;   // ev_done: end of the last enqueued search
-  uint32_t compact_base;            // query base of the grouped hit table in d_compact (0 after a search)
+  uint32_t compact_base;            // query base of the grouped hit table in d_compact (query_base after a search)
+  uint32_t query_base;              // ugs_batch_set_query_base: what the search's own grouping adds to ugs_hit.query (a shard's offset)
   bool searched, synced;
   unsigned long long ctr[UGS_CTR_N];
   unsigned long long cigar_used_host;
