@@ -171,3 +171,22 @@ def test_c3_model_across_the_natural_latch_equals_the_reference_files(tmp_path):
     assert sha(ucp) == m["uc_sha256"]
     assert sha(cp) == m["centroids_sha256"]
     res.close()
+
+
+def test_candidate_buffer_grows_on_demand_and_the_search_is_run_again(tmp_path, monkeypatch):
+    """The ranking kernel's candidate-key buffer is sized by what earlier searches needed, not by the worst case (tens of GB for
+    late cluster_fast batches); a unit that emits more flags it, ugs_batch_sync grows the buffer to the demand and runs the search
+    again.  Forced here with a buffer of one key per workgroup on the one-dominant-species golden: same files, and the path ran."""
+    import ctypes
+    L = capi.lib()
+    L.ugs_debug_emit_regrows.restype = ctypes.c_uint64
+    before = L.ugs_debug_emit_regrows()
+    monkeypatch.setenv("UGS_EMIT_LIMIT", "1")
+    c, r, uc, cen = G.load_cluster("cl_skew")
+    res = _cluster(c, r)
+    labels = r.labels()
+    ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
+    res.write_uc(labels, ucp)
+    res.write_centroids(labels, cp)
+    assert open(ucp).read() == uc and open(cp).read() == cen
+    assert L.ugs_debug_emit_regrows() > before

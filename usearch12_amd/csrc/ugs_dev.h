@@ -106,7 +106,7 @@ struct UgsBatchView {
 #define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited): a walk that reaches the end of a full candidate list is an error
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
-       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_N };  // T*: phase clocks (profiling)
+       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
 enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64 };
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates

@@ -2,6 +2,7 @@
 // HBM residency, hit gathering, and the blast6/uc text writers.  No CPU compute fallback:
 // every search entry point needs a gfx950 device.
 #include "ugs_host.h"
+#include <atomic>
 
 #include <cctype>
 #include <cmath>
@@ -601,6 +602,9 @@ static int plan_local(ugs_batch *b)
   return UGS_OK;
 }
 
+static std::atomic<uint64_t> g_emit_regrows{0};
+extern "C" uint64_t ugs_debug_emit_regrows(void) { return g_emit_regrows.load(); }    // diagnostic: searches re-run with a larger candidate buffer
+
 static int plan_launch(ugs_batch *b)
 {
   ugs_db *db = b->db;
@@ -649,7 +653,15 @@ static int plan_launch(ugs_batch *b)
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well
   // a target with count c is emitted c times (deduplicated at selection): bounded by the postings read
-  uint64_t ecap = std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20) + (uint64_t)db->v.np * 4 * b->K + 64;
+  // ... and by what the searches of this batch object have actually needed: the worst case (every posting of a unit's longest rows)
+  // runs into tens of GB for cluster_fast's late batches, and a multi-GB hipMalloc / hipFree per growth step costs 0.1-0.9 s each
+  // (2.7 s of one C3 run).  A unit that emits more sets UGS_ERR_EMIT and its demand; ugs_batch_sync grows the buffer and runs
+  // the search again.
+  if (!b->emit_limit) {
+    b->emit_limit = 1u << 16;
+    if (const char *e = getenv("UGS_EMIT_LIMIT")) { const long v = atol(e); if (v >= 1) b->emit_limit = (uint64_t)v; }      // tests: force the regrow path
+  }
+  uint64_t ecap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20), b->emit_limit) + (getenv("UGS_EMIT_LIMIT") ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
   if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
     // (a database that grows - cluster_fast - asks for a little more with every batch: over-allocate then, a multi-GB
     // hipMalloc per batch costs more than the batch's kernels)
@@ -813,10 +825,27 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
   if (!b || !b->searched) return UGS_E_ARG;
   ugs_db *db = b->db;
   HIPCHK(hipSetDevice(db->device));
+  int emit_tries = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIPCHK(hipStreamSynchronize(db->stream));
     HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
+    if ((b->ctr[UGS_CTR_ERR] & UGS_ERR_EMIT) && emit_tries < 6) {     // (other flags of such a run may be consequences of the truncated lists)
+      // the candidate buffer was sized by earlier demand: grow it to this search's and run the search again
+      ++emit_tries; ++g_emit_regrows;
+      const uint64_t wpb = (uint64_t)b->rl.wpb, demand = b->ctr[UGS_CTR_EMIT_MAX] * wpb;
+      b->emit_limit = std::max<uint64_t>(2 * b->emit_limit, demand + demand / 4 + 4096);
+      const uint64_t ecap = b->emit_limit + (getenv("UGS_EMIT_LIMIT") ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64, want = ecap * (uint64_t)b->rl.grid;
+      if (want > b->emit_cap_alloc) {
+        HIPCHK(hipFree(b->d_emit)); b->d_emit = nullptr;
+        HIPCHK(hipMalloc(&b->d_emit, want * 8));
+        b->emit_cap_alloc = want;
+      }
+      b->v.emit_buf = b->d_emit; b->v.emit_cap = ecap;
+      RCCHK(ugs_batch_search(b));
+      --attempt;
+      continue;
+    }
     if (b->ctr[UGS_CTR_ERR]) {
       if (b->ctr[UGS_CTR_ERR] == UGS_ERR_LOCAL_HITS) {
         ugs_set_error("more than max_hsps = %u HSPs on one accepted target; raise ugs_params.max_hsps", db->p.max_hsps);

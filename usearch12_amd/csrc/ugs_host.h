@@ -50,6 +50,7 @@ struct ugs_batch {
   uint32_t *d_qkey, *d_qsize; bool have_qkey, have_qsize;
   unsigned long long *d_cigar_used, *d_ctr;
   uint64_t cigar_cap, emit_cap_alloc, tb_alloc, runs_alloc;
+  uint64_t emit_limit;              // keys per workgroup the candidate buffer is sized for (grown on demand by ugs_batch_sync)
   int rank_grid_alloc, align_waves_alloc;
   UgsRankLaunch rl; UgsAlignLaunch al;
   hipEvent_t ev0, ev0s, ev1, ev2;

@@ -1296,7 +1296,10 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     const uint32_t elw = sc.elw; const uint64_t ecapw = sc.ecapw;
     uint32_t woff1 = 0, woff2 = 0, woff3 = 0, n_emit = 0;
     auto read_counts = [&]() {
-      const uint32_t n0 = sh->wn[0], n1 = wpb > 1 ? sh->wn[1] : 0u, n2 = wpb > 2 ? sh->wn[2] : 0u, n3 = wpb > 3 ? sh->wn[3] : 0u;
+      // (a wave that emitted more than its share holds only the first elw + ecapw keys: the unit is flagged below and searched again
+      // with a larger buffer; until then nothing past the stored keys is read)
+      const uint32_t wcap = (uint32_t)std::min<uint64_t>((uint64_t)elw + ecapw, 0xffffffffull);
+      const uint32_t n0 = min(sh->wn[0], wcap), n1 = wpb > 1 ? min(sh->wn[1], wcap) : 0u, n2 = wpb > 2 ? min(sh->wn[2], wcap) : 0u, n3 = wpb > 3 ? min(sh->wn[3], wcap) : 0u;
       woff1 = n0; woff2 = n0 + n1; woff3 = n0 + n1 + n2; n_emit = n0 + n1 + n2 + n3;
     };
     read_counts();
@@ -1708,8 +1711,14 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     }
     tacc0 += tk1 - tk0; tacc1 += tk2w - tk1; tacc2 += tk2 - tk2w; tacc3 += clock64() - tk2;
     if (tid == 0) {
-      bv.cand_n[unit] = sh->n_sel;
-      for (int w2 = 0; w2 < wpb; ++w2) if ((uint64_t)sh->wn[w2] > (uint64_t)elw + ecapw) atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
+      bool over = false;
+      for (int w2 = 0; w2 < wpb; ++w2)
+        if ((uint64_t)sh->wn[w2] > (uint64_t)elw + ecapw) {      // the host grows the buffer to the demand and runs the search again
+          atomicOr(&bv.counters[UGS_CTR_ERR], (unsigned long long)UGS_ERR_EMIT);
+          atomicMax(&bv.counters[UGS_CTR_EMIT_MAX], (unsigned long long)sh->wn[w2]);
+          over = true;
+        }
+      bv.cand_n[unit] = over ? 0u : sh->n_sel;                   // (no walk over a list chosen from truncated keys)
       sh->pad1 = next_unit;
     }
     __syncthreads();
