@@ -126,7 +126,9 @@ struct ScanCtx {
   int wave, wpb, lane; bool small_path;
 };
 
+#ifndef UGS_ELDS
 #define UGS_ELDS 1024u
+#endif
 __device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)     // idx: position in this wave's segment
 {
   if (idx < s.elw) s.s_ebuf[idx] = key;
