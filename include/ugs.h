@@ -243,7 +243,8 @@ typedef struct ugs_batch_stats {
   float    ms_total;
   uint64_t postings;         /* sum over queries of P(q)                  */
   uint64_t query_letters;
-  uint64_t target_letters;   /* letters of candidates actually aligned    */
+  uint64_t target_letters;   /* bytes of candidate targets fetched by the alignment stage: the letters, or for nt targets up to 1024
+                              * letters their 2-bit planes (8 bytes per 16 letters) + the letters of the pairs that reach the chain gate */
   uint64_t pairs_aligned;
   uint64_t dp_cells;
   uint64_t hits;

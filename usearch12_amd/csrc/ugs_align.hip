@@ -923,11 +923,24 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       cto = db.offs[ct];
       clen = (uint32_t)(db.offs[ct + 1] - cto);
     }
-    // the NEXT candidate's letters travel while the current pair is aligned (4 x 4 letters per lane)
+    // the NEXT candidate's letters travel while the current pair is aligned.  nt databases keep their letters a second time packed
+    // 2 bits each (UgsDbView::p2 / pi, BASELINE north_star): a target of up to 1024 letters is then fetched as <= 65 words per plane
+    // (lane j takes the words that hold its 16 letters) for the seed search and the ungapped extension, and its BYTES (case, IUPAC:
+    // identity tests, DP scores) only if the pair gets as far as the chain gate - most pairs of a search are random candidates of
+    // queries without a hit and never do.  Everything else (aa, longer targets, the in-batch pair stage of cluster_fast whose targets
+    // are query letters): 4 x 4 letters per lane from the byte array as before.
     uint32_t pre[4] = {0, 0, 0, 0};
+    const bool have_packed = c.nt && db.p2 != nullptr;
     auto prefetch = [&](uint32_t k2) {
       const uint64_t to2 = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k2) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k2);
       const uint32_t L2 = (uint32_t)rl((int)clen, (int)k2);
+      if (have_packed && L2 <= 1024) {
+        const uint64_t w0 = (to2 >> 4) + (uint32_t)lane;
+        const bool on = (uint32_t)lane * 16u < L2 + 16u;                 // words 0 .. ceil(L2 / 16) (one more than the letters fill: the shift)
+        pre[0] = on ? db.p2[w0] : 0u; pre[1] = on ? db.p2[w0 + 1] : 0u;
+        pre[2] = on ? db.pi[w0] : 0u; pre[3] = on ? db.pi[w0 + 1] : 0u;
+        return;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
@@ -945,7 +958,38 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
       c.LB = LB;
       const bool pack_direct = c.nt && LB <= 1024;             // nt: a lane's 4 letters are one byte of the packed arrays
+      const bool from_packed = have_packed && LB <= 1024;
+      bool classes_loaded = !from_packed;
+      // the target's class bytes (c.B) for a pair fetched from the packed arrays: loaded when the pair first needs them
+      auto load_classes = [&]() {
+        if (classes_loaded) return;
+        classes_loaded = true;
+        w_tletters += LB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
+          if (o < LB) {
+            uint32_t v = 0, cls4 = 0;
+            __builtin_memcpy(&v, db.seqs + to + o, 4);
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) cls4 |= (uint32_t)s_cls[(v >> (8 * b)) & 0xffu] << (8 * b);
+            *(uint32_t *)(c.B + o) = cls4;
+          }
+        }
+        wave_sync();
+      };
       bool anyb = false;                                       // a target letter that is not A/C/G/T/U
+      if (from_packed) {
+        const uint32_t nw = (LB + 15) >> 4, sh2 = ((uint32_t)to & 15u) * 2u;
+        uint32_t w2 = __builtin_amdgcn_alignbit(pre[1], pre[0], sh2), wi = __builtin_amdgcn_alignbit(pre[3], pre[2], sh2);
+        const uint32_t j = (uint32_t)lane;
+        if (j + 1 == nw && (LB & 15u)) { const uint32_t m = (1u << (2u * (LB & 15u))) - 1u; w2 &= m; wi &= m; }   // letters behind the target's end belong to its neighbour
+        if (j >= nw) { w2 = 0; wi = 0; }
+        if (j < nw + 3) { c.B2[j] = w2; c.Bi[j] = wi; }
+        if (nw + 3 > 64 && j < nw + 3 - 64) { c.B2[64 + j] = 0; c.Bi[64 + j] = 0; }
+        if (lane < 2) { c.B2[-1 - lane] = 0; c.Bi[-1 - lane] = 0; }
+        anyb = wi != 0;
+      } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
@@ -965,6 +1009,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
         }
       }
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; const uint8_t sc = s_sc[cl & 31]; c.B[p] = cl; c.Bs[p] = sc; anyb = anyb || sc > 3; }
+      }
       c.b_inv = c.nt && __ballot(anyb) != 0;
       if (k + 1 < ncand) prefetch(k + 1);
       wave_sync();
@@ -979,6 +1024,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
           rej = ((pm & UGS_P_SELF) && same) || ((pm & UGS_P_NOTSELF) && !same);
         }
         if (!rej && (pm & UGS_P_SELFID) && LB == LA) {         // same length and identical stored letters
+          load_classes();
           bool diff = false;
           for (uint32_t p0 = 0; p0 < LA && !diff; p0 += 64) { const uint32_t p = p0 + lane; diff = __ballot(p < LA && c.A[p] != c.B[p]) != 0; }
           rej = !diff;
@@ -999,7 +1045,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
           continue;
         }
       }
-      w_tletters += LB; ++w_pairs;
+      w_tletters += from_packed ? (((LB + 15u) >> 4) + 1u) * 8u : LB; ++w_pairs;      // bytes of the target fetched for this pair (packed planes, or the letters)
       // ---- GlobalAlign_AllOpts (globalalignmem.cpp:129-236), FailIfNoHSPs = true
       uint32_t MinHSPLength = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
       if (MinHSPLength > LA / 4) MinHSPLength = LA / 4;
@@ -1017,6 +1063,7 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       const uint32_t nchain = c.ws->nchain;
       bool accept = false;
       if (nchain || force_all) {
+        load_classes();
         uint32_t TotLen = 0, TotSame = 0;
         for (uint32_t q = 0; q < nchain; ++q) {
           const HSPd h = c.hsps[c.chain[q]];

@@ -77,6 +77,45 @@ int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int 
   return UGS_OK;
 }
 
+// The stored (masked) nt letters once more, 2 bits per letter + a plane of "not A/C/G/T/U" bits, 16 letters per word by global letter
+// index (BASELINE north_star: letters packed 2-bit in HBM).  k_align fetches a target's letters for the seed search and the ungapped
+// extension from these arrays - a quarter of the bytes and no per-letter table look-ups per pair; the byte array stays what the
+// reference's SeqDB is (case, IUPAC letters: identities, masking, output) and is read for the pairs that reach the DP.
+// Code of a letter = what k_align's s_sc table gives it: hsp_letter (alpha2.cpp order A,C,G,T/U = 0..3) for a letter that can be part
+// of a word whatever its case, "other" for the rest.  One thread per word; words [word_lo, word_hi).
+__global__ void k_pack_letters(const UgsTables *tab, const uint8_t *seqs, uint64_t word_lo, uint64_t word_hi, uint32_t *p2, uint32_t *pi)
+{
+  __shared__ uint8_t code[256];
+  for (int k = threadIdx.x; k < 256; k += blockDim.x) {
+    const uint8_t cl = tab->cls[k] & 31;
+    code[k] = (cl < 26 && tab->udb_letter['A' + cl] != 0xff) ? tab->hsp_letter['A' + cl] : 4;
+  }
+  __syncthreads();
+  const uint64_t w = word_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= word_hi) return;
+  const uint4 d4 = *(const uint4 *)(seqs + 16 * w);
+  const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+  uint32_t v = 0, iv = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t sc = code[(d[q] >> (8 * b)) & 0xffu];
+      v |= (sc & 3u) << (8 * q + 2 * b);
+      iv |= (sc >> 2) << (8 * q + 2 * b);
+    }
+  p2[w] = v; pi[w] = iv;
+}
+
+int ugs_launch_pack(const UgsTables *d_tab, const uint8_t *d_seqs, uint64_t word_lo, uint64_t word_hi, uint32_t *d_p2, uint32_t *d_pi, hipStream_t st)
+{
+  if (word_hi <= word_lo) return UGS_OK;
+  const uint64_t n = word_hi - word_lo;
+  hipLaunchKernelGGL(k_pack_letters, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_tab, d_seqs, word_lo, word_hi, d_p2, d_pi);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
+
 // One wave per sequence; lane = position.  key = word<<32 | target, or slots<<32 (sorts last)
 // when the position has no valid word.
 __global__ void k_word_keys(const UgsTables *tab, const uint8_t *seqs, const uint64_t *offs, uint32_t nseq,
