@@ -142,13 +142,19 @@ def main():
                          "tables travel through the host) - not a measurement")
     args = ap.parse_args()
 
+    # ONE line on stdout: whatever the libraries below print there (RCCL's version banner at communicator creation, for one) goes to
+    # stderr; the JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.call(cmd, env=env))
+        sys.exit(subprocess.call(cmd, env=env, stdout=real_stdout))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,7 +235,7 @@ def main():
     if comm is not None and rank == 0:                              # rank 0's result buffers: page-locked once, reused every step
         cap_h = total_q * (p.max_accepts or 64) + 1
         from usearch12_amd.abi import HIT_DTYPE
-        gbuf = [np.zeros(cap_h, HIT_DTYPE), np.zeros(total_q + 1, np.uint32), np.zeros(24 * total_q + 4096, np.uint32)]
+        gbuf = [np.zeros(cap_h, HIT_DTYPE), np.zeros(total_q + 1, np.uint32), np.zeros(8 * total_q + 4096, np.uint32)]   # (runs: grown on demand)
         for a in gbuf:
             capi._chk(capi.lib().ugs_host_register(a.ctypes.data, a.nbytes))
     t0 = time.time()
@@ -438,7 +444,8 @@ def main():
                        "db_hbm_bytes": gdb.stats()["hbm_bytes"],
                        "gpu_over_cpu": (value / world / cb["value"]) if cb else None},
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
     if dist is not None:
