@@ -639,16 +639,7 @@ static int plan_launch(ugs_batch *b)
   const size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;      // + 64 dummy words per wave
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
-  (void)bits;   // (no LDS copy of the partition-table rows: the fast path reads them with scalar loads)
-  const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words);
-  int wpb = 4;
-  while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
-  if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
-  const size_t rlds = fixed + wpb * tbl_bytes;
-  const uint64_t units = (uint64_t)b->nq * b->nstrand;
-  int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds);      // real residency (VGPRs, LDS, wave slots)
-  per_cu = std::max(1, std::min(per_cu, 8));
-  if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
+  // which instantiation will run (ugs_rank.hip rank_kernel): the LDS carve and the residency differ between them
   b->rl.fast8 = bits >= 8 && !db->sparse;
   // very long index rows (the longest row 16x the average or more: an abundant family of sequences shares its words):
   // sub-rows longer than a wavefront are then common and get their own path (ugs_rank.hip range_long)
@@ -658,6 +649,20 @@ static int plan_launch(ugs_batch *b)
   // it as soon as an abundant species has a few hundred centroids).  UGS_LONGROWS=0/1 overrides (tuning).
   b->rl.longrows = db->max_row > 56u * db->v.np;
   if (const char *e = getenv("UGS_LONGROWS")) b->rl.longrows = atoi(e) != 0;
+  const int hot = ugs_rank_is_hot(db->v.big, bits, b->rl.fast8, b->rl.longrows);
+  if (hot && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30))) {
+    ugs_set_error("index too large for the 32-bit offsets of the ranking kernel's partition-table loads (%u slots x %u partitions, longest row %u)", db->v.slots, db->v.np, db->max_row);
+    return UGS_E_ENVELOPE;
+  }
+  const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words, hot);
+  int wpb = 4;
+  while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
+  if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
+  const size_t rlds = fixed + wpb * tbl_bytes;
+  const uint64_t units = (uint64_t)b->nq * b->nstrand;
+  int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds, db->v.big, bits, b->rl.fast8, b->rl.longrows);      // real residency (VGPRs, LDS, wave slots)
+  per_cu = std::max(1, std::min(per_cu, 8));
+  if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well

@@ -129,6 +129,9 @@ struct ScanCtx {
 #ifndef UGS_ELDS
 #define UGS_ELDS 1024u
 #endif
+#ifndef UGS_ELDS_HOT
+#define UGS_ELDS_HOT 512u      // keys of a unit that stay in LDS in the HOT instantiation (its LDS must fit five workgroups per CU)
+#endif
 __device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)     // idx: position in this wave's segment
 {
   if (idx < s.elw) s.s_ebuf[idx] = key;
@@ -661,22 +664,75 @@ typedef const uint64_t __attribute__((address_space(4))) *cptr64;
 
 template <int NR> struct Batch { uint32_t v[NR]; uint32_t len[NR]; bool tail; };
 
-template <int NR> struct Rows { uint32_t slot[NR]; const uint32_t *base[NR]; };
+// slot: the row's index slot; off: byte offset of the row's line in the partition table (slot * (np + 1) * 4 < 2^32, checked on the
+// host); base: the row's first posting
+template <int NR> struct Rows { uint32_t slot[NR]; uint32_t off[NR]; const uint32_t *base[NR]; };
 
-template <int NR>
+// HOT instantiation (Big path, 4-bit counters, uniform rows: C2 / C4): the partition-table entries (start, end of the sub-row) of
+// all NR rows for one partition as NR scalar loads that share ONE base pointer (table + p * 4) and take the row's line as their
+// SGPR offset operand, then one wait - written as one asm block because the compiler never selects the soffset form of s_load: it
+// adds a 64-bit offset to the pointer per row and partition, keeps the NR offsets in spilled SGPR pairs and, out of scalar
+// registers, moves the NR row pointers into VGPR pairs.  With the block the kernel fits 96 VGPRs without a spill in the partition
+// loop, i.e. FIVE workgroups per CU instead of four - and the loop is a latency chain that more waves hide (DESIGN section 4, round 3:
+// 62.7 -> 58.9 ms on C2; the block alone at four workgroups is slower, 65.1 ms: one long wait instead of six short ones).
+#define UGS_SL(k) "s_load_dwordx2 %" #k ", %[pp], %[o" #k "]\n"
+template <int NR> __device__ __forceinline__ void part_pairs(const void *pp, const Rows<NR> &R, uint64_t (&d)[NR]);
+template <> __device__ __forceinline__ void part_pairs<8>(const void *pp, const Rows<8> &R, uint64_t (&d)[8])
+{
+  asm volatile(UGS_SL(0) UGS_SL(1) UGS_SL(2) UGS_SL(3) UGS_SL(4) UGS_SL(5) UGS_SL(6) UGS_SL(7) "s_waitcnt lgkmcnt(0)"
+               : "=&s"(d[0]), "=&s"(d[1]), "=&s"(d[2]), "=&s"(d[3]), "=&s"(d[4]), "=&s"(d[5]), "=&s"(d[6]), "=&s"(d[7])
+               : [pp] "s"(pp), [o0] "s"(R.off[0]), [o1] "s"(R.off[1]), [o2] "s"(R.off[2]), [o3] "s"(R.off[3]), [o4] "s"(R.off[4]),
+                 [o5] "s"(R.off[5]), [o6] "s"(R.off[6]), [o7] "s"(R.off[7]) : "memory");
+}
+template <> __device__ __forceinline__ void part_pairs<11>(const void *pp, const Rows<11> &R, uint64_t (&d)[11])
+{
+  asm volatile(UGS_SL(0) UGS_SL(1) UGS_SL(2) UGS_SL(3) UGS_SL(4) UGS_SL(5) UGS_SL(6) UGS_SL(7) UGS_SL(8) UGS_SL(9) UGS_SL(10) "s_waitcnt lgkmcnt(0)"
+               : "=&s"(d[0]), "=&s"(d[1]), "=&s"(d[2]), "=&s"(d[3]), "=&s"(d[4]), "=&s"(d[5]), "=&s"(d[6]), "=&s"(d[7]), "=&s"(d[8]),
+                 "=&s"(d[9]), "=&s"(d[10])
+               : [pp] "s"(pp), [o0] "s"(R.off[0]), [o1] "s"(R.off[1]), [o2] "s"(R.off[2]), [o3] "s"(R.off[3]), [o4] "s"(R.off[4]),
+                 [o5] "s"(R.off[5]), [o6] "s"(R.off[6]), [o7] "s"(R.off[7]), [o8] "s"(R.off[8]), [o9] "s"(R.off[9]), [o10] "s"(R.off[10]) : "memory");
+}
+template <> __device__ __forceinline__ void part_pairs<12>(const void *pp, const Rows<12> &R, uint64_t (&d)[12])
+{
+  asm volatile(UGS_SL(0) UGS_SL(1) UGS_SL(2) UGS_SL(3) UGS_SL(4) UGS_SL(5) UGS_SL(6) UGS_SL(7) UGS_SL(8) UGS_SL(9) UGS_SL(10) UGS_SL(11) "s_waitcnt lgkmcnt(0)"
+               : "=&s"(d[0]), "=&s"(d[1]), "=&s"(d[2]), "=&s"(d[3]), "=&s"(d[4]), "=&s"(d[5]), "=&s"(d[6]), "=&s"(d[7]), "=&s"(d[8]),
+                 "=&s"(d[9]), "=&s"(d[10]), "=&s"(d[11])
+               : [pp] "s"(pp), [o0] "s"(R.off[0]), [o1] "s"(R.off[1]), [o2] "s"(R.off[2]), [o3] "s"(R.off[3]), [o4] "s"(R.off[4]),
+                 [o5] "s"(R.off[5]), [o6] "s"(R.off[6]), [o7] "s"(R.off[7]), [o8] "s"(R.off[8]), [o9] "s"(R.off[9]), [o10] "s"(R.off[10]),
+                 [o11] "s"(R.off[11]) : "memory");
+}
+#undef UGS_SL
+
+template <int NR, bool SL>
 __device__ __forceinline__ void issue_batch(const ScanCtx &s, const Rows<NR> &R, uint32_t p, Batch<NR> &B)
 {
   const int lane = s.lane;
   uint32_t mx = 0;
+  if constexpr (SL) {
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    uint64_t d[NR];
+    part_pairs<NR>((const char *)s.part + (uint64_t)p * 4u, R, d);
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    cptr32 pp = (cptr32)(uintptr_t)s.part + (uint64_t)R.slot[r] * (s.np + 1) + p;     // uniform address -> scalar load
-    const uint32_t pa = pp[0], pb = pp[1];
-    const uint32_t len = (uint32_t)r < s.ns ? pb - pa : 0u;
-    B.len[r] = len;
-    mx = len > mx ? len : mx;
-    const uint32_t *rowp = R.base[r] + pa;          // wave-uniform pointer (SALU); the load is "scalar base + lane*4"
-    B.v[r] = rowp[(uint32_t)lane];
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t pa = (uint32_t)d[r], pb = (uint32_t)(d[r] >> 32);
+      const uint32_t len = (uint32_t)r < s.ns ? pb - pa : 0u;
+      B.len[r] = len;
+      mx = len > mx ? len : mx;
+      // "scalar row pointer + 32-bit byte offset in a VGPR" (global_load ... saddr): pa * 4 + lane * 4 cannot wrap, a row holds
+      // fewer than 2^30 postings (host check)
+      B.v[r] = *(const uint32_t *)((const char *)R.base[r] + (pa * 4u + lane4));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      cptr32 pp = (cptr32)(uintptr_t)s.part + (uint64_t)R.slot[r] * (s.np + 1) + p;     // uniform address -> scalar load
+      const uint32_t pa = pp[0], pb = pp[1];
+      const uint32_t len = (uint32_t)r < s.ns ? pb - pa : 0u;
+      B.len[r] = len;
+      mx = len > mx ? len : mx;
+      const uint32_t *rowp = R.base[r] + pa;          // wave-uniform pointer (SALU); the load is "scalar base + lane*4"
+      B.v[r] = rowp[(uint32_t)lane];
+    }
   }
   B.tail = mx > 64;
 }
@@ -825,7 +881,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
   }
 }
 
-template <int NR, bool LONG>
+template <int NR, bool LONG, bool SL = false>
 __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
 {
   Rows<NR> R;
@@ -833,6 +889,7 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   for (int r = 0; r < NR; ++r) {
     const uint32_t slot = __builtin_amdgcn_readfirstlane(s.s_slots[(uint32_t)r < s.ns ? r : 0]);
     R.slot[r] = slot;
+    R.off[r] = slot * (s.np + 1u) * 4u;
     R.base[r] = s.postings + ((cptr64)(uintptr_t)s.row_off)[slot];
   }
   unsigned long long cache1 = KEY_INF;          // register copy of fp[1] (a stale-high filter)
@@ -841,14 +898,14 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   if (p0 >= s.np) return;
   const uint32_t last = s.np - 1;
   Batch<NR> A, B;
-  issue_batch<NR>(s, R, p0, A);
+  issue_batch<NR, SL>(s, R, p0, A);
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
-    issue_batch<NR>(s, R, p1 < last ? p1 : last, B);
+    issue_batch<NR, SL>(s, R, p1 < last ? p1 : last, B);
     process_batch<NR, LONG>(s, R, A, p0, cache1, c1row);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
-    issue_batch<NR>(s, R, p2 < last ? p2 : last, A);
+    issue_batch<NR, SL>(s, R, p2 < last ? p2 : last, A);
     process_batch<NR, LONG>(s, R, B, p1, cache1, c1row);
     if (p2 >= s.np) break;
     p0 = p2;
@@ -995,12 +1052,12 @@ __device__ __forceinline__ void scan_fast8(const ScanCtx &s)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <bool FILL, bool BATCH, bool FAST8, bool LONG>
+template <bool FILL, bool BATCH, bool FAST8, bool LONG, bool HOT = false>
 __device__ __forceinline__ void scan_dispatch(const ScanCtx &s, int cb, uint32_t need, uint64_t fill_limit)
 {
   if (cb == 4) {
     if (!FILL && s.ns <= 12 && s.tbl_words * 8 >= s.gsize) {
-      if (s.ns <= 8) scan_fast4<8, LONG>(s); else if (s.ns <= 11) scan_fast4<11, LONG>(s); else scan_fast4<12, LONG>(s);
+      if (s.ns <= 8) scan_fast4<8, LONG, HOT>(s); else if (s.ns <= 11) scan_fast4<11, LONG, HOT>(s); else scan_fast4<12, LONG, HOT>(s);
     }
     else scan_generic<4, FILL, BATCH, BATCH && !FAST8>(s, need, fill_limit);
   } else if (cb == 8) {
@@ -1224,8 +1281,13 @@ template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #ifndef UGS_RANK_WGS
 #define UGS_RANK_WGS 4
 #endif
-__global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
+#ifndef UGS_RANK_WGS_HOT
+#define UGS_RANK_WGS_HOT 5
+#endif
+__global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RANK_WGS_HOT : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
+  constexpr bool HOT = !SMALL && !BATCH && !FAST8 && !LONG;       // Big path, 4-bit counters, uniform rows: five workgroups per CU (issue_batch<.., true>)
+  constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : UGS_ELDS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave index in an SGPR
@@ -1234,7 +1296,7 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
   size_t off = 0;
   RankShared *sh = (RankShared *)(smem + off); off += (sizeof(RankShared) + 15) & ~(size_t)15;
   unsigned long long *s_fp = (unsigned long long *)(smem + off); off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;
-  uint64_t *s_ebuf = (uint64_t *)(smem + off); off += (size_t)UGS_ELDS * 8;
+  uint64_t *s_ebuf = (uint64_t *)(smem + off); off += (size_t)ELDS * 8;
   uint32_t *s_slots = (uint32_t *)(smem + off); off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
@@ -1278,14 +1340,14 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
     sc.s_part = nullptr;
     sc.hist = (cb0 == 4 && !small_path) ? sh->hist : nullptr;
     sc.s_fp = s_fp; sc.sh = sh; sc.ecap = ecap; sc.ns = ns; sc.np = db.np; sc.gsize = db.gsize;
-    sc.elw = UGS_ELDS / (uint32_t)wpb; sc.ecapw = ecap / (uint64_t)wpb;
+    sc.elw = ELDS / (uint32_t)wpb; sc.ecapw = ecap / (uint64_t)wpb;
     sc.s_ebuf = s_ebuf + (size_t)wave * sc.elw; sc.ebuf = ebuf + (uint64_t)wave * sc.ecapw;
     uint32_t wave_n = 0;
     sc.wn = &wave_n;
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
-    scan_dispatch<false, BATCH, FAST8, LONG>(sc, cb, 0, 0);
+    scan_dispatch<false, BATCH, FAST8, LONG, HOT>(sc, cb, 0, 0);
     // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
@@ -1733,23 +1795,40 @@ __global__ __launch_bounds__(256, UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBat
 
 // resident workgroups per CU for a given block size / dynamic LDS (VGPR- and LDS-limited): the
 // persistent grid must not exceed it, or the surplus workgroups run as a second, unbalanced round
-int ugs_rank_blocks_per_cu(int threads, size_t lds)
+static const void *rank_kernel(int big, int bits, int fast8, int longrows)
+{
+  const int mode = bits == 4 ? 0 : (fast8 ? 2 : 1);
+#ifdef UGS_ONLY_HOT               // tuning builds (tools/build_variant.sh): only the C2 instantiation, compiles in seconds
+  (void)big; (void)mode; (void)longrows;
+  return (const void *)k_rank<false, false, false, false>;
+#else
+  if (longrows)
+    return big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
+               : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
+  return big ? (mode == 0 ? (const void *)k_rank<false, false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, false>)
+             : (mode == 0 ? (const void *)k_rank<true, false, false, false> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, false>);
+#endif
+}
+// the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
+int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { return big && bits == 4 && !longrows && !(bits != 4 && fast8); }
+
+int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows)
 {
   int n = 0;
-  // (both instantiations have the same register budget; the Big one is asked)
-  if (hipFuncSetAttribute((const void *)k_rank<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_rank<false, false, false, false>, threads, lds) != hipSuccess || n < 1) n = 1;
+  const void *fn = rank_kernel(big, bits, fast8, longrows);      // (the instantiations differ in their register budget: the one that will run is asked)
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
 // LDS bytes of everything in k_rank's carve except the per-wave counter tables (must mirror the kernel)
-size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words)
+size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words, int hot)
 {
   const size_t maxq = (max_qlen + 15u) & ~15u;
   size_t off = 0;
   off += (sizeof(RankShared) + 15) & ~(size_t)15;
   off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;        // s_fp
-  off += (size_t)UGS_ELDS * 8;                                 // s_ebuf
+  off += (size_t)(hot ? UGS_ELDS_HOT : UGS_ELDS) * 8;            // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
   off += ((size_t)4 * UGS_KMAX + 8) * 8;                       // s_wsel (+8 pad)
@@ -1775,20 +1854,10 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
-  const int mode = L.bits == 4 ? 0 : (L.fast8 ? 2 : 1);
-  const void *fn;
-#ifdef UGS_ONLY_HOT               // tuning builds (tools/build_variant.sh): only the C2 instantiation, compiles in seconds
-  fn = (const void *)k_rank<false, false, false, false>;
-  if (!(db.big && mode == 0 && !L.longrows)) { ugs_set_error("UGS_ONLY_HOT build"); return UGS_E_ENVELOPE; }
-#else
-  if (L.longrows) {
-    fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
-                : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
-  } else {
-    fn = db.big ? (mode == 0 ? (const void *)k_rank<false, false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, false>)
-                : (mode == 0 ? (const void *)k_rank<true, false, false, false> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, false>);
-  }
+#ifdef UGS_ONLY_HOT
+  if (!(db.big && L.bits == 4 && !L.longrows)) { ugs_set_error("UGS_ONLY_HOT build"); return UGS_E_ENVELOPE; }
 #endif
+  const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
