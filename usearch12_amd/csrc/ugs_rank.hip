@@ -1288,6 +1288,10 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RA
 {
   constexpr bool HOT = !SMALL && !BATCH && !FAST8 && !LONG;       // Big path, 4-bit counters, uniform rows: five workgroups per CU (issue_batch<.., true>)
   constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : UGS_ELDS;
+#ifndef UGS_RANK_SL_LONG
+#define UGS_RANK_SL_LONG 1
+#endif
+  constexpr bool SLOAD = HOT || (UGS_RANK_SL_LONG && !SMALL && !BATCH && !FAST8 && LONG);   // the asm partition-table loads (issue_batch<.., true>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave index in an SGPR
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RA
     sc.tbl_words = tbl_words; sc.wave = wave; sc.wpb = wpb; sc.lane = lane; sc.small_path = small_path;
     const int cb = cb0;
     const unsigned long long tk1 = clock64();
-    scan_dispatch<false, BATCH, FAST8, LONG, HOT>(sc, cb, 0, 0);
+    scan_dispatch<false, BATCH, FAST8, LONG, SLOAD>(sc, cb, 0, 0);
     // the next unit's index is fetched here: late enough to stay out of the scan's register budget, early enough
     // for the atomic's latency to hide behind the selection
     if (tid == 0) next_unit = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
