@@ -172,7 +172,6 @@ bool seq_eq_rc(const uint8_t *a, const uint8_t *b, uint32_t L) { for (uint32_t i
 
 uint32_t derep_full(const char *seqs, const uint64_t *offs, uint32_t nseq, bool revcomp, std::vector<uint32_t> &seq_unique, std::vector<uint32_t> &uniq_seed)
 {
-  std::vector<uint32_t> tab;
   seq_unique.assign(nseq, 0); uniq_seed.clear();
   // the hashes are independent of each other: computed by a few host threads; the grouping itself stays in input order
   std::vector<uint32_t> hv(nseq);
@@ -201,7 +200,6 @@ uint32_t derep_full(const char *seqs, const uint64_t *offs, uint32_t nseq, bool 
   unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
   if (nseq < 100000) nt = 1;
   std::vector<uint32_t> first(nseq);
-  (void)tab;
   auto group = [&](unsigned t) {
     uint64_t mine = 0;
     for (uint32_t i = 0; i < nseq; ++i) mine += (hv[i] % nt) == t;

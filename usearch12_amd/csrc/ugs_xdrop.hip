@@ -179,6 +179,8 @@ thread_local uint64_t g_last_cells = 0;
 #ifndef UGS_XD_HOSTMODE
 #define UGS_XD_HOSTMODE 1
 #endif
+// (kept until the process ends - like the index build's scratch, ugs_index.hip: the device may be gone when thread-locals are destroyed;
+// a thread that uses more than eight devices falls back to a stream and events of its own per call)
 struct XdHostCtx { int dev = -1; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; };
 thread_local XdHostCtx g_ctx[8];
 
