@@ -924,21 +924,22 @@ __global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv,
       clen = (uint32_t)(db.offs[ct + 1] - cto);
     }
     // the NEXT candidate's letters travel while the current pair is aligned.  nt databases keep their letters a second time packed
-    // 2 bits each (UgsDbView::p2 / pi, BASELINE north_star): a target of up to 1024 letters is then fetched as <= 65 words per plane
+    // 2 bits each (UgsDbView::pk, BASELINE north_star): a target of up to 1024 letters is then fetched as <= 65 uint2 (one stream: the 2-bit word and the "other letter" word of 16 letters side by side)
     // (lane j takes the words that hold its 16 letters) for the seed search and the ungapped extension, and its BYTES (case, IUPAC:
     // identity tests, DP scores) only if the pair gets as far as the chain gate - most pairs of a search are random candidates of
     // queries without a hit and never do.  Everything else (aa, longer targets, the in-batch pair stage of cluster_fast whose targets
     // are query letters): 4 x 4 letters per lane from the byte array as before.
     uint32_t pre[4] = {0, 0, 0, 0};
-    const bool have_packed = c.nt && db.p2 != nullptr;
+    const bool have_packed = c.nt && db.pk != nullptr;
     auto prefetch = [&](uint32_t k2) {
       const uint64_t to2 = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k2) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k2);
       const uint32_t L2 = (uint32_t)rl((int)clen, (int)k2);
       if (have_packed && L2 <= 1024) {
         const uint64_t w0 = (to2 >> 4) + (uint32_t)lane;
         const bool on = (uint32_t)lane * 16u < L2 + 16u;                 // words 0 .. ceil(L2 / 16) (one more than the letters fill: the shift)
-        pre[0] = on ? db.p2[w0] : 0u; pre[1] = on ? db.p2[w0 + 1] : 0u;
-        pre[2] = on ? db.pi[w0] : 0u; pre[3] = on ? db.pi[w0 + 1] : 0u;
+        uint2 lo = make_uint2(0u, 0u), hi = lo;
+        if (on) { lo = db.pk[w0]; hi = db.pk[w0 + 1]; }
+        pre[0] = lo.x; pre[1] = hi.x; pre[2] = lo.y; pre[3] = hi.y;
         return;
       }
 #pragma unroll

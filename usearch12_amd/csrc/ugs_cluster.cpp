@@ -89,15 +89,15 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
     const uint64_t need = (db->nletters + add + 64) / 16 + 8;
     if (need > db->pack_cap) {
       const uint64_t cap = need * 2;
-      uint32_t *a = nullptr, *c2 = nullptr;
-      HIPCHK(hipMalloc(&a, cap * 4)); HIPCHK(hipMalloc(&c2, cap * 4));
-      HIPCHK(hipMemsetAsync(a, 0, cap * 4, st)); HIPCHK(hipMemsetAsync(c2, 0, cap * 4, st));
-      if (db->d_p2) { HIPCHK(hipMemcpyAsync(a, db->d_p2, db->pack_cap * 4, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(c2, db->d_pi, db->pack_cap * 4, hipMemcpyDeviceToDevice, st)); }
+      uint2 *a = nullptr;
+      HIPCHK(hipMalloc(&a, cap * 8));
+      HIPCHK(hipMemsetAsync(a, 0, cap * 8, st));
+      if (db->d_pk) HIPCHK(hipMemcpyAsync(a, db->d_pk, db->pack_cap * 8, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
-      (void)hipFree(db->d_p2); (void)hipFree(db->d_pi);
-      db->d_p2 = a; db->d_pi = c2; db->pack_cap = cap;
+      (void)hipFree(db->d_pk);
+      db->d_pk = a; db->pack_cap = cap;
     }
-    RCCHK(ugs_launch_pack(db->d_tab, db->d_seqs, db->nletters / 16, (db->nletters + add + 15) / 16, db->d_p2, db->d_pi, st));
+    RCCHK(ugs_launch_pack(db->d_tab, db->d_seqs, db->nletters / 16, (db->nletters + add + 15) / 16, db->d_pk, st));
   }
   HIPCHK(hipMemcpyAsync(db->d_offs + old_n, abs_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
   struct Tmp {                                    // released on every way out, error returns included
@@ -569,7 +569,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
       HIPCHK(hipMemcpyAsync(d_pcand.p, pc.data(), (size_t)npu * Kp * 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(d_pcandn.p, pcandn.data(), (size_t)npu * 4, hipMemcpyHostToDevice, st));
       UgsDbView pv = db->v;
-      pv.seqs = b->d_qseqs; pv.offs = b->d_qoffs; pv.nseq = B; pv.p2 = nullptr; pv.pi = nullptr;     // (targets = the batch's own letters: bytes only)
+      pv.seqs = b->d_qseqs; pv.offs = b->d_qoffs; pv.nseq = B; pv.pk = nullptr;     // (targets = the batch's own letters: bytes only)
       pv.max_accepts = (int32_t)Kp; pv.max_rejects = 0x7fffffff; pv.align_flags |= UGS_A_NOTERM;
       for (int attempt = 0;; ++attempt) {
         // the path pool is shared with the frozen stage's hits: make room for the pairs behind them

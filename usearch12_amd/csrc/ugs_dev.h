@@ -22,8 +22,9 @@ struct UgsTables {
 
 struct UgsDbView {
   const uint8_t  *seqs;      // masked DB letters
-  const uint32_t *p2, *pi;   // nt only (null otherwise): the same letters 2 bits each, 16 per word, by GLOBAL letter index (letter i of the
-                             // array = bits 2(i%16).. of word i/16; A,C,G,T/U = 0..3, anything else 0) and the "anything else" bits in the same layout
+  const uint2 *pk;           // nt only (null otherwise): the same letters packed, one uint2 per 16 letters by GLOBAL letter index (letter i of
+                             // the array -> bits 2(i%16).. of entry i/16): .x = 2 bits per letter (A,C,G,T/U = 0..3, anything else 0),
+                             // .y = the "anything else" bits in the same layout; the two words side by side so that a target is one stream
   const uint64_t *offs;      // [nseq+1]
   uint32_t nseq;
   uint32_t slots;
@@ -131,7 +132,7 @@ struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; uint32_
 
 // kernels' host-callable launchers (defined in the .hip files)
 int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int dbmask, hipStream_t st);
-int ugs_launch_pack(const UgsTables *d_tab, const uint8_t *d_seqs, uint64_t word_lo, uint64_t word_hi, uint32_t *d_p2, uint32_t *d_pi, hipStream_t st);
+int ugs_launch_pack(const UgsTables *d_tab, const uint8_t *d_seqs, uint64_t word_lo, uint64_t word_hi, uint2 *d_pk, hipStream_t st);
 int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq,
                     uint64_t nletters, int word_len, int alpha, uint32_t slots, uint64_t **d_row_off,
                     uint32_t **d_postings, uint64_t *n_postings, uint32_t *max_row, hipStream_t st);

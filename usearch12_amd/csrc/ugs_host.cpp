@@ -227,7 +227,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
 {
   if (!db) return;
   (void)hipSetDevice(db->device);
-  (void)hipFree(db->d_p2); (void)hipFree(db->d_pi);
+  (void)hipFree(db->d_pk);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
   (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
   (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls); (void)hipFree(db->d_tkey); (void)hipFree(db->d_tsize);
@@ -292,7 +292,7 @@ int ugs_db_replan(ugs_db *db)
   HIPCHK(hipStreamSynchronize(db->stream));
   UgsDbView &v = db->v;
   v.seqs = db->d_seqs; v.offs = db->d_offs; v.row_off = db->d_row_off; v.postings = db->d_postings; v.part = db->d_part;
-  v.p2 = db->d_p2; v.pi = db->d_pi;
+  v.pk = getenv("UGS_NO_PACKED") ? nullptr : db->d_pk;       // UGS_NO_PACKED: k_align fetches every target from the byte array (A/B, fault isolation)
   v.np = np; v.gsize = gsize; v.big = nseq > db->p.big ? 1 : 0; v.max_tlen = db->max_tlen;
   db->hbm_bytes = db->nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
                   (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
@@ -348,7 +348,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
-  db->d_p2 = nullptr; db->d_pi = nullptr; db->pack_cap = 0;
+  db->d_pk = nullptr; db->pack_cap = 0;
   db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0; db->gsize_limit = 0;
   db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
   memset(&db->lv, 0, sizeof(db->lv));
@@ -374,11 +374,11 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (p->dbmask < 0 || p->dbmask > 3) { ugs_set_error("dbmask must be 0..3"); return fail(UGS_E_ARG); }
   if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask == 3 ? (1 | ((p->is_nucleo ? 'N' : 'X') << 8)) : p->dbmask, db->stream)) != UGS_OK) return fail(rc);
-  if (p->is_nucleo) {                                       // the masked letters packed 2 bits each (UgsDbView::p2 / pi)
+  if (p->is_nucleo) {                                       // the masked letters packed 2 bits each (UgsDbView::pk)
     db->pack_cap = (nletters + 64) / 16 + 8;
-    DBCHK(hipMalloc(&db->d_p2, db->pack_cap * 4)); DBCHK(hipMalloc(&db->d_pi, db->pack_cap * 4));
-    DBCHK(hipMemsetAsync(db->d_p2, 0, db->pack_cap * 4, db->stream)); DBCHK(hipMemsetAsync(db->d_pi, 0, db->pack_cap * 4, db->stream));
-    if ((rc = ugs_launch_pack(db->d_tab, db->d_seqs, 0, (nletters + 15) / 16, db->d_p2, db->d_pi, db->stream)) != UGS_OK) return fail(rc);
+    DBCHK(hipMalloc(&db->d_pk, db->pack_cap * 8));
+    DBCHK(hipMemsetAsync(db->d_pk, 0, db->pack_cap * 8, db->stream));
+    if ((rc = ugs_launch_pack(db->d_tab, db->d_seqs, 0, (nletters + 15) / 16, db->d_pk, db->stream)) != UGS_OK) return fail(rc);
   }
   const uint32_t slots = (uint32_t)slots64;
   if ((rc = ugs_build_index(db->d_tab, db->d_seqs, db->d_offs, nseq, nletters, p->word_len, alpha, slots,

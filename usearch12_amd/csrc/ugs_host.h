@@ -16,7 +16,7 @@ struct ugs_db {
   UgsDbView v;
   // owned device memory
   uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
-  uint32_t *d_p2, *d_pi; uint64_t pack_cap;   // nt: 2-bit letters + "other" plane (words of 16 letters, ugs_dev.h UgsDbView::p2)
+  uint2 *d_pk; uint64_t pack_cap;   // nt: 2-bit letters + "other" bits, one uint2 per 16 letters (ugs_dev.h UgsDbView::pk)
   uint32_t *d_step; UgsTables *d_tab;
   std::vector<uint32_t> step;       // host copy: step[Nu]
   uint64_t n_postings, hbm_bytes;

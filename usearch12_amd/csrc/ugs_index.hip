@@ -83,7 +83,7 @@ int ugs_launch_mask(uint8_t *d_seqs, const uint64_t *d_offs, uint32_t nseq, int 
 // reference's SeqDB is (case, IUPAC letters: identities, masking, output) and is read for the pairs that reach the DP.
 // Code of a letter = what k_align's s_sc table gives it: hsp_letter (alpha2.cpp order A,C,G,T/U = 0..3) for a letter that can be part
 // of a word whatever its case, "other" for the rest.  One thread per word; words [word_lo, word_hi).
-__global__ void k_pack_letters(const UgsTables *tab, const uint8_t *seqs, uint64_t word_lo, uint64_t word_hi, uint32_t *p2, uint32_t *pi)
+__global__ void k_pack_letters(const UgsTables *tab, const uint8_t *seqs, uint64_t word_lo, uint64_t word_hi, uint2 *pk)
 {
   __shared__ uint8_t code[256];
   for (int k = threadIdx.x; k < 256; k += blockDim.x) {
@@ -104,14 +104,14 @@ __global__ void k_pack_letters(const UgsTables *tab, const uint8_t *seqs, uint64
       v |= (sc & 3u) << (8 * q + 2 * b);
       iv |= (sc >> 2) << (8 * q + 2 * b);
     }
-  p2[w] = v; pi[w] = iv;
+  pk[w] = make_uint2(v, iv);
 }
 
-int ugs_launch_pack(const UgsTables *d_tab, const uint8_t *d_seqs, uint64_t word_lo, uint64_t word_hi, uint32_t *d_p2, uint32_t *d_pi, hipStream_t st)
+int ugs_launch_pack(const UgsTables *d_tab, const uint8_t *d_seqs, uint64_t word_lo, uint64_t word_hi, uint2 *d_pk, hipStream_t st)
 {
   if (word_hi <= word_lo) return UGS_OK;
   const uint64_t n = word_hi - word_lo;
-  hipLaunchKernelGGL(k_pack_letters, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_tab, d_seqs, word_lo, word_hi, d_p2, d_pi);
+  hipLaunchKernelGGL(k_pack_letters, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_tab, d_seqs, word_lo, word_hi, d_pk);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }
