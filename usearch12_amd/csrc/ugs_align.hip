@@ -794,7 +794,10 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
 #endif
 #define ACLK() (UGS_ALIGN_CLOCKS ? clock64() : 0ull)
 template <bool PAIR>
-__global__ __launch_bounds__(256, 4) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
+#ifndef UGS_ALIGN_WGS
+#define UGS_ALIGN_WGS 4
+#endif
+__global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
