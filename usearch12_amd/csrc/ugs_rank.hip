@@ -789,6 +789,12 @@ __device__ __forceinline__ void tail_mixed(const ScanCtx &s, const Rows<NR> &R, 
   }
 }
 
+#ifndef UGS_RANK_LEAN
+#define UGS_RANK_LEAN 1
+#endif
+#ifndef UGS_RANK_NOAD
+#define UGS_RANK_NOAD 0
+#endif
 template <int NR, bool LONG>
 __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &R, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
 {
@@ -813,11 +819,17 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const uint32_t x = (uint32_t)lane < B.len[r] ? B.v[r] - sub : dummy_x;
-    ad[r] = (x >> 1) & ~3u;
+    ad[r] = (x >> 1) & ~3u;          // (UGS_RANK_NOAD: not kept - derived from the shift again in each phase, two fast VALU ops)
     sh[r] = x << 2;                    // only bits [4:0] are ever used (shift amounts, bit-field offset)
   }
+#if UGS_RANK_NOAD
+  auto adof = [&](int r) -> uint32_t { uint32_t t = sh[r]; asm volatile("" : "+v"(t)); return (t >> 3) & ~3u; };
+#define ADR(r) adof(r)
+#else
+#define ADR(r) ad[r]
+#endif
 #pragma unroll
-  for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ad[r], 1u << (sh[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int r = 0; r < NR; ++r) __hip_atomic_fetch_add((lds32)(uintptr_t)ADR(r), 1u << (sh[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   // The clears below must find the final counts: every add of the batch has completed before the first clear issues
   // (explicit wait; it costs nothing measurable - the wave would wait for the clears' return values a few instructions
   // later anyway - and the result no longer rests on the order in which the LDS unit executes a wave's atomics).
@@ -830,7 +842,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
   // later rows of the same target read 0.
   uint32_t old[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[r], ~(15u << (sh[r] & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int r = 0; r < NR; ++r) old[r] = __hip_atomic_fetch_and((lds32)(uintptr_t)ADR(r), ~(15u << (sh[r] & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t c[NR];            // count if this lane's posting is the first touch of its target, else 0
   uint32_t cnt = 0;          // rows in which this lane holds a first touch with count >= 2
 #pragma unroll
@@ -839,7 +851,8 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
     c[r] = (uint32_t)lane < B.len[r] ? __builtin_amdgcn_ubfe(old[r], sh[r], 4u) : 0u;
     cnt += c[r] >= 2u ? 1u : 0u;
     if (s.small_path || (uint32_t)r <= c1row) {     // scalar test (c1row = row of the cached fp[1], kept in an SGPR): can this row still lower fp[1]?
-      const uint64_t pos = s.small_path ? (uint64_t)B.v[r] : (((uint64_t)r << 32) | B.v[r]);
+      const uint32_t vr = UGS_RANK_LEAN ? (sh[r] >> 2) + sub : B.v[r];          // LEAN: the posting is not kept, it follows from its shift
+      const uint64_t pos = s.small_path ? (uint64_t)vr : (((uint64_t)r << 32) | vr);
       const bool f1 = c[r] == 1 && pos < cache1;
       if (__ballot(f1)) {
         if (f1) atomicMin(&s.s_fp[1], (unsigned long long)pos);
@@ -869,18 +882,19 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
 #pragma unroll
       for (int r = NR - 1; r >= 0; --r) {
         const bool take = c[r] >= 2u;
-        csel = take ? c[r] : csel; vsel = take ? B.v[r] : vsel; rsel = take ? (uint32_t)r : rsel;
+        csel = take ? c[r] : csel; vsel = take ? (UGS_RANK_LEAN ? sh[r] : B.v[r]) : vsel; rsel = take ? (uint32_t)r : rsel;
       }
-      if (cnt) emit(csel, vsel, rsel);
+      if (cnt) emit(csel, UGS_RANK_LEAN ? (vsel >> 2) + sub : vsel, rsel);
       if (__ballot(cnt >= 2u)) {                       // rare: further items of a lane, rows above the one just emitted
 #pragma unroll
         for (int r = 1; r < NR; ++r)
-          if (c[r] >= 2u && (uint32_t)r > rsel) emit(c[r], B.v[r], (uint32_t)r);
+          if (c[r] >= 2u && (uint32_t)r > rsel) emit(c[r], UGS_RANK_LEAN ? (sh[r] >> 2) + sub : B.v[r], (uint32_t)r);
       }
     }
   }
 }
 
+#undef ADR
 template <int NR, bool LONG, bool SL = false>
 __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
 {
