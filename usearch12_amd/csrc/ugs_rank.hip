@@ -130,7 +130,7 @@ struct ScanCtx {
 #define UGS_ELDS 1024u
 #endif
 #ifndef UGS_ELDS_HOT
-#define UGS_ELDS_HOT 512u      // keys of a unit that stay in LDS in the HOT instantiation (its LDS must fit five workgroups per CU)
+#define UGS_ELDS_HOT 128u      // keys of a unit that stay in LDS in the HOT instantiation (its LDS must fit six workgroups per CU)
 #endif
 __device__ __forceinline__ void put_key(const ScanCtx &s, uint64_t idx, uint64_t key)     // idx: position in this wave's segment
 {
@@ -1296,7 +1296,7 @@ template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #define UGS_RANK_WGS 4
 #endif
 #ifndef UGS_RANK_WGS_HOT
-#define UGS_RANK_WGS_HOT 5
+#define UGS_RANK_WGS_HOT 6
 #endif
 __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RANK_WGS_HOT : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
@@ -1318,9 +1318,13 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RA
   uint32_t *s_slots = (uint32_t *)(smem + off); off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;
   uint32_t *s_ev_c = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;     // -bump events
   uint32_t *s_ev_minu = (uint32_t *)(smem + off); off += (((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15;
-  uint64_t *s_wsel = (uint64_t *)(smem + off); off += ((size_t)4 * UGS_KMAX + 8) * 8;           // per-wave selections (+8 pad)
+  // per-wave selections (+8 pad).  HOT: they live in wave 0's counter table, which is idle (and clean) between a unit's scan and the
+  // next unit's - the words used are zeroed again when the unit is done; 2 KB less LDS is what lets a sixth workgroup fit a CU
+  constexpr uint32_t WSEL_WORDS = (4 * UGS_KMAX + 8) * 2;
+  uint64_t *s_wsel = (uint64_t *)(smem + off); if (!HOT) off += (size_t)WSEL_WORDS * 4;
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * (tbl_words + 64);      // +64 dummy words per wave
+  if (HOT) s_wsel = (uint64_t *)(smem + off);                                       // (= wave 0's table; off is a multiple of 16)
 
   const UgsTables *tab = db.tab;
   const uint32_t units = bv.nq * bv.nstrand;
@@ -1803,6 +1807,7 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RA
       bv.cand_n[unit] = over ? 0u : sh->n_sel;                   // (no walk over a list chosen from truncated keys)
       sh->pad1 = next_unit;
     }
+    if (HOT) for (uint32_t k = tid; k < WSEL_WORDS; k += nthr) ((uint32_t *)s_wsel)[k] = 0;     // wave 0's table is a counter table again
     __syncthreads();
   }
   if (tid == 0) {
@@ -1849,7 +1854,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   off += (size_t)(hot ? UGS_ELDS_HOT : UGS_ELDS) * 8;            // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
-  off += ((size_t)4 * UGS_KMAX + 8) * 8;                       // s_wsel (+8 pad)
+  if (!hot) off += ((size_t)4 * UGS_KMAX + 8) * 8;             // s_wsel (+8 pad; HOT: inside wave 0's counter table)
   off += (size_t)part_words * 4;                               // s_part
   return (off + 15) & ~(size_t)15;
 }
