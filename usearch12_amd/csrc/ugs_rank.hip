@@ -1298,10 +1298,17 @@ template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #ifndef UGS_RANK_WGS_HOT
 #define UGS_RANK_WGS_HOT 6
 #endif
-__global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !LONG) ? UGS_RANK_WGS_HOT : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
+#ifndef UGS_RANK_WGS_LONG
+#define UGS_RANK_WGS_LONG 4
+#endif
+#ifndef UGS_ELDS_LONG
+#define UGS_ELDS_LONG UGS_ELDS
+#endif
+__global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RANK_WGS_LONG : UGS_RANK_WGS_HOT) : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   constexpr bool HOT = !SMALL && !BATCH && !FAST8 && !LONG;       // Big path, 4-bit counters, uniform rows: five workgroups per CU (issue_batch<.., true>)
-  constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : UGS_ELDS;
+  constexpr bool HOTL = !SMALL && !BATCH && !FAST8 && LONG;     // the same path on a skewed database (cluster_fast's centroids)
+  constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : (HOTL ? UGS_ELDS_LONG : UGS_ELDS);
 #ifndef UGS_RANK_SL_LONG
 #define UGS_RANK_SL_LONG 1
 #endif
@@ -1833,7 +1840,7 @@ static const void *rank_kernel(int big, int bits, int fast8, int longrows)
 #endif
 }
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
-int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { return big && bits == 4 && !longrows && !(bits != 4 && fast8); }
+int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return (big && bits == 4) ? (longrows ? 2 : 1) : 0; }   // 1 = HOT, 2 = its LONG twin
 
 int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows)
 {
@@ -1851,10 +1858,10 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   size_t off = 0;
   off += (sizeof(RankShared) + 15) & ~(size_t)15;
   off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;        // s_fp
-  off += (size_t)(hot ? UGS_ELDS_HOT : UGS_ELDS) * 8;            // s_ebuf
+  off += (size_t)(hot == 1 ? UGS_ELDS_HOT : (hot == 2 ? UGS_ELDS_LONG : UGS_ELDS)) * 8;            // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
-  if (!hot) off += ((size_t)4 * UGS_KMAX + 8) * 8;             // s_wsel (+8 pad; HOT: inside wave 0's counter table)
+  if (hot != 1) off += ((size_t)4 * UGS_KMAX + 8) * 8;         // s_wsel (+8 pad; HOT: inside wave 0's counter table)
   off += (size_t)part_words * 4;                               // s_part
   return (off + 15) & ~(size_t)15;
 }
