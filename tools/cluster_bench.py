@@ -41,6 +41,10 @@ def main():
                queries_redone=st.queries_redone, inbatch_entries=st.inbatch_entries, pairs_in_batch=st.pairs_in_batch,
                hits_in_batch=st.hits_in_batch, pairs_frozen=st.pairs_frozen, postings=st.postings, ms_rank=st.ms_rank,
                ms_align=st.ms_align, gen_s=gen_s, host_s={k: round(getattr(st, k), 3) for k in ("s_derep", "s_search", "s_inbatch", "s_d2h", "s_replay", "s_pairs", "s_append", "s_total")}, strand="both" if a.both else "plus")
+    # the ranking kernels over the whole run against the HBM roofline: 4 bytes per posting scanned / their summed device time
+    out["roofline_k_rank"] = {"bound": "hbm", "algorithmic_bytes": 4 * int(st.postings), "kernel_ms": st.ms_rank,
+                              "achieved_GBps": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / 1e9, "peak_GBps": 8000.0,
+                              "frac": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / 8e12}
     # size-independent properties: every unique in exactly one cluster, sizes add up, centroids are their own cluster's founder
     assert int(res.cluster_size.sum()) == a.reads
     assert np.array_equal(res.uniq_cluster[res.centroid_uniq], np.arange(res.n_clusters, dtype=np.uint32))

@@ -56,7 +56,10 @@ def main():
                    args.kind, qs.n, args.len, "aa" if args.aa else "nt", db.n, ", both strands" if kw["strand_both"] else "", "" if args.id is None else ", id %g" % args.id),
                queries_per_s=qs.n / (st['ms_total'] * 1e-3), ms_total=st['ms_total'], ms_rank=st['ms_rank'] + st['ms_rank_setup'],
                ms_local=st['ms_align'], hits=int(len(hits)), pairs=int(st['pairs_aligned']), xdrop_cells=int(st['dp_cells']),
-               gcells_per_s=st['dp_cells'] / (st['ms_align'] * 1e-3) / 1e9, wall_s=wall)
+               gcells_per_s=st['dp_cells'] / (st['ms_align'] * 1e-3) / 1e9, wall_s=wall,
+               roofline_k_rank={"bound": "hbm", "algorithmic_bytes": 4 * int(st['postings']) + int(st['query_letters']), "kernel_ms": st['ms_rank'],
+                                "achieved_GBps": (4 * st['postings'] + st['query_letters']) / (st['ms_rank'] * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                                "frac": (4 * st['postings'] + st['query_letters']) / (st['ms_rank'] * 1e-3) / 8e12})
     # parity on a sample
     if args.check:
         import orc

@@ -795,7 +795,7 @@ __device__ __forceinline__ void tail_mixed(const ScanCtx &s, const Rows<NR> &R, 
 #ifndef UGS_RANK_NOAD
 #define UGS_RANK_NOAD 0
 #endif
-template <int NR, bool LONG>
+template <int NR, bool LONG, bool LEANT = false>
 __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &R, const Batch<NR> &B, uint32_t p, unsigned long long &cache1, uint32_t &c1row)
 {
   const int lane = s.lane;
@@ -851,7 +851,7 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
     c[r] = (uint32_t)lane < B.len[r] ? __builtin_amdgcn_ubfe(old[r], sh[r], 4u) : 0u;
     cnt += c[r] >= 2u ? 1u : 0u;
     if (s.small_path || (uint32_t)r <= c1row) {     // scalar test (c1row = row of the cached fp[1], kept in an SGPR): can this row still lower fp[1]?
-      const uint32_t vr = UGS_RANK_LEAN ? (sh[r] >> 2) + sub : B.v[r];          // LEAN: the posting is not kept, it follows from its shift
+      const uint32_t vr = (UGS_RANK_LEAN && LEANT) ? (sh[r] >> 2) + sub : B.v[r];          // LEAN: the posting is not kept, it follows from its shift
       const uint64_t pos = s.small_path ? (uint64_t)vr : (((uint64_t)r << 32) | vr);
       const bool f1 = c[r] == 1 && pos < cache1;
       if (__ballot(f1)) {
@@ -882,13 +882,13 @@ __device__ __forceinline__ void process_batch(const ScanCtx &s, const Rows<NR> &
 #pragma unroll
       for (int r = NR - 1; r >= 0; --r) {
         const bool take = c[r] >= 2u;
-        csel = take ? c[r] : csel; vsel = take ? (UGS_RANK_LEAN ? sh[r] : B.v[r]) : vsel; rsel = take ? (uint32_t)r : rsel;
+        csel = take ? c[r] : csel; vsel = take ? ((UGS_RANK_LEAN && LEANT) ? sh[r] : B.v[r]) : vsel; rsel = take ? (uint32_t)r : rsel;
       }
-      if (cnt) emit(csel, UGS_RANK_LEAN ? (vsel >> 2) + sub : vsel, rsel);
+      if (cnt) emit(csel, (UGS_RANK_LEAN && LEANT) ? (vsel >> 2) + sub : vsel, rsel);
       if (__ballot(cnt >= 2u)) {                       // rare: further items of a lane, rows above the one just emitted
 #pragma unroll
         for (int r = 1; r < NR; ++r)
-          if (c[r] >= 2u && (uint32_t)r > rsel) emit(c[r], UGS_RANK_LEAN ? (sh[r] >> 2) + sub : B.v[r], (uint32_t)r);
+          if (c[r] >= 2u && (uint32_t)r > rsel) emit(c[r], (UGS_RANK_LEAN && LEANT) ? (sh[r] >> 2) + sub : B.v[r], (uint32_t)r);
       }
     }
   }
@@ -916,11 +916,11 @@ __device__ __forceinline__ void scan_fast4(const ScanCtx &s)
   for (;;) {
     const uint32_t p1 = p0 + s.wpb;
     issue_batch<NR, SL>(s, R, p1 < last ? p1 : last, B);
-    process_batch<NR, LONG>(s, R, A, p0, cache1, c1row);
+    process_batch<NR, LONG, SL>(s, R, A, p0, cache1, c1row);
     if (p1 >= s.np) break;
     const uint32_t p2 = p1 + s.wpb;
     issue_batch<NR, SL>(s, R, p2 < last ? p2 : last, A);
-    process_batch<NR, LONG>(s, R, B, p1, cache1, c1row);
+    process_batch<NR, LONG, SL>(s, R, B, p1, cache1, c1row);
     if (p2 >= s.np) break;
     p0 = p2;
   }
