@@ -650,7 +650,7 @@ static int plan_launch(ugs_batch *b)
   b->rl.longrows = db->max_row > 56u * db->v.np;
   if (const char *e = getenv("UGS_LONGROWS")) b->rl.longrows = atoi(e) != 0;
   const int hot = ugs_rank_is_hot(db->v.big, bits, b->rl.fast8, b->rl.longrows);
-  if (hot && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30))) {       // (both twins use the asm loads)
+  if ((hot == 1 || hot == 2) && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30))) {       // (both twins use the asm loads)
     ugs_set_error("index too large for the 32-bit offsets of the ranking kernel's partition-table loads (%u slots x %u partitions, longest row %u)", db->v.slots, db->v.np, db->max_row);
     return UGS_E_ENVELOPE;
   }

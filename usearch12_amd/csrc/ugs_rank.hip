@@ -1304,11 +1304,14 @@ template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #ifndef UGS_ELDS_LONG
 #define UGS_ELDS_LONG UGS_ELDS
 #endif
+#ifndef UGS_ELDS_BATCH
+#define UGS_ELDS_BATCH 128u       // 8- and 16-bit counter kernels: thousands of keys per unit, nearly all of them in the HBM part anyway
+#endif
 __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RANK_WGS_LONG : UGS_RANK_WGS_HOT) : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   constexpr bool HOT = !SMALL && !BATCH && !FAST8 && !LONG;       // Big path, 4-bit counters, uniform rows: five workgroups per CU (issue_batch<.., true>)
   constexpr bool HOTL = !SMALL && !BATCH && !FAST8 && LONG;     // the same path on a skewed database (cluster_fast's centroids)
-  constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : (HOTL ? UGS_ELDS_LONG : UGS_ELDS);
+  constexpr uint32_t ELDS = HOT ? UGS_ELDS_HOT : (HOTL ? UGS_ELDS_LONG : (BATCH ? UGS_ELDS_BATCH : UGS_ELDS));
 #ifndef UGS_RANK_SL_LONG
 #define UGS_RANK_SL_LONG 1
 #endif
@@ -1669,6 +1672,12 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
         const uint32_t want = K - nsel;
         const uint32_t cap = 4 * UGS_KMAX < 64u * (uint32_t)wpb ? 4 * UGS_KMAX : 64u * (uint32_t)wpb;
         auto eligible = [&](uint64_t key) -> bool { return ((nsel == 0 && last == 0) || key > last) && kept(key); };
+        // (r03: this barrier was missing.  A LONG 4-bit kernel comes here from the class-histogram attempt above, whose last shared read
+        // is `ncl = sh->ncl` - behind ITS last barrier.  Without a barrier here thread 0 could reset sh->ncl before a slower wave had read
+        // it; that wave then saw 0, took the "fits the ranking buffer" branch with its own barriers, and the workgroup's waves ran
+        // different code: cluster_fast C3 gave a different clustering in 1 of 40 runs with the round-2 kernels, in 1 of 6 with the
+        // faster round-3 ones (tools/cluster_repeat.py).)
+        __syncthreads();
         if (tid == 0) { sh->red[0] = 0; sh->red[1] = 0; sh->qcut = 0; sh->pad2 = 0xffffffffu; sh->pad3 = 0; sh->ncl = 0; }
         __syncthreads();
         for (int shift = 48; shift >= 0; shift -= 8) {
@@ -1840,7 +1849,7 @@ static const void *rank_kernel(int big, int bits, int fast8, int longrows)
 #endif
 }
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
-int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return (big && bits == 4) ? (longrows ? 2 : 1) : 0; }   // 1 = HOT, 2 = its LONG twin
+int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return bits != 4 ? 3 : (big ? (longrows ? 2 : 1) : 0); }   // 1 = HOT, 2 = its LONG twin, 3 = wider counters (BATCH kernels)
 
 int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows)
 {
@@ -1858,7 +1867,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   size_t off = 0;
   off += (sizeof(RankShared) + 15) & ~(size_t)15;
   off += (((size_t)ns_max + 1) * 8 + 15) & ~(size_t)15;        // s_fp
-  off += (size_t)(hot == 1 ? UGS_ELDS_HOT : (hot == 2 ? UGS_ELDS_LONG : UGS_ELDS)) * 8;            // s_ebuf
+  off += (size_t)(hot == 1 ? UGS_ELDS_HOT : (hot == 2 ? UGS_ELDS_LONG : (hot == 3 ? UGS_ELDS_BATCH : UGS_ELDS))) * 8;            // s_ebuf
   off += (((size_t)ns_max) * 4 + 15) & ~(size_t)15;            // s_slots
   off += 2 * ((((size_t)ns_max + 1) * 4 + 15) & ~(size_t)15);  // s_ev_c, s_ev_minu
   if (hot != 1) off += ((size_t)4 * UGS_KMAX + 8) * 8;         // s_wsel (+8 pad; HOT: inside wave 0's counter table)
