@@ -156,6 +156,7 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.call(cmd, env=env, stdout=real_stdout))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL between processes needs it on this driver)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,12 +224,27 @@ def main():
     # travels through torch.distributed, which is otherwise only the launcher's rendezvous, barrier and max-reduction.
     # gloo backend (dry run on a box with fewer GPUs than ranks): torch.distributed gathers through the host.
     comm = None
+    gather_note = None
     use_cpp_gather = (world > 1 and args.backend == "nccl") or (world == 1 and args.force_gather)
     if use_cpp_gather:
         ids = [capi.UgsComm.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        comm = capi.UgsComm.init_rank(ids[0], rank, world, local_rank)
+        comm_err = None
+        try:
+            comm = capi.UgsComm.init_rank(ids[0], rank, world, local_rank)
+        except Exception as e:                                      # (reported in the line; the ranks agree on the path below)
+            comm_err = "%s: %s" % (type(e).__name__, e)
+        if world > 1:
+            okt = torch.tensor([0 if comm is None else 1], device=cdev, dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:                                # some rank has no communicator: every rank gathers through torch.distributed
+                sys.stderr.write("bench.py rank %d: C++ communicator unavailable (%s); gathering through torch.distributed\n" % (rank, comm_err))
+                comm = None
+                gather_note = "torch.distributed (%s) - the product's communicator could not be created on every rank" % args.backend
+        elif comm is None:
+            raise RuntimeError(comm_err)
+    if comm is not None:
         for b in bats:
             b.set_query_base(lo)                                    # the search's own grouping stamps global query ids
     gbuf = None
@@ -399,7 +415,7 @@ def main():
         # the CPU baseline is a single-GPU-run item (rank 0 at N=1): the other ranks of a multi-GPU run would only wait for it
         cb = cpu_baseline(args.cpu_baseline if (world == 1 and workload == "C2") else "none", db, qs, args.id, sample_q, threads)
         how = ("ugs_gather_results (libugs_rccl.so: ncclAllGather of sizes + grouped ncclSend/ncclRecv), issued beside the next step's kernels"
-               if comm is not None else ("torch.distributed gloo through the host (dry run)" if dist is not None else "none (one GPU: plain fetch)"))
+               if comm is not None else (gather_note or ("torch.distributed gloo through the host (dry run)" if dist is not None else "none (one GPU: plain fetch)")))
         if workload == "C2":
             wl = ("C2: usearch_global %d x %d nt queries per GPU and step vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
                   "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one%s" %
