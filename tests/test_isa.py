@@ -6,16 +6,31 @@ import os
 import re
 import subprocess
 
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "usearch12_amd", "csrc", "ugs_rank.hip")
-OUT = "/tmp/ugs_rank_isa_%d.s" % int(os.path.getmtime(SRC))
+sys.path.insert(0, ROOT)
+from usearch12_amd.build import asm_is_fresh, asm_path, flags_for, real_src  # noqa: E402  (the product's own compiler options, per source)
+CSRC = os.path.join(ROOT, "usearch12_amd", "csrc")
+BUILD_PY = os.path.join(ROOT, "usearch12_amd", "build.py")
+
+
+def _asm(name):
+    """gfx950 assembly of one of the build's translation units: the file the build's own compilation left behind (build.py,
+    -save-temps) when it is current, else compiled here with the build's options for that unit"""
+    if asm_is_fresh(name):
+        return open(asm_path(name)).read()
+    src = real_src(name)
+    out = "/tmp/%s_isa_%d_%d.s" % (name, int(max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "ugs_xdrop_dev.h")))), int(os.path.getmtime(BUILD_PY)))
+    if not os.path.exists(out):
+        subprocess.check_call(["hipcc"] + [f for f in flags_for(name) if f != "-fPIC"] + ["--cuda-device-only", "-S", src, "-o", out],
+                              stderr=subprocess.DEVNULL)
+    return open(out).read()
 
 
 def _isa():
-    if not os.path.exists(OUT):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip",
-                               "--cuda-device-only", "-S", SRC, "-o", OUT], stderr=subprocess.DEVNULL)
-    return open(OUT).read().split("\n")
+    # k_rank is two translation units (ugs_rank.hip, UGS_RANK_TU): the HOT instantiation and everything else
+    return (_asm("ugs_rank.hip") + "\n" + _asm("ugs_rank_hot.hip")).split("\n")
 
 
 def test_counter_clears_wait_for_the_adds_of_their_batch():
@@ -41,13 +56,7 @@ def test_counter_clears_wait_for_the_adds_of_their_batch():
 
 
 def _isa_of(name):
-    src = os.path.join(ROOT, "usearch12_amd", "csrc", name)
-    dep = os.path.join(ROOT, "usearch12_amd", "csrc", "ugs_xdrop_dev.h")
-    out = "/tmp/%s_isa_%d_%d.s" % (name, int(os.path.getmtime(src)), int(os.path.getmtime(dep)))
-    if not os.path.exists(out):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip",
-                               "--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
-    return open(out).read()
+    return _asm(name)
 
 
 def _kernel_body(isa, name):

@@ -7,10 +7,41 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
-DEPS = SOURCES + ["ugs_dev.h", "ugs_host.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
+DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
+# per-source compiler options.  k_rank's partition loop lives on the edge of its register budget: of the machine
+# schedulers LLVM offers for AMDGPU, "iterative-maxocc" gives the fastest HOT instantiation (54.5 vs 55.7 ms on C2; max-ilp 56.6,
+# iterative-minreg 128) but costs the mid-identity instantiations 10 %, so the HOT kernel is a translation unit of its own
+# (ugs_rank.hip, UGS_RANK_TU); ugs_align.hip gains nothing from any of them and does not compile with this one
+EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"],
+         "ugs_rank_hot.hip": ["-DUGS_RANK_TU=1", "-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]}
+# objects compiled from another source file's text under other options: ugs_rank_hot.o = the HOT instantiation of k_rank alone
+ALIAS = {"ugs_rank_hot.hip": "ugs_rank.hip"}
+
+
+KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_xdrop.hip", "ugs_local.hip")      # sources whose emitted code tests/test_isa.py pins
+
+
+def asm_path(src):
+    """gfx950 assembly of a KEEP_ASM source as emitted by the build's own compilation (git-ignored)"""
+    return os.path.join(CSRC, os.path.splitext(os.path.basename(src))[0] + ".gfx950.s")
+
+
+def real_src(src):
+    """the file a SOURCES entry is compiled from (ALIAS: the same text under other options)"""
+    b = os.path.basename(src)
+    return os.path.join(CSRC, ALIAS.get(b, b))
+
+
+def asm_is_fresh(src):
+    a = asm_path(src)
+    return os.path.exists(a) and _mtime(a) >= _newest(real_src(src))
+
+
+def flags_for(src):
+    return FLAGS + EXTRA.get(os.path.basename(src), [])
 
 
 def _mtime(path):
@@ -31,7 +62,7 @@ def _deps(path, seen=None):
 
 
 def _newest(src):
-    return max(_mtime(d) for d in _deps(src))
+    return max([_mtime(d) for d in _deps(src)] + [_mtime(os.path.abspath(__file__))])          # (the flags live in this file)
 
 
 def build(force=False, verbose=False):
@@ -39,8 +70,25 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _mtime(obj) < _newest(os.path.join(CSRC, src)):
-            cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        path = real_src(src)
+        if force or _mtime(obj) < _newest(path):
+            if src in KEEP_ASM:
+                # the same compilation also leaves the device assembly behind (-save-temps): tests/test_isa.py reads it
+                import shutil
+                import tempfile
+                tmpd = tempfile.mkdtemp(prefix="ugs_build_")
+                try:
+                    base = os.path.splitext(os.path.basename(path))[0]              # (the temporaries are named after the input file)
+                    cmd = ["hipcc"] + flags_for(src) + ["-save-temps=obj", "-c", path, "-o", os.path.join(tmpd, base + ".o")]
+                    if verbose:
+                        print(" ".join(cmd))
+                    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)           # (-save-temps repeats every warning of the unused-result kind)
+                    shutil.move(os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s"), asm_path(src))
+                    shutil.move(os.path.join(tmpd, base + ".o"), obj)
+                finally:
+                    shutil.rmtree(tmpd, ignore_errors=True)
+                continue
+            cmd = ["hipcc"] + flags_for(src) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -33,6 +33,9 @@
 #define POS_BITS 44
 #define POS_MASK ((1ull << POS_BITS) - 1)
 #define CMAXV 4095u
+#ifndef UGS_RANK_TU
+#define UGS_RANK_TU 0       // see the end of this file
+#endif
 #define KEY_INF 0xffffffffffffffffull
 #define RB 16                  // rows per register batch
 #define SEL_REGS 8             // emitted entries held per thread during block-wide selection
@@ -1131,6 +1134,7 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, in
   return r;
 }
 
+#if UGS_RANK_TU != 1
 // Chooses the sampled index rows of every unit (= query x strand) ahead of the scan: query letters -> UDB words
 // (udbparams.cpp:540-555) -> unique words in first-occurrence order (udbsearcher.cpp:161-194) -> every step-th of them
 // (GetWordCountingParams wordparams.cpp:179-191 via the host's step table).  One wavefront per unit, no block barriers:
@@ -1248,6 +1252,8 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor((long long)psum, o);
   if (lane == 0 && psum) atomicAdd(&bv.counters[UGS_CTR_POSTINGS], psum);
 }
+
+#endif   // UGS_RANK_TU != 1
 
 // Big path, fewer than K targets with count >= 2 and MinValue <= 1: the count-1 targets in first-touch order are the postings of
 // row 0 in ascending target order, then those of row 1 that no earlier row holds, ...  A target has count 1 exactly when it is not
@@ -1832,6 +1838,21 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
   }
 }
 
+// ---- two translation units from this one file (usearch12_amd/build.py):
+//   UGS_RANK_TU == 1: nothing but the HOT instantiation k_rank<false,false,false,false> (C2 / C4), compiled with LLVM's
+//                     "iterative-maxocc" machine scheduler: 54.5 ms against 55.7 ms with the default scheduler on C2, the C4 shard 148
+//                     against 155 ms - while the mid-identity kernels lose 10 % under the same option (135 against 122 ms)
+//   UGS_RANK_TU == 2: every other instantiation, the setup kernel and the host side; the HOT kernel is an extern template here
+//   undefined / 0:    everything in one unit (tools/build_variant.sh)
+#ifndef UGS_RANK_TU
+#define UGS_RANK_TU 0
+#endif
+#if UGS_RANK_TU == 1
+template __global__ void k_rank<false, false, false, false>(UgsDbView, UgsBatchView, uint32_t, uint32_t, uint32_t);
+#else
+#if UGS_RANK_TU == 2
+extern template __global__ void k_rank<false, false, false, false>(UgsDbView, UgsBatchView, uint32_t, uint32_t, uint32_t);
+#endif
 // resident workgroups per CU for a given block size / dynamic LDS (VGPR- and LDS-limited): the
 // persistent grid must not exceed it, or the surplus workgroups run as a second, unbalanced round
 static const void *rank_kernel(int big, int bits, int fast8, int longrows)
@@ -1906,3 +1927,4 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }
+#endif   // UGS_RANK_TU != 1
