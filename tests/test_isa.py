@@ -1,7 +1,8 @@
 """Pins a property of the emitted gfx950 code the ranking kernel's fast paths depend on (ugs_rank.hip process_batch,
 scan_fast8): the ordered clear-with-return of a partition's counters (ds_and_rtn_b32) is only issued after every counter
 increment of the partition (ds_add_u32) has COMPLETED - an `s_waitcnt lgkmcnt(0)` stands between the two batches in every
-basic block that holds both.  Compiles the kernel to assembly (hipcc cross-compiles without a GPU)."""
+basic block that holds both.  Reads the assembly the build's own compilation left behind (usearch12_amd/build.py keeps it) or, when that
+is missing or stale, compiles the kernel to assembly with the build's options (hipcc cross-compiles without a GPU)."""
 import os
 import re
 import subprocess
