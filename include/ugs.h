@@ -267,6 +267,25 @@ int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uint32_t nq, i
 int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap);
 /* k of this batch: max_accepts + max_rejects - 1, plus the spare candidates kept for -selfid on the small path (<= 64) */
 int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
+/* Diagnostic: which ranking code the last synced search of this batch ran (the test-suite asserts that every compiled path is
+ * reached by an oracle-compared test).  out[0] = units ranked by the bitmap kernel (ugs_rank2.hip), out[1] = units it deferred to the
+ * general kernel, out[2] = the general kernel's instantiation (big | counter bits << 1 | fast8 << 8 | longrows << 9), out[3] = 1 if
+ * the bitmap kernel was launched.  n >= 4. */
+int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
+
+/*
+ * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the
+ * environment ONCE per database handle (at ugs_db_create, never inside a search call) and default to "unset":
+ *   UGS_NO_PACKED=1         k_align fetches every target from the byte array instead of the packed letters
+ *   UGS_LONGROWS=0|1        force the long-row ranking instantiations off / on
+ *   UGS_GSIZE=n UGS_GSHIFT=k  partition size of k_rank (targets, a multiple of 64 / a power of two)
+ *   UGS_RANK_WGS_PER_CU=n UGS_ALIGN_WGS_PER_CU=n   cap on resident workgroups per CU
+ *   UGS_EMIT_LIMIT=n        candidate-key buffer of k_rank (forces the regrow path)
+ *   UGS_RANK2=0|1           bitmap ranking kernel off / on wherever the index allows it (default: on for dense Big-path indexes)
+ *   UGS_R2_G=n UGS_R2_KCAP=n UGS_R2_WAVES=n   its partition size (multiple of 8192), kept-key capacity, waves per CU
+ *   UGS_DEBUG_SYNC=1 UGS_PHASE_CLOCKS=1       finish and log every stage / print the kernels' phase clocks with the stats
+ * (ugs_cluster_fast reads UGS_CLUSTER_BATCH / UGS_CLUSTER_PROFILE at its start; ugs_cli reads UGS_CLI_PROFILE / UGS_CLI_FORCE_GATHER.)
+ */
 
 /*
  * Device-resident, query-grouped results of the last synced search (valid until the next search

@@ -1,14 +1,15 @@
 """Builds the product's HIP extension in-tree: usearch12_amd/libugs.so (gfx950 only)."""
 import os
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
-DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
+DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 # per-source compiler options.  k_rank's partition loop lives on the edge of its register budget: of the machine
@@ -22,7 +23,7 @@ EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"],
 ALIAS = {"ugs_rank_hot.hip": "ugs_rank.hip"}
 
 
-KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_xdrop.hip", "ugs_local.hip")      # sources whose emitted code tests/test_isa.py pins
+KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_xdrop.hip", "ugs_local.hip")      # sources whose emitted code tests/test_isa.py pins
 
 
 def asm_path(src):
@@ -83,7 +84,10 @@ def build(force=False, verbose=False):
                     cmd = ["hipcc"] + flags_for(src) + ["-save-temps=obj", "-c", path, "-o", os.path.join(tmpd, base + ".o")]
                     if verbose:
                         print(" ".join(cmd))
-                    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)           # (-save-temps repeats every warning of the unused-result kind)
+                    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)      # (-save-temps repeats every warning of the unused-result kind: shown only on failure)
+                    if r.returncode != 0:
+                        sys.stderr.write(r.stderr)
+                        raise subprocess.CalledProcessError(r.returncode, cmd)
                     shutil.move(os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s"), asm_path(src))
                     shutil.move(os.path.join(tmpd, base + ".o"), obj)
                 finally:

@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -323,6 +323,14 @@ class UgsBatch:
         _chk(lib().ugs_batch_device_results(self.h, query_base, C.byref(ph), C.byref(bh), C.byref(pn), C.byref(bn),
                                             C.byref(pc), C.byref(bc)))
         return (ph.value, bh.value), (pn.value, bn.value), (pc.value, bc.value)
+
+    def kernel_hits(self):
+        """which ranking code the last synced search ran: dict(r2_units, deferred, rank_kernel, r2_launched)"""
+        out = (C.c_uint64 * 4)()
+        f = lib().ugs_debug_kernel_hits
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]; f.restype = C.c_int
+        _chk(f(self.h, out, 4))
+        return {"r2_units": int(out[0]), "deferred": int(out[1]), "rank_kernel": int(out[2]), "r2_launched": int(out[3])}
 
     def candidates(self):
         p = self.db.p

@@ -33,6 +33,8 @@ struct UgsDbView {
   const uint32_t *part;      // [slots*(np+1)] offset (relative to row start) of first posting with target >= p*gsize
   uint32_t np;               // number of target partitions
   uint32_t gsize;            // targets per partition (multiple of 64)
+  const uint32_t *part2;     // dense Big-path indexes only (null otherwise): the same table for the bitmap kernel's larger partitions (ugs_rank2.hip)
+  uint32_t np2, gsize2;      // its partition count and size (a multiple of 8192, <= 65536)
   const uint32_t *step_tab;  // [step_n] Big-path QueryStep for Nu unique words (wordparams.cpp:167-192)
   uint32_t step_n;
   const UgsTables *tab;
@@ -103,13 +105,15 @@ struct UgsBatchView {
   uint32_t *cl_info;         // [units*4] M, NextValue, number of prefix maxima, -
   uint32_t *walk_n;          // [units] candidates the alignment walk visited
   const uint32_t *unit_map;  // [units] pair stage: unit -> query << 1 | strand (several units per query)
+  uint32_t *defer_list;      // [units] units the bitmap ranking kernel (ugs_rank2.hip) hands on to k_rank; counters[UGS_CTR_DEFER] of them
+  uint32_t use_defer;        // k_rank (HOT instantiation): take the units from defer_list instead of 0 .. units-1
 };
 #define UGS_CL_EV 16
 #define UGS_A_NOTERM 0x100u  // internal align flag: rejects never end a walk (the in-batch pair stage of cluster_fast)
 #define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited): a walk that reaches the end of a full candidate list is an error
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
-       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
+       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
 enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64 };
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates
@@ -146,7 +150,9 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
                      uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, uint32_t query_base,
                      hipStream_t st);
 size_t ugs_compact_tmp_bytes(uint32_t nq);
-int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done);
+struct UgsRank2Params;
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
+                    const UgsRank2Params *r2 = nullptr, int r2_grid = 0);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t max_tlen, uint32_t seed_cap);
 int ugs_local_blocks_per_cu(int threads, size_t lds);

@@ -228,7 +228,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   if (!db) return;
   (void)hipSetDevice(db->device);
   (void)hipFree(db->d_pk);
-  (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part);
+  (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part); (void)hipFree(db->d_part2);
   (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
   (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls); (void)hipFree(db->d_tkey); (void)hipFree(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
@@ -246,6 +246,34 @@ static int db_step_table(ugs_db *db, uint32_t n)
   HIPCHK(hipMemcpy(db->d_step, db->step.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
   db->v.step_tab = db->d_step; db->v.step_n = (uint32_t)n;
   return UGS_OK;
+}
+
+static int env_int(const char *name, int lo, int hi, int unset)
+{
+  const char *e = getenv(name);
+  if (!e || !*e) return unset;
+  const long v = atol(e);
+  return (v >= lo && v <= hi) ? (int)v : unset;
+}
+
+// the debug switches (ugs_host.h UgsTune; listed in include/ugs.h), read once per database handle
+UgsTune ugs_tune_read()
+{
+  UgsTune t;
+  t.no_packed = getenv("UGS_NO_PACKED") != nullptr;
+  t.longrows = env_int("UGS_LONGROWS", 0, 1, -1);
+  t.gsize = env_int("UGS_GSIZE", 64, 65536, 0); if (t.gsize % 64) t.gsize = 0;
+  t.gshift = env_int("UGS_GSHIFT", 6, 16, 0);
+  t.rank_wgs = env_int("UGS_RANK_WGS_PER_CU", 1, 8, 0);
+  t.align_wgs = env_int("UGS_ALIGN_WGS_PER_CU", 1, 8, 0);
+  { const char *e = getenv("UGS_EMIT_LIMIT"); const long v = e ? atol(e) : 0; t.emit_limit = v >= 1 ? v : 0; }
+  t.debug_sync = getenv("UGS_DEBUG_SYNC") != nullptr;
+  t.phase_clocks = getenv("UGS_PHASE_CLOCKS") != nullptr;
+  t.rank2 = env_int("UGS_RANK2", 0, 1, -1);
+  t.r2_g = env_int("UGS_R2_G", 8192, 65536, 0); if (t.r2_g % 8192) t.r2_g = 0;
+  t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
+  t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
+  return t;
 }
 
 // Partition size and table, the Big latch and the index-dependent fields of the device view; called when the index was
@@ -277,8 +305,8 @@ int ugs_db_replan(ugs_db *db)
     // (queries with more than 255 words need 16-bit counters on the small path: partitions are then kept small enough for
     // four workgroups per CU, and their short sub-rows take the flattened scan - 2.4x on cluster_fast's small-path phase)
     if (db->gsize_limit && nseq <= db->p.big && gsize > db->gsize_limit) gsize = db->gsize_limit;
-    if (const char *e = getenv("UGS_GSIZE")) { int v = atoi(e); if (v >= 64 && v <= 65536 && v % 64 == 0) gsize = (uint32_t)v; }
-    if (const char *e = getenv("UGS_GSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 16) gsize = 1u << v; }
+    if (db->tune.gsize) gsize = (uint32_t)db->tune.gsize;
+    if (db->tune.gshift) gsize = 1u << db->tune.gshift;
   }
   const uint32_t np = nseq ? (uint32_t)(((uint64_t)nseq - 1) / gsize + 1) : 1;
   const uint64_t need = (uint64_t)slots * (np + 1);
@@ -290,12 +318,36 @@ int ugs_db_replan(ugs_db *db)
   }
   RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np, gsize, db->d_part, db->stream));
   HIPCHK(hipStreamSynchronize(db->stream));
+  // The bitmap ranking kernel (ugs_rank2.hip) for dense Big-path indexes: one LDS bit per target, so its partitions are
+  // larger (G2 targets, a multiple of 8192 up to 65536) and have a table of their own.  G2 is chosen so that a (row,
+  // partition) sub-row averages <= ~230 postings: it is read as ONE 16-byte load per lane (256 postings per wave
+  // instruction).  Keys carry 24-bit targets, hence nseq <= 2^24; sparse dictionaries (protein) keep k_rank.
+  uint32_t gsize2 = 0, np2 = 0;
+  if (nseq > db->p.big && !db->sparse && nseq <= (1u << 24) && db->n_postings && db->tune.rank2 != 0) {
+    const double dens = ((double)db->n_postings / (double)slots) / (double)nseq;        // a row's postings per target
+    uint64_t g = dens > 0 ? (uint64_t)(232.0 / dens) / 8192 * 8192 : 65536;
+    g = std::min<uint64_t>(65536, std::max<uint64_t>(8192, g));
+    if (db->tune.r2_g) g = (uint64_t)db->tune.r2_g;
+    if (dens * (double)g >= 64.0 || db->tune.rank2 == 1) { gsize2 = (uint32_t)g; np2 = (uint32_t)(((uint64_t)nseq - 1) / gsize2 + 1); }
+  }
+  if (gsize2) {
+    const uint64_t need2 = (uint64_t)slots * (np2 + 1);
+    if (!db->d_part2 || need2 > db->part2_cap) {
+      if (db->d_part2) HIPCHK(hipFree(db->d_part2));
+      db->d_part2 = nullptr;
+      db->part2_cap = need2 + need2 / 4;
+      HIPCHK(hipMalloc(&db->d_part2, (size_t)db->part2_cap * sizeof(uint32_t)));
+    }
+    RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np2, gsize2, db->d_part2, db->stream));
+    HIPCHK(hipStreamSynchronize(db->stream));
+  }
   UgsDbView &v = db->v;
   v.seqs = db->d_seqs; v.offs = db->d_offs; v.row_off = db->d_row_off; v.postings = db->d_postings; v.part = db->d_part;
-  v.pk = getenv("UGS_NO_PACKED") ? nullptr : db->d_pk;       // UGS_NO_PACKED: k_align fetches every target from the byte array (A/B, fault isolation)
+  v.part2 = gsize2 ? db->d_part2 : nullptr; v.np2 = np2; v.gsize2 = gsize2;
+  v.pk = db->tune.no_packed ? nullptr : db->d_pk;       // UGS_NO_PACKED: k_align fetches every target from the byte array (A/B, fault isolation)
   v.np = np; v.gsize = gsize; v.big = nseq > db->p.big ? 1 : 0; v.max_tlen = db->max_tlen;
   db->hbm_bytes = db->nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
-                  (size_t)slots * (np + 1) * 4 + sizeof(UgsTables);
+                  (size_t)slots * (np + 1) * 4 + (gsize2 ? (size_t)slots * (np2 + 1) * 4 : 0) + sizeof(UgsTables);
   return UGS_OK;
 }
 
@@ -347,6 +399,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   ugs_db *db = new ugs_db();
   memset(&db->v, 0, sizeof(db->v));
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
+  db->tune = ugs_tune_read();
+  db->d_part2 = nullptr; db->part2_cap = 0;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
   db->d_pk = nullptr; db->pack_cap = 0;
   db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0; db->gsize_limit = 0;
@@ -511,7 +565,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipSetDevice(b->db->device);
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
-  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots);
+  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer);
   (void)hipFree(b->d_qkey); (void)hipFree(b->d_qsize);
   (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
@@ -548,6 +602,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cand_cnt, std::max<uint64_t>(units * b->K, 1) * 4));
   BCHK(hipMalloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
   BCHK(hipMalloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
+  BCHK(hipMalloc(&b->d_defer, std::max<uint64_t>(units, 1) * 4));
   BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
   b->cigar_cap = units * std::max(db->p.max_accepts, 1) * 12 + 4096;
   if (db->p.local) BCHK(hipMalloc(&b->d_qthr, std::max<uint64_t>(max_queries, 1) * sizeof(int2)));
@@ -648,7 +703,7 @@ static int plan_launch(ugs_batch *b)
   // queries that hold its word (uniform data stays below: C2 3.9 k vs 5.0 k, C4 19 k vs 25 k; cluster_fast's centroid index passes
   // it as soon as an abundant species has a few hundred centroids).  UGS_LONGROWS=0/1 overrides (tuning).
   b->rl.longrows = db->max_row > 56u * db->v.np;
-  if (const char *e = getenv("UGS_LONGROWS")) b->rl.longrows = atoi(e) != 0;
+  if (db->tune.longrows >= 0) b->rl.longrows = db->tune.longrows != 0;
   const int hot = ugs_rank_is_hot(db->v.big, bits, b->rl.fast8, b->rl.longrows);
   if ((hot == 1 || hot == 2) && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30))) {       // (both twins use the asm loads)
     ugs_set_error("index too large for the 32-bit offsets of the ranking kernel's partition-table loads (%u slots x %u partitions, longest row %u)", db->v.slots, db->v.np, db->max_row);
@@ -662,7 +717,7 @@ static int plan_launch(ugs_batch *b)
   const uint64_t units = (uint64_t)b->nq * b->nstrand;
   int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds, db->v.big, bits, b->rl.fast8, b->rl.longrows);      // real residency (VGPRs, LDS, wave slots)
   per_cu = std::max(1, std::min(per_cu, 8));
-  if (const char *e = getenv("UGS_RANK_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = std::min(per_cu, v); }
+  if (db->tune.rank_wgs) per_cu = std::min(per_cu, db->tune.rank_wgs);
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well
@@ -673,9 +728,9 @@ static int plan_launch(ugs_batch *b)
   // the search again.
   if (!b->emit_limit) {
     b->emit_limit = 1u << 16;
-    if (const char *e = getenv("UGS_EMIT_LIMIT")) { const long v = atol(e); if (v >= 1) b->emit_limit = (uint64_t)v; }      // tests: force the regrow path
+    if (db->tune.emit_limit) b->emit_limit = (uint64_t)db->tune.emit_limit;      // tests: force the regrow path
   }
-  uint64_t ecap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20), b->emit_limit) + (getenv("UGS_EMIT_LIMIT") ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
+  uint64_t ecap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20), b->emit_limit) + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
   if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
     // (a database that grows - cluster_fast - asks for a little more with every batch: over-allocate then, a multi-GB
     // hipMalloc per batch costs more than the batch's kernels)
@@ -694,6 +749,21 @@ static int plan_launch(ugs_batch *b)
       HIPCHK(hipMalloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
       b->unit_slots_alloc = need;
     }
+  }
+  // ---- the bitmap ranking kernel (ugs_rank2.hip) where the index and the launch allow it: dense Big-path index (part2), at most 15
+  // sampled rows for the typical query (4-bit count field; a longer query is deferred per unit), uniform rows.  Units outside its
+  // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
+  b->r2_grid = 0;
+  if (db->v.part2 && bits == 4 && !b->rl.longrows && b->K <= 64) {
+    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(256u, 6u * b->K);
+    b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
+    // a window = as many partitions as the chunk list (256 descriptors, 2 KB) holds with some room for sub-rows of two chunks
+    b->r2.clcap = 256;
+    b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>((db->v.np2 + 3u) / 4u * 4u, (200u / std::min<uint32_t>(ns_max, 15u)) / 4u * 4u));
+    b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap);
+    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds), 32));
+    if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
+    b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   }
   if (p.local) return plan_local(b);
   // ---- alignment geometry
@@ -714,7 +784,7 @@ static int plan_launch(ugs_batch *b)
   const size_t alds = 2112 + awpb * wave_lds;
   int aper_cu = ugs_align_blocks_per_cu(64 * awpb, alds);
   aper_cu = std::max(1, std::min(aper_cu, 8));
-  if (const char *e = getenv("UGS_ALIGN_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) aper_cu = std::min(aper_cu, v); }
+  if (db->tune.align_wgs) aper_cu = std::min(aper_cu, db->tune.align_wgs);
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
   b->al.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + awpb - 1) / awpb, (uint64_t)db->num_cu * aper_cu));
   const int waves = b->al.grid * awpb;
@@ -785,7 +855,7 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   UgsBatchView &v = b->v;
   v.qseqs = b->d_qseqs; v.qoffs = b->d_qoffs; v.nq = nq; v.nstrand = b->nstrand; v.K = b->K; v.max_qlen = maxl;
   v.cand = b->d_cand; v.cand_cnt = b->d_cand_cnt; v.cand_n = b->d_cand_n; v.emit_buf = b->d_emit;
-  v.unit_ns = b->d_unit_ns; v.unit_slots = b->d_unit_slots;
+  v.unit_ns = b->d_unit_ns; v.unit_slots = b->d_unit_slots; v.defer_list = b->d_defer; v.use_defer = 0;
   v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
   v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
   b->have_qkey = b->have_qsize = false; b->v.q_key = nullptr; b->v.q_size = nullptr;     // keys belong to one uploaded batch
@@ -818,9 +888,11 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipStreamWaitEvent(db->stream, b->ev_up, 0));          // the batch's letters and offsets have arrived
   HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
   HIPCHK(hipEventRecord(b->ev0, db->stream));
-  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
+  // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
+  const bool r2 = b->r2_grid > 0 && !b->v.cand_key && !b->v.cl_ev;
+  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
   HIPCHK(hipEventRecord(b->ev1, db->stream));
-  const bool dbg = getenv("UGS_DEBUG_SYNC") != nullptr;             // fault isolation: finish each stage before the next
+  const bool dbg = db->tune.debug_sync != 0;             // fault isolation: finish each stage before the next
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] ranking stage done\n"); }
   if (b->nq) RCCHK(enqueue_align(b)); else HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
   HIPCHK(hipEventRecord(b->ev2, db->stream));
@@ -849,7 +921,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
       ++emit_tries; ++g_emit_regrows;
       const uint64_t wpb = (uint64_t)b->rl.wpb, demand = b->ctr[UGS_CTR_EMIT_MAX] * wpb;
       b->emit_limit = std::max<uint64_t>(2 * b->emit_limit, demand + demand / 4 + 4096);
-      const uint64_t ecap = b->emit_limit + (getenv("UGS_EMIT_LIMIT") ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64, want = ecap * (uint64_t)b->rl.grid;
+      const uint64_t ecap = b->emit_limit + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64, want = ecap * (uint64_t)b->rl.grid;
       if (want > b->emit_cap_alloc) {
         HIPCHK(hipFree(b->d_emit)); b->d_emit = nullptr;
         HIPCHK(hipMalloc(&b->d_emit, want * 8));
@@ -974,12 +1046,24 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
   st->pairs_aligned = b->ctr[UGS_CTR_PAIRS];
   st->dp_cells = b->ctr[UGS_CTR_CELLS];
   st->hits = b->ctr[UGS_CTR_HITS];
-  if (getenv("UGS_PHASE_CLOCKS"))
+  if (b->db->tune.phase_clocks)
     fprintf(stderr, "[ugs] rank phase clocks (sum over WGs, thread 0): setup %llu scan %llu scan-wait %llu select %llu | align: %llu %llu %llu %llu\n",
             b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5],
             b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]),
     fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu, bits %d ns_max %u gsize %u np %u | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
             b->rl.bits, b->rl.ns_max, b->db->v.gsize, b->db->v.np, b->al.grid, b->al.wpb, b->al.lds);
+  return UGS_OK;
+}
+
+// diagnostic (tests/test_gpu_paths.py): which ranking code the last synced search of this batch ran.
+//   out[0] units ranked by the bitmap kernel (ugs_rank2.hip)   out[1] units it deferred to k_rank
+//   out[2] k_rank instantiation: big | bits << 1 | fast8 << 8 | longrows << 9      out[3] 1 if the bitmap kernel was launched
+extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
+{
+  if (!b || !out || n < 4 || !b->synced) return UGS_E_ARG;
+  out[0] = b->ctr[UGS_CTR_R2_DONE]; out[1] = b->ctr[UGS_CTR_DEFER];
+  out[2] = (uint64_t)(b->db->v.big ? 1 : 0) | ((uint64_t)b->rl.bits << 1) | ((uint64_t)b->rl.fast8 << 8) | ((uint64_t)b->rl.longrows << 9);
+  out[3] = (b->r2_grid > 0 && !b->v.cand_key && !b->v.cl_ev) ? 1 : 0;
   return UGS_OK;
 }
 

@@ -1,6 +1,7 @@
 // ugs_host.h - handle structs shared by the host translation units (ugs_host.cpp, ugs_cluster.cpp).  Internal.
 #pragma once
 #include "ugs_dev.h"
+#include "ugs_rank2.h"
 #include <vector>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
@@ -8,14 +9,31 @@
 
 static const size_t LDS_MAX = 160 * 1024;
 
+// Debug / tuning switches, read from the environment ONCE per database handle, at ugs_db_create (never inside a search call).  Not part of the ABI: they exist
+// for A/B measurements and fault isolation; the test-suite runs with none of them set unless a test names one.
+struct UgsTune {
+  int no_packed;          // UGS_NO_PACKED       k_align fetches every target from the byte array
+  int longrows;           // UGS_LONGROWS        -1 unset, 0/1 force the LONG ranking instantiations off/on
+  int gsize, gshift;      // UGS_GSIZE/UGS_GSHIFT partition size of k_rank (0 unset)
+  int rank_wgs, align_wgs;// UGS_RANK_WGS_PER_CU / UGS_ALIGN_WGS_PER_CU  cap on resident workgroups (0 unset)
+  long emit_limit;        // UGS_EMIT_LIMIT      candidate buffer of k_rank in keys (forces the regrow path in tests; 0 unset)
+  int debug_sync;         // UGS_DEBUG_SYNC      finish every stage before the next, log
+  int phase_clocks;       // UGS_PHASE_CLOCKS    print the kernels' phase clocks with the stats
+  int rank2;              // UGS_RANK2           -1 unset (= on where eligible), 0 off, 1 on
+  int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
+};
+UgsTune ugs_tune_read();
+
 struct ugs_db {
   ugs_params p;
+  UgsTune tune;                     // the environment's debug switches as they stood at ugs_db_create
   int device;
   hipStream_t stream;
   int num_cu;
   UgsDbView v;
   // owned device memory
   uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
+  uint32_t *d_part2; uint64_t part2_cap;   // dense Big-path indexes: the partition table of the bitmap ranking kernel (ugs_rank2.hip)
   uint2 *d_pk; uint64_t pack_cap;   // nt: 2-bit letters + "other" bits, one uint2 per 16 letters (ugs_dev.h UgsDbView::pk)
   uint32_t *d_step; UgsTables *d_tab;
   std::vector<uint32_t> step;       // host copy: step[Nu]
@@ -43,6 +61,8 @@ struct ugs_batch {
   uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
   ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
   uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
+  uint32_t *d_defer;                // units the bitmap ranking kernel hands on to k_rank
+  UgsRank2Params r2; int r2_grid;   // its launch (r2_grid == 0: not used for this batch)
   // usearch_local
   uint32_t hit_slots;               // hit table entries per unit
   int2 *d_qthr; uint8_t *d_ltb; uint2 *d_lrow; uint32_t *d_lruns;
@@ -65,6 +85,7 @@ struct ugs_batch {
   unsigned long long cigar_used_host;
   uint64_t q_letters;
 };
+
 
 
 // internal entry points of ugs_host.cpp used by the cluster_fast driver

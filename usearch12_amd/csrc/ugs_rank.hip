@@ -24,11 +24,13 @@
 // (count desc, first-touch position asc) are selected, after applying the reference's
 // "MinValue = prevMax/2" (and, on the small path, -bump) cut-offs exactly.
 #include "ugs_dev.h"
+#include "ugs_rank2.h"
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+#define RCCHK_(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
 
 #define POS_BITS 44
 #define POS_MASK ((1ull << POS_BITS) - 1)
@@ -1343,7 +1345,9 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
   if (HOT) s_wsel = (uint64_t *)(smem + off);                                       // (= wave 0's table; off is a multiple of 16)
 
   const UgsTables *tab = db.tab;
-  const uint32_t units = bv.nq * bv.nstrand;
+  // HOT only: behind the bitmap kernel (ugs_rank2.hip) this kernel takes the units that one deferred, from its list
+  const bool deferred = HOT && bv.use_defer != 0;
+  const uint32_t units = deferred ? (uint32_t)bv.counters[UGS_CTR_DEFER] : bv.nq * bv.nstrand;
   const uint32_t K = bv.K;
   const int W = db.word_len;
   constexpr bool small_path = SMALL;
@@ -1358,7 +1362,8 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
   uint32_t next_unit = 0;
   if (tid == 0) sh->pad1 = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
   __syncthreads();
-  for (uint32_t unit = sh->pad1; unit < units; unit = sh->pad1) {
+  for (uint32_t uq = sh->pad1; uq < units; uq = sh->pad1) {
+    const uint32_t unit = deferred ? bv.defer_list[uq] : uq;
     __syncthreads();                     // everyone has read sh->pad1
     const unsigned long long tk0 = clock64();
     // ---- the sampled index rows of this unit were chosen by k_rank_setup
@@ -1896,7 +1901,8 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   return (off + 15) & ~(size_t)15;
 }
 
-int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done)
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
+                    const UgsRank2Params *r2, int r2_grid)
 {
   const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
@@ -1917,10 +1923,13 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
 #ifdef UGS_ONLY_HOT
   if (!(db.big && L.bits == 4 && !L.longrows)) { ugs_set_error("UGS_ONLY_HOT build"); return UGS_E_ENVELOPE; }
 #endif
+  // dense Big-path index: the bitmap kernel ranks the units and lists the ones outside its envelope, which k_rank (below) then takes
+  if (r2) RCCHK_(ugs_launch_rank2(db, b, *r2, r2_grid, st));
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
+    a1.use_defer = r2 ? 1u : 0u;
     void *args[] = {&a0, &a1, &a2, &a3, &a4};
     HIPCHK(hipLaunchKernel(fn, grid, block, args, L.lds, st));
   }

@@ -1,0 +1,17 @@
+// ugs_rank2.h - launch interface of the dense-index Big-path ranking kernel (ugs_rank2.hip).  Internal.
+#pragma once
+#include "ugs_dev.h"
+
+struct UgsRank2Params {
+  uint32_t ns_max;     // stride of UgsBatchView::unit_slots
+  uint32_t G;          // targets per partition: a multiple of 8192, <= 65536 (one bit per target in LDS)
+  uint32_t np;         // partitions = ceil(nseq / G) = UgsDbView::np2
+  uint32_t kcap;       // kept keys per unit the LDS list holds (more defers the unit to k_rank)
+  uint32_t W;          // partitions per window of the scan (a multiple of 4)
+  uint32_t clcap;      // chunk descriptors the LDS list of a window holds
+  uint32_t lds;        // dynamic LDS bytes per wave
+};
+
+size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap);
+int ugs_rank2_blocks_per_cu(size_t lds);
+int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st);

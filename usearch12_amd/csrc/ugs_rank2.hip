@@ -1,0 +1,480 @@
+// ugs_rank2.hip - the Big-path ranking kernel for dense indexes ("bitmap kernel"), gfx950.
+//
+// Replaces the same reference code as k_rank's Big path (ugs_rank.hip):
+//   UDBUsortedSearcher::UDBSearchBig  scan + first-touch list            udbusortedsearcherbig.cpp:82-100
+//   CountSortSubsetDesc (+ the NextValue / MinValue = prevMax/2 cut-off)   countsort.cpp:110-191
+//   GetWordCountingParams' sampled words come from k_rank_setup            wordparams.cpp:167-192
+//
+// What the reference computes per query: U[t] = number of sampled index rows that hold target t, the targets in
+// first-touch order (row-major over the sampled rows, targets ascending inside a row), a stable descending counting
+// sort of them, of which the candidate loop can consume at most K.  So the result is the K smallest keys
+// (count desc, first row asc, target asc) plus the cut-off that depends on the first position of every count value.
+//
+// Design (DESIGN.md section 3 "K-rank2"): ONE WAVE PER UNIT (query x strand), no workgroup barriers anywhere.
+//   * the target space is cut into partitions of G targets (G <= 65536); the wave keeps ONE BIT per target of the
+//     current partition in LDS (8 KB) instead of a 4-bit counter (k_rank: 5.6 KB for 11 264 targets), so a partition
+//     is six times larger, a (row, partition) sub-row holds ~220 postings instead of ~39 and is read as ONE 16-byte load
+//     per lane (four consecutive postings): 1 KB per load instruction, sub-rows cover their cache lines, and the
+//     partition-table look-ups per unit drop from 979 to 187
+//   * the rows of a partition are walked in DESCENDING row order with one ds_or_rtn per posting: a posting whose bit
+//     was already set is a "second or later touch" and leaves a RECORD (row, target).  A target with count c leaves
+//     c - 1 records, the last of them from its LOWEST row = its first-touch row: count and first touch of every
+//     target with count >= 2 follow from the records alone (count-1 targets never matter individually: the fill walks
+//     the first rows against the selected list, as k_rank's big_path_fill)
+//   * posting loads run D chunks ahead of their use (ring of D register quads, the compiler's counted s_waitcnt vmcnt)
+//   * when a partition is done its ~44 records are grouped by target (two 2048-bit hash filters tell the few
+//     records that may share a target from the rest; those are compared all-pairs with readlane), turned into 32-bit
+//     sortable keys [15 - count : 4][row : 4][target : 24] and PRUNED: a count-2 key is dropped when K count-2 keys of
+//     earlier partitions (smaller targets) with the same or a lower row are already kept - it cannot be among the K
+//     smallest, and the smallest key of every count value (all the cut-off needs) is never dropped
+//   * the few kept keys (~100) are ranked all-pairs at the end of the unit
+// A unit outside this kernel's envelope (more than 15 sampled rows, more than 128 records in one partition, more kept
+// keys than the LDS list holds) is DEFERRED: its index goes to a list that the general kernel (k_rank, ugs_rank.hip)
+// processes right behind this one.  Never a different result, never a CPU path.
+#include "ugs_dev.h"
+#include "ugs_rank2.h"
+#include <cstdlib>
+#include <cstdio>
+#include <algorithm>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
+
+typedef uint32_t __attribute__((address_space(3))) *lds32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define R2_SCAP 128u            // records of one partition the grouping handles (two register batches)
+#define R2_HB_BITS 2048u        // bits of each of the two hash filters
+#define R2_KEY_INF 0xffffffffu
+#ifndef UGS_R2_DEPTH
+#define UGS_R2_DEPTH 8          // posting chunks in flight per wave
+#endif
+
+__device__ __forceinline__ uint32_t r2_mbcnt(uint64_t m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint64_t r2_readlane64(uint64_t v, uint32_t l)
+{
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+  return ((uint64_t)hi << 32) | lo;
+}
+// inclusive prefix sum inside each row of 16 lanes (DPP row shifts)
+__device__ __forceinline__ uint32_t r2_row16_incl_sum(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  return v;
+}
+
+// one chunk of a sub-row (<= 256 consecutive postings), 8 bytes in the unit's LDS chunk list:
+//   lo = low 32 bits of the chunk's first element index in the postings array
+//   hi = n (1..256 valid postings; 0 = padding) | row << 9 | partition << 13 (11 bits) | high 8 bits of the element index << 24
+#define R2D_N(m) ((m) & 511u)
+#define R2D_ROW(m) (((m) >> 9) & 15u)
+#define R2D_PART(m) (((m) >> 13) & 2047u)
+#define R2D_AHI(m) ((m) >> 24)
+// what the emission of a chunk needs after its atomics were issued
+struct R2Stage { uint32_t old[4], bit[4], rec[4]; };
+
+template <int D>
+__global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lane4 = lane * 4u;
+  // ---- LDS carve (the bitmap sits at offset 0 so that a posting's word address needs no add)
+  const uint32_t G = prm.G, np = prm.np, K = bv.K, kcap = prm.kcap;
+  const uint32_t bm_bytes = G / 8u;
+  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP] records of the partition being scanned
+  uint32_t *s_hba = s_stg + R2_SCAP;                                    // [64] hash filter A
+  uint32_t *s_hbb = s_hba + R2_HB_BITS / 32;                            // [64] hash filter B
+  uint32_t *s_c2 = s_hbb + R2_HB_BITS / 32;                             // [16] kept count-2 keys per row
+  uint32_t *s_cum = s_c2 + 16;                                          // [16] ... with that row or a lower one
+  uint32_t *s_fpk = s_cum + 16;                                         // [16] smallest key per (15 - count)
+  uint32_t *s_slots = s_fpk + 16;                                       // [16] sampled slots of the unit
+  uint32_t *s_sel = s_slots + 16;                                       // [64] selected targets (for the fill)
+  uint64_t *s_rs = (uint64_t *)(s_sel + 64);                            // [16] first posting (element index) of the unit's rows
+  uint2 *s_cl = (uint2 *)(s_rs + 16);                                   // [clcap] chunk list of the window being scanned
+  const uint32_t W = prm.W, clcap = prm.clcap;
+  uint32_t *s_kl = (uint32_t *)(s_cl + clcap);                          // [kcap + 4] kept keys
+  const uint32_t amask = (bm_bytes - 1u) & ~3u;
+  const uint32_t units = bv.nq * bv.nstrand;
+  const uint32_t ns_max = prm.ns_max;
+  const uint32_t *postings = db.postings;
+  unsigned long long n_done_local = 0;
+#ifdef R2_CLOCKS
+  unsigned long long tc_pre = 0, tc_scan = 0, tc_fin = 0, tc_sel = 0;
+#define R2_CLK(...) __VA_ARGS__
+#else
+#define R2_CLK(...)
+#endif
+
+  for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;      // both filters start clean and are left clean
+
+  uint32_t ubase = 0, uidx = 4;
+  for (;;) {
+    // ---- next unit (handed out four at a time: one same-address atomic per unit would be a tenth of this kernel)
+    if (uidx == 4) {
+      uint32_t v = 0;
+      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK2], 4ull);
+      ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+      uidx = 0;
+    }
+    const uint32_t unit = ubase + uidx;
+    ++uidx;
+    if (unit >= units) break;
+    const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
+    bool bad = ns > 15u;                                                  // 4-bit count field of the keys
+    if (ns == 0) { if (lane == 0) bv.cand_n[unit] = 0; continue; }
+    uint32_t nk = 0, n_stg = 0;
+    bool any_posting = false;
+    R2_CLK(const unsigned long long tk0 = clock64(); unsigned long long tfin = 0, tpre = 0;)
+    if (!bad) {
+      // ---- row descriptors
+      {
+        const bool rowlane = lane < ns;
+        const uint32_t slot = rowlane ? bv.unit_slots[(uint64_t)unit * ns_max + lane] : 0u;
+        const uint64_t rs = rowlane ? db.row_off[slot] : 0ull;            // the row's first posting (element index)
+        if (lane < 16) { s_slots[lane] = slot; s_rs[lane] = rs; s_c2[lane] = 0; s_cum[lane] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      // one ds_or_rtn per posting; invalid postings OR a zero into an in-range word
+      auto count_chunk = [&](const u32x4 &q, uint32_t meta, R2Stage &S) {
+        const int vlen = (int)R2D_N(meta) - (int)lane4;
+        const uint32_t sub = R2D_PART(meta) * G;
+        const uint32_t rtag = R2D_ROW(meta) << 24;
+        // (lanes beyond the chunk hold copies of lane 0's postings: an atomic of theirs, even one that ORs a zero, would go to the SAME
+        // word as lane 0's and same-address atomics are served one after the other - they stay out of the LDS instructions altogether)
+        const bool lane_on = vlen > 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { S.old[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t t = q[j];
+          const uint32_t ad = ((t - sub) >> 3) & amask;
+          const uint32_t bit = j < vlen ? (1u << (t & 31u)) : 0u;
+          S.bit[j] = bit;
+          S.rec[j] = t | rtag;
+#if defined(R2_PROBE_NOATOM)                 // timing probes (tools/r2_probe.sh): wrong results
+          S.old[j] = 0; if (ad == 0xffffffffu) S.old[j] = bit;
+#elif defined(R2_PROBE_NOCONFLICT)           // every lane its own bank (wrong results)
+          S.old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)((lane & 31u) * 4u + (ad & 0x1f80u)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif defined(R2_PROBE_READONLY)             // (wrong results)
+          S.old[j] = *(volatile lds32)(uintptr_t)ad;
+#elif defined(R2_READ_OR)                    // plain read + non-returning or: the same result (only this wave touches its bitmap, a row holds a target once)
+          S.old[j] = *(volatile lds32)(uintptr_t)ad;
+          __hip_atomic_fetch_or((lds32)(uintptr_t)ad, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+          if (lane_on) S.old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)ad, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+        }
+      };
+      // postings that found their bit set leave a record
+      auto emit_chunk = [&](const R2Stage &S) {
+#if defined(R2_PROBE_NOEMIT)
+        if ((S.old[0] & S.bit[0]) == 0x12345u) s_stg[0] = S.rec[0];
+        return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool hit = (S.old[j] & S.bit[j]) != 0u;
+          const uint64_t m = __ballot(hit);
+          uint32_t pos = n_stg + r2_mbcnt(m);
+          pos = pos < R2_SCAP - 1u ? pos : R2_SCAP - 1u;               // (beyond the capacity the unit is deferred: n_stg tells)
+          if (hit) s_stg[pos] = S.rec[j];
+          n_stg += (uint32_t)__popcll(m);
+        }
+      };
+      auto zero_bitmap = [&]() {
+        uint4 z; z.x = z.y = z.z = z.w = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t o = lane * 16u; o < bm_bytes; o += 1024u) *(uint4 *)(smem + o) = z;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+      // ---- a partition is done: group its records by target, make keys, prune, keep
+      auto finalize = [&]() {
+        const uint32_t n = n_stg;
+        n_stg = 0;
+        if (n == 0) return;
+#if defined(R2_PROBE_NOFIN)
+        return;
+#endif
+        if (n > R2_SCAP) { bad = true; return; }
+        uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint32_t i = (uint32_t)b * 64u + lane;
+          act[b] = i < n;
+          rec[b] = act[b] ? s_stg[i] : 0u;
+          t[b] = rec[b] & 0xffffffu; row[b] = rec[b] >> 24;
+          const uint32_t h = (t[b] ^ (t[b] >> 11)) & (R2_HB_BITS - 1u);
+          wofs[b] = h >> 5; hbit[b] = 1u << (h & 31u);
+          cnt[b] = 2; drop[b] = false;
+          cumv[b] = act[b] ? s_cum[row[b]] : 0u;
+        }
+        // filter A: "a record with this hash came before me"; those set filter B, which then marks every record of a shared bucket
+        uint32_t olda[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int b = 0; b < 2; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }     // both filters clean again
+        // the flagged records (a handful) against all records: count = records of the target + 1, first row = the lowest row
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          uint64_t m = __ballot(fl[bb]);
+          while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L), rL = (uint32_t)__builtin_amdgcn_readlane((int)row[bb], L);
+            const bool s0 = act[0] && t[0] == tL, s1 = act[1] && t[1] == tL;
+            const uint32_t nsame = (uint32_t)__popcll(__ballot(s0)) + (uint32_t)__popcll(__ballot(s1));
+            if (nsame >= 2u) {
+              const uint32_t lower = (uint32_t)__popcll(__ballot(s0 && row[0] < rL)) + (uint32_t)__popcll(__ballot(s1 && row[1] < rL));
+              if (lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = lower != 0u; }
+            }
+          }
+        }
+        // keys; a count-2 key stays only while fewer than K count-2 keys of EARLIER partitions with its row or a lower one are kept
+        uint32_t nk_new = nk;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint32_t key = ((15u - cnt[b]) << 28) | rec[b];
+          const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
+          const uint64_t m = __ballot(keep);
+          uint32_t pos = nk_new + r2_mbcnt(m);
+          pos = pos < kcap ? pos : kcap;                                 // (slot kcap is scratch; nk > kcap defers the unit)
+          if (keep) s_kl[pos] = key;
+          if (keep && cnt[b] == 2u) atomicAdd(&s_c2[row[b]], 1u);
+          nk_new += (uint32_t)__popcll(m);
+        }
+        nk = nk_new;
+        if (nk > kcap) { bad = true; return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+          const uint32_t c = lane < 16u ? s_c2[lane] : 0u;
+          const uint32_t incl = r2_row16_incl_sum(c);
+          if (lane < 16u) s_cum[lane] = incl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+
+      // ---- the scan, a window of W partitions at a time
+      uint32_t cur_p = 0xffffffffu;
+      for (uint32_t p0 = 0; p0 < np && !bad; p0 += W) {
+        const uint32_t Wn = np - p0 < W ? np - p0 : W;
+        // (1) the window's chunk list -> LDS.  Lane = (partition of the window: lane >> 4, row: ns - 1 - (lane & 15)), so lane order is the
+        // scan order (partition ascending, row DESCENDING); a sub-row's bounds are two adjacent words of the row's partition-table
+        // line; a sub-row longer than 256 postings gives several chunks.  Inside the scan nothing but the posting loads touches
+        // global memory.
+        uint32_t nch = 0;
+        for (uint32_t pl0 = 0; pl0 < Wn; pl0 += 4u) {
+          const uint32_t pl = pl0 + (lane >> 4), rr = lane & 15u;
+          const bool valid = rr < ns && pl < Wn;
+          const uint32_t r = valid ? ns - 1u - rr : 0u, p = p0 + pl;
+          u32x2 lh; lh.x = 0; lh.y = 0;
+          if (valid) __builtin_memcpy(&lh, db.part2 + (uint64_t)s_slots[r] * (np + 1u) + p, 8);
+          const uint32_t len = lh.y - lh.x;
+          const uint64_t a0 = s_rs[r] + lh.x;
+          const uint32_t nc = (len + 255u) >> 8;
+          uint32_t incl = nc;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += x; }
+          const uint32_t base = nch + incl - nc;
+          for (uint32_t j = 0; __ballot(j < nc) != 0ull; ++j) {
+            if (j < nc && base + j < clcap) {
+              const uint64_t a = a0 + (uint64_t)j * 256u;
+              const uint32_t n = len - j * 256u < 256u ? len - j * 256u : 256u;
+              uint2 e; e.x = (uint32_t)a; e.y = n | (r << 9) | (p << 13) | ((uint32_t)(a >> 32) << 24);
+              s_cl[base + j] = e;
+            }
+          }
+          nch += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (nch == 0) continue;
+        any_posting = true;
+        R2_CLK(tpre = clock64() - tk0;)
+        // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
+        const uint32_t nch_pad = (nch + (uint32_t)D - 1u) / (uint32_t)D * (uint32_t)D;
+        if (nch_pad + (uint32_t)D > clcap) { bad = true; break; }      // (a window with more chunks than the list holds: very long rows)
+        for (uint32_t i = nch + lane; i < nch_pad + (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // (2) the ring.  The posting loads are asm statements the compiler does not count; q[k] is waited for with vmcnt(D - 1): loads
+        // complete in order and every stage issues exactly one, so D - 1 younger ones are in flight when chunk k's data is needed.
+        u32x4 q[D];
+        // (a descriptor is fetched from LDS at the top of a stage, before the stage's atomics are queued: behind them its wait would
+        // sit out their round trip)
+        auto fetch = [&](uint32_t j, uint32_t &elo, uint32_t &ehi) {
+          const uint2 e = s_cl[j];                                       // (uniform address: an LDS broadcast read)
+          elo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); ehi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        };
+        auto issue = [&](uint32_t elo, uint32_t ehi, u32x4 &dst) {
+          const uint64_t a = ((uint64_t)R2D_AHI(ehi) << 32) | elo;
+          const uint32_t *src = postings + a;                             // (scalar add: the base register pair is written by the scalar unit)
+          // lane l reads postings [4l, 4l+4) of the chunk; lanes beyond it re-read the chunk's first 16 bytes (no traffic) and are masked
+          const uint32_t voff = lane4 < R2D_N(ehi) ? lane4 * 4u : 0u;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(src) : "memory");
+        };
+#pragma unroll
+        for (int k = 0; k < D; ++k) { uint32_t elo, ehi; fetch((uint32_t)k, elo, ehi); issue(elo, ehi, q[k]); }
+        R2Stage prev; bool prev_valid = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { prev.old[j] = 0; prev.bit[j] = 0; prev.rec[j] = 0; }
+        for (uint32_t i0 = 0; i0 < nch_pad; i0 += (uint32_t)D) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cl[i0 + (uint32_t)k].y);
+            uint32_t nlo, nhi;
+            fetch(i0 + (uint32_t)D + (uint32_t)k, nlo, nhi);
+            if (prev_valid) emit_chunk(prev);
+            prev_valid = false;
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[k]) : "n"(D - 1) : "memory");
+            if (meta != 0u && !bad) {
+              const uint32_t p = R2D_PART(meta);
+              if (p != cur_p) { R2_CLK(const unsigned long long tf0 = clock64();) finalize(); zero_bitmap(); cur_p = p; R2_CLK(tfin += clock64() - tf0;) }
+              if (n_stg > R2_SCAP) bad = true;
+#if defined(R2_PROBE_NOCOUNT)
+              if (!bad) { prev.old[0] = q[k][0] ^ q[k][1] ^ q[k][2] ^ q[k][3]; prev.bit[0] = 0x40000000u; prev_valid = true; }
+#else
+              if (!bad) { count_chunk(q[k], meta, prev); prev_valid = true; }
+#endif
+            }
+            issue(nlo, nhi, q[k]);
+          }
+        }
+        if (prev_valid) emit_chunk(prev);
+        // every load has landed before the compiler may give q's registers to anything else
+#pragma unroll
+        for (int k = 0; k < D; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[k]) : : "memory");
+      }
+      if (!bad) finalize();
+    }
+    if (bad) {
+      // outside this kernel's envelope: the general kernel takes the unit (it writes cand / cand_cnt / cand_n)
+      if (lane == 0) {
+        const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
+        bv.defer_list[idx] = unit;
+      }
+      continue;
+    }
+    ++n_done_local;
+#if defined(R2_PROBE_NOSEL)
+    if (nk != 0x7fffffffu) { if (lane == 0) bv.cand_n[unit] = 0; continue; }
+#endif
+    R2_CLK(const unsigned long long tk1 = clock64();)
+    // ---- cut-offs from the smallest key of every count value (countsort.cpp:13-24,114-126)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 16u) s_fpk[lane] = R2_KEY_INF;
+    if (lane < 4u) s_kl[nk + lane] = R2_KEY_INF;                         // (padding for the 4-wide ranking loop; nk <= kcap)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t i = lane; i < nk; i += 64u) { const uint32_t key = s_kl[i]; atomicMin(&s_fpk[key >> 28], key); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t M = 0, nv = 0;
+    {
+      // lane c (2..15) looks at count c
+      const uint32_t f = (lane >= 2u && lane <= 15u) ? s_fpk[15u - lane] : R2_KEY_INF;
+      const uint64_t vm = __ballot(f != R2_KEY_INF);
+      if (vm) {
+        M = 63u - (uint32_t)__builtin_clzll(vm);
+        const uint32_t fM = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)M) & 0x0fffffffu;
+        const uint64_t lm = __ballot(f != R2_KEY_INF && lane < M && (f & 0x0fffffffu) < fM);
+        // (a count-1 first position below fp[M] gives NextValue 1 when no higher count qualifies: MinValue = NextValue / 2 is 0 either way)
+        nv = lm ? 63u - (uint32_t)__builtin_clzll(lm) : 0u;
+      } else M = any_posting ? 1u : 0u;
+    }
+    const uint32_t min_value = nv / 2u;
+    const uint32_t cmin = min_value > 2u ? min_value : 2u;
+    const uint32_t limit = (16u - cmin) << 28;                            // keys below it have count >= cmin
+    // ---- rank the kept keys all-pairs (nk is small: ~K + the targets with count >= 3)
+    uint32_t nsel = 0;
+    {
+      uint32_t nelig = 0;
+      for (uint32_t e0 = 0; e0 < nk; e0 += 64u) {
+        const uint32_t i = e0 + lane;
+        const uint32_t key = i < nk ? s_kl[i] : R2_KEY_INF;
+        const bool elig = key < limit;
+        nelig += (uint32_t)__popcll(__ballot(elig));
+        uint32_t rank = 0;
+        const uint4 *k4 = (const uint4 *)s_kl;
+        for (uint32_t j = 0; j < nk; j += 4u) {
+          const uint4 x = k4[j >> 2];
+          rank += (x.x < key) + (x.y < key) + (x.z < key) + (x.w < key);
+        }
+        if (elig && rank < K) {
+          const uint32_t tg = key & 0xffffffu;
+          bv.cand[(uint64_t)unit * K + rank] = tg;
+          bv.cand_cnt[(uint64_t)unit * K + rank] = 15u - (key >> 28);
+          s_sel[rank] = tg;
+        }
+      }
+      nsel = nelig < K ? nelig : K;
+    }
+    // ---- fewer than K targets with count >= 2 and the cut-off keeps count-1 targets: they follow in first-touch order = the postings
+    // of row 0 ascending, then those of row 1 that no earlier row holds, ... - a target has count 1 exactly when it is not selected
+    // (every count >= 2 target is, the list being exhausted): udbusortedsearcherbig.cpp:82-100 order, countsort.cpp:110-191
+    if (nsel < K && min_value <= 1u && M >= 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t mine = lane < nsel ? s_sel[lane] : 0xffffffffu;
+      uint32_t filled = nsel;
+      for (uint32_t r = 0; r < ns && filled < K; ++r) {
+        const uint32_t slot = s_slots[r];
+        const uint64_t ra = db.row_off[slot], rb = db.row_off[slot + 1];
+        for (uint64_t k0 = ra; k0 < rb && filled < K; k0 += 64) {
+          const bool on = k0 + (uint64_t)lane < rb;
+          const uint32_t t = on ? postings[k0 + lane] : 0u;
+          bool in_set = false;
+          for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+          const bool e = on && !in_set;
+          const uint64_t m = __ballot(e);
+          const uint32_t rank = r2_mbcnt(m);
+          if (e && filled + rank < K) { bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u; }
+          const uint32_t n = (uint32_t)__popcll(m);
+          filled = filled + n < K ? filled + n : K;
+        }
+      }
+      nsel = filled;
+    }
+    if (lane == 0) bv.cand_n[unit] = nsel;
+    R2_CLK(tc_pre += tpre; tc_fin += tfin; tc_scan += tk1 - tk0 - tpre - tfin; tc_sel += clock64() - tk1;)
+  }
+#ifdef R2_CLOCKS
+  if (lane == 0) { atomicAdd(&bv.counters[UGS_CTR_T0], tc_pre); atomicAdd(&bv.counters[UGS_CTR_T1], tc_scan); atomicAdd(&bv.counters[UGS_CTR_T2], tc_fin); atomicAdd(&bv.counters[UGS_CTR_T3], tc_sel); }
+#endif
+  if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
+}
+
+static const void *rank2_kernel() { return (const void *)k_rank2<UGS_R2_DEPTH>; }
+
+size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
+{
+  return (size_t)G / 8 + (R2_SCAP + 2 * (R2_HB_BITS / 32) + 16 * 4 + 64 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
+}
+
+int ugs_rank2_blocks_per_cu(size_t lds)
+{
+  int n = 0;
+  const void *fn = rank2_kernel();
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
+int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st)
+{
+  const void *fn = rank2_kernel();
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));
+  UgsDbView a0 = db; UgsBatchView a1 = b; UgsRank2Params a2 = prm;
+  void *args[] = {&a0, &a1, &a2};
+  HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(64), args, prm.lds, st));
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
