@@ -320,12 +320,12 @@ int ugs_db_replan(ugs_db *db)
   HIPCHK(hipStreamSynchronize(db->stream));
   // The bitmap ranking kernel (ugs_rank2.hip) for dense Big-path indexes: one LDS bit per target, so its partitions are
   // larger (G2 targets, a multiple of 8192 up to 65536) and have a table of their own.  G2 is chosen so that a (row,
-  // partition) sub-row averages <= ~230 postings: it is read as ONE 16-byte load per lane (256 postings per wave
+  // partition) sub-row averages <= ~205 postings (7 of 8 lanes of the 256-posting load busy, a second chunk rare): it is read as ONE 16-byte load per lane (256 postings per wave
   // instruction).  Keys carry 24-bit targets, hence nseq <= 2^24; sparse dictionaries (protein) keep k_rank.
   uint32_t gsize2 = 0, np2 = 0;
   if (nseq > db->p.big && !db->sparse && nseq <= (1u << 24) && db->n_postings && db->tune.rank2 != 0) {
     const double dens = ((double)db->n_postings / (double)slots) / (double)nseq;        // a row's postings per target
-    uint64_t g = dens > 0 ? (uint64_t)(232.0 / dens) / 8192 * 8192 : 65536;
+    uint64_t g = dens > 0 ? (uint64_t)(205.0 / dens) / 8192 * 8192 : 65536;
     g = std::min<uint64_t>(65536, std::max<uint64_t>(8192, g));
     if (db->tune.r2_g) g = (uint64_t)db->tune.r2_g;
     if (dens * (double)g >= 64.0 || db->tune.rank2 == 1) { gsize2 = (uint32_t)g; np2 = (uint32_t)(((uint64_t)nseq - 1) / gsize2 + 1); }
@@ -755,11 +755,13 @@ static int plan_launch(ugs_batch *b)
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
   if (db->v.part2 && bits == 4 && !b->rl.longrows && b->K <= 64) {
-    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(256u, 6u * b->K);
+    const uint32_t nsm = std::min<uint32_t>(ns_typ, 15u);
+    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
-    // a window = as many partitions as the chunk list (256 descriptors, 2 KB) holds with some room for sub-rows of two chunks
-    b->r2.clcap = 256;
-    b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>((db->v.np2 + 3u) / 4u * 4u, (200u / std::min<uint32_t>(ns_max, 15u)) / 4u * 4u));
+    // the chunk list of a window: every partition takes its rows' chunks rounded up to a multiple of 4; sized for 16 partitions of
+    // the typical query with room for sub-rows of two chunks (the kernel fits each unit's window to the list)
+    b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
+    b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>(28u, (db->v.np2 + 3u) / 4u * 4u));
     b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap);
     int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);

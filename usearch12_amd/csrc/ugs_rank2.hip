@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
+#include <type_traits>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
@@ -47,7 +48,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define R2_HB_BITS 2048u        // bits of each of the two hash filters
 #define R2_KEY_INF 0xffffffffu
 #ifndef UGS_R2_DEPTH
-#define UGS_R2_DEPTH 8          // posting chunks in flight per wave
+#define UGS_R2_DEPTH 4          // ring slots: posting chunks in flight per wave (3 behind the one being counted)
 #endif
 
 __device__ __forceinline__ uint32_t r2_mbcnt(uint64_t m)
@@ -77,8 +78,29 @@ __device__ __forceinline__ uint32_t r2_row16_incl_sum(uint32_t v)
 #define R2D_ROW(m) (((m) >> 9) & 15u)
 #define R2D_PART(m) (((m) >> 13) & 2047u)
 #define R2D_AHI(m) ((m) >> 24)
+// The ring's posting loads land in ACCUMULATOR registers a[4k : 4k+3] (slot k).  They are asm statements the compiler does not
+// count, so that their waits can be counted by hand (vmcnt(D - 1)) - and the accumulator file is where such a load is safe:
+// the compiler never touches those registers (this kernel has no MFMA and spills nothing: tests/test_isa.py pins both), whereas a
+// VGPR destination may be copied or re-used by the register allocator between the load and its wait (seen at a loop
+// back-edge).  r2_take<K> waits for slot K and DEFINES four fresh VGPR values from it.
+template <int K> __device__ __forceinline__ void r2_issue(uint32_t voff, const uint32_t *src)
+{
+  static_assert(K >= 0 && K < 4, "four ring slots");
+  if constexpr (K == 0) asm volatile("global_load_dwordx4 a[0:3], %0, %1" : : "v"(voff), "s"(src) : "memory", "a0", "a1", "a2", "a3");
+  if constexpr (K == 1) asm volatile("global_load_dwordx4 a[4:7], %0, %1" : : "v"(voff), "s"(src) : "memory", "a4", "a5", "a6", "a7");
+  if constexpr (K == 2) asm volatile("global_load_dwordx4 a[8:11], %0, %1" : : "v"(voff), "s"(src) : "memory", "a8", "a9", "a10", "a11");
+  if constexpr (K == 3) asm volatile("global_load_dwordx4 a[12:15], %0, %1" : : "v"(voff), "s"(src) : "memory", "a12", "a13", "a14", "a15");
+}
+template <int K> __device__ __forceinline__ void r2_take(uint32_t (&t)[4])
+{
+  if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
+  if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\tv_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
+  if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
+  if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\tv_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
+}
+
 // what the emission of a chunk needs after its atomics were issued
-struct R2Stage { uint32_t old[4], bit[4], rec[4]; };
+struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 
 template <int D>
 __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
@@ -96,12 +118,13 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
   uint32_t *s_cum = s_c2 + 16;                                          // [16] ... with that row or a lower one
   uint32_t *s_fpk = s_cum + 16;                                         // [16] smallest key per (15 - count)
   uint32_t *s_slots = s_fpk + 16;                                       // [16] sampled slots of the unit
-  uint32_t *s_sel = s_slots + 16;                                       // [64] selected targets (for the fill)
-  uint64_t *s_rs = (uint64_t *)(s_sel + 64);                            // [16] first posting (element index) of the unit's rows
-  uint2 *s_cl = (uint2 *)(s_rs + 16);                                   // [clcap] chunk list of the window being scanned
-  const uint32_t W = prm.W, clcap = prm.clcap;
+  uint32_t *s_sel = s_stg;                                              // [64] selected targets for the fill (the staging area is idle by then)
+  uint64_t *s_rs = (uint64_t *)(s_slots + 16);                            // [16] first posting (element index) of the unit's rows
+  uint32_t *s_pe = (uint32_t *)(s_rs + 16);                             // [32] chunk index at which each partition of the window ends (W <= 28)
+  uint2 *s_cl = (uint2 *)(s_pe + 32);                                   // [clcap] chunk list of the window being scanned
+  const uint32_t clcap = prm.clcap;
   uint32_t *s_kl = (uint32_t *)(s_cl + clcap);                          // [kcap + 4] kept keys
-  const uint32_t amask = (bm_bytes - 1u) & ~3u;
+  const uint32_t amax = bm_bytes - 4u;                                  // last word of the bitmap (G need not be a power of two)
   const uint32_t units = bv.nq * bv.nstrand;
   const uint32_t ns_max = prm.ns_max;
   const uint32_t *postings = db.postings;
@@ -143,10 +166,9 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
       // one ds_or_rtn per posting; invalid postings OR a zero into an in-range word
-      auto count_chunk = [&](const u32x4 &q, uint32_t meta, R2Stage &S) {
+      auto count_chunk = [&](uint32_t meta, R2Stage &S) {
         const int vlen = (int)R2D_N(meta) - (int)lane4;
         const uint32_t sub = R2D_PART(meta) * G;
-        const uint32_t rtag = R2D_ROW(meta) << 24;
         // (lanes beyond the chunk hold copies of lane 0's postings: an atomic of theirs, even one that ORs a zero, would go to the SAME
         // word as lane 0's and same-address atomics are served one after the other - they stay out of the LDS instructions altogether)
         const bool lane_on = vlen > 0;
@@ -154,11 +176,11 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         for (int j = 0; j < 4; ++j) { S.old[j] = 0; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t t = q[j];
-          const uint32_t ad = ((t - sub) >> 3) & amask;
+          const uint32_t t = S.t[j];
+          uint32_t ad = ((t - sub) >> 3) & ~3u;
+          ad = ad < amax ? ad : amax;                                    // (only a posting behind the chunk's end can be out of range: it ORs a zero)
           const uint32_t bit = j < vlen ? (1u << (t & 31u)) : 0u;
           S.bit[j] = bit;
-          S.rec[j] = t | rtag;
 #if defined(R2_PROBE_NOATOM)                 // timing probes (tools/r2_probe.sh): wrong results
           S.old[j] = 0; if (ad == 0xffffffffu) S.old[j] = bit;
 #elif defined(R2_PROBE_NOCONFLICT)           // every lane its own bank (wrong results)
@@ -173,20 +195,23 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
 #endif
         }
       };
-      // postings that found their bit set leave a record
-      auto emit_chunk = [&](const R2Stage &S) {
+      // postings that found their bit set leave a record (row << 24 | target); the chunk's postings are still in its ring slot
+      auto emit_chunk = [&](const R2Stage &S, uint32_t meta) {
 #if defined(R2_PROBE_NOEMIT)
-        if ((S.old[0] & S.bit[0]) == 0x12345u) s_stg[0] = S.rec[0];
+        if ((S.old[0] & S.bit[0]) == 0x12345u) s_stg[0] = S.t[0];
         return;
 #endif
+        const uint32_t rtag = R2D_ROW(meta) << 24;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool hit = (S.old[j] & S.bit[j]) != 0u;
           const uint64_t m = __ballot(hit);
-          uint32_t pos = n_stg + r2_mbcnt(m);
-          pos = pos < R2_SCAP - 1u ? pos : R2_SCAP - 1u;               // (beyond the capacity the unit is deferred: n_stg tells)
-          if (hit) s_stg[pos] = S.rec[j];
-          n_stg += (uint32_t)__popcll(m);
+          if (m) {
+            uint32_t pos = n_stg + r2_mbcnt(m);
+            pos = pos < R2_SCAP - 1u ? pos : R2_SCAP - 1u;             // (beyond the capacity the unit is deferred: n_stg tells)
+            if (hit) s_stg[pos] = S.t[j] | rtag;
+            n_stg += (uint32_t)__popcll(m);
+          }
         }
       };
       auto zero_bitmap = [&]() {
@@ -195,18 +220,12 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         for (uint32_t o = lane * 16u; o < bm_bytes; o += 1024u) *(uint4 *)(smem + o) = z;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
-      // ---- a partition is done: group its records by target, make keys, prune, keep
-      auto finalize = [&]() {
-        const uint32_t n = n_stg;
-        n_stg = 0;
-        if (n == 0) return;
-#if defined(R2_PROBE_NOFIN)
-        return;
-#endif
-        if (n > R2_SCAP) { bad = true; return; }
-        uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2];
+      // ---- a partition is done: group its records by target, make keys, prune, keep (NB register batches of 64 records)
+      auto finalize_nb = [&](auto nbc, uint32_t n) {
+        constexpr int NB = decltype(nbc)::value;
+        uint32_t rec[NB], t[NB], row[NB], wofs[NB], hbit[NB], cnt[NB], cumv[NB]; bool act[NB], fl[NB], drop[NB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
           const uint32_t i = (uint32_t)b * 64u + lane;
           act[b] = i < n;
           rec[b] = act[b] ? s_stg[i] : 0u;
@@ -217,37 +236,39 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           cumv[b] = act[b] ? s_cum[row[b]] : 0u;
         }
         // filter A: "a record with this hash came before me"; those set filter B, which then marks every record of a shared bucket
-        uint32_t olda[2];
+        uint32_t olda[NB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
+        for (int b = 0; b < NB; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
+        for (int b = 0; b < NB; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
+        for (int b = 0; b < NB; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int b = 0; b < 2; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }     // both filters clean again
+        for (int b = 0; b < NB; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }     // both filters clean again
         // the flagged records (a handful) against all records: count = records of the target + 1, first row = the lowest row
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
+        for (int bb = 0; bb < NB; ++bb) {
           uint64_t m = __ballot(fl[bb]);
           while (m) {
             const int L = __ffsll((long long)m) - 1;
             m &= m - 1;
             const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L), rL = (uint32_t)__builtin_amdgcn_readlane((int)row[bb], L);
-            const bool s0 = act[0] && t[0] == tL, s1 = act[1] && t[1] == tL;
-            const uint32_t nsame = (uint32_t)__popcll(__ballot(s0)) + (uint32_t)__popcll(__ballot(s1));
-            if (nsame >= 2u) {
-              const uint32_t lower = (uint32_t)__popcll(__ballot(s0 && row[0] < rL)) + (uint32_t)__popcll(__ballot(s1 && row[1] < rL));
-              if (lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = lower != 0u; }
+            uint32_t nsame = 0, lower = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const bool sb = act[b] && t[b] == tL;
+              nsame += (uint32_t)__popcll(__ballot(sb));
+              lower += (uint32_t)__popcll(__ballot(sb && row[b] < rL));
             }
+            if (nsame >= 2u && lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = lower != 0u; }
           }
         }
         // keys; a count-2 key stays only while fewer than K count-2 keys of EARLIER partitions with its row or a lower one are kept
         uint32_t nk_new = nk;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
           const uint32_t key = ((15u - cnt[b]) << 28) | rec[b];
           const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
           const uint64_t m = __ballot(keep);
@@ -267,18 +288,32 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
+      auto finalize = [&]() {
+        const uint32_t n = n_stg;
+        n_stg = 0;
+        if (n == 0) return;
+#if defined(R2_PROBE_NOFIN)
+        return;
+#endif
+        if (n > R2_SCAP) { bad = true; return; }
+        if (n > 64u) finalize_nb(std::integral_constant<int, 2>{}, n); else finalize_nb(std::integral_constant<int, 1>{}, n);
+      };
 
       // ---- the scan, a window of W partitions at a time
-      uint32_t cur_p = 0xffffffffu;
+      // (as many partitions per window as the chunk list holds for this unit's row count: a multiple of 4)
+      uint32_t W = ((clcap - 16u) / ((ns + 4u) & ~3u)) & ~3u;
+      W = W < 4u ? 4u : (W > prm.W ? prm.W : W);
       for (uint32_t p0 = 0; p0 < np && !bad; p0 += W) {
         const uint32_t Wn = np - p0 < W ? np - p0 : W;
         // (1) the window's chunk list -> LDS.  Lane = (partition of the window: lane >> 4, row: ns - 1 - (lane & 15)), so lane order is the
         // scan order (partition ascending, row DESCENDING); a sub-row's bounds are two adjacent words of the row's partition-table
         // line; a sub-row longer than 256 postings gives several chunks.  Inside the scan nothing but the posting loads touches
         // global memory.
+        // Every partition's chunks are padded to a multiple of D with empty descriptors: a partition then always ends where the ring's
+        // loop body ends, and its grouping has one call site instead of one per ring stage.
         uint32_t nch = 0;
         for (uint32_t pl0 = 0; pl0 < Wn; pl0 += 4u) {
-          const uint32_t pl = pl0 + (lane >> 4), rr = lane & 15u;
+          const uint32_t grp = lane >> 4, pl = pl0 + grp, rr = lane & 15u;
           const bool valid = rr < ns && pl < Wn;
           const uint32_t r = valid ? ns - 1u - rr : 0u, p = p0 + pl;
           u32x2 lh; lh.x = 0; lh.y = 0;
@@ -286,10 +321,16 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           const uint32_t len = lh.y - lh.x;
           const uint64_t a0 = s_rs[r] + lh.x;
           const uint32_t nc = (len + 255u) >> 8;
-          uint32_t incl = nc;
+          const uint32_t incl = r2_row16_incl_sum(nc);                    // inside the partition's 16 lanes
+          uint32_t gbase = nch, mybase = 0, mytot = 0, mypad = 0;
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += x; }
-          const uint32_t base = nch + incl - nc;
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, g * 16 + 15);
+            const uint32_t pad = (tot + (uint32_t)D - 1u) / (uint32_t)D * (uint32_t)D;
+            if (grp == (uint32_t)g) { mybase = gbase; mytot = tot; mypad = pad; }
+            gbase += pad;
+          }
+          const uint32_t base = mybase + incl - nc;
           for (uint32_t j = 0; __ballot(j < nc) != 0ull; ++j) {
             if (j < nc && base + j < clcap) {
               const uint64_t a = a0 + (uint64_t)j * 256u;
@@ -298,65 +339,73 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
               s_cl[base + j] = e;
             }
           }
-          nch += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          if (rr < mypad - mytot && mybase + mytot + rr < clcap) { uint2 e; e.x = 0; e.y = 0; s_cl[mybase + mytot + rr] = e; }
+          if (rr == 15u && pl < 32u) s_pe[pl] = mybase + mypad;           // list index at which this partition ends
+          nch = gbase;
         }
         if (nch == 0) continue;
         any_posting = true;
         R2_CLK(tpre = clock64() - tk0;)
         // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
-        const uint32_t nch_pad = (nch + (uint32_t)D - 1u) / (uint32_t)D * (uint32_t)D;
-        if (nch_pad + (uint32_t)D > clcap) { bad = true; break; }      // (a window with more chunks than the list holds: very long rows)
-        for (uint32_t i = nch + lane; i < nch_pad + (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
+        if (nch + 2u * (uint32_t)D > clcap) { bad = true; break; }     // (a window with more chunks than the list holds: very long rows)
+        for (uint32_t i = nch + lane; i < nch + 2u * (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // (2) the ring.  The posting loads are asm statements the compiler does not count; q[k] is waited for with vmcnt(D - 1): loads
-        // complete in order and every stage issues exactly one, so D - 1 younger ones are in flight when chunk k's data is needed.
-        u32x4 q[D];
-        // (a descriptor is fetched from LDS at the top of a stage, before the stage's atomics are queued: behind them its wait would
-        // sit out their round trip)
-        auto fetch = [&](uint32_t j, uint32_t &elo, uint32_t &ehi) {
+        // (2) the ring: D = 4 chunk slots, three posting loads in flight behind the chunk being counted (r2_issue / r2_take above).  A
+        // slot is waited for with vmcnt(D - 1): loads complete in order and every stage issues exactly one, so D - 1 younger ones are
+        // in flight when a chunk's data is needed.  Stage k (chunk c + k): the records of the previous chunk are emitted, slot k is
+        // taken into registers and loaded again with the chunk D ahead, then the chunk is counted.
+        uint32_t mt[D];
+        auto fetch = [&](uint32_t j, uint32_t &meta, uint32_t &voff) -> const uint32_t * {
           const uint2 e = s_cl[j];                                       // (uniform address: an LDS broadcast read)
-          elo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); ehi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
-        };
-        auto issue = [&](uint32_t elo, uint32_t ehi, u32x4 &dst) {
+          const uint32_t elo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), ehi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+          meta = ehi;
           const uint64_t a = ((uint64_t)R2D_AHI(ehi) << 32) | elo;
-          const uint32_t *src = postings + a;                             // (scalar add: the base register pair is written by the scalar unit)
           // lane l reads postings [4l, 4l+4) of the chunk; lanes beyond it re-read the chunk's first 16 bytes (no traffic) and are masked
-          const uint32_t voff = lane4 < R2D_N(ehi) ? lane4 * 4u : 0u;
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(src) : "memory");
+          voff = lane4 < R2D_N(ehi) ? lane4 * 4u : 0u;
+          return postings + a;                                           // (scalar add: the base register pair is written by the scalar unit)
         };
+        { uint32_t vo; const uint32_t *sp;
+          sp = fetch(0, mt[0], vo); r2_issue<0>(vo, sp); sp = fetch(1, mt[1], vo); r2_issue<1>(vo, sp);
+          sp = fetch(2, mt[2], vo); r2_issue<2>(vo, sp); sp = fetch(3, mt[3], vo); r2_issue<3>(vo, sp); }
+        static_assert(D == 4, "the ring is written for four slots");
+        R2Stage S; uint32_t pm = 0; bool pv = false;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { uint32_t elo, ehi; fetch((uint32_t)k, elo, ehi); issue(elo, ehi, q[k]); }
-        R2Stage prev; bool prev_valid = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { prev.old[j] = 0; prev.bit[j] = 0; prev.rec[j] = 0; }
-        for (uint32_t i0 = 0; i0 < nch_pad; i0 += (uint32_t)D) {
-#pragma unroll
-          for (int k = 0; k < D; ++k) {
-            const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cl[i0 + (uint32_t)k].y);
-            uint32_t nlo, nhi;
-            fetch(i0 + (uint32_t)D + (uint32_t)k, nlo, nhi);
-            if (prev_valid) emit_chunk(prev);
-            prev_valid = false;
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[k]) : "n"(D - 1) : "memory");
-            if (meta != 0u && !bad) {
-              const uint32_t p = R2D_PART(meta);
-              if (p != cur_p) { R2_CLK(const unsigned long long tf0 = clock64();) finalize(); zero_bitmap(); cur_p = p; R2_CLK(tfin += clock64() - tf0;) }
-              if (n_stg > R2_SCAP) bad = true;
+        for (int j = 0; j < 4; ++j) { S.old[j] = 0; S.bit[j] = 0; S.t[j] = 0; }
+        uint32_t pi = 0, pend = 0;
 #if defined(R2_PROBE_NOCOUNT)
-              if (!bad) { prev.old[0] = q[k][0] ^ q[k][1] ^ q[k][2] ^ q[k][3]; prev.bit[0] = 0x40000000u; prev_valid = true; }
+#define R2_COUNT S.old[0] = S.t[0] ^ S.t[1] ^ S.t[2] ^ S.t[3]; S.bit[0] = 0x40000000u; pv = true;
 #else
-              if (!bad) { count_chunk(q[k], meta, prev); prev_valid = true; }
+#define R2_COUNT count_chunk(pm, S); pv = true;
 #endif
-            }
-            issue(nlo, nhi, q[k]);
+#define R2_STAGE(k)                                                                                              \
+          {                                                                                                      \
+            uint32_t nm, vo;                                                                                     \
+            const uint32_t *sp = fetch(c + (uint32_t)(k) + (uint32_t)D, nm, vo);                                 \
+            if (pv) { emit_chunk(S, pm); pv = false; }                                                           \
+            r2_take<k>(S.t);                                                                                     \
+            r2_issue<k>(vo, sp);                                                                                 \
+            pm = mt[k]; mt[k] = nm;                                                                              \
+            if (R2D_N(pm) != 0u) { R2_COUNT }                 /* (padding descriptors are not counted) */         \
           }
+        for (uint32_t c = 0; c < nch && !bad; c += (uint32_t)D) {
+          // the last chunk of the previous loop body, then - where a partition ended there - its grouping
+          if (pv) { emit_chunk(S, pm); pv = false; }
+          if (c == pend) {
+            if (c != 0) { finalize(); if (bad) break; }
+            do { pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pe[pi]); ++pi; } while (pend == c);      // (partitions without a posting)
+            zero_bitmap();
+          }
+          R2_STAGE(0) R2_STAGE(1) R2_STAGE(2) R2_STAGE(3)
         }
-        if (prev_valid) emit_chunk(prev);
-        // every load has landed before the compiler may give q's registers to anything else
-#pragma unroll
-        for (int k = 0; k < D; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[k]) : : "memory");
+#undef R2_STAGE
+#undef R2_COUNT
+        if (!bad) {
+          if (pv) { emit_chunk(S, pm); pv = false; }
+          finalize();
+        }
+        // every load of the ring has landed before the next window (or unit) issues into the same slots
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
       }
-      if (!bad) finalize();
     }
     if (bad) {
       // outside this kernel's envelope: the general kernel takes the unit (it writes cand / cand_cnt / cand_n)
@@ -456,7 +505,7 @@ static const void *rank2_kernel() { return (const void *)k_rank2<UGS_R2_DEPTH>; 
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
 {
-  return (size_t)G / 8 + (R2_SCAP + 2 * (R2_HB_BITS / 32) + 16 * 4 + 64 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
+  return (size_t)G / 8 + (R2_SCAP + 2 * (R2_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
 }
 
 int ugs_rank2_blocks_per_cu(size_t lds)
