@@ -270,7 +270,8 @@ int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
 /* Diagnostic: which ranking code the last synced search of this batch ran (the test-suite asserts that every compiled path is
  * reached by an oracle-compared test).  out[0] = units ranked by the bitmap kernel (ugs_rank2.hip), out[1] = units it deferred to the
  * general kernel, out[2] = the general kernel's instantiation (big | counter bits << 1 | fast8 << 8 | longrows << 9), out[3] = 1 if
- * the bitmap kernel was launched.  n >= 4. */
+ * the bitmap kernel was launched; with n >= 6 also out[4] / out[5] = microseconds of the bitmap kernel / of the general kernel behind it
+ * (HIP events on the handle's stream).  n >= 4. */
 int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
 
 /*

@@ -152,7 +152,7 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
 size_t ugs_compact_tmp_bytes(uint32_t nq);
 struct UgsRank2Params;
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
-                    const UgsRank2Params *r2 = nullptr, int r2_grid = 0);
+                    const UgsRank2Params *r2 = nullptr, int r2_grid = 0, hipEvent_t ev_r2_done = nullptr);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t max_tlen, uint32_t seed_cap);
 int ugs_local_blocks_per_cu(int threads, size_t lds);

@@ -571,6 +571,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
+  if (b->ev0r) (void)hipEventDestroy(b->ev0r);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev2) (void)hipEventDestroy(b->ev2);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
@@ -615,7 +616,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cigar_used, 8));
   BCHK(hipMemset(b->d_cigar_used, 0, 8));
   BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
-  BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
+  BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev0r)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
   BCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   BCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
@@ -892,7 +893,8 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
   const bool r2 = b->r2_grid > 0 && !b->v.cand_key && !b->v.cl_ev;
-  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
+  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
+  b->r2_ran = r2 && b->nq;
   HIPCHK(hipEventRecord(b->ev1, db->stream));
   const bool dbg = db->tune.debug_sync != 0;             // fault isolation: finish each stage before the next
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] ranking stage done\n"); }
@@ -1065,7 +1067,12 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
   if (!b || !out || n < 4 || !b->synced) return UGS_E_ARG;
   out[0] = b->ctr[UGS_CTR_R2_DONE]; out[1] = b->ctr[UGS_CTR_DEFER];
   out[2] = (uint64_t)(b->db->v.big ? 1 : 0) | ((uint64_t)b->rl.bits << 1) | ((uint64_t)b->rl.fast8 << 8) | ((uint64_t)b->rl.longrows << 9);
-  out[3] = (b->r2_grid > 0 && !b->v.cand_key && !b->v.cl_ev) ? 1 : 0;
+  out[3] = b->r2_ran ? 1 : 0;
+  if (n >= 6) {
+    float a = 0, c = 0;
+    if (b->r2_ran) { HIPCHK(hipEventElapsedTime(&a, b->ev0s, b->ev0r)); HIPCHK(hipEventElapsedTime(&c, b->ev0r, b->ev1)); }
+    out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
+  }
   return UGS_OK;
 }
 

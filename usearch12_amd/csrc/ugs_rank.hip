@@ -1902,7 +1902,7 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
 }
 
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
-                    const UgsRank2Params *r2, int r2_grid)
+                    const UgsRank2Params *r2, int r2_grid, hipEvent_t ev_r2_done)
 {
   const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
@@ -1924,7 +1924,10 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   if (!(db.big && L.bits == 4 && !L.longrows)) { ugs_set_error("UGS_ONLY_HOT build"); return UGS_E_ENVELOPE; }
 #endif
   // dense Big-path index: the bitmap kernel ranks the units and lists the ones outside its envelope, which k_rank (below) then takes
-  if (r2) RCCHK_(ugs_launch_rank2(db, b, *r2, r2_grid, st));
+  if (r2) {
+    RCCHK_(ugs_launch_rank2(db, b, *r2, r2_grid, st));
+    if (ev_r2_done) HIPCHK(hipEventRecord(ev_r2_done, st));
+  }
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
