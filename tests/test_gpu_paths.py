@@ -1,0 +1,120 @@
+"""Which ranking code a search ran is a tested property: the bitmap kernel (ugs_rank2.hip) must take the
+dense Big-path shapes, its deferral path (units handed on to k_rank) must give the same candidates, and searching the same batch
+repeatedly must give byte-identical candidate lists and hit tables on every ranking path."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import orc
+from usearch12_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(db, qs, env=None, reps=1, **kw):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k); os.environ[k] = v
+    try:
+        gdb = capi.UgsDB(capi.params(**kw), db.seqs, db.offs, device=0)          # (the debug switches are read at ugs_db_create)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs)
+    outs = []
+    for _ in range(reps):
+        bat.search(); bat.sync()
+        cand, cnt, n = bat.candidates()
+        h, nh, pool = bat.fetch()
+        K = cand.shape[1]
+        mask = np.arange(K)[None, :] < n[:, None]
+        crc = zlib.crc32(np.where(mask, cand, 0).tobytes()) ^ zlib.crc32(np.where(mask, cnt, 0).tobytes()) ^ zlib.crc32(n.tobytes())
+        for f in ("query", "target", "ids", "mism", "aln_len", "qlo", "qhi", "tlo", "thi", "strand"):
+            if f in h.dtype.names:
+                crc ^= zlib.crc32(np.ascontiguousarray(h[f]).tobytes())
+        outs.append((crc, bat.kernel_hits(), (np.where(mask, cand, 0), np.where(mask, cnt, 0), n.copy())))
+    return outs
+
+
+@pytest.fixture(scope="module")
+def c2_small():
+    db = synth.make_db(12, 300000, 250)
+    qs = synth.make_queries(12, db, 20000, 250)
+    return db, qs
+
+
+def test_bitmap_kernel_takes_the_dense_big_path_and_equals_k_rank(c2_small):
+    db, qs = c2_small
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, None, is_nucleo=True, id=0.97)[0]
+    assert a[1]["r2_launched"] == 0 and a[1]["r2_units"] == 0
+    assert b[1]["r2_launched"] == 1 and b[1]["r2_units"] > 0.95 * qs.n and b[1]["r2_units"] + b[1]["deferred"] == qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+
+
+def test_units_deferred_to_k_rank_give_the_same_candidates(c2_small):
+    """a kept-key list of 8 entries defers nearly every unit: the general kernel behind the bitmap kernel then ranks them"""
+    db, qs = c2_small
+    a = _search(db, qs, None, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, {"UGS_R2_KCAP": "8"}, is_nucleo=True, id=0.97)[0]
+    assert b[1]["r2_launched"] == 1 and b[1]["deferred"] > 0.5 * qs.n and b[1]["r2_units"] + b[1]["deferred"] == qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+
+
+def test_bitmap_kernel_with_small_partitions_and_several_windows(c2_small):
+    """8192-target partitions: 37 partitions in several windows of the chunk list, sub-rows of ~30 postings"""
+    db, qs = c2_small
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, {"UGS_R2_G": "8192", "UGS_RANK2": "1"}, is_nucleo=True, id=0.97)[0]
+    assert b[1]["r2_units"] > 0.9 * qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+
+
+def test_bitmap_kernel_both_strands_and_oracle(c2_small):
+    db, _ = c2_small
+    qs = synth.make_queries(13, db, 600, 250)
+    out = _search(db, qs, None, is_nucleo=True, id=0.97, strand_both=1)[0]
+    assert out[1]["r2_launched"] == 1
+    op = orc.params(is_nucleo=True, id=0.97, strand_both=1)
+    odb = orc.OrcDB(op, db.seqs, db.offs)
+    cand, cnt, n = out[2]
+    for qi in range(0, qs.n, 7):
+        q = qs.seqs[int(qs.offs[qi]):int(qs.offs[qi + 1])]
+        for s in range(2):
+            on, oc, occ = odb.rank(q if s == 0 else orc.revcomp(q), cap=cand.shape[1])
+            u = qi * 2 + s
+            m = min(on, cand.shape[1])
+            assert n[u] == m and np.array_equal(cand[u, :m], oc[:m]) and np.array_equal(cnt[u, :m], occ[:m]), (qi, s)
+
+
+@pytest.mark.parametrize("shape", ["c2", "c2_krank", "id90", "both", "small", "aa"])
+def test_same_batch_ten_times_gives_the_same_bytes(shape, c2_small):
+    """determinism of every ranking path: candidate lists and hit tables of ten searches of one uploaded batch"""
+    if shape in ("c2", "c2_krank", "id90", "both"):
+        db, qs = c2_small
+        kw = dict(is_nucleo=True, id=0.9 if shape == "id90" else 0.97, strand_both=1 if shape == "both" else 0)
+        env = {"UGS_RANK2": "0"} if shape == "c2_krank" else None
+        if shape in ("id90", "both"):
+            qs = synth.make_queries(14, db, 4000, 250)
+    elif shape == "small":
+        db = synth.make_db(15, 50000, 250); qs = synth.make_queries(15, db, 4000, 250); kw = dict(is_nucleo=True, id=0.97); env = None
+    else:
+        db = synth.make_db(16, 150000, 300, aa=True); qs = synth.make_queries(16, db, 4000, 300, aa=True); kw = dict(is_nucleo=False, id=0.8); env = None
+    outs = _search(db, qs, env, reps=10, **kw)
+    assert len({o[0] for o in outs}) == 1, [o[0] for o in outs]
+    if shape == "c2":
+        assert outs[0][1]["r2_launched"] == 1
+    if shape in ("c2_krank", "id90", "small", "aa"):
+        assert outs[0][1]["r2_launched"] == 0 or shape == "aa" and outs[0][1]["r2_launched"] == 0

@@ -79,3 +79,27 @@ def test_xdrop_cross_lane_traffic_is_explicit():
     assert all("_x2" in a or " sc0" in a for a in atom), atom                # job counter (returning), arena offset / cell counter (64-bit): no 32-bit adds into the arena
     lo = _kernel_body(_isa_of("ugs_local.hip"), "k_local")
     assert len(re.findall(r"global_load_ubyte [^\n]* sc1", lo)) >= 3
+
+
+def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
+    """k_rank2 (ugs_rank2.hip) hides its posting loads from the compiler (asm) and counts their waits by hand.  That is only
+    sound while (1) the loads land in accumulator registers the compiler never touches - no spill code, no compiler-made
+    v_accvgpr_* - (2) every ring stage issues exactly one load and waits with vmcnt(3) = ring depth - 1, (3) the kernel makes no
+    scratch access (a scratch store or load would sit in the same in-order VMEM queue), and (4) the ring is drained (vmcnt(0))
+    before the slots are used again."""
+    isa = _isa_of("ugs_rank2.hip")
+    body = _kernel_body(isa, "k_rank2")
+    meta = isa[isa.index(".name:           _Z7k_rank2"):]
+    assert re.search(r"\.vgpr_spill_count:\s*0\b", meta[:2000]), "k_rank2 spills vector registers"
+    assert re.search(r"\.agpr_count:\s*16\b", isa), "the ring's 16 accumulator registers"
+    assert "scratch_" not in body
+    loads = re.findall(r"global_load_dwordx4 (a\[\d+:\d+\])", body)
+    assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) == 8, loads      # prologue + ring, one slot each
+    assert not re.search(r"global_load_dwordx4 v\[", body), "a posting load with a VGPR destination"
+    reads = re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", body)
+    assert len(reads) == 16 and sorted(set(reads), key=lambda a: int(a[1:])) == ["a%d" % i for i in range(16)], reads
+    assert "v_accvgpr_write" not in body and "v_accvgpr_mov" not in body
+    # every block of four reads follows its own counted wait inside one asm statement
+    assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == 4
+    # the atomics of the bitmap are LDS instructions (not flat), with return
+    assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "flat_atomic" not in body
