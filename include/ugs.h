@@ -269,7 +269,7 @@ int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32
 int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
 /* Diagnostic: which ranking code the last synced search of this batch ran (the test-suite asserts that every compiled path is
  * reached by an oracle-compared test).  out[0] = units ranked by the bitmap kernel (ugs_rank2.hip), out[1] = units it deferred to the
- * general kernel, out[2] = the general kernel's instantiation (big | counter bits << 1 | fast8 << 8 | longrows << 9), out[3] = 1 if
+ * general kernel, out[2] = the general kernel's instantiation (big | counter bits << 1 | fast8 << 8 | longrows << 9 | wide offsets << 10), out[3] = 1 if
  * the bitmap kernel was launched; with n >= 6 also out[4] / out[5] = microseconds of the bitmap kernel / of the general kernel behind it
  * (HIP events on the handle's stream).  n >= 4. */
 int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
@@ -282,6 +282,7 @@ int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
  *   UGS_GSIZE=n UGS_GSHIFT=k  partition size of k_rank (targets, a multiple of 64 / a power of two)
  *   UGS_RANK_WGS_PER_CU=n UGS_ALIGN_WGS_PER_CU=n   cap on resident workgroups per CU
  *   UGS_EMIT_LIMIT=n        candidate-key buffer of k_rank (forces the regrow path)
+ *   UGS_WIDE_OFFSETS=1      k_rank's Big-path 4-bit kernels with 64-bit table / row offsets (chosen by themselves for an index that needs them)
  *   UGS_RANK2=0|1           bitmap ranking kernel off / on wherever the index allows it (default: on for dense Big-path indexes)
  *   UGS_R2_G=n UGS_R2_KCAP=n UGS_R2_WAVES=n   its partition size (multiple of 8192), kept-key capacity, waves per CU
  *   UGS_DEBUG_SYNC=1 UGS_PHASE_CLOCKS=1       finish and log every stage / print the kernels' phase clocks with the stats

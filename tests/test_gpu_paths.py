@@ -118,3 +118,15 @@ def test_same_batch_ten_times_gives_the_same_bytes(shape, c2_small):
         assert outs[0][1]["r2_launched"] == 1
     if shape in ("c2_krank", "id90", "small", "aa"):
         assert outs[0][1]["r2_launched"] == 0 or shape == "aa" and outs[0][1]["r2_launched"] == 0
+
+
+def test_wide_offset_instantiations_of_k_rank(c2_small):
+    """an index whose partition table reaches 4 GiB takes the Big-path 4-bit kernels with 64-bit offsets; forced here"""
+    db, qs = c2_small
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, {"UGS_RANK2": "0", "UGS_WIDE_OFFSETS": "1"}, is_nucleo=True, id=0.97)[0]
+    c = _search(db, qs, {"UGS_RANK2": "0", "UGS_WIDE_OFFSETS": "1", "UGS_LONGROWS": "1"}, is_nucleo=True, id=0.97)[0]
+    assert (a[1]["rank_kernel"] >> 10) & 1 == 0 and (b[1]["rank_kernel"] >> 10) & 1 == 1 and (c[1]["rank_kernel"] >> 9) & 3 == 3
+    for x, y, z in zip(a[2], b[2], c[2]):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert a[0] == b[0] == c[0]

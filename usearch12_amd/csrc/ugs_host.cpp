@@ -269,6 +269,7 @@ UgsTune ugs_tune_read()
   { const char *e = getenv("UGS_EMIT_LIMIT"); const long v = e ? atol(e) : 0; t.emit_limit = v >= 1 ? v : 0; }
   t.debug_sync = getenv("UGS_DEBUG_SYNC") != nullptr;
   t.phase_clocks = getenv("UGS_PHASE_CLOCKS") != nullptr;
+  t.wide_offsets = getenv("UGS_WIDE_OFFSETS") != nullptr;
   t.rank2 = env_int("UGS_RANK2", 0, 1, -1);
   t.r2_g = env_int("UGS_R2_G", 8192, 65536, 0); if (t.r2_g % 8192) t.r2_g = 0;
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
@@ -670,6 +671,15 @@ static int plan_local(ugs_batch *b)
 static std::atomic<uint64_t> g_emit_regrows{0};
 extern "C" uint64_t ugs_debug_emit_regrows(void) { return g_emit_regrows.load(); }    // diagnostic: searches re-run with a larger candidate buffer
 
+// keys per workgroup of k_rank's candidate buffer: what earlier searches of this batch object demanded (emit_limit), never more than the
+// worst case (every posting of a unit's longest rows); one rule for the first sizing and for the regrow in ugs_batch_sync
+static uint64_t emit_cap_for(const ugs_batch *b, uint32_t ns_max)
+{
+  const ugs_db *db = b->db;
+  const uint64_t worst = (uint64_t)ns_max * db->max_row + 1;
+  return std::min<uint64_t>(worst, b->emit_limit) + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
+}
+
 static int plan_launch(ugs_batch *b)
 {
   ugs_db *db = b->db;
@@ -706,17 +716,18 @@ static int plan_launch(ugs_batch *b)
   b->rl.longrows = db->max_row > 56u * db->v.np;
   if (db->tune.longrows >= 0) b->rl.longrows = db->tune.longrows != 0;
   const int hot = ugs_rank_is_hot(db->v.big, bits, b->rl.fast8, b->rl.longrows);
-  if ((hot == 1 || hot == 2) && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30))) {       // (both twins use the asm loads)
-    ugs_set_error("index too large for the 32-bit offsets of the ranking kernel's partition-table loads (%u slots x %u partitions, longest row %u)", db->v.slots, db->v.np, db->max_row);
-    return UGS_E_ENVELOPE;
-  }
+  // the two Big-path 4-bit kernels address the partition table and the rows with 32-bit byte offsets (asm loads); an index that outgrows
+  // them (table of 4 GiB, a row of 2^30 postings) gets the instantiations with 64-bit address arithmetic instead (UGS_WIDE_OFFSETS=1 forces them)
+  b->rl.wide = (hot == 1 || hot == 2) && ((uint64_t)db->v.slots * (db->v.np + 1) * 4 >= (1ull << 32) || db->max_row >= (1u << 30) || db->tune.wide_offsets);
   const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words, hot);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
   if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
-  const size_t rlds = fixed + wpb * tbl_bytes;
+  // (the HOT kernel keeps its selection scratch, (4 * UGS_KMAX + 8) keys, inside the counter tables at the end of the carve: with a partition
+  // size forced far below the planner's the tables alone would not hold it - the allocation then covers the scratch)
+  const size_t rlds = fixed + std::max<size_t>(wpb * tbl_bytes, hot == 1 ? ((size_t)4 * UGS_KMAX + 8) * 8 : 0);
   const uint64_t units = (uint64_t)b->nq * b->nstrand;
-  int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds, db->v.big, bits, b->rl.fast8, b->rl.longrows);      // real residency (VGPRs, LDS, wave slots)
+  int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds, db->v.big, bits, b->rl.fast8, b->rl.longrows, b->rl.wide);      // real residency (VGPRs, LDS, wave slots)
   per_cu = std::max(1, std::min(per_cu, 8));
   if (db->tune.rank_wgs) per_cu = std::min(per_cu, db->tune.rank_wgs);
   b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
@@ -731,7 +742,7 @@ static int plan_launch(ugs_batch *b)
     b->emit_limit = 1u << 16;
     if (db->tune.emit_limit) b->emit_limit = (uint64_t)db->tune.emit_limit;      // tests: force the regrow path
   }
-  uint64_t ecap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)ns_max * db->max_row + 1, 4ull << 20), b->emit_limit) + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
+  const uint64_t ecap = emit_cap_for(b, ns_max);
   if (!b->d_emit || ecap * (uint64_t)b->rl.grid > b->emit_cap_alloc) {
     // (a database that grows - cluster_fast - asks for a little more with every batch: over-allocate then, a multi-GB
     // hipMalloc per batch costs more than the batch's kernels)
@@ -924,8 +935,8 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
       // the candidate buffer was sized by earlier demand: grow it to this search's and run the search again
       ++emit_tries; ++g_emit_regrows;
       const uint64_t wpb = (uint64_t)b->rl.wpb, demand = b->ctr[UGS_CTR_EMIT_MAX] * wpb;
-      b->emit_limit = std::max<uint64_t>(2 * b->emit_limit, demand + demand / 4 + 4096);
-      const uint64_t ecap = b->emit_limit + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64, want = ecap * (uint64_t)b->rl.grid;
+      b->emit_limit = std::max<uint64_t>(b->emit_limit, demand + demand / 4 + 4096);      // (to the reported demand, not doubling blindly)
+      const uint64_t ecap = emit_cap_for(b, b->rl.ns_max), want = ecap * (uint64_t)b->rl.grid;
       if (want > b->emit_cap_alloc) {
         HIPCHK(hipFree(b->d_emit)); b->d_emit = nullptr;
         HIPCHK(hipMalloc(&b->d_emit, want * 8));
@@ -1066,7 +1077,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
 {
   if (!b || !out || n < 4 || !b->synced) return UGS_E_ARG;
   out[0] = b->ctr[UGS_CTR_R2_DONE]; out[1] = b->ctr[UGS_CTR_DEFER];
-  out[2] = (uint64_t)(b->db->v.big ? 1 : 0) | ((uint64_t)b->rl.bits << 1) | ((uint64_t)b->rl.fast8 << 8) | ((uint64_t)b->rl.longrows << 9);
+  out[2] = (uint64_t)(b->db->v.big ? 1 : 0) | ((uint64_t)b->rl.bits << 1) | ((uint64_t)b->rl.fast8 << 8) | ((uint64_t)b->rl.longrows << 9) | ((uint64_t)b->rl.wide << 10);
   out[3] = b->r2_ran ? 1 : 0;
   if (n >= 6) {
     float a = 0, c = 0;

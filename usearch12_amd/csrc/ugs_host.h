@@ -19,6 +19,7 @@ struct UgsTune {
   long emit_limit;        // UGS_EMIT_LIMIT      candidate buffer of k_rank in keys (forces the regrow path in tests; 0 unset)
   int debug_sync;         // UGS_DEBUG_SYNC      finish every stage before the next, log
   int phase_clocks;       // UGS_PHASE_CLOCKS    print the kernels' phase clocks with the stats
+  int wide_offsets;       // UGS_WIDE_OFFSETS    force the 64-bit-offset instantiations of the Big-path 4-bit ranking kernels
   int rank2;              // UGS_RANK2           -1 unset (= on where eligible), 0 off, 1 on
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
 };

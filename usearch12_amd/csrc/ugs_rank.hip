@@ -1299,7 +1299,7 @@ __device__ __forceinline__ uint32_t big_path_fill(const uint64_t *row_off, const
 // which flattens their short sub-rows - again an instantiation of its own, so that neither pays for the other's registers
 // LONG: databases with very long index rows (an abundant family shares its words) - the partitions whose sub-rows exceed a
 // wavefront then go through range_long; again an instantiation of its own (see range_long)
-template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
+template <bool SMALL, bool BATCH, bool FAST8, bool LONG, bool WIDE = false>
 #ifndef UGS_RANK_WGS
 #define UGS_RANK_WGS 4
 #endif
@@ -1315,7 +1315,7 @@ template <bool SMALL, bool BATCH, bool FAST8, bool LONG>
 #ifndef UGS_ELDS_BATCH
 #define UGS_ELDS_BATCH 128u       // 8- and 16-bit counter kernels: thousands of keys per unit, nearly all of them in the HBM part anyway
 #endif
-__global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RANK_WGS_LONG : UGS_RANK_WGS_HOT) : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
+__global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !WIDE) ? (LONG ? UGS_RANK_WGS_LONG : UGS_RANK_WGS_HOT) : UGS_RANK_WGS) void k_rank(UgsDbView db, UgsBatchView bv, uint32_t ns_max, uint32_t tbl_words, uint32_t part_words)
 {
   constexpr bool HOT = !SMALL && !BATCH && !FAST8 && !LONG;       // Big path, 4-bit counters, uniform rows: five workgroups per CU (issue_batch<.., true>)
   constexpr bool HOTL = !SMALL && !BATCH && !FAST8 && LONG;     // the same path on a skewed database (cluster_fast's centroids)
@@ -1323,7 +1323,10 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
 #ifndef UGS_RANK_SL_LONG
 #define UGS_RANK_SL_LONG 1
 #endif
-  constexpr bool SLOAD = HOT || (UGS_RANK_SL_LONG && !SMALL && !BATCH && !FAST8 && LONG);   // the asm partition-table loads (issue_batch<.., true>)
+  // the asm partition-table loads (issue_batch<.., true>) address the table and the rows with 32-bit byte offsets; WIDE: the instantiations
+  // for an index whose partition table reaches 4 GiB or whose longest row reaches 2^30 postings keep the compiler's 64-bit address
+  // arithmetic (issue_batch<.., false>) - slower, never selected for the BASELINE shapes (ugs_host.cpp plan_launch)
+  constexpr bool SLOAD = !WIDE && (HOT || (UGS_RANK_SL_LONG && !SMALL && !BATCH && !FAST8 && LONG));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave index in an SGPR
@@ -1342,7 +1345,7 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8) ? (LONG ? UGS_RAN
   uint64_t *s_wsel = (uint64_t *)(smem + off); if (!HOT) off += (size_t)WSEL_WORDS * 4;
   uint32_t *s_part = (uint32_t *)(smem + off); off += (size_t)part_words * 4;       // cached partition-table rows of the sampled words
   uint32_t *tbl = (uint32_t *)(smem + off) + (size_t)wave * (tbl_words + 64);      // +64 dummy words per wave
-  if (HOT) s_wsel = (uint64_t *)(smem + off);                                       // (= wave 0's table; off is a multiple of 16)
+  if (HOT) s_wsel = (uint64_t *)(smem + off);                                       // (= the first waves' tables, WSEL_WORDS * 4 = 2112 bytes: plan_launch checks that the tables are that large; off is a multiple of 16)
 
   const UgsTables *tab = db.tab;
   // HOT only: behind the bitmap kernel (ugs_rank2.hip) this kernel takes the units that one deferred, from its list
@@ -1860,13 +1863,15 @@ extern template __global__ void k_rank<false, false, false, false>(UgsDbView, Ug
 #endif
 // resident workgroups per CU for a given block size / dynamic LDS (VGPR- and LDS-limited): the
 // persistent grid must not exceed it, or the surplus workgroups run as a second, unbalanced round
-static const void *rank_kernel(int big, int bits, int fast8, int longrows)
+static const void *rank_kernel(int big, int bits, int fast8, int longrows, int wide = 0)
 {
   const int mode = bits == 4 ? 0 : (fast8 ? 2 : 1);
 #ifdef UGS_ONLY_HOT               // tuning builds (tools/build_variant.sh): only the C2 instantiation, compiles in seconds
-  (void)big; (void)mode; (void)longrows;
+  (void)big; (void)mode; (void)longrows; (void)wide;
   return (const void *)k_rank<false, false, false, false>;
 #else
+  if (wide && big && mode == 0)    // (only the two Big-path 4-bit kernels have 32-bit offsets to outgrow)
+    return longrows ? (const void *)k_rank<false, false, false, true, true> : (const void *)k_rank<false, false, false, false, true>;
   if (longrows)
     return big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
                : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
@@ -1877,10 +1882,10 @@ static const void *rank_kernel(int big, int bits, int fast8, int longrows)
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return bits != 4 ? 3 : (big ? (longrows ? 2 : 1) : 0); }   // 1 = HOT, 2 = its LONG twin, 3 = wider counters (BATCH kernels)
 
-int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows)
+int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows, int wide)
 {
   int n = 0;
-  const void *fn = rank_kernel(big, bits, fast8, longrows);      // (the instantiations differ in their register budget: the one that will run is asked)
+  const void *fn = rank_kernel(big, bits, fast8, longrows, wide);      // (the instantiations differ in their register budget: the one that will run is asked)
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
@@ -1928,7 +1933,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     RCCHK_(ugs_launch_rank2(db, b, *r2, r2_grid, st));
     if (ev_r2_done) HIPCHK(hipEventRecord(ev_r2_done, st));
   }
-  const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows);
+  const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
