@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["auto", "C2", "C4"], default="auto", help="auto = C2 (weak scaling: 1M queries per GPU and step); "
                     "C4 = 10M queries in N shards vs a 5M-sequence DB (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="C2 only: weak = every GPU its own batch of the C2 size per step "
+                    "(the default, what the driver's per-N lines compare); strong = the SAME batch of the C2 size split into N contiguous "
+                    "shards (125 k queries per GPU at N = 8: set-up, launch gaps and the gather are then a visible share of a step)")
     ap.add_argument("--force-gather", action="store_true", help="--gpus 1 only: run the N > 1 step (C++ gather through a communicator "
                     "of one rank) instead of the plain fetch - exercises that code on a one-GPU box")
     ap.add_argument("--db", type=int, default=0, help="DB sequences (default: the workload's)")
@@ -182,7 +185,12 @@ def main():
     workload = args.workload if args.workload != "auto" else "C2"
     seed = 2 if workload == "C2" else 4
     db_n = args.db or (1_000_000 if workload == "C2" else 5_000_000)
-    if workload == "C2":                                            # weak: every rank its own batch of the C2 size
+    strong_c2 = workload == "C2" and args.scaling == "strong"
+    if strong_c2:                                                   # strong: ONE batch of the C2 size in N contiguous shards
+        total_q = args.queries or 1_000_000
+        lo, hi = multigpu.shard_range(total_q, world, rank)
+        shard_n = hi - lo
+    elif workload == "C2":                                          # weak: every rank its own batch of the C2 size
         shard_n = args.queries or 1_000_000
         total_q = shard_n * world
         lo = rank * shard_n
@@ -431,6 +439,8 @@ def main():
             wl = ("C2: usearch_global %d x %d nt queries per GPU and step vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
                   "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one%s" %
                   (shard_n, args.length, db.n, args.id, "" if world == 1 else "; %d GPUs = %d queries per step, DB replicated, one gather of the hit tables to rank 0 per step" % (world, total_q)))
+            if strong_c2:
+                wl = "STRONG scaling, " + wl.replace("per GPU and step", "per GPU (= %d per step over all GPUs, contiguous shards)" % total_q)
         else:
             wl = ("C4: usearch_global %d x %d nt queries in %d contiguous shard(s) vs a %d-seq DB replicated per GPU, -id %.2f "
                   "-strand plus, reference defaults; one RCCL gather of the hit tables to rank 0 per step" %
@@ -438,7 +448,7 @@ def main():
         line = {
             "metric": "query-seqs/s usearch_global -id 0.97 (search phase: query batch on the host -> hit table on the host)",
             "value": value, "unit": "query-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak" if workload == "C2" else "strong",
+            "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak" if (workload == "C2" and not strong_c2) else "strong",
             "vs_baseline": None, "dtype": "u8/u32 (int32 half-unit DP scores)", "data": "synthetic",
             "config": {"workload": wl, "queries_per_step": total_q, "queries_per_gpu": shard_n, "db_seqs": db.n, "seq_len": args.length,
                        "parallelism": "query shards, DB replicated per GPU" if world > 1 else "single GPU", "gather": how},

@@ -33,7 +33,7 @@ def test_two_gloo_ranks_one_gathering_rank_and_one_plain_rank_agree():
         assert j["n_gpus"] == n and j["steps"] == 2 and j["warmup"] == 1 and j["unit"] == "query-seqs/s"
         assert j["scaling"] == "weak" and j["config"]["queries_per_step"] == 8000 and j["config"]["queries_per_gpu"] == 8000 // n
         assert j["value"] > 0 and abs(j["value"] - 8000 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
-        assert j["roofline"]["kernel"] in ("k_rank", "k_align") and "traffic_source" in j["roofline"]
+        assert j["roofline"]["kernel"] in ("k_rank", "k_rank2", "k_align") and "traffic_source" in j["roofline"]
     assert one["detail"]["hits_per_step"] > 5000
     assert gat["detail"]["hits_per_step"] == one["detail"]["hits_per_step"]
     assert two["detail"]["hits_per_step"] == one["detail"]["hits_per_step"]
@@ -41,3 +41,14 @@ def test_two_gloo_ranks_one_gathering_rank_and_one_plain_rank_agree():
     pr = two["detail"]["per_rank"]
     assert len(pr) == 2 and all(r["queries"] == 4000 and r["ms_rank"] > 0 for r in pr)
     assert gat["detail"]["host_ms_gather"] > 0
+
+
+def test_strong_scaling_variant_splits_one_batch():
+    """`--scaling strong`: the same C2-sized batch in N contiguous shards - same hits as one GPU, labelled strong"""
+    one = _bench("--gpus", "1", "--queries", "8000")
+    two = _bench("--gpus", "2", "--queries", "8000", "--backend", "gloo", "--scaling", "strong")
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["config"]["queries_per_step"] == 8000 and two["config"]["queries_per_gpu"] == 4000
+    assert two["detail"]["hits_per_step"] == one["detail"]["hits_per_step"]
+    assert "STRONG" in two["config"]["workload"]
+    pr = two["detail"]["per_rank"]
+    assert len(pr) == 2 and all(r["queries"] == 4000 for r in pr)

@@ -113,3 +113,39 @@ def test_cli_gather_path_text_identical_to_reference(name, tmp_path):
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL, env=dict(os.environ, UGS_CLI_FORCE_GATHER="1"))
     assert open(tmp_path / "o.b6").read() == b6
     assert open(tmp_path / "o.uc").read() == uc
+
+
+def test_rccl_gather_over_every_device_of_the_box():
+    """ugs_comm_init_all over ALL devices the box has: the index replicated per device, contiguous query shards,
+    one host thread per rank, the grouped ncclSend / ncclRecv gather to rank 0.  On a one-GPU box this is the world of one; on an
+    8-GPU node it is the first thing that runs RCCL between devices - and it must equal one fetch over all queries."""
+    ndev = capi.device_count() if hasattr(capi, "device_count") else int(capi.lib().ugs_device_count())
+    assert ndev >= 1
+    db = synth.make_db(33, 3000, 220)
+    qs = synth.make_queries(33, db, 1200, 220)
+    p = capi.params(is_nucleo=True, id=0.9, max_accepts=3, max_rejects=16)
+    g0 = capi.UgsDB(p, db.seqs, db.offs, device=0)
+    b0 = capi.UgsBatch(g0, qs.n, int(qs.offs[-1]))
+    b0.upload(qs.seqs, qs.offs); b0.search(); b0.sync()
+    want = b0.fetch()
+    gdbs = [g0] + [capi.UgsDB(p, db.seqs, db.offs, device=d) for d in range(1, ndev)]
+    shards = []
+    for r in range(ndev):
+        lo, hi = (qs.n * r) // ndev, (qs.n * (r + 1)) // ndev
+        sub = qs.slice(lo, hi)
+        b = capi.UgsBatch(gdbs[r], max(1, sub.n), max(1, int(sub.offs[-1])))
+        b.upload(sub.seqs, sub.offs); b.search(); b.sync()
+        shards.append((lo, b))
+    comms = capi.UgsComm.init_all(list(range(ndev)))
+    res, err = [None] * ndev, []
+
+    def run(r):
+        try:
+            res[r] = comms[r].gather(shards[r][1], shards[r][0], dst=0)
+        except Exception as e:
+            err.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(ndev)]
+    [t.start() for t in th]; [t.join(300) for t in th]
+    assert not err, err
+    _same(res[0], want)
+    [c.close() for c in comms]
