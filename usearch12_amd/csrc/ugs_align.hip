@@ -32,6 +32,9 @@
 #define LTB 1024               // per-wave LDS traceback bytes (holes up to ~25x36 cells)
 #define LRUNS 32               // runs kept in LDS per wave before spilling to HBM scratch
 
+#ifndef UGS_ALIGN_CLOCKS
+#define UGS_ALIGN_CLOCKS 0
+#endif
 __device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : x + c; }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
@@ -633,6 +636,22 @@ __device__ __forceinline__ void flush_runs(WaveCtx &c)
   }
 }
 
+// wave-wide inclusive prefix max and shift by one lane with DPP (row shifts + row broadcasts: no LDS crossbar round trips; r04: the row
+// sweep of viterbi_hole made eight ds_bpermute round trips per row)
+__device__ __forceinline__ int wave_incl_max_i32(int v)
+{
+  int x;
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x111, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:1
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x112, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:2
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x114, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:4
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x118, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:8
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x142, 0xa, 0xf, false); v = x > v ? x : v;      // row_bcast:15 -> rows 1, 3
+  x = __builtin_amdgcn_update_dpp(NEG, v, 0x143, 0xc, 0xf, false); v = x > v ? x : v;      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// lane l gets v of lane l - 1, lane 0 gets `first`
+__device__ __forceinline__ int wave_shr1(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
+
 // diagbox.h:150-171
 __device__ __forceinline__ void get_range_j(uint32_t LA, uint32_t LB, uint32_t dlo, uint32_t dhi, uint32_t i,
                                             uint32_t &Startj, uint32_t &Endj)
@@ -650,13 +669,31 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
                              const Pen &P, unsigned long long *counters)
 {
   const int lane = c.lane;
+#if UGS_ALIGN_CLOCKS == 3
+  const unsigned long long tv0 = clock64();
+#endif
   uint32_t dlo = LA < LB ? LA : LB, dhi = LA > LB ? LA : LB;
   if (dlo > band) dlo -= band; else dlo = 1;
   dhi += band;
   if (dhi > LA + LB - 1) dhi = LA + LB - 1;
   const uint32_t stride = (dhi - dlo + 1) + 3;
-  uint8_t *TB = ((uint64_t)(LA + 1) * stride <= LTB) ? c.lds_tb : c.tb;       // small holes trace back from LDS
+  // Where the traceback bytes live: the 1 KB LDS area of the wave for small holes; for larger ones the part of the union region (seed
+  // list / DP rows / chainer scratch - idle here except for the rows) that the two DP rows of THIS hole leave free: they need LB + 8
+  // entries each, not max_tlen + 8.  r04: the average hole of a C2 hit is 35 x 35 = 1.3 KB of traceback bytes and went through HBM scratch
+  // (a store round trip per row behind the fence, a dependent global load per traceback step: 178 k cycles per hole); only holes beyond
+  // ~50 x 50 still do.
   int32_t *Mrow = c.Mrow, *Drow = c.Drow;
+  uint8_t *TB;
+  const uint64_t tb_bytes = (uint64_t)(LA + 1) * stride;
+  if (tb_bytes <= LTB) TB = c.lds_tb;
+  else {
+    const uint32_t row_words = LB + 8u;                               // Mrow[-1 .. LB], Drow[0 .. LB]
+    const uint64_t tb_off = (((uint64_t)4 + 2ull * row_words) * 4 + 15) & ~15ull;      // bytes from the union base (Mrow starts 4 words in)
+    if (tb_off + tb_bytes <= (uint64_t)c.union_words * 4) {
+      Drow = Mrow - 4 + 4 + row_words;                                // rows packed at the front of the region
+      TB = (uint8_t *)(Mrow - 4) + tb_off;
+    } else TB = c.tb;
+  }
   for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
   wave_sync();
   unsigned long long cells = 0;
@@ -676,15 +713,15 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
       const bool act = j < Endj;
       const int oldM = act ? Mrow[j] : NEG;
       const int oldD = act ? Drow[j] : NEG;
-      int saved = __shfl_up(oldM, 1); if (lane == 0) saved = carryM;
+      const int saved = wave_shr1(oldM, carryM);
       const int mi = act ? sat_add(saved, OpenA) : NEG;
       // in-row insert recurrence I[k] = max(mi[k], I[k-1]+ExtA) as a max-plus prefix scan
       int v = mi <= NEGT ? NEG : mi - lane * ExtA;
-      for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (lane >= o && x > v) v = x; }
+      v = wave_incl_max_i32(v);
       const int fromscan = v <= NEGT ? NEG : v + lane * ExtA;
       const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * ExtA;
       const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
-      int Iprev = __shfl_up(Iout, 1); if (lane == 0) Iprev = carryI;
+      const int Iprev = wave_shr1(Iout, carryI);
       uint8_t bits = 0;
       int xM = saved;
       if (oldD > xM) { xM = oldD; bits = TB_DM; }
@@ -725,17 +762,20 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     const bool act = j < Endj;
     const int mi = act ? sat_add(Mrow[(int)j - 1], P.ROpenA) : NEG;
     int v = mi <= NEGT ? NEG : mi - lane * P.RExtA;
-    for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (lane >= o && x > v) v = x; }
+    v = wave_incl_max_i32(v);
     const int fromscan = v <= NEGT ? NEG : v + lane * P.RExtA;
     const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * P.RExtA;
     const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
-    int Iprev = __shfl_up(Iout, 1); if (lane == 0) Iprev = carryI;
+    const int Iprev = wave_shr1(Iout, carryI);
     const int iext = sat_add(Iprev, P.RExtA);
     if (act) TBlast[j - Startj + 1] = (mi > iext) ? TB_MI : 0;
     const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
     carryI = rl(Iout, lastl);
   }
   wave_sync();
+#if UGS_ALIGN_CLOCKS == 3
+  const unsigned long long tv1 = clock64();
+#endif
   if (lane == 0) {
     atomicAdd(&counters[UGS_CTR_CELLS], cells);
     const int FinalM = Mrow[LB - 1], FinalD = Drow[LB], FinalI = carryI;
@@ -767,6 +807,9 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     for (int k = (int)nrt - 1; k >= 0; --k) { const uint32_t r = get_rt(c, (uint32_t)k); push_run(c, r & 3, r >> 2); }
   }
   wave_sync();
+#if UGS_ALIGN_CLOCKS == 3
+  if (lane == 0) { atomicAdd(&counters[UGS_CTR_T4], 1ull); atomicAdd(&counters[UGS_CTR_T5], (unsigned long long)LA << 32 | LB); atomicAdd(&counters[UGS_CTR_T6], tv1 - tv0); atomicAdd(&counters[UGS_CTR_T7], clock64() - tv1); }
+#endif
 }
 
 // globalalignmem.cpp:70-112 AlignHSPMem on a hole
@@ -789,10 +832,8 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
 // code (and register allocation) it was tuned with
 // phase clocks (UGS_PHASE_CLOCKS report): reading the clock waits for every outstanding LDS / scalar-memory operation of the wave,
 // four times per pair - compiled in only for tuning builds (-DUGS_ALIGN_CLOCKS=1)
-#ifndef UGS_ALIGN_CLOCKS
-#define UGS_ALIGN_CLOCKS 0
-#endif
-#define ACLK() (UGS_ALIGN_CLOCKS ? clock64() : 0ull)
+#define ACLK() (UGS_ALIGN_CLOCKS == 1 ? clock64() : 0ull)
+#define ACLK2() (UGS_ALIGN_CLOCKS == 2 ? clock64() : 0ull)      // finer clocks inside the post-HSP part: T4 chain, T5 classes + HSP identity, T6 holes, T7 FillLo + hit
 template <bool PAIR>
 #ifndef UGS_ALIGN_WGS
 #define UGS_ALIGN_WGS 4
@@ -1062,8 +1103,10 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
       }
       ta2 += ACLK() - tq; tq = ACLK();
+      unsigned long long tq2 = ACLK2();
       if (lane == 0) { if (fulldp) c.ws->nchain = 0; else chain_lane0(c); }
       wave_sync();
+      ta0 += ACLK2() - tq2; tq2 = ACLK2();
       const uint32_t nchain = c.ws->nchain;
       bool accept = false;
       if (nchain || force_all) {
@@ -1079,6 +1122,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           }
         }
         const float HSPFractId = TotLen == 0 ? 0.0f : (float)TotSame / (float)TotLen;
+        ta1 += ACLK2() - tq2; tq2 = ACLK2();
         if (force_all || !(HSPFractId < db.min_hsp_fract_id)) {
           // ---- stitch holes and HSPs into the path
           if (lane == 0) { c.ws->nruns = 0; c.ws->cur_len = 0; c.ws->cur_op = 0; c.ws->overflow = 0; }
@@ -1094,6 +1138,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           if (lane == 0) { flush_runs(c); if (c.ws->overflow) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_RUNS); }
           wave_sync();
           const uint32_t nr = c.ws->nruns < c.runs_cap ? c.ws->nruns : c.runs_cap;
+          ta2 += ACLK2() - tq2; tq2 = ACLK2();
           // ---- AlignResult::FillLo on the run list
           int fm = -1, lm = -1; uint32_t cols = 0;
           for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = get_run(c, r); cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
@@ -1165,7 +1210,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           }
         }
       }
-      ta3 += ACLK() - tq;
+      ta3 += ACLK() - tq; ta3 += ACLK2() - tq2;
       // Terminator::Terminate (terminator.cpp:64-100)
       if constexpr (PAIR) if (tflags && t_hits && (((tflags & UGS_A_TERMID) && (double)t_min <= (double)db.termid) ||
                                                     ((tflags & UGS_A_TERMIDD) && (double)(t_max - t_min) > (double)db.termidd))) {
@@ -1188,7 +1233,9 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   }
   if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs); }
   if (tid == 0) {
+#if UGS_ALIGN_CLOCKS != 3
     atomicAdd(&ctr[UGS_CTR_T4], ta0); atomicAdd(&ctr[UGS_CTR_T5], ta1); atomicAdd(&ctr[UGS_CTR_T6], ta2); atomicAdd(&ctr[UGS_CTR_T7], ta3);
+#endif
   }
 }
 
