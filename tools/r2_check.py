@@ -1,24 +1,26 @@
 """bitmap ranking kernel (ugs_rank2.hip) against k_rank on the C2 shape: the candidate lists of every unit must be identical;
-prints both kernels' times and which code ran.  python tools/r2_check.py [queries] [db_seqs] [--env K=V ...]"""
+prints both kernels' times and which code ran.  python tools/r2_check.py [queries] [db_seqs] [aa] [K=V ...]"""
 import os, sys, time, zlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from usearch12_amd import capi, synth
 
-args = [a for a in sys.argv[1:] if "=" not in a]
+AA = "aa" in sys.argv[1:]            # protein shape (C5): 300 aa, -id 0.8 -> the gather variant k_rank2g
+args = [a for a in sys.argv[1:] if "=" not in a and a != "aa"]
 for a in sys.argv[1:]:
     if "=" in a:
         k, v = a.split("=", 1); os.environ[k] = v
 nq = int(args[0]) if len(args) > 0 else 200000
 ndb = int(args[1]) if len(args) > 1 else 1000000
 seed = 2 if ndb == 1000000 else 4
-db = synth.make_db(seed, ndb, 250)
-qs = synth.make_queries(seed, db, nq, 250)
+if AA: seed = 5
+db = synth.make_db(seed, ndb, 300 if AA else 250, aa=AA)
+qs = synth.make_queries(seed, db, nq, 300 if AA else 250, aa=AA)
 res = {}
 for mode in ("0", "1"):
     os.environ["UGS_RANK2"] = mode
-    gdb = capi.UgsDB(capi.params(is_nucleo=True, id=0.97), db.seqs, db.offs, device=0)
+    gdb = capi.UgsDB(capi.params(is_nucleo=not AA, id=0.8 if AA else 0.97), db.seqs, db.offs, device=0)
     bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
     bat.upload(qs.seqs, qs.offs)
     r = []

@@ -331,6 +331,15 @@ int ugs_db_replan(ugs_db *db)
     if (db->tune.r2_g) g = (uint64_t)db->tune.r2_g;
     if (dens * (double)g >= 64.0 || db->tune.rank2 == 1) { gsize2 = (uint32_t)g; np2 = (uint32_t)(((uint64_t)nseq - 1) / gsize2 + 1); }
   }
+  // sparse Big-path index (protein): the gather variant (k_rank2g) - one chunk holds the sub-rows of all sampled rows of a partition, so
+  // the partitions are as large as the bitmap allows; its row lanes read a table line of at most 64 words and address the postings with
+  // 32-bit byte offsets
+  db->r2_gather = false;
+  if (nseq > db->p.big && db->sparse && nseq <= (1u << 24) && db->n_postings && db->n_postings < (1ull << 30) - 1024 && db->tune.rank2 != 0) {
+    const uint64_t g = db->tune.r2_g ? (uint64_t)db->tune.r2_g : 65536;
+    const uint64_t n2 = ((uint64_t)nseq - 1) / g + 1;
+    if (n2 <= 63 && g % 8192 == 0 && g <= 65536) { gsize2 = (uint32_t)g; np2 = (uint32_t)n2; db->r2_gather = true; }
+  }
   if (gsize2) {
     const uint64_t need2 = (uint64_t)slots * (np2 + 1);
     if (!db->d_part2 || need2 > db->part2_cap) {
@@ -766,7 +775,17 @@ static int plan_launch(ugs_batch *b)
   // sampled rows for the typical query (4-bit count field; a longer query is deferred per unit), uniform rows.  Units outside its
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
-  if (db->v.part2 && bits == 4 && !b->rl.longrows && b->K <= 64) {
+  b->r2.gather = 0;
+  if (db->v.part2 && db->r2_gather && bits == 8 && ns_typ <= 63 && !b->rl.longrows && b->K <= 64) {
+    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
+    b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
+    b->r2.clcap = 0; b->r2.W = 0; b->r2.gather = 1;
+    b->r2.lds = (uint32_t)ugs_rank2g_lds(db->v.gsize2, kcap, db->v.np2);
+    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 1), 32));
+    if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
+    b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
+  } else
+  if (db->v.part2 && !db->r2_gather && bits == 4 && !b->rl.longrows && b->K <= 64) {
     const uint32_t nsm = std::min<uint32_t>(ns_typ, 15u);
     const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
@@ -775,7 +794,7 @@ static int plan_launch(ugs_batch *b)
     b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
     b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>(28u, (db->v.np2 + 3u) / 4u * 4u));
     b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap);
-    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds), 32));
+    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   }

@@ -46,6 +46,7 @@ struct ugs_db {
   // pair filters / -abskew
   uint32_t *d_tkey, *d_tsize; bool have_tkey, have_tsize;
   bool sparse;                      // sparse dictionary (protein): short index rows
+  bool r2_gather;                   // part2 was built for the gather variant of the bitmap kernel (k_rank2g: sparse Big-path index)
   // capacities (elements) of the growable arrays and the letter count: ugs_db_append grows the DB in place
   uint64_t nletters, seq_cap, off_cap, post_cap, part_cap;
   uint32_t gsize_limit;             // small ranking path only: cap on the partition size (0 = none), see ugs_cluster.cpp

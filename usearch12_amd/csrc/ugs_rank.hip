@@ -1348,8 +1348,8 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !WIDE) ? (LONG 
   if (HOT) s_wsel = (uint64_t *)(smem + off);                                       // (= the first waves' tables, WSEL_WORDS * 4 = 2112 bytes: plan_launch checks that the tables are that large; off is a multiple of 16)
 
   const UgsTables *tab = db.tab;
-  // HOT only: behind the bitmap kernel (ugs_rank2.hip) this kernel takes the units that one deferred, from its list
-  const bool deferred = HOT && bv.use_defer != 0;
+  // Big path: behind a bitmap kernel (ugs_rank2.hip) this kernel takes the units that one deferred, from its list
+  const bool deferred = !SMALL && bv.use_defer != 0;
   const uint32_t units = deferred ? (uint32_t)bv.counters[UGS_CTR_DEFER] : bv.nq * bv.nstrand;
   const uint32_t K = bv.K;
   const int W = db.word_len;

@@ -501,17 +501,401 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
   if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
 }
 
-static const void *rank2_kernel() { return (const void *)k_rank2<UGS_R2_DEPTH>; }
+// ================================================================================================================================
+// k_rank2g - the same kernel for SPARSE indexes (protein dictionaries: rows of a few hundred postings, 16-63 sampled rows per query).
+// A (row, partition) sub-row holds a handful of postings there, so one chunk = the sub-rows of ALL sampled rows of a partition:
+// every lane has its own descriptor (four consecutive postings of one row's sub-row: a 16-byte gather load), found per chunk from the
+// rows' sub-row lengths (a prefix sum over the row lanes, a scatter of owner tags + a DPP max fill, three ds_bpermute).  Rows are laid
+// out in DESCENDING order over the lanes and over a partition's chunks, so an earlier chunk never holds a lower row; inside a chunk
+// the first touch of a target may be any of its lanes, so a record does not carry its own row but the LOWEST row among the chunk's
+// postings of that target (the last matching lane).  Counts up to 63 and 64 rows do not fit the 32-bit keys: the kept keys are 64-bit
+// ((255 - count) << 32 | row << 24 | target).  udbusortedsearcherbig.cpp:82-110, countsort.cpp:110-191 as k_rank2.
+// ================================================================================================================================
+__device__ __forceinline__ uint32_t r2_wave_incl_sum(uint32_t v, uint32_t lane)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  const uint32_t t0 = __builtin_amdgcn_readlane((int)v, 15), t1 = __builtin_amdgcn_readlane((int)v, 31), t2 = __builtin_amdgcn_readlane((int)v, 47);
+  const uint32_t row = lane >> 4;
+  return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
+}
+__device__ __forceinline__ uint32_t r2_wave_incl_max(uint32_t v)          // (unsigned, identity 0)
+{
+  uint32_t x;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = x > v ? x : v;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = x > v ? x : v;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = x > v ? x : v;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = x > v ? x : v;
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = x > v ? x : v;      // row_bcast:15 -> rows 1, 3
+  x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = x > v ? x : v;      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+#define R2G_KEY_INF 0xffffffffffffffffull
+#define R2G_MAXROWS 63u
+
+__global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t G = prm.G, np = prm.np, K = bv.K, kcap = prm.kcap;
+  const uint32_t bm_bytes = G / 8u;
+  // ---- LDS carve
+  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP + 256] records of the partition being scanned (+ slack of one chunk)
+  uint32_t *s_hba = s_stg + R2_SCAP + 256;                              // [64] hash filter A
+  uint32_t *s_hbb = s_hba + R2_HB_BITS / 32;                            // [64] hash filter B
+  uint32_t *s_c2 = s_hbb + R2_HB_BITS / 32;                             // [64] kept count-2 keys per row
+  uint32_t *s_cum = s_c2 + 64;                                          // [64] ... with that row or a lower one
+  uint32_t *s_slots = s_cum + 64;                                       // [64] sampled slots of the unit (by row)
+  uint32_t *s_sel = s_slots + 64;                                       // [64] selected targets (for the fill)
+  uint32_t *s_tag = s_sel + 64;                                         // [64] owner tags of a chunk's descriptor lanes
+  uint64_t *s_fpk = (uint64_t *)(s_tag + 64);                           // [64] smallest key per count value
+  uint64_t *s_kl = s_fpk + 64;                                          // [kcap + 2] kept keys
+  uint8_t *s_len = (uint8_t *)(s_kl + kcap + 2);                        // [np * 64] sub-row length of (partition, row lane)
+  const uint32_t units = bv.nq * bv.nstrand;
+  const uint32_t ns_max = prm.ns_max;
+  const uint32_t *postings = db.postings;
+  unsigned long long n_done_local = 0;
+
+  for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+
+  uint32_t ubase = 0, uidx = 4;
+  for (;;) {
+    if (uidx == 4) {
+      uint32_t v = 0;
+      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK2], 4ull);
+      ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+      uidx = 0;
+    }
+    const uint32_t unit = ubase + uidx;
+    ++uidx;
+    if (unit >= units) break;
+    const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
+    bool bad = ns > R2G_MAXROWS;
+    if (ns == 0) { if (lane == 0) bv.cand_n[unit] = 0; continue; }
+    uint32_t nk = 0, n_stg = 0;
+    bool any_posting = false;
+    if (!bad) {
+      // ---- row lanes: lane l < ns owns row ns - 1 - l (DESCENDING rows over ascending lanes)
+      const bool rowlane = lane < ns;
+      const uint32_t myrow = rowlane ? ns - 1u - lane : 0u;
+      const uint32_t slot = rowlane ? bv.unit_slots[(uint64_t)unit * ns_max + myrow] : 0u;
+      const uint64_t rs = rowlane ? db.row_off[slot] : 0ull;
+      const uint32_t rsb = (uint32_t)(rs * 4u);                            // byte offset of the row in the postings array (< 4 GiB: host check)
+      s_slots[lane < ns ? myrow : lane] = slot;                             // (by row: the fill walks rows 0, 1, ...)
+      s_c2[lane] = 0; s_cum[lane] = 0;
+      // the row's line of the partition table -> sub-row lengths of all partitions in LDS (one byte each); all loads in flight together
+      {
+        const uint32_t *pp = db.part2 + (uint64_t)slot * (np + 1u);
+        u32x4 e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { e[i].x = e[i].y = e[i].z = e[i].w = 0; if (rowlane && (uint32_t)i * 4u <= np) __builtin_memcpy(&e[i], pp + i * 4, 16); }
+        uint32_t prev = 0; bool big = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t p0 = (uint32_t)i * 4u;
+          if (p0 > np) break;
+          const uint32_t l3 = e[i].x - prev, l0 = e[i].y - e[i].x, l1 = e[i].z - e[i].y, l2 = e[i].w - e[i].z;
+          if (i > 0) { big = big || (rowlane && l3 > 255u); s_len[(p0 - 1u) * 64u + lane] = rowlane ? (uint8_t)l3 : 0; }
+          if (p0 < np) { big = big || (rowlane && l0 > 255u); s_len[p0 * 64u + lane] = rowlane ? (uint8_t)l0 : 0; }
+          if (p0 + 1u < np) { big = big || (rowlane && l1 > 255u); s_len[(p0 + 1u) * 64u + lane] = rowlane ? (uint8_t)l1 : 0; }
+          if (p0 + 2u < np) { big = big || (rowlane && l2 > 255u); s_len[(p0 + 2u) * 64u + lane] = rowlane ? (uint8_t)l2 : 0; }
+          prev = e[i].w;
+        }
+        if (__ballot(big)) bad = true;                                      // (a sub-row of more than 255 postings: not a sparse row)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+      // ---- the chunk cursor: partition cp, chunk cq of it; per row lane the layout of the partition's descriptor lanes
+      uint32_t cp = 0xffffffffu, cq = 0, ctot = 0;
+      uint32_t r_st = 0, r_len = 0, r_base = 0, r_nl = 0, cur_off = 0;     // row-lane state of partition cp: first descriptor lane, length, byte offset of the sub-row, lanes
+      bool exhausted = false;
+      // next chunk: per-lane descriptor (byte offset of the lane's four postings, valid count, row) + the chunk's partition
+      auto next_chunk = [&](uint32_t &voff, uint32_t &lmeta, uint32_t &part) -> bool {
+        if (exhausted) { voff = 0; lmeta = 0; part = 0xffffffffu; return false; }
+        if (cp != 0xffffffffu && (cq + 1u) * 64u < ctot) ++cq;
+        else {
+          for (;;) {
+            ++cp;
+            if (cp >= np) { exhausted = true; voff = 0; lmeta = 0; part = 0xffffffffu; return false; }
+            r_len = rowlane ? (uint32_t)s_len[cp * 64u + lane] : 0u;
+            r_nl = (r_len + 3u) >> 2;
+            const uint32_t incl = r2_wave_incl_sum(r_nl, lane);
+            r_st = incl - r_nl;
+            ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            r_base = rsb + cur_off * 4u;
+            cur_off += r_len;
+            cq = 0;
+            if (ctot) break;
+          }
+        }
+        // owner of descriptor lane d = 64 cq + lane: the row lane o with r_st[o] <= d < r_st[o] + r_nl[o]
+        const uint32_t d0 = cq * 64u, d = d0 + lane;
+        s_tag[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (r_nl && r_st >= d0 && r_st < d0 + 64u) s_tag[r_st - d0] = lane + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t own = r2_wave_incl_max(s_tag[lane]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {   // lanes before the chunk's first tag belong to the row lane that straddles d0
+          const uint64_t m0 = __ballot(r_nl != 0u && r_st < d0 && d0 < r_st + r_nl);
+          const uint32_t o0 = m0 ? (uint32_t)__ffsll((long long)m0) : 0u;
+          own = own ? own : o0;
+        }
+        const bool valid = d < ctot && own != 0u;
+        const uint32_t o = valid ? own - 1u : 0u;
+        const uint32_t ost = (uint32_t)__shfl((int)r_st, (int)o), olen = (uint32_t)__shfl((int)r_len, (int)o), obase = (uint32_t)__shfl((int)r_base, (int)o);
+        const uint32_t kq = d - ost;                                        // which quad of the owner's sub-row
+        const uint32_t rem = olen - kq * 4u;
+        const uint32_t n = valid ? (rem < 4u ? rem : 4u) : 0u;
+        voff = valid ? obase + kq * 16u : 0u;
+        lmeta = n | ((ns - 1u - o) << 8);
+        part = cp;
+        return true;
+      };
+      auto zero_bitmap = [&]() {
+        uint4 z; z.x = z.y = z.z = z.w = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t o = lane * 16u; o < bm_bytes; o += 1024u) *(uint4 *)(smem + o) = z;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+      // ---- a partition is done: group its records by target, make keys, prune, keep (as k_rank2, 64-bit keys)
+      auto finalize = [&]() {
+        const uint32_t n = n_stg;
+        n_stg = 0;
+        if (n == 0) return;
+        if (n > R2_SCAP) { bad = true; return; }
+        uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint32_t i = (uint32_t)b * 64u + lane;
+          act[b] = i < n;
+          rec[b] = act[b] ? s_stg[i] : 0u;
+          t[b] = rec[b] & 0xffffffu; row[b] = rec[b] >> 24;
+          const uint32_t h = (t[b] ^ (t[b] >> 11)) & (R2_HB_BITS - 1u);
+          wofs[b] = h >> 5; hbit[b] = 1u << (h & 31u);
+          cnt[b] = 2; drop[b] = false;
+          cumv[b] = act[b] ? s_cum[row[b] & 63u] : 0u;
+        }
+        uint32_t olda[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int b = 0; b < 2; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }
+        // a target's records: count = records + 1, first row = the lowest row a record carries; the representative is the FIRST
+        // record (lowest index) among those with that lowest row (several records of a chunk may carry the same row)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          uint64_t m = __ballot(fl[bb]);
+          while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L), rL = (uint32_t)__builtin_amdgcn_readlane((int)row[bb], L);
+            const uint32_t iL = (uint32_t)bb * 64u + (uint32_t)L;
+            uint32_t nsame = 0, better = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const bool sb = act[b] && t[b] == tL;
+              const uint32_t ib = (uint32_t)b * 64u + lane;
+              nsame += (uint32_t)__popcll(__ballot(sb));
+              better += (uint32_t)__popcll(__ballot(sb && (row[b] < rL || (row[b] == rL && ib < iL))));
+            }
+            if (nsame >= 2u && lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = better != 0u; }
+          }
+        }
+        uint32_t nk_new = nk;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint64_t key = ((uint64_t)(255u - cnt[b]) << 32) | rec[b];
+          const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
+          const uint64_t m = __ballot(keep);
+          uint32_t pos = nk_new + r2_mbcnt(m);
+          pos = pos < kcap ? pos : kcap;
+          if (keep) s_kl[pos] = key;
+          if (keep && cnt[b] == 2u) atomicAdd(&s_c2[row[b] & 63u], 1u);
+          nk_new += (uint32_t)__popcll(m);
+        }
+        nk = nk_new;
+        if (nk > kcap) { bad = true; return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        s_cum[lane] = r2_wave_incl_sum(s_c2[lane], lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+
+      // ---- the ring (four accumulator-register slots as k_rank2); per slot the lanes' descriptors and the chunk's partition
+      uint32_t lm[4] = {0, 0, 0, 0}, pt[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      { uint32_t vo;
+        next_chunk(vo, lm[0], pt[0]); r2_issue<0>(vo, postings); next_chunk(vo, lm[1], pt[1]); r2_issue<1>(vo, postings);
+        next_chunk(vo, lm[2], pt[2]); r2_issue<2>(vo, postings); next_chunk(vo, lm[3], pt[3]); r2_issue<3>(vo, postings); }
+      any_posting = pt[0] != 0xffffffffu;
+      uint32_t S_old[4] = {0, 0, 0, 0}, S_bit[4] = {0, 0, 0, 0}, S_t[4] = {0, 0, 0, 0}, S_lm = 0;
+      bool pv = false;
+      uint32_t cur_part = 0xffffffffu;
+      bool scanning = any_posting;
+      // records of the counted chunk: a posting that found its bit set; the record carries the LOWEST row among the chunk's postings of
+      // its target (the last matching lane: lanes are in descending row order) - the first touch may be any of them
+      auto emit_chunk = [&]() {
+        const uint32_t myrow8 = S_lm >> 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool hit = (S_old[j] & S_bit[j]) != 0u;
+          uint64_t m = __ballot(hit);
+          uint32_t rrow = myrow8;
+          uint64_t rest = m;
+          while (rest) {                                                   // (a handful of hits per unit)
+            const int L = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)S_t[j], L);
+            uint64_t mm = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) mm |= __ballot(S_bit[jj] != 0u && S_t[jj] == tL);
+            const int last = 63 - __builtin_clzll(mm);                      // (mm holds lane L itself)
+            const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)myrow8, last);
+            if (lane == (uint32_t)L) rrow = low;
+          }
+          if (hit) s_stg[n_stg + r2_mbcnt(m)] = S_t[j] | (rrow << 24);
+          n_stg += (uint32_t)__popcll(m);
+        }
+      };
+#define R2G_STAGE(k)                                                                                             \
+      if (scanning) {                                                                                            \
+        const uint32_t part = pt[k];                                                                             \
+        if (part == 0xffffffffu || bad) scanning = false;                                                        \
+        else {                                                                                                   \
+          uint32_t T[4];                                                                                         \
+          r2_take<k>(T);                                                                                         \
+          const uint32_t tlm = lm[k];                                                                            \
+          { uint32_t vo; next_chunk(vo, lm[k], pt[k]); r2_issue<k>(vo, postings); }                              \
+          if (pv) { if (R2_UG(n_stg) <= R2_SCAP) emit_chunk(); else bad = true; pv = false; }                    \
+          if (part != cur_part) { finalize(); zero_bitmap(); cur_part = part; }                                  \
+          if (!bad) {                                                                                            \
+            const uint32_t nvalid = tlm & 0xffu, sub = part * G;                                                 \
+            uint32_t ad[4];                                                                                      \
+            S_lm = tlm;                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+              const uint32_t t = T[j];                                                                           \
+              S_t[j] = t;                                                                                        \
+              ad[j] = ((t - sub) >> 3) & ~3u;                                                                    \
+              ad[j] = ad[j] < bm_bytes - 4u ? ad[j] : bm_bytes - 4u;                                             \
+              ad[j] = (uint32_t)j < nvalid ? ad[j] : lane * 4u;     /* (the quad's tail belongs to the next partition: a word of its own, bit 0) */ \
+              S_bit[j] = (uint32_t)j < nvalid ? (1u << (t & 31u)) : 0u;                                          \
+              S_old[j] = 0;                                                                                      \
+            }                                                                                                    \
+            if (nvalid) { _Pragma("unroll") for (int j = 0; j < 4; ++j) S_old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)ad[j], S_bit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } \
+            pv = true;                                                                                           \
+          }                                                                                                      \
+        }                                                                                                        \
+      }
+#define R2_UG(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+      while (scanning) { R2G_STAGE(0) R2G_STAGE(1) R2G_STAGE(2) R2G_STAGE(3) }
+#undef R2G_STAGE
+      // every load of the ring has landed before the next unit issues into the same slots
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      if (!bad) {
+        if (pv) { if (R2_UG(n_stg) <= R2_SCAP) emit_chunk(); else bad = true; pv = false; }
+        if (!bad) finalize();
+      }
+#undef R2_UG
+    }
+    if (bad) {
+      for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+      if (lane == 0) {
+        const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
+        bv.defer_list[idx] = unit;
+      }
+      continue;
+    }
+    ++n_done_local;
+    // ---- cut-offs from the smallest key of every count value (countsort.cpp:13-24,114-126)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    s_fpk[lane] = R2G_KEY_INF;
+    if (lane < 2u) s_kl[nk + lane] = R2G_KEY_INF;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t i = lane; i < nk; i += 64u) { const uint64_t key = s_kl[i]; atomicMin((unsigned long long *)&s_fpk[(255u - (uint32_t)(key >> 32)) & 63u], (unsigned long long)key); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t M = 0, nv = 0;
+    {
+      const uint64_t f = (lane >= 2u) ? s_fpk[lane] : R2G_KEY_INF;            // lane c looks at count c
+      const uint64_t vm = __ballot(f != R2G_KEY_INF);
+      if (vm) {
+        M = 63u - (uint32_t)__builtin_clzll(vm);
+        const uint32_t fM = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f, (int)M);
+        const uint64_t lmk = __ballot(f != R2G_KEY_INF && lane < M && (uint32_t)f < fM);
+        nv = lmk ? 63u - (uint32_t)__builtin_clzll(lmk) : 0u;
+      } else M = any_posting ? 1u : 0u;
+    }
+    const uint32_t min_value = nv / 2u;
+    const uint32_t cmin = min_value > 2u ? min_value : 2u;
+    const uint64_t limit = (uint64_t)(256u - cmin) << 32;                   // keys below it have count >= cmin
+    uint32_t nsel = 0;
+    {
+      uint32_t nelig = 0;
+      for (uint32_t e0 = 0; e0 < nk; e0 += 64u) {
+        const uint32_t i = e0 + lane;
+        const uint64_t key = i < nk ? s_kl[i] : R2G_KEY_INF;
+        const bool elig = key < limit;
+        nelig += (uint32_t)__popcll(__ballot(elig));
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nk; j += 2u) { rank += (s_kl[j] < key) + (s_kl[j + 1u] < key); }
+        if (elig && rank < K) {
+          const uint32_t tg = (uint32_t)key & 0xffffffu;
+          bv.cand[(uint64_t)unit * K + rank] = tg;
+          bv.cand_cnt[(uint64_t)unit * K + rank] = 255u - (uint32_t)(key >> 32);
+          s_sel[rank] = tg;
+        }
+      }
+      nsel = nelig < K ? nelig : K;
+    }
+    if (nsel < K && min_value <= 1u && M >= 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t mine = lane < nsel ? s_sel[lane] : 0xffffffffu;
+      uint32_t filled = nsel;
+      for (uint32_t r = 0; r < ns && filled < K; ++r) {
+        const uint32_t slot = s_slots[r];
+        const uint64_t ra = db.row_off[slot], rb = db.row_off[slot + 1];
+        for (uint64_t k0 = ra; k0 < rb && filled < K; k0 += 64) {
+          const bool on = k0 + (uint64_t)lane < rb;
+          const uint32_t t = on ? postings[k0 + lane] : 0u;
+          bool in_set = false;
+          for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+          const bool e = on && !in_set;
+          const uint64_t m = __ballot(e);
+          const uint32_t rank = r2_mbcnt(m);
+          if (e && filled + rank < K) { bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u; }
+          const uint32_t n = (uint32_t)__popcll(m);
+          filled = filled + n < K ? filled + n : K;
+        }
+      }
+      nsel = filled;
+    }
+    if (lane == 0) bv.cand_n[unit] = nsel;
+  }
+  if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
+}
+
+static const void *rank2_kernel(int gather = 0) { return gather ? (const void *)k_rank2g : (const void *)k_rank2<UGS_R2_DEPTH>; }
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
 {
   return (size_t)G / 8 + (R2_SCAP + 2 * (R2_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
 }
 
-int ugs_rank2_blocks_per_cu(size_t lds)
+size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
+{
+  return (size_t)G / 8 + ((size_t)R2_SCAP + 256 + 2 * (R2_HB_BITS / 32) + 64 * 5) * 4 + 64 * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64 + 16;
+}
+
+int ugs_rank2_blocks_per_cu(size_t lds, int gather)
 {
   int n = 0;
-  const void *fn = rank2_kernel();
+  const void *fn = rank2_kernel(gather);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess || n < 1) n = 1;
   return n;
@@ -519,7 +903,7 @@ int ugs_rank2_blocks_per_cu(size_t lds)
 
 int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st)
 {
-  const void *fn = rank2_kernel();
+  const void *fn = rank2_kernel((int)prm.gather);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));
   UgsDbView a0 = db; UgsBatchView a1 = b; UgsRank2Params a2 = prm;
   void *args[] = {&a0, &a1, &a2};
