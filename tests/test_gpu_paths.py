@@ -116,8 +116,88 @@ def test_same_batch_ten_times_gives_the_same_bytes(shape, c2_small):
     assert len({o[0] for o in outs}) == 1, [o[0] for o in outs]
     if shape == "c2":
         assert outs[0][1]["r2_launched"] == 1
-    if shape in ("c2_krank", "id90", "small", "aa"):
-        assert outs[0][1]["r2_launched"] == 0 or shape == "aa" and outs[0][1]["r2_launched"] == 0
+    if shape == "aa":                     # sparse Big-path index: the gather variant (k_rank2g)
+        assert outs[0][1]["r2_launched"] == 1 and outs[0][1]["r2_units"] > 0.9 * qs.n * 1
+    if shape in ("c2_krank", "id90", "small"):
+        assert outs[0][1]["r2_launched"] == 0
+
+
+@pytest.fixture(scope="module")
+def aa_small():
+    db = synth.make_db(21, 300000, 300, aa=True)
+    qs = synth.make_queries(21, db, 20000, 300, aa=True)
+    return db, qs
+
+
+@pytest.mark.parametrize("g", ["", "8192", "24576"])
+def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g):
+    """protein index (rows of tens of postings): k_rank2g ranks every unit, same candidates as the counter kernel; also with small
+    partitions (37 of them for 300 k sequences: sub-rows of 0-3 postings, many chunks per unit)"""
+    db, qs = aa_small
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, {"UGS_R2_G": g} if g else None, is_nucleo=False, id=0.8)[0]
+    assert a[1]["r2_launched"] == 0 and a[1]["r2_units"] == 0
+    assert b[1]["r2_launched"] == 1 and b[1]["r2_units"] > 0.95 * qs.n and b[1]["r2_units"] + b[1]["deferred"] == qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+
+
+def test_gather_kernel_deferred_units_and_oracle(aa_small):
+    """a kept-key list of 8 entries defers the units with hits to the 8-bit counter kernel behind k_rank2g; both against the oracle"""
+    db, _ = aa_small
+    qs = synth.make_queries(22, db, 900, 300, aa=True)
+    outs = [_search(db, qs, env, is_nucleo=False, id=0.8)[0] for env in (None, {"UGS_R2_KCAP": "8"})]
+    assert outs[0][1]["r2_launched"] == 1 and outs[0][1]["deferred"] == 0
+    assert outs[1][1]["r2_launched"] == 1 and outs[1][1]["deferred"] > 0 and outs[1][1]["r2_units"] + outs[1][1]["deferred"] == qs.n
+    assert outs[0][0] == outs[1][0]
+    odb = orc.OrcDB(orc.params(is_nucleo=False, id=0.8), db.seqs, db.offs)
+    for out in outs:
+        cand, cnt, n = out[2]
+        for qi in range(0, qs.n, 9):
+            q = qs.seqs[int(qs.offs[qi]):int(qs.offs[qi + 1])]
+            on, oc, occ = odb.rank(q, cap=cand.shape[1])
+            m = min(on, cand.shape[1])
+            assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
+
+
+def test_gather_kernel_defers_units_of_abundant_families():
+    """families of near-identical sequences give sub-rows far longer than a quad (300 copies: > 255 postings of a row in one partition;
+    60 copies: more descriptor lanes than a partition's table holds): those units go to k_rank, the others stay"""
+    base = synth.make_db(23, 200000, 300, aa=True)
+    rng = np.random.default_rng(23)
+    L = 300
+    seqs = base.seqs.reshape(base.n, L).copy()
+    fams = []
+    for start, copies in ((50000, 300), (120000, 60)):
+        proto = seqs[start].copy()
+        for c in range(copies):
+            row = proto.copy()
+            pos = rng.integers(0, L, size=6)
+            row[pos] = seqs[start + 1000 + c][pos]              # a few substitutions per copy
+            seqs[start + c] = row
+        fams.append((start, copies))
+    db = synth.SeqSet(seqs.reshape(-1), base.offs, lambda i: "t%d" % i)
+    qs0 = synth.make_queries(23, db, 3000, 300, aa=True)
+    # queries: the synthetic set plus mutated members of both families
+    extra = []
+    for start, copies in fams:
+        for c in range(0, copies, 3):
+            row = seqs[start + c].copy()
+            pos = rng.integers(0, L, size=20)
+            row[pos] = seqs[start + 5000 + c][pos]
+            extra.append(row)
+    eseq = np.concatenate(extra)
+    qseqs = np.concatenate([qs0.seqs, eseq])
+    qoffs = np.concatenate([qs0.offs, qs0.offs[-1] + np.arange(1, len(extra) + 1, dtype=np.uint64) * np.uint64(L)])
+    qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
+    a = _search(db, qs, {"UGS_RANK2": "0", "UGS_LONGROWS": "0"}, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, {"UGS_LONGROWS": "0"}, is_nucleo=False, id=0.8)[0]
+    assert b[1]["r2_launched"] == 1 and b[1]["deferred"] >= len(extra) // 2 and b[1]["r2_units"] > 2000
+    assert b[1]["r2_units"] + b[1]["deferred"] == qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
 
 
 def test_wide_offset_instantiations_of_k_rank(c2_small):

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
 #else
 #define R2_CLK(...)
 #endif
+#ifdef R2_CLOCKS2
+#define R2_CLK2(...) __VA_ARGS__
+#else
+#define R2_CLK2(...)
+#endif
 
   for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;      // both filters start clean and are left clean
 
@@ -534,6 +539,7 @@ __device__ __forceinline__ uint32_t r2_wave_incl_max(uint32_t v)          // (un
 }
 #define R2G_KEY_INF 0xffffffffffffffffull
 #define R2G_MAXROWS 63u
+#define R2G_DCAP 256u            // descriptor lanes (quads of postings) of one partition; more: the unit is deferred
 
 __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
@@ -549,14 +555,16 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   uint32_t *s_cum = s_c2 + 64;                                          // [64] ... with that row or a lower one
   uint32_t *s_slots = s_cum + 64;                                       // [64] sampled slots of the unit (by row)
   uint32_t *s_sel = s_slots + 64;                                       // [64] selected targets (for the fill)
-  uint32_t *s_tag = s_sel + 64;                                         // [64] owner tags of a chunk's descriptor lanes
-  uint64_t *s_fpk = (uint64_t *)(s_tag + 64);                           // [64] smallest key per count value
+  uint2 *s_desc = (uint2 *)(s_sel + 64);                                // [R2G_DCAP] descriptor lanes of the partition being scanned
+  uint64_t *s_fpk = (uint64_t *)(s_desc + R2G_DCAP);                           // [64] smallest key per count value
   uint64_t *s_kl = s_fpk + 64;                                          // [kcap + 2] kept keys
   uint8_t *s_len = (uint8_t *)(s_kl + kcap + 2);                        // [np * 64] sub-row length of (partition, row lane)
   const uint32_t units = bv.nq * bv.nstrand;
   const uint32_t ns_max = prm.ns_max;
   const uint32_t *postings = db.postings;
   unsigned long long n_done_local = 0;
+  R2_CLK(unsigned long long tc_pre = 0, tc_scan = 0, tc_sel = 0;)
+  R2_CLK2(unsigned long long tq[5] = {0, 0, 0, 0, 0};)
 
   for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
 
@@ -571,6 +579,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
     const uint32_t unit = ubase + uidx;
     ++uidx;
     if (unit >= units) break;
+    R2_CLK(const unsigned long long tg0 = clock64(); unsigned long long tg1 = tg0, tg2 = tg0;)
     const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
     bool bad = ns > R2G_MAXROWS;
     if (ns == 0) { if (lane == 0) bv.cand_n[unit] = 0; continue; }
@@ -585,23 +594,27 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       const uint32_t rsb = (uint32_t)(rs * 4u);                            // byte offset of the row in the postings array (< 4 GiB: host check)
       s_slots[lane < ns ? myrow : lane] = slot;                             // (by row: the fill walks rows 0, 1, ...)
       s_c2[lane] = 0; s_cum[lane] = 0;
-      // the row's line of the partition table -> sub-row lengths of all partitions in LDS (one byte each); all loads in flight together
+      // the row's line of the partition table -> sub-row lengths of all partitions in LDS (one byte each).  Eight 16-byte loads in flight
+      // together (all lanes load: the others read slot 0's line); words past the line's end (index np) are read at np and never used
       {
         const uint32_t *pp = db.part2 + (uint64_t)slot * (np + 1u);
-        u32x4 e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { e[i].x = e[i].y = e[i].z = e[i].w = 0; if (rowlane && (uint32_t)i * 4u <= np) __builtin_memcpy(&e[i], pp + i * 4, 16); }
         uint32_t prev = 0; bool big = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t p0 = (uint32_t)i * 4u;
-          if (p0 > np) break;
-          const uint32_t l3 = e[i].x - prev, l0 = e[i].y - e[i].x, l1 = e[i].z - e[i].y, l2 = e[i].w - e[i].z;
-          if (i > 0) { big = big || (rowlane && l3 > 255u); s_len[(p0 - 1u) * 64u + lane] = rowlane ? (uint8_t)l3 : 0; }
-          if (p0 < np) { big = big || (rowlane && l0 > 255u); s_len[p0 * 64u + lane] = rowlane ? (uint8_t)l0 : 0; }
-          if (p0 + 1u < np) { big = big || (rowlane && l1 > 255u); s_len[(p0 + 1u) * 64u + lane] = rowlane ? (uint8_t)l1 : 0; }
-          if (p0 + 2u < np) { big = big || (rowlane && l2 > 255u); s_len[(p0 + 2u) * 64u + lane] = rowlane ? (uint8_t)l2 : 0; }
-          prev = e[i].w;
+        for (int h = 0; h < 2; ++h) {
+          if ((uint32_t)h * 32u > np) break;
+          u32x4 e[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const uint32_t w = (uint32_t)(h * 8 + i) * 4u; __builtin_memcpy(&e[i], pp + (w <= np ? w : np), 16); }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const uint32_t p0 = (uint32_t)(h * 8 + i) * 4u;
+            const uint32_t l3 = e[i].x - prev, l0 = e[i].y - e[i].x, l1 = e[i].z - e[i].y, l2 = e[i].w - e[i].z;
+            if (p0 > 0u && p0 <= np) { big = big || (rowlane && l3 > 255u); s_len[(p0 - 1u) * 64u + lane] = rowlane ? (uint8_t)l3 : 0; }
+            if (p0 < np) { big = big || (rowlane && l0 > 255u); s_len[p0 * 64u + lane] = rowlane ? (uint8_t)l0 : 0; }
+            if (p0 + 1u < np) { big = big || (rowlane && l1 > 255u); s_len[(p0 + 1u) * 64u + lane] = rowlane ? (uint8_t)l1 : 0; }
+            if (p0 + 2u < np) { big = big || (rowlane && l2 > 255u); s_len[(p0 + 2u) * 64u + lane] = rowlane ? (uint8_t)l2 : 0; }
+            prev = e[i].w;
+          }
         }
         if (__ballot(big)) bad = true;                                      // (a sub-row of more than 255 postings: not a sparse row)
       }
@@ -609,13 +622,14 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
 
       // ---- the chunk cursor: partition cp, chunk cq of it; per row lane the layout of the partition's descriptor lanes
       uint32_t cp = 0xffffffffu, cq = 0, ctot = 0;
-      uint32_t r_st = 0, r_len = 0, r_base = 0, r_nl = 0, cur_off = 0;     // row-lane state of partition cp: first descriptor lane, length, byte offset of the sub-row, lanes
+      uint32_t cur_off = 0;                                                // row lanes: postings of the row before partition cp
       bool exhausted = false;
       // next chunk: per-lane descriptor (byte offset of the lane's four postings, valid count, row) + the chunk's partition
       auto next_chunk = [&](uint32_t &voff, uint32_t &lmeta, uint32_t &part) -> bool {
         if (exhausted) { voff = 0; lmeta = 0; part = 0xffffffffu; return false; }
         if (cp != 0xffffffffu && (cq + 1u) * 64u < ctot) ++cq;
         else {
+          uint32_t r_len, r_nl, r_st;
           for (;;) {
             ++cp;
             if (cp >= np) { exhausted = true; voff = 0; lmeta = 0; part = 0xffffffffu; return false; }
@@ -624,34 +638,23 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             const uint32_t incl = r2_wave_incl_sum(r_nl, lane);
             r_st = incl - r_nl;
             ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            r_base = rsb + cur_off * 4u;
-            cur_off += r_len;
-            cq = 0;
             if (ctot) break;
           }
+          if (ctot > R2G_DCAP) { bad = true; exhausted = true; voff = 0; lmeta = 0; part = 0xffffffffu; return false; }
+          // the partition's descriptor lanes: every row lane writes the quads of its sub-row (byte offset of the quad, valid postings | row << 8)
+          const uint32_t base = rsb + cur_off * 4u;
+          cur_off += r_len;
+          for (uint32_t q = 0; __ballot(q < r_nl) != 0ull; ++q) {
+            const uint32_t rem = r_len - q * 4u;
+            if (q < r_nl) s_desc[r_st + q] = make_uint2(base + q * 16u, (rem < 4u ? rem : 4u) | (myrow << 8));
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          cq = 0;
         }
-        // owner of descriptor lane d = 64 cq + lane: the row lane o with r_st[o] <= d < r_st[o] + r_nl[o]
-        const uint32_t d0 = cq * 64u, d = d0 + lane;
-        s_tag[lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (r_nl && r_st >= d0 && r_st < d0 + 64u) s_tag[r_st - d0] = lane + 1u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        uint32_t own = r2_wave_incl_max(s_tag[lane]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {   // lanes before the chunk's first tag belong to the row lane that straddles d0
-          const uint64_t m0 = __ballot(r_nl != 0u && r_st < d0 && d0 < r_st + r_nl);
-          const uint32_t o0 = m0 ? (uint32_t)__ffsll((long long)m0) : 0u;
-          own = own ? own : o0;
-        }
-        const bool valid = d < ctot && own != 0u;
-        const uint32_t o = valid ? own - 1u : 0u;
-        const uint32_t ost = (uint32_t)__shfl((int)r_st, (int)o), olen = (uint32_t)__shfl((int)r_len, (int)o), obase = (uint32_t)__shfl((int)r_base, (int)o);
-        const uint32_t kq = d - ost;                                        // which quad of the owner's sub-row
-        const uint32_t rem = olen - kq * 4u;
-        const uint32_t n = valid ? (rem < 4u ? rem : 4u) : 0u;
-        voff = valid ? obase + kq * 16u : 0u;
-        lmeta = n | ((ns - 1u - o) << 8);
-        part = cp;
+        const uint32_t d = cq * 64u + lane;
+        uint2 e = make_uint2(0u, 0u);
+        if (d < ctot) e = s_desc[d];
+        voff = e.x; lmeta = e.y; part = cp;
         return true;
       };
       auto zero_bitmap = [&]() {
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         next_chunk(vo, lm[0], pt[0]); r2_issue<0>(vo, postings); next_chunk(vo, lm[1], pt[1]); r2_issue<1>(vo, postings);
         next_chunk(vo, lm[2], pt[2]); r2_issue<2>(vo, postings); next_chunk(vo, lm[3], pt[3]); r2_issue<3>(vo, postings); }
       any_posting = pt[0] != 0xffffffffu;
+      R2_CLK(tg1 = clock64();)
       uint32_t S_old[4] = {0, 0, 0, 0}, S_bit[4] = {0, 0, 0, 0}, S_t[4] = {0, 0, 0, 0}, S_lm = 0;
       bool pv = false;
       uint32_t cur_part = 0xffffffffu;
@@ -743,6 +747,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       // its target (the last matching lane: lanes are in descending row order) - the first touch may be any of them
       auto emit_chunk = [&]() {
         const uint32_t myrow8 = S_lm >> 8;
+        if (__ballot(((S_old[0] & S_bit[0]) | (S_old[1] & S_bit[1]) | (S_old[2] & S_bit[2]) | (S_old[3] & S_bit[3])) != 0u) == 0ull) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool hit = (S_old[j] & S_bit[j]) != 0u;
@@ -770,11 +775,16 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         if (part == 0xffffffffu || bad) scanning = false;                                                        \
         else {                                                                                                   \
           uint32_t T[4];                                                                                         \
+          R2_CLK2(const unsigned long long q0 = clock64();)                                                      \
           r2_take<k>(T);                                                                                         \
+          R2_CLK2(const unsigned long long q1 = clock64();)                                                      \
           const uint32_t tlm = lm[k];                                                                            \
           { uint32_t vo; next_chunk(vo, lm[k], pt[k]); r2_issue<k>(vo, postings); }                              \
+          R2_CLK2(const unsigned long long q2 = clock64();)                                                      \
           if (pv) { if (R2_UG(n_stg) <= R2_SCAP) emit_chunk(); else bad = true; pv = false; }                    \
+          R2_CLK2(const unsigned long long q3 = clock64();)                                                      \
           if (part != cur_part) { finalize(); zero_bitmap(); cur_part = part; }                                  \
+          R2_CLK2(const unsigned long long q4 = clock64();)                                                      \
           if (!bad) {                                                                                            \
             const uint32_t nvalid = tlm & 0xffu, sub = part * G;                                                 \
             uint32_t ad[4];                                                                                      \
@@ -782,15 +792,14 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
               const uint32_t t = T[j];                                                                           \
               S_t[j] = t;                                                                                        \
-              ad[j] = ((t - sub) >> 3) & ~3u;                                                                    \
-              ad[j] = ad[j] < bm_bytes - 4u ? ad[j] : bm_bytes - 4u;                                             \
-              ad[j] = (uint32_t)j < nvalid ? ad[j] : lane * 4u;     /* (the quad's tail belongs to the next partition: a word of its own, bit 0) */ \
+              /* (the quad's tail belongs to the next partition or row: a word of the lane's own, bit 0) */      \
+              ad[j] = (uint32_t)j < nvalid ? (((t - sub) >> 3) & ~3u) : lane * 4u;                               \
               S_bit[j] = (uint32_t)j < nvalid ? (1u << (t & 31u)) : 0u;                                          \
-              S_old[j] = 0;                                                                                      \
             }                                                                                                    \
-            if (nvalid) { _Pragma("unroll") for (int j = 0; j < 4; ++j) S_old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)ad[j], S_bit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) S_old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)ad[j], S_bit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
             pv = true;                                                                                           \
           }                                                                                                      \
+          R2_CLK2(tq[0] += q1 - q0; tq[1] += q2 - q1; tq[2] += q3 - q2; tq[3] += q4 - q3; tq[4] += clock64() - q4;) \
         }                                                                                                        \
       }
 #define R2_UG(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -803,6 +812,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         if (!bad) finalize();
       }
 #undef R2_UG
+      R2_CLK(tg2 = clock64();)
     }
     if (bad) {
       for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
@@ -876,7 +886,14 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       nsel = filled;
     }
     if (lane == 0) bv.cand_n[unit] = nsel;
+    R2_CLK(tc_pre += tg1 - tg0; tc_scan += tg2 - tg1; tc_sel += clock64() - tg2;)
   }
+#ifdef R2_CLOCKS
+  if (lane == 0) { atomicAdd(&bv.counters[UGS_CTR_T0], tc_pre); atomicAdd(&bv.counters[UGS_CTR_T1], tc_scan); atomicAdd(&bv.counters[UGS_CTR_T3], tc_sel); }
+#endif
+#ifdef R2_CLOCKS2     // the stage's sections: take (posting wait) | next chunk + issue | emission | partition boundary | count
+  if (lane == 0) { atomicAdd(&bv.counters[UGS_CTR_T0], tq[0]); atomicAdd(&bv.counters[UGS_CTR_T1], tq[1]); atomicAdd(&bv.counters[UGS_CTR_T2], tq[2]); atomicAdd(&bv.counters[UGS_CTR_T3], tq[3]); atomicAdd(&bv.counters[UGS_CTR_T4], tq[4]); }
+#endif
   if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
 }
 
@@ -889,7 +906,7 @@ size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
 
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
 {
-  return (size_t)G / 8 + ((size_t)R2_SCAP + 256 + 2 * (R2_HB_BITS / 32) + 64 * 5) * 4 + 64 * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64 + 16;
+  return (size_t)G / 8 + ((size_t)R2_SCAP + 256 + 2 * (R2_HB_BITS / 32) + 64 * 4) * 4 + (size_t)R2G_DCAP * 8 + 64 * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64 + 16;
 }
 
 int ugs_rank2_blocks_per_cu(size_t lds, int gather)
