@@ -33,3 +33,9 @@ def _heap_guard(request):
     bad = g.check()
     g.plant()
     assert not bad, "host heap memory changed behind the process's back during this test (size, offset, byte): %r" % (bad[:8],)
+
+
+def pytest_runtest_setup(item):
+    """count the GPU tests of this session (tests/test_zz_gpu_coverage.py only judges a full run)"""
+    if item.get_closest_marker("gpu") is not None:
+        item.session.__dict__["_ugs_gpu_tests"] = item.session.__dict__.get("_ugs_gpu_tests", 0) + 1

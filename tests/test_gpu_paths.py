@@ -200,6 +200,31 @@ def test_gather_kernel_defers_units_of_abundant_families():
     assert a[0] == b[0]
 
 
+def test_small_path_short_queries_with_long_row_kernel():
+    """queries of <= 22 letters have <= 15 words: 4-bit counters on the small path; with the long-row switch forced that is the
+    instantiation k_rank<SMALL, .., LONG> (found unreached by tests/test_zz_gpu_coverage.py) - same candidates as its twin and the oracle"""
+    db = synth.make_db(31, 40000, 250)
+    rng = np.random.default_rng(31)
+    nq, L = 1500, 22
+    src = rng.integers(0, db.n, size=nq); pos = rng.integers(0, 250 - L, size=nq)
+    rows = db.seqs.reshape(db.n, 250)
+    qseqs = np.stack([rows[s, p:p + L] for s, p in zip(src, pos)]).reshape(-1)
+    qs = synth.SeqSet(qseqs, np.arange(nq + 1, dtype=np.uint64) * np.uint64(L), lambda i: "q%d" % i)
+    a = _search(db, qs, {"UGS_LONGROWS": "0"}, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, {"UGS_LONGROWS": "1"}, is_nucleo=True, id=0.97)[0]
+    assert a[1]["rank_kernel"] & 1 == 0 and (a[1]["rank_kernel"] >> 1) & 0x7f == 4 and (a[1]["rank_kernel"] >> 9) & 1 == 0
+    assert b[1]["rank_kernel"] & 1 == 0 and (b[1]["rank_kernel"] >> 1) & 0x7f == 4 and (b[1]["rank_kernel"] >> 9) & 1 == 1
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+    odb = orc.OrcDB(orc.params(is_nucleo=True, id=0.97), db.seqs, db.offs)
+    cand, cnt, n = b[2]
+    for qi in range(0, nq, 11):
+        on, oc, occ = odb.rank(qs.seqs[qi * L:(qi + 1) * L], cap=cand.shape[1])
+        m = min(on, cand.shape[1])
+        assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
+
+
 def test_wide_offset_instantiations_of_k_rank(c2_small):
     """an index whose partition table reaches 4 GiB takes the Big-path 4-bit kernels with 64-bit offsets; forced here"""
     db, qs = c2_small

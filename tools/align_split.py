@@ -3,10 +3,14 @@ import os, sys, numpy as np
 sys.path.insert(0, "/root/repo")
 os.environ["UGS_PHASE_CLOCKS"] = "1"
 from usearch12_amd import capi, synth
-db = synth.make_db(2, 1000000, 250)
-gdb = capi.UgsDB(capi.params(is_nucleo=True, id=0.97), db.seqs, db.offs, device=0)
+AA = os.environ.get("RQ_SHAPE", "") == "aa"          # RQ_SHAPE=aa: the C5 shape
+if AA:
+    db = synth.make_db(5, 2000000, 300, aa=True)
+else:
+    db = synth.make_db(2, 1000000, 250)
+gdb = capi.UgsDB(capi.params(is_nucleo=not AA, id=0.8 if AA else 0.97), db.seqs, db.offs, device=0)
 for fr in (0.0, 1.0):
-    qs = synth.make_queries(2, db, 100000, 250, frac_random=fr)
+    qs = synth.make_queries(5 if AA else 2, db, 100000, 300 if AA else 250, aa=AA, frac_random=fr)
     bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
     bat.upload(qs.seqs, qs.offs)
     for _ in range(2):

@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -106,6 +106,15 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise UgsError(rc, lib().ugs_last_error().decode())
+
+
+def rank_instances():
+    """(seen, compiled): bit masks of the ranking kernels this process launched so far / the library holds (include/ugs.h)"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    f = lib().ugs_debug_rank_instances
+    f.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; f.restype = C.c_int
+    _chk(f(C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):

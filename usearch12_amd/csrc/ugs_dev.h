@@ -143,6 +143,7 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
 int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
                    uint32_t gsize, uint32_t *d_part, hipStream_t st);
 int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows, int wide);
+unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows);
 int ugs_align_blocks_per_cu(int threads, size_t lds);
 size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words, int hot);

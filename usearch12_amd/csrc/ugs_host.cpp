@@ -777,7 +777,8 @@ static int plan_launch(ugs_batch *b)
   b->r2_grid = 0;
   b->r2.gather = 0;
   if (db->v.part2 && db->r2_gather && bits == 8 && ns_typ <= 63 && !b->rl.longrows && b->K <= 64) {
-    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
+    // (a sparse index gives a unit tens of count-2 targets, not hundreds: a kept-key list of 4 K, and the eleventh wave per CU that buys)
+    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(116u, 4u * b->K - 12u);
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
     b->r2.clcap = 0; b->r2.W = 0; b->r2.gather = 1;
     b->r2.lds = (uint32_t)ugs_rank2g_lds(db->v.gsize2, kcap, db->v.np2);
@@ -1084,8 +1085,18 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
     fprintf(stderr, "[ugs] rank phase clocks (sum over WGs, thread 0): setup %llu scan %llu scan-wait %llu select %llu | align: %llu %llu %llu %llu\n",
             b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5],
             b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]),
-    fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu, bits %d ns_max %u gsize %u np %u | align grid %d x %d waves, lds %zu\n", b->rl.grid, b->rl.wpb, b->rl.lds,
-            b->rl.bits, b->rl.ns_max, b->db->v.gsize, b->db->v.np, b->al.grid, b->al.wpb, b->al.lds);
+    fprintf(stderr, "[ugs] launch: rank grid %d x %d waves, lds %zu, bits %d ns_max %u gsize %u np %u | align grid %d x %d waves, lds %zu | bitmap kernel: grid %d lds %u G %u np %u kcap %u gather %u\n", b->rl.grid, b->rl.wpb, b->rl.lds,
+            b->rl.bits, b->rl.ns_max, b->db->v.gsize, b->db->v.np, b->al.grid, b->al.wpb, b->al.lds, b->r2_grid, b->r2.lds, b->r2.G, b->r2.np, b->r2.kcap, b->r2.gather);
+  return UGS_OK;
+}
+
+// diagnostic: the ranking kernels this PROCESS has launched so far / the ones the library holds (bit numbers: ugs_rank.hip rank_kernel)
+extern "C" int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled)
+{
+  unsigned long long c = 0;
+  const unsigned long long s = ugs_rank_instances_seen(&c);
+  if (seen) *seen = s;
+  if (compiled) *compiled = c;
   return UGS_OK;
 }
 

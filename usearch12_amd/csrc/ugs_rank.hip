@@ -23,6 +23,7 @@
 // can consume at most K = maxaccepts+maxrejects-1 of them, so only the K smallest keys
 // (count desc, first-touch position asc) are selected, after applying the reference's
 // "MinValue = prevMax/2" (and, on the small path, -bump) cut-offs exactly.
+#include <atomic>
 #include "ugs_dev.h"
 #include "ugs_rank2.h"
 #include <cstdlib>
@@ -1863,21 +1864,38 @@ extern template __global__ void k_rank<false, false, false, false>(UgsDbView, Ug
 #endif
 // resident workgroups per CU for a given block size / dynamic LDS (VGPR- and LDS-limited): the
 // persistent grid must not exceed it, or the surplus workgroups run as a second, unbalanced round
-static const void *rank_kernel(int big, int bits, int fast8, int longrows, int wide = 0)
+// ordinal of the instantiation rank_kernel() picks (0 .. UGS_RANK_INSTANCES - 1): the library records which ones a process launched
+// (ugs_rank_instances_seen; the test-suite asserts at its end that every compiled instantiation ran)
+static const void *rank_kernel(int big, int bits, int fast8, int longrows, int wide = 0, int *ordinal = nullptr)
 {
   const int mode = bits == 4 ? 0 : (fast8 ? 2 : 1);
+  int dummy; int &id = ordinal ? *ordinal : dummy;
 #ifdef UGS_ONLY_HOT               // tuning builds (tools/build_variant.sh): only the C2 instantiation, compiles in seconds
   (void)big; (void)mode; (void)longrows; (void)wide;
+  id = 0;
   return (const void *)k_rank<false, false, false, false>;
 #else
-  if (wide && big && mode == 0)    // (only the two Big-path 4-bit kernels have 32-bit offsets to outgrow)
+  if (wide && big && mode == 0) {  // (only the two Big-path 4-bit kernels have 32-bit offsets to outgrow)
+    id = longrows ? 13 : 12;
     return longrows ? (const void *)k_rank<false, false, false, true, true> : (const void *)k_rank<false, false, false, false, true>;
-  if (longrows)
+  }
+  if (longrows) {
+    id = big ? (mode == 0 ? 1 : mode == 1 ? 2 : 4) : (mode == 0 ? 6 : mode == 1 ? 7 : 9);
     return big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
                : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
+  }
+  id = big ? (mode == 0 ? 0 : mode == 1 ? 2 : 3) : (mode == 0 ? 5 : mode == 1 ? 7 : 8);
   return big ? (mode == 0 ? (const void *)k_rank<false, false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, false>)
              : (mode == 0 ? (const void *)k_rank<true, false, false, false> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, false>);
 #endif
+}
+// bit i: instantiation i was launched by this process (0 HOT, 1 its LONG twin, 2 Big 8/16-bit flattened, 3 / 4 Big 8/16-bit dense /
+// long rows, 5-9 the same five of the small path, 12 / 13 HOT / LONG with 64-bit offsets, 14 k_rank2, 15 k_rank2g)
+static std::atomic<unsigned long long> g_rank_seen{0};
+unsigned long long ugs_rank_instances_seen(unsigned long long *compiled)
+{
+  if (compiled) *compiled = 0x3ffull | (3ull << 12) | (3ull << 14);
+  return g_rank_seen.load();
 }
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return bits != 4 ? 3 : (big ? (longrows ? 2 : 1) : 0); }   // 1 = HOT, 2 = its LONG twin, 3 = wider counters (BATCH kernels)
@@ -1933,7 +1951,9 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     RCCHK_(ugs_launch_rank2(db, b, *r2, r2_grid, st));
     if (ev_r2_done) HIPCHK(hipEventRecord(ev_r2_done, st));
   }
-  const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide);
+  int ordinal = 0;
+  const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide, &ordinal);
+  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather ? 15 : 14)) : 0ull));
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;

@@ -36,7 +36,6 @@
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
-#include <type_traits>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 
@@ -539,6 +538,7 @@ __device__ __forceinline__ uint32_t r2_wave_incl_max(uint32_t v)          // (un
 }
 #define R2G_KEY_INF 0xffffffffffffffffull
 #define R2G_MAXROWS 63u
+#define R2G_HB_BITS 512u          // bits of each hash filter of the grouping (a handful of records per partition)
 #define R2G_DCAP 256u            // descriptor lanes (quads of postings) of one partition; more: the unit is deferred
 
 __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
@@ -548,16 +548,16 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   const uint32_t G = prm.G, np = prm.np, K = bv.K, kcap = prm.kcap;
   const uint32_t bm_bytes = G / 8u;
   // ---- LDS carve
-  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP + 256] records of the partition being scanned (+ slack of one chunk)
-  uint32_t *s_hba = s_stg + R2_SCAP + 256;                              // [64] hash filter A
-  uint32_t *s_hbb = s_hba + R2_HB_BITS / 32;                            // [64] hash filter B
-  uint32_t *s_c2 = s_hbb + R2_HB_BITS / 32;                             // [64] kept count-2 keys per row
+  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP + 64] records of the partition being scanned (+ slack)
+  uint32_t *s_sel = s_stg;                                              //   after the scan: [64] selected targets (for the fill)
+  uint64_t *s_fpk = (uint64_t *)(s_stg + 64);                           //   after the scan: [64] smallest key per count value
+  uint32_t *s_hba = s_stg + R2_SCAP + 64;                               // [R2G_HB_BITS / 32] hash filter A
+  uint32_t *s_hbb = s_hba + R2G_HB_BITS / 32;                           // ... B
+  uint32_t *s_c2 = s_hbb + R2G_HB_BITS / 32;                            // [64] kept count-2 keys per row
   uint32_t *s_cum = s_c2 + 64;                                          // [64] ... with that row or a lower one
   uint32_t *s_slots = s_cum + 64;                                       // [64] sampled slots of the unit (by row)
-  uint32_t *s_sel = s_slots + 64;                                       // [64] selected targets (for the fill)
-  uint2 *s_desc = (uint2 *)(s_sel + 64);                                // [R2G_DCAP] descriptor lanes of the partition being scanned
-  uint64_t *s_fpk = (uint64_t *)(s_desc + R2G_DCAP);                           // [64] smallest key per count value
-  uint64_t *s_kl = s_fpk + 64;                                          // [kcap + 2] kept keys
+  uint2 *s_desc = (uint2 *)(s_slots + 64);                              // [R2G_DCAP] descriptor lanes of the partition being scanned
+  uint64_t *s_kl = (uint64_t *)(s_desc + R2G_DCAP);                     // [kcap + 2] kept keys
   uint8_t *s_len = (uint8_t *)(s_kl + kcap + 2);                        // [np * 64] sub-row length of (partition, row lane)
   const uint32_t units = bv.nq * bv.nstrand;
   const uint32_t ns_max = prm.ns_max;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   R2_CLK(unsigned long long tc_pre = 0, tc_scan = 0, tc_sel = 0;)
   R2_CLK2(unsigned long long tq[5] = {0, 0, 0, 0, 0};)
 
-  for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+  for (uint32_t k = lane; k < R2G_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
 
   uint32_t ubase = 0, uidx = 4;
   for (;;) {
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
           act[b] = i < n;
           rec[b] = act[b] ? s_stg[i] : 0u;
           t[b] = rec[b] & 0xffffffu; row[b] = rec[b] >> 24;
-          const uint32_t h = (t[b] ^ (t[b] >> 11)) & (R2_HB_BITS - 1u);
+          const uint32_t h = (t[b] ^ (t[b] >> 11)) & (R2G_HB_BITS - 1u);
           wofs[b] = h >> 5; hbit[b] = 1u << (h & 31u);
           cnt[b] = 2; drop[b] = false;
           cumv[b] = act[b] ? s_cum[row[b] & 63u] : 0u;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)myrow8, last);
             if (lane == (uint32_t)L) rrow = low;
           }
-          if (hit) s_stg[n_stg + r2_mbcnt(m)] = S_t[j] | (rrow << 24);
+          { const uint32_t pos = n_stg + r2_mbcnt(m); if (hit && pos < R2_SCAP + 64u) s_stg[pos] = S_t[j] | (rrow << 24); }    // (more than R2_SCAP: the unit is deferred in finalize)
           n_stg += (uint32_t)__popcll(m);
         }
       };
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       R2_CLK(tg2 = clock64();)
     }
     if (bad) {
-      for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+      for (uint32_t k = lane; k < R2G_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
       if (lane == 0) {
         const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
         bv.defer_list[idx] = unit;
@@ -901,12 +901,12 @@ static const void *rank2_kernel(int gather = 0) { return gather ? (const void *)
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
 {
-  return (size_t)G / 8 + (R2_SCAP + 2 * (R2_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
+  return (size_t)G / 8 + (R2_SCAP + 2 * (R2G_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
 }
 
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
 {
-  return (size_t)G / 8 + ((size_t)R2_SCAP + 256 + 2 * (R2_HB_BITS / 32) + 64 * 4) * 4 + (size_t)R2G_DCAP * 8 + 64 * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64 + 16;
+  return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + 2 * (R2G_HB_BITS / 32) + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
 }
 
 int ugs_rank2_blocks_per_cu(size_t lds, int gather)
