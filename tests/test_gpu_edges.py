@@ -50,6 +50,25 @@ def test_protein_short_sequences():
     both([t, t[:4], "X" * 20], [t, t[5:25], "MKV", "XXXXXXXX", t.lower()], aa=True, ident=0.5, big=0)
 
 
+def test_protein_queries_with_repeats_and_full_word_buckets():
+    """aa HSP words (8000) are looked up through a table of 1000 buckets of eight words, <= 15 query positions per bucket: a query
+    whose bucket is fuller (a homopolymer run, a short tandem repeat) sorts and searches the general way; a word with more than
+    MaxReps = 8 positions keeps its first eight either way (hspfinder.cpp SetA)"""
+    rng = np.random.default_rng(41)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    rnd = lambda n: "".join(aa[i] for i in rng.integers(0, 20, n))
+    core = [rnd(120) for _ in range(6)]
+    t0 = core[0] + "A" * 26 + core[1]                    # 24 x the word AAA: a bucket over its limit
+    t1 = core[2] + "ACD" * 7 + core[3]                    # three words seven times each, all in one bucket (ACD, CDA, DAC differ: other buckets) -> repeats within MaxReps
+    t2 = core[4] + "LKLKLKLKLKLKLKLKLKLKLKLK" + core[5]    # two words 11 x each (more than MaxReps, fewer than 16)
+    t3 = rnd(60) + "AAAC" * 5 + rnd(60)                    # AAA, AAC in the SAME bucket (8 consecutive codes), 5 + 5 positions
+    db = [t0, t1, t2, t3] + [rnd(200) for _ in range(20)]
+    mut = lambda s, k: "".join((aa[(aa.index(c) + 1) % 20] if i % k == k - 1 else c) for i, c in enumerate(s))
+    qs = [t0, t1, t2, t3, mut(t0, 17), mut(t1, 13), mut(t2, 19), mut(t3, 11), t0[100:200], t2[90:], "A" * 40, "LK" * 30]
+    both(db, qs, aa=True, ident=0.5, big=0)
+    both(db, qs, aa=True, ident=0.8)
+
+
 def test_query_beyond_envelope_is_an_error_not_a_crash():
     rng = np.random.default_rng(3)
     dseq, doff = pack(["".join("ACGT"[i] for i in rng.integers(0, 4, 300))])

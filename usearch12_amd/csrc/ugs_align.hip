@@ -52,7 +52,11 @@ struct WaveCtx {
   uint8_t *As, *Bs;           // score codes: nt 0..3 = A,C,G,T/U, 4 = anything else; aa = letter 0..25 (31 other)
   uint32_t *A2, *Ai, *B2, *Bi; // nt: the score codes packed 2 bits per letter (16 letters per word) and, in the same layout, one bit per
                               // letter that is not A/C/G/T/U (bit 2k of its word); two zero words in front, three behind
-  uint16_t *wstart;           // per HSP word: first index in qsort (12 bits) | min(count,8) << 12 (0 = absent), or null
+  uint16_t *wstart;           // per HSP word: first index in qsort (12 bits) | min(count,8) << 12 (0 = absent), or null.  With more than
+                              // 1024 words (aa: 8000) the table is per BUCKET (word >> bsh): first index | entries << 12 (<= 15; a query
+                              // with a fuller bucket sorts and searches the general way: use_tab false); qsort is then ordered by
+                              // (bucket, position) and a look-up filters the bucket's entries by word
+  uint32_t bsh; bool use_tab;
   uint32_t *seeds; uint32_t seed_cap; uint32_t union_words;   // seed list of the current pair: bpos << 16 | apos, in reference order
   bool nt;
   uint32_t *qsort;            // sorted (hsp word << 16 | pos) of the query
@@ -132,29 +136,43 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
   c.nwA = LA >= (uint32_t)w ? LA - w + 1 : 0;
   uint32_t n2 = 64; while (n2 < c.nwA) n2 <<= 1;
   c.nA2 = n2;
-  if (c.wstart && (uint64_t)c.nwA * 3 / 2 + 16 <= c.union_words) {
-    // ---- counting sort by word (<= 1024 words), stable in position: O(L^2/64) equal-word ranks with
+  c.use_tab = c.wstart != nullptr;
+  bool counting = c.wstart && (uint64_t)c.nwA * 3 / 2 + 16 <= c.union_words;
+  if (counting) {
+    // ---- counting sort by word (<= 1024 words; or by bucket of words), stable in position: O(L^2/64) equal-word ranks with
     // 128-bit LDS reads instead of a 36-stage bitonic network
     uint32_t *tw = c.seeds;                               // word per position (union region, free here)
-    uint16_t *tr = (uint16_t *)(c.seeds + ((c.nwA + 3) & ~3u));       // rank among earlier equal words
-    const uint32_t nwords = c.nwords, nwA = c.nwA;
-    for (uint32_t k = lane; k < (nwords + 1) / 2; k += 64) ((uint32_t *)c.wstart)[k] = 0;
+    uint16_t *tr = (uint16_t *)(c.seeds + ((c.nwA + 3) & ~3u));       // rank among earlier equal words (buckets)
+    const uint32_t bsh = c.bsh, ntab = ((c.nwords - 1u) >> bsh) + 1u, nwA = c.nwA;
+    for (uint32_t k = lane; k < (ntab + 1) / 2; k += 64) ((uint32_t *)c.wstart)[k] = 0;
     for (uint32_t p = lane; p < ((nwA + 3) & ~3u); p += 64) {
       uint32_t word = 0xffffffffu;
       if (p < nwA) { if (c.nt) word = nt_word(c.A2, p, w); else { word = 0; for (int k = 0; k < w; ++k) word = word * alpha + c.s_hl[c.A[p + k] & 31]; } }
       tw[p] = word;
     }
     lds_sync();
-    for (uint32_t p = lane; p < nwA; p += 64)
-      atomicAdd(&((uint32_t *)c.wstart)[tw[p] >> 1], 1u << ((tw[p] & 1u) * 16));   // 16-bit counters, two per LDS word
+    for (uint32_t p = lane; p < nwA; p += 64) {
+      const uint32_t bk = tw[p] >> bsh;
+      atomicAdd(&((uint32_t *)c.wstart)[bk >> 1], 1u << ((bk & 1u) * 16));   // 16-bit counters, two per LDS word
+    }
     lds_sync();
+    if (bsh) {                                             // a bucket's entry count has four bits in the table
+      bool over = false;
+      for (uint32_t k = lane; k < ntab; k += 64) over = over || c.wstart[k] > 15;
+      if (__ballot(over)) { counting = false; c.use_tab = false; }
+    }
+  }
+  if (counting) {
+    uint32_t *tw = c.seeds;
+    uint16_t *tr = (uint16_t *)(c.seeds + ((c.nwA + 3) & ~3u));
+    const uint32_t bsh = c.bsh, ntab = ((c.nwords - 1u) >> bsh) + 1u, nwA = c.nwA;
     // only the positions of words that occur more than once need a rank (about a fifth of a random query): they are listed
     // densely first, so that the O(L) rank scans fill whole wavefronts
     uint32_t *dup = c.qsort;                               // (free until the final scatter)
     uint32_t ndup = 0;
     for (uint32_t p0 = 0; p0 < nwA; p0 += 64) {
       const uint32_t p = p0 + lane;
-      const bool need = p < nwA && c.wstart[tw[p < nwA ? p : 0]] > 1;
+      const bool need = p < nwA && c.wstart[tw[p < nwA ? p : 0] >> bsh] > 1;
       if (p < nwA) tr[p] = 0;
       const uint64_t m = __ballot(need);
       if (need) dup[ndup + __popcll(m & ((1ull << lane) - 1ull))] = p;
@@ -162,34 +180,36 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     }
     lds_sync();
     for (uint32_t i = lane; i < ndup; i += 64) {
-      const uint32_t p = dup[i], wd = tw[p];
+      const uint32_t p = dup[i], wd = tw[p] >> bsh;
       const uint4 *v4 = (const uint4 *)tw;
       uint32_t rank = 0;
       const uint32_t nq4 = p >> 2;
-      for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += (x.x == wd) + (x.y == wd) + (x.z == wd) + (x.w == wd); }
-      for (uint32_t q = nq4 << 2; q < p; ++q) rank += tw[q] == wd;
+      for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += ((x.x >> bsh) == wd) + ((x.y >> bsh) == wd) + ((x.z >> bsh) == wd) + ((x.w >> bsh) == wd); }
+      for (uint32_t q = nq4 << 2; q < p; ++q) rank += (tw[q] >> bsh) == wd;
       tr[p] = (uint16_t)rank;
     }
     lds_sync();
     {   // exclusive prefix sum of the counts: each lane owns a contiguous block of words
-      const uint32_t per = (nwords + 63) / 64;
+      const uint32_t per = (ntab + 63) / 64;
+      const uint32_t ncap = bsh ? 15u : (uint32_t)UGS_MAXREPS;
       uint32_t sum = 0;
-      for (uint32_t k = 0; k < per; ++k) { const uint32_t wi = lane * per + k; if (wi < nwords) sum += c.wstart[wi]; }
+      for (uint32_t k = 0; k < per; ++k) { const uint32_t wi = lane * per + k; if (wi < ntab) sum += c.wstart[wi]; }
       const uint32_t incl = wave_incl_sum_u32(sum);
       uint32_t run = incl - sum;
       for (uint32_t k = 0; k < per; ++k) {
         const uint32_t wi = lane * per + k;
-        if (wi < nwords) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = (uint16_t)(n ? (run | ((n < UGS_MAXREPS ? n : UGS_MAXREPS) << 12)) : 0u); run += n; }
+        if (wi < ntab) { const uint32_t n = c.wstart[wi]; c.wstart[wi] = (uint16_t)(n ? (run | ((n < ncap ? n : ncap) << 12)) : 0u); run += n; }
       }
     }
     lds_sync();
     for (uint32_t p = lane; p < nwA; p += 64) {
       const uint32_t wd = tw[p];
-      c.qsort[(c.wstart[wd] & 0xfffu) + tr[p]] = (wd << 16) | p;
+      c.qsort[(c.wstart[wd >> bsh] & 0xfffu) + tr[p]] = (wd << 16) | p;
     }
     lds_sync();
     return;
   }
+  if (c.bsh) c.use_tab = false;                            // (bucket tables are only built by the counting sort)
   for (uint32_t p = lane; p < n2; p += 64) {
     uint32_t key = 0xffffffffu;
     if (p < c.nwA) {
@@ -212,7 +232,7 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
       }
       lds_sync();
     }
-  if (c.wstart) {
+  if (c.use_tab) {
     // direct word -> (first sorted index | min(count, MaxReps) << 16) table: replaces a binary
     // search per target position; count 0 = word absent from the query
     const uint32_t nwords = c.nwords;
@@ -437,7 +457,7 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       // ---- list seeds until the list is comfortably full or the target is exhausted
       if (idx >= count) { idx = 0; count = 0; }
       while (scan < nwB && count + 64 * UGS_MAXREPS <= c.seed_cap) {
-        if (NT && c.wstart && nwB - scan > 64u) {
+        if (NT && c.use_tab && c.bsh == 0 && nwB - scan > 64u) {
           // four instructions' worth of target positions at once: the word and table look-ups of all four are in flight together
           // and two prefix sums over packed 16-bit counts place them (a lane's count is <= MaxReps, a chunk's total <= 512)
           uint32_t bp[4], lo4[4], cn[4];
@@ -478,12 +498,13 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
           }
         }
         const uint32_t bpos = scan + lane;
-        uint32_t lo = 0, cnt = 0;
+        uint32_t lo = 0, cnt = 0, wordv = 0;
         if (bpos < nwB) {
           uint32_t word = 0;
           if (NT) word = nt_word(c.B2, bpos, w);
           else for (int k = 0; k < w; ++k) word = word * db.alpha + c.s_hl[c.B[bpos + k] & 31];
-          if (c.wstart) { const uint32_t e = c.wstart[word]; lo = e & 0xfffu; cnt = e >> 12; }
+          wordv = word;
+          if (c.use_tab) { const uint32_t e = c.wstart[word >> c.bsh]; lo = e & 0xfffu; cnt = e >> 12; }
           else {
             const uint32_t want = word << 16;
             uint32_t hi = c.nwA;
@@ -492,6 +513,18 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
           }
         }
         uint32_t okm1 = 0;
+        if (c.use_tab && c.bsh) {
+          // a bucket's entries in query-position order: the first MaxReps of THIS word are the word's positions (HSPFinder::SetA)
+          uint32_t nm = 0;
+          for (uint32_t r = 0; r < cnt; ++r) {
+            const uint32_t e = c.qsort[lo + r];
+            if ((e >> 16) == wordv) {
+              const int d = (int)(e & 0xffffu) - (int)bpos;
+              if (nm < UGS_MAXREPS) okm1 |= (d >= dlo && d <= dhi ? 1u : 0u) << r;
+              ++nm;
+            }
+          }
+        } else
         for (uint32_t r = 0; r < cnt; ++r) { const int d = (int)(c.qsort[lo + r] & 0xffffu) - (int)bpos; okm1 |= (d >= dlo && d <= dhi ? 1u : 0u) << r; }
         cnt = (uint32_t)__popc(okm1);
         const uint32_t incl = wave_incl_sum_u32(cnt);
@@ -877,8 +910,9 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     c.B2 = (uint32_t *)(wb + off) + 2; off += wt; c.Bi = (uint32_t *)(wb + off) + 2; off += wt;
   }
   c.nwords = (uint32_t)db.hsp_words;
-  c.wstart = nullptr;
-  if (db.hsp_words <= 1024 && bv.max_qlen < 4096) { c.wstart = (uint16_t *)(wb + off); off += ((size_t)db.hsp_words * 2 + 15) & ~(size_t)15; }
+  c.wstart = nullptr; c.bsh = 0; c.use_tab = false;
+  while (((uint32_t)db.hsp_words - 1u) >> c.bsh >= 1024u) ++c.bsh;           // (aa: 8000 words -> 1000 buckets of 8)
+  if (bv.max_qlen < 4096) { c.wstart = (uint16_t *)(wb + off); off += ((size_t)(((uint32_t)db.hsp_words - 1u) >> c.bsh) * 2 + 2 + 15) & ~(size_t)15; }
   c.lds_runs = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_tb = wb + off; off += LTB;
@@ -891,7 +925,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   c.union_words = (uint32_t)(us / 4);
   // the sorted query words need a power-of-two array only for the bitonic fallback; when every query of the batch
   // takes the counting sort (word table present and its scratch fits the union region) maxq entries do
-  const bool always_counting = c.wstart != nullptr && (uint64_t)maxq * 3 / 2 + 16 <= c.union_words;
+  const bool always_counting = c.wstart != nullptr && c.bsh == 0 && (uint64_t)maxq * 3 / 2 + 16 <= c.union_words;
   c.qsort = (uint32_t *)(wb + off); off += (size_t)(always_counting ? maxq : q2) * 4;
   c.hsps = (HSPd *)(wb + off); off += (size_t)hsp_cap * sizeof(HSPd);
   c.chain = (uint32_t *)(wb + off); off += (size_t)hsp_cap * 4;

@@ -803,12 +803,14 @@ static int plan_launch(ugs_batch *b)
   // ---- alignment geometry
   const uint32_t hsp_cap = db->max_tlen / (uint32_t)p.hsp_word_len + 2;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  const size_t wstart_b = (db->v.hsp_words <= 1024 && b->max_qlen < 4096) ? (((size_t)db->v.hsp_words * 2 + 15) & ~(size_t)15) : 0;
+  uint32_t bsh = 0;                                          // more than 1024 HSP words (aa: 8000): a table per bucket of words (k_align)
+  while (((uint32_t)db->v.hsp_words - 1u) >> bsh >= 1024u) ++bsh;
+  const size_t wstart_b = b->max_qlen < 4096 ? (((size_t)(((uint32_t)db->v.hsp_words - 1u) >> bsh) * 2 + 2 + 15) & ~(size_t)15) : 0;
   const uint32_t seed_cap = 64 * UGS_MAXREPS + 128;      // one listing round always fits; rounds of 64 seeds are extended at a time
   // per-wave LDS (mirrors the carve in k_align): control block, class + score codes of both sequences, word table,
   // sorted query words, run buffers, small-hole traceback, HSPs + chain, union{seed list | DP rows + chainer scratch}
   const size_t u_region = std::max<size_t>((size_t)seed_cap * 4, std::max<size_t>(2 * ((size_t)maxt + 8) * 4, (size_t)hsp_cap * 28));
-  const bool always_counting = wstart_b != 0 && (uint64_t)maxq * 3 / 2 + 16 <= u_region / 4;
+  const bool always_counting = wstart_b != 0 && bsh == 0 && (uint64_t)maxq * 3 / 2 + 16 <= u_region / 4;
   const size_t packed_b = 2 * ((((size_t)maxq / 16 + 6) * 4 + 15) & ~(size_t)15) + 2 * ((((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15);   // 2-bit letters
   const size_t wave_lds = (32 + ((size_t)maxq + maxt) + ((size_t)maxq + maxt + 64) + packed_b + wstart_b + (size_t)(always_counting ? maxq : q2) * 4 +
                            2 * 32 * 4 + 1024 + (size_t)hsp_cap * (16 + 4) + u_region + 15 + 16) & ~(size_t)15;
