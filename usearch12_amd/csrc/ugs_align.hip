@@ -356,6 +356,73 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
   }
 }
 
+// wave-wide inclusive prefix maximum (identity INT_MIN)
+__device__ __forceinline__ int coop_incl_max(int v)
+{
+  const int NEGI = (int)0x80000000;
+  int x;
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x111, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:1
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x112, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:2
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x114, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:4
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x118, 0xf, 0xf, false); v = x > v ? x : v;      // row_shr:8
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x142, 0xa, 0xf, false); v = x > v ? x : v;      // row_bcast:15 -> rows 1, 3
+  x = __builtin_amdgcn_update_dpp(NEGI, v, 0x143, 0xc, 0xf, false); v = x > v ? x : v;      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// The same seed extension (ungappedblast.cpp:62-180, byte score codes) by the WHOLE wave: one letter pair per lane and step.  The
+// serial rule "score += s; if (score > best) best = score, pos = here; else if (best - score > X) stop" in prefix form: with P_i the
+// running score and M_i the running maximum (the earlier best included), the walk stops at the first i with M_i - P_i > X (when P_i
+// exceeds the earlier maximum the difference is 0), the best is M at the last consumed position and its position the first that
+// attains it.  Used for the first seed of a round whose diagonal holds many of the round's seeds (a homologous pair: all those lanes
+// would walk the same hundreds of letters eight at a time); same outputs as extend_seed, wave-uniform.
+__device__ __forceinline__ bool extend_seed_coop(const WaveCtx &c, const UgsDbView &db, uint32_t apos, uint32_t bpos, uint32_t MinLength,
+                                                 uint32_t &oAlo, uint32_t &oBlo, uint32_t &oLen, int &oBest)
+{
+  const int w = db.hsp_w, X = db.xdrop2;
+  const uint32_t LA = c.LA, LB = c.LB, lane = (uint32_t)c.lane;
+  int score = 0;
+  for (int k = 0; k < w; ++k) score += (int)c.s_sub2[((uint32_t)c.As[apos + k] << 5) | c.Bs[bpos + k]];
+  int best = score;
+  uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
+  uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    uint32_t rem = dir == 0 ? ((LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2)) : (b1 < a1 ? b1 : a1);
+    if (dir == 1) score = best;
+    while (rem) {
+      const uint32_t n = rem < 64u ? rem : 64u;
+      const bool valid = lane < n;
+      int sc = 0;
+      if (valid) {
+        const uint32_t av = dir == 0 ? c.As[a2 + 1 + lane] : c.As[a1 - 1 - lane], bv = dir == 0 ? c.Bs[b2 + 1 + lane] : c.Bs[b1 - 1 - lane];
+        sc = (int)c.s_sub2[(av << 5) | bv];
+      }
+      const int P = score + (int)wave_incl_sum_u32((uint32_t)sc);
+      int M = coop_incl_max(valid ? P : (int)0x80000000);
+      M = M > best ? M : best;
+      const uint64_t sm = __ballot(valid && M - P > X);
+      const uint32_t lim = sm ? (uint32_t)__ffsll((long long)sm) - 1u : n;        // positions [0, lim) are consumed
+      if (lim) {
+        const int nb = rl(M, (int)lim - 1);
+        if (nb > best) {
+          const uint32_t j = (uint32_t)__ffsll((long long)__ballot(lane < lim && P == nb)) - 1u;
+          if (dir == 0) bestb2 = b2 + 1 + j; else bestb1 = b1 - 1 - j;
+          best = nb;
+        }
+      }
+      if (sm) break;
+      score = rl(P, (int)n - 1);
+      if (dir == 0) { a2 += n; b2 += n; } else { a1 -= n; b1 -= n; }
+      rem -= n;
+    }
+  }
+  const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
+  const uint32_t Alo = apos - (bpos - bestb1);
+  oAlo = Alo; oBlo = Blo; oLen = Len; oBest = best;
+  return Len >= MinLength && best >= db.minscore2 && is_global_hsp(Alo, Blo, LA, LB);
+}
+
 // One seed of UngappedBlast (ungappedblast.cpp:62-180): seed score, x-drop extension right then
 // left, acceptance test.  nt: byte-SWAR - a run of matching letters is consumed per step (a match
 // always raises the score, so inside a run the best is the run's end and the x-drop test cannot
@@ -540,15 +607,33 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       const uint32_t me = idx + lane;
       bool ok = false;
       uint32_t rAlo = 0, rBlo = 0, rLen = 0; int rBest = 0;
-      if (me < count) {
-        const uint32_t sd = c.seeds[me];
-        ok = extend_seed<NT>(c, db, m2, mm2, sd & 0xffffu, sd >> 16, MinLength, rAlo, rBlo, rLen, rBest);
+      uint32_t sd = 0;
+      if (me < count) sd = c.seeds[me];
+      bool first_done = false, first_ok = false;
+      uint32_t uAlo = 0, uBlo = 0, uLen = 0; int uBest = 0;
+      if (!NT) {
+        // a round whose first seed shares its diagonal with many others (a homologous pair): that seed is extended by the whole
+        // wave; accepted, it is the round's winner whatever the others give (first in list order); rejected, the round goes on without it
+        const uint32_t sd0 = (uint32_t)rl((int)sd, 0);
+        const int d0 = (int)(sd0 & 0xffffu) - (int)(sd0 >> 16);
+        const bool same = me < count && (int)(sd & 0xffffu) - (int)(sd >> 16) == d0;
+        if (__popcll(__ballot(same)) >= 8) {
+          first_ok = extend_seed_coop(c, db, sd0 & 0xffffu, sd0 >> 16, MinLength, uAlo, uBlo, uLen, uBest);
+          first_done = true;
+        }
       }
-      const uint64_t m = __ballot(ok);
-      if (!m) { idx += 64; continue; }
-      const int f = __ffsll((long long)m) - 1;
-      const uint32_t Alo = rl((int)rAlo, f), Blo = rl((int)rBlo, f), Len = rl((int)rLen, f);
-      const int Best = rl(rBest, f);
+      int f = 0;
+      uint32_t Alo, Blo, Len; int Best;
+      if (first_ok) { Alo = uAlo; Blo = uBlo; Len = uLen; Best = uBest; }
+      else {
+        if (me < count && !(first_done && lane == 0))
+          ok = extend_seed<NT>(c, db, m2, mm2, sd & 0xffffu, sd >> 16, MinLength, rAlo, rBlo, rLen, rBest);
+        const uint64_t m = __ballot(ok);
+        if (!m) { idx += 64; continue; }
+        f = __ffsll((long long)m) - 1;
+        Alo = rl((int)rAlo, f); Blo = rl((int)rBlo, f); Len = rl((int)rLen, f);
+        Best = rl(rBest, f);
+      }
       if (nh < c.hsp_cap) {
         if (lane == 0) { c.hsps[nh].Loi = Alo; c.hsps[nh].Loj = Blo; c.hsps[nh].Len = Len; c.hsps[nh].Score2 = Best; }
         ++nh;

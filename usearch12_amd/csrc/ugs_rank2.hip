@@ -44,7 +44,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define R2_SCAP 128u            // records of one partition the grouping handles (two register batches)
+#ifndef R2_HB_BITS
 #define R2_HB_BITS 2048u        // bits of each of the two hash filters
+#endif
 #define R2_KEY_INF 0xffffffffu
 #ifndef UGS_R2_DEPTH
 #define UGS_R2_DEPTH 4          // ring slots: posting chunks in flight per wave (3 behind the one being counted)
@@ -669,33 +671,50 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         n_stg = 0;
         if (n == 0) return;
         if (n > R2_SCAP) { bad = true; return; }
+        if (n == 1u) {
+          // the common partition: one record = one count-2 target (no grouping; the running totals are bumped in place)
+          const uint32_t rec1 = s_stg[0], row1 = (rec1 >> 24) & 63u;
+          if (s_cum[row1] < K) {
+            if (nk < kcap) {
+              if (lane == 0) s_kl[nk] = ((uint64_t)253u << 32) | rec1;
+              if (lane == row1) s_c2[lane] += 1u;
+              if (lane >= row1) s_cum[lane] += 1u;
+              ++nk;
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else bad = true;
+          }
+          return;
+        }
+        const bool two = n > 64u;                                          // (a second register batch of records: rare)
         uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+          act[b] = false; rec[b] = 0; t[b] = 0; row[b] = 0; wofs[b] = 0; hbit[b] = 0; cnt[b] = 2; drop[b] = false; cumv[b] = 0; fl[b] = false;
+          if (b == 1 && !two) continue;
           const uint32_t i = (uint32_t)b * 64u + lane;
           act[b] = i < n;
           rec[b] = act[b] ? s_stg[i] : 0u;
           t[b] = rec[b] & 0xffffffu; row[b] = rec[b] >> 24;
           const uint32_t h = (t[b] ^ (t[b] >> 11)) & (R2G_HB_BITS - 1u);
           wofs[b] = h >> 5; hbit[b] = 1u << (h & 31u);
-          cnt[b] = 2; drop[b] = false;
           cumv[b] = act[b] ? s_cum[row[b] & 63u] : 0u;
         }
-        uint32_t olda[2];
+        uint32_t olda[2] = {0, 0};
 #pragma unroll
-        for (int b = 0; b < 2; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u; }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int b = 0; b < 2; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; } }
         // a target's records: count = records + 1, first row = the lowest row a record carries; the representative is the FIRST
         // record (lowest index) among those with that lowest row (several records of a chunk may carry the same row)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
+          if (bb == 1 && !two) continue;
           uint64_t m = __ballot(fl[bb]);
           while (m) {
             const int L = __ffsll((long long)m) - 1;
@@ -705,6 +724,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             uint32_t nsame = 0, better = 0;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
+              if (b == 1 && !two) continue;
               const bool sb = act[b] && t[b] == tL;
               const uint32_t ib = (uint32_t)b * 64u + lane;
               nsame += (uint32_t)__popcll(__ballot(sb));
@@ -716,6 +736,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         uint32_t nk_new = nk;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+          if (b == 1 && !two) continue;
           const uint64_t key = ((uint64_t)(255u - cnt[b]) << 32) | rec[b];
           const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
           const uint64_t m = __ballot(keep);
