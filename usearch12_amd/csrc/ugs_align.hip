@@ -375,14 +375,20 @@ __device__ __forceinline__ int coop_incl_max(int v)
 // running score and M_i the running maximum (the earlier best included), the walk stops at the first i with M_i - P_i > X (when P_i
 // exceeds the earlier maximum the difference is 0), the best is M at the last consumed position and its position the first that
 // attains it.  Used for the first seed of a round whose diagonal holds many of the round's seeds (a homologous pair: all those lanes
-// would walk the same hundreds of letters eight at a time); same outputs as extend_seed, wave-uniform.
-__device__ __forceinline__ bool extend_seed_coop(const WaveCtx &c, const UgsDbView &db, uint32_t apos, uint32_t bpos, uint32_t MinLength,
+// would walk the same hundreds of letters, eight (aa) or a run of matches (nt) at a time); same outputs as extend_seed, wave-uniform.
+template <bool NT>
+__device__ __forceinline__ bool extend_seed_coop(const WaveCtx &c, const UgsDbView &db, int m2, int mm2, uint32_t apos, uint32_t bpos, uint32_t MinLength,
                                                  uint32_t &oAlo, uint32_t &oBlo, uint32_t &oLen, int &oBest)
 {
   const int w = db.hsp_w, X = db.xdrop2;
   const uint32_t LA = c.LA, LB = c.LB, lane = (uint32_t)c.lane;
+  const bool inv_any = NT && (c.a_inv || c.b_inv);
   int score = 0;
-  for (int k = 0; k < w; ++k) score += (int)c.s_sub2[((uint32_t)c.As[apos + k] << 5) | c.Bs[bpos + k]];
+  if (NT) {
+    const uint32_t ninv = inv_any ? (uint32_t)__popc((nt_word(c.Ai, apos, w) | nt_word(c.Bi, bpos, w))) : 0u;      // (as extend_seed)
+    score = ((int)w - (int)ninv) * m2;
+  } else
+    for (int k = 0; k < w; ++k) score += (int)c.s_sub2[((uint32_t)c.As[apos + k] << 5) | c.Bs[bpos + k]];
   int best = score;
   uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
@@ -395,8 +401,13 @@ __device__ __forceinline__ bool extend_seed_coop(const WaveCtx &c, const UgsDbVi
       const bool valid = lane < n;
       int sc = 0;
       if (valid) {
-        const uint32_t av = dir == 0 ? c.As[a2 + 1 + lane] : c.As[a1 - 1 - lane], bv = dir == 0 ? c.Bs[b2 + 1 + lane] : c.Bs[b1 - 1 - lane];
-        sc = (int)c.s_sub2[(av << 5) | bv];
+        const uint32_t pa = dir == 0 ? a2 + 1 + lane : a1 - 1 - lane, pb = dir == 0 ? b2 + 1 + lane : b1 - 1 - lane;
+        if (NT) {
+          const uint32_t la = (c.A2[pa >> 4] >> ((pa & 15u) * 2u)) & 3u, lb = (c.B2[pb >> 4] >> ((pb & 15u) * 2u)) & 3u;
+          sc = la == lb ? m2 : mm2;
+          if (inv_any && (((c.Ai[pa >> 4] >> ((pa & 15u) * 2u)) | (c.Bi[pb >> 4] >> ((pb & 15u) * 2u))) & 1u)) sc = 0;   // a pair with a non-ACGT letter scores 0 (setnucmx.cpp)
+        } else
+          sc = (int)c.s_sub2[((uint32_t)c.As[pa] << 5) | c.Bs[pb]];
       }
       const int P = score + (int)wave_incl_sum_u32((uint32_t)sc);
       int M = coop_incl_max(valid ? P : (int)0x80000000);
@@ -611,14 +622,14 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       if (me < count) sd = c.seeds[me];
       bool first_done = false, first_ok = false;
       uint32_t uAlo = 0, uBlo = 0, uLen = 0; int uBest = 0;
-      if (!NT) {
+      {
         // a round whose first seed shares its diagonal with many others (a homologous pair): that seed is extended by the whole
         // wave; accepted, it is the round's winner whatever the others give (first in list order); rejected, the round goes on without it
         const uint32_t sd0 = (uint32_t)rl((int)sd, 0);
         const int d0 = (int)(sd0 & 0xffffu) - (int)(sd0 >> 16);
         const bool same = me < count && (int)(sd & 0xffffu) - (int)(sd >> 16) == d0;
         if (__popcll(__ballot(same)) >= 8) {
-          first_ok = extend_seed_coop(c, db, sd0 & 0xffffu, sd0 >> 16, MinLength, uAlo, uBlo, uLen, uBest);
+          first_ok = extend_seed_coop<NT>(c, db, m2, mm2, sd0 & 0xffffu, sd0 >> 16, MinLength, uAlo, uBlo, uLen, uBest);
           first_done = true;
         }
       }
