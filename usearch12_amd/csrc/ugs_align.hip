@@ -533,6 +533,9 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
     uint32_t count = 0, idx = 0;
     for (;;) {
       // ---- list seeds until the list is comfortably full or the target is exhausted
+#if UGS_ALIGN_CLOCKS == 4
+      const unsigned long long tb0 = clock64();
+#endif
       if (idx >= count) { idx = 0; count = 0; }
       while (scan < nwB && count + 64 * UGS_MAXREPS <= c.seed_cap) {
         if (NT && c.use_tab && c.bsh == 0 && nwB - scan > 64u) {
@@ -614,6 +617,10 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
       }
       lds_sync();
       if (idx >= count) { if (scan >= nwB) break; else continue; }
+#if UGS_ALIGN_CLOCKS == 4
+      const unsigned long long tb1 = clock64();
+      if (lane == 0) { atomicAdd(&counters[UGS_CTR_T4], tb1 - tb0); atomicAdd(&counters[UGS_CTR_T6], 1ull); atomicAdd(&counters[UGS_CTR_T7], (unsigned long long)((count - idx) < 64u ? (count - idx) : 64u)); }
+#endif
       // ---- extend one round of (up to) 64 seeds
       const uint32_t me = idx + lane;
       bool ok = false;
@@ -640,6 +647,9 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
         if (me < count && !(first_done && lane == 0))
           ok = extend_seed<NT>(c, db, m2, mm2, sd & 0xffffu, sd >> 16, MinLength, rAlo, rBlo, rLen, rBest);
         const uint64_t m = __ballot(ok);
+#if UGS_ALIGN_CLOCKS == 4
+        if (lane == 0) atomicAdd(&counters[UGS_CTR_T5], clock64() - tb1);
+#endif
         if (!m) { idx += 64; continue; }
         f = __ffsll((long long)m) - 1;
         Alo = rl((int)rAlo, f); Blo = rl((int)rBlo, f); Len = rl((int)rLen, f);
@@ -961,6 +971,7 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
 // code (and register allocation) it was tuned with
 // phase clocks (UGS_PHASE_CLOCKS report): reading the clock waits for every outstanding LDS / scalar-memory operation of the wave,
 // four times per pair - compiled in only for tuning builds (-DUGS_ALIGN_CLOCKS=1)
+// (-DUGS_ALIGN_CLOCKS=4: inside ungapped_blast - T4 seed listing, T5 extension rounds, T6 rounds, T7 seeds extended; the per-round atomics slow the kernel several times: ratios only)
 #define ACLK() (UGS_ALIGN_CLOCKS == 1 ? clock64() : 0ull)
 #define ACLK2() (UGS_ALIGN_CLOCKS == 2 ? clock64() : 0ull)      // finer clocks inside the post-HSP part: T4 chain, T5 classes + HSP identity, T6 holes, T7 FillLo + hit
 template <bool PAIR>
