@@ -113,6 +113,7 @@ extern "C" void ugs_comm_destroy(ugs_comm *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();        // (as ugs_db_destroy: nothing in flight when streams go)
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (int k = 0; k < 3; ++k) if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
   if (c->d_my) (void)hipFree(c->d_my);

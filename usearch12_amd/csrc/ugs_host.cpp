@@ -227,6 +227,9 @@ extern "C" void ugs_db_destroy(ugs_db *db)
 {
   if (!db) return;
   (void)hipSetDevice(db->device);
+  // no stream or event is destroyed while anything of this device is in flight (a completion signal is a 64-bit word the runtime
+  // DECREMENTS: DESIGN section 4, "host heap"): hipFree would wait as well, this makes it independent of the order below
+  (void)hipDeviceSynchronize();
   (void)hipFree(db->d_pk);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part); (void)hipFree(db->d_part2);
   (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
@@ -573,6 +576,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
 {
   if (!b) return;
   (void)hipSetDevice(b->db->device);
+  (void)hipDeviceSynchronize();        // (as ugs_db_destroy)
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
   (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer);
