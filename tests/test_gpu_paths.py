@@ -143,6 +143,24 @@ def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g):
     assert a[0] == b[0]
 
 
+def test_gather_kernel_short_protein_queries(aa_small):
+    """queries of 40-70 residues sample <= 15 rows (4-bit counters in k_rank): the gather kernel takes them all the same"""
+    db, _ = aa_small
+    rng = np.random.default_rng(24)
+    rows = db.seqs.reshape(db.n, 300)
+    parts, offs = [], [0]
+    for _ in range(3000):
+        L = int(rng.integers(40, 71)); t = int(rng.integers(0, db.n)); p0 = int(rng.integers(0, 300 - L))
+        parts.append(rows[t, p0:p0 + L]); offs.append(offs[-1] + L)
+    qs = synth.SeqSet(np.concatenate(parts), np.array(offs, dtype=np.uint64), lambda i: "q%d" % i)
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, None, is_nucleo=False, id=0.8)[0]
+    assert (a[1]["rank_kernel"] >> 1) & 0x7f == 4 and b[1]["r2_launched"] == 1 and b[1]["r2_units"] > 0.95 * qs.n
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+
+
 def test_gather_kernel_deferred_units_and_oracle(aa_small):
     """a kept-key list of 8 entries defers the units with hits to the 8-bit counter kernel behind k_rank2g; both against the oracle"""
     db, _ = aa_small

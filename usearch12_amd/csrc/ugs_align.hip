@@ -1086,13 +1086,25 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     bool walk_ended = false;          // the terminator ended the walk (not the end of the list)
     uint32_t nacc = 0, nrej = 0;
     if (ncand) {
+      // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
+      bool planes = c.nt && bv.qpk != nullptr;
+      if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
       for (uint32_t p = lane; p < LA; p += 64) {
         uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
         const uint8_t cl = s_cls[ch];
-        c.A[p] = cl; c.As[p] = s_sc[cl & 31];
+        c.A[p] = cl;
+        if (!planes) c.As[p] = s_sc[cl & 31];
+      }
+      if (planes) {
+        const uint2 *qp = bv.qpk + (uint64_t)unit * bv.qpk_stride;
+        const uint32_t nw = (LA + 15) >> 4;
+        bool any = false;
+        for (uint32_t k = lane; k < nw + 3; k += 64) { const uint2 e = qp[k]; c.A2[k] = e.x; c.Ai[k] = e.y; any = any || e.y != 0u; }
+        if (lane < 2) { c.A2[-1 - lane] = 0; c.Ai[-1 - lane] = 0; }
+        c.a_inv = __ballot(any) != 0;
       }
       wave_sync();
-      if (c.nt) {
+      if (c.nt && !planes) {
         pack_codes(c.As, LA, c.A2, c.Ai, lane);
         bool any = false;
         for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;

@@ -586,6 +586,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
         bv2.nq = npu; bv2.nstrand = 1; bv2.K = Kp;
         bv2.cand = (uint32_t *)d_pcand.p; bv2.cand_n = (uint32_t *)d_pcandn.p; bv2.hits = (ugs_hit *)d_phits.p; bv2.hit_n = (uint32_t *)d_phitn.p;
         bv2.unit_map = (const uint32_t *)d_pmap.p; bv2.walk_n = nullptr; bv2.cand_key = nullptr; bv2.cl_ev = nullptr; bv2.cl_info = nullptr;
+        bv2.qpk = nullptr;               // (the planes k_rank_setup packed are indexed by the search's units, not by this stage's pairs)
         const unsigned long long fr = frozen_runs;
         HIPCHK(hipMemcpyAsync(b->d_cigar_used, &fr, 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(b->d_ctr + UGS_CTR_NEXT_UNIT, 0, 8, st));

@@ -82,6 +82,9 @@ struct UgsBatchView {
   // sampled index rows per unit, written by k_rank_setup and read by k_rank
   uint32_t *unit_ns;         // [units]
   uint32_t *unit_slots;      // [units * ns_max]
+  // nt: the unit's letters (strand applied) packed 2 bits each + the "other letter" plane, written once by k_rank_setup, read by k_align
+  // (BASELINE north_star "query batches packed 2-bit"): word k of unit u at qpk[u * qpk_stride + k] = {letters, other-letter bits}; null = k_align packs
+  uint2 *qpk; uint32_t qpk_stride;
   // ranking scratch: per resident workgroup
   uint64_t *emit_buf;        // [rank_wgs * emit_cap]
   uint64_t emit_cap;

@@ -277,6 +277,7 @@ UgsTune ugs_tune_read()
   t.r2_g = env_int("UGS_R2_G", 8192, 65536, 0); if (t.r2_g % 8192) t.r2_g = 0;
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
+  t.no_qpk = getenv("UGS_NO_QPK") != nullptr;
   return t;
 }
 
@@ -579,7 +580,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipDeviceSynchronize();        // (as ugs_db_destroy)
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
-  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer);
+  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer); (void)hipFree(b->d_qpk);
   (void)hipFree(b->d_qkey); (void)hipFree(b->d_qsize);
   (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
@@ -775,12 +776,26 @@ static int plan_launch(ugs_batch *b)
       b->unit_slots_alloc = need;
     }
   }
+  {   // packed query planes (nt searches; not cluster_fast, whose pair stage runs k_align over other views of the batch): 8 bytes per 16 letters
+    b->qpk_stride = 0;
+    const uint32_t stride = (b->max_qlen + 15u) / 16u + 4u;
+    const uint64_t need = units * (uint64_t)stride * 8u;
+    if (p.is_nucleo && !p.local && !db->tune.no_qpk && need <= (1ull << 30)) {
+      if (!b->d_qpk || need > b->qpk_alloc) {
+        if (b->d_qpk) HIPCHK(hipFree(b->d_qpk));
+        b->d_qpk = nullptr;
+        HIPCHK(hipMalloc(&b->d_qpk, (size_t)std::max<uint64_t>(need, 8)));
+        b->qpk_alloc = need;
+      }
+      b->qpk_stride = stride;
+    }
+  }
   // ---- the bitmap ranking kernel (ugs_rank2.hip) where the index and the launch allow it: dense Big-path index (part2), at most 15
   // sampled rows for the typical query (4-bit count field; a longer query is deferred per unit), uniform rows.  Units outside its
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
   b->r2.gather = 0;
-  if (db->v.part2 && db->r2_gather && bits == 8 && ns_typ <= 63 && !b->rl.longrows && b->K <= 64) {
+  if (db->v.part2 && db->r2_gather && bits <= 8 && ns_typ <= 63 && !b->rl.longrows && b->K <= 64) {
     // (a sparse index gives a unit tens of count-2 targets, not hundreds: a kept-key list of 4 K, and the eleventh wave per CU that buys)
     const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(116u, 4u * b->K - 12u);
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
@@ -896,6 +911,7 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   v.qseqs = b->d_qseqs; v.qoffs = b->d_qoffs; v.nq = nq; v.nstrand = b->nstrand; v.K = b->K; v.max_qlen = maxl;
   v.cand = b->d_cand; v.cand_cnt = b->d_cand_cnt; v.cand_n = b->d_cand_n; v.emit_buf = b->d_emit;
   v.unit_ns = b->d_unit_ns; v.unit_slots = b->d_unit_slots; v.defer_list = b->d_defer; v.use_defer = 0;
+  v.qpk = b->qpk_stride ? (uint2 *)b->d_qpk : nullptr; v.qpk_stride = b->qpk_stride;
   v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
   v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
   b->have_qkey = b->have_qsize = false; b->v.q_key = nullptr; b->v.q_size = nullptr;     // keys belong to one uploaded batch

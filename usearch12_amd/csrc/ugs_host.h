@@ -21,6 +21,7 @@ struct UgsTune {
   int phase_clocks;       // UGS_PHASE_CLOCKS    print the kernels' phase clocks with the stats
   int wide_offsets;       // UGS_WIDE_OFFSETS    force the 64-bit-offset instantiations of the Big-path 4-bit ranking kernels
   int rank2;              // UGS_RANK2           -1 unset (= on where eligible), 0 off, 1 on
+  bool no_qpk;                  // UGS_NO_QPK=1               k_align packs the query letters itself (no planes from k_rank_setup)
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
 };
 UgsTune ugs_tune_read();
@@ -63,6 +64,7 @@ struct ugs_batch {
   uint32_t *d_cand, *d_cand_cnt, *d_cand_n, *d_hit_n, *d_cigar, *d_runs;
   ugs_hit *d_hits; uint64_t *d_emit; uint8_t *d_tb;
   uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
+  void *d_qpk; uint64_t qpk_alloc; uint32_t qpk_stride;          // packed query planes (nt), see UgsBatchView::qpk
   uint32_t *d_defer;                // units the bitmap ranking kernel hands on to k_rank
   UgsRank2Params r2; int r2_grid;   // its launch (r2_grid == 0: not used for this batch)
   // usearch_local

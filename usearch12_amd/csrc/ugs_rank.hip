@@ -1148,14 +1148,18 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
   const uint32_t maxq = (bv.max_qlen + 15u) & ~15u;
-  uint8_t *s_udb = smem;
-  unsigned char *wb = smem + 256 + (size_t)wave * ((size_t)maxq * 8 + 2048);
+  uint8_t *s_udb = smem, *s_sc = smem + 256;                       // letter -> index letter / alignment score code (k_align's s_sc over its class table)
+  unsigned char *wb = smem + 512 + (size_t)wave * ((size_t)maxq * 8 + 2048);
   uint32_t *s_words = (uint32_t *)wb;
   uint8_t *s_q = wb + (size_t)maxq * 4, *s_first = s_q + maxq;
   uint16_t *s_dup = (uint16_t *)(s_first + maxq);                 // positions whose word may have occurred before
   uint32_t *s_hc = (uint32_t *)(wb + (size_t)maxq * 8);            // hash counts
   const UgsTables *tab = db.tab;
-  for (int k = tid; k < 256; k += blockDim.x) s_udb[k] = tab->udb_letter[k];
+  for (int k = tid; k < 256; k += blockDim.x) {
+    s_udb[k] = tab->udb_letter[k];
+    const uint32_t cl = tab->cls[k] & 31u;
+    s_sc[k] = (cl < 26u && tab->udb_letter['A' + cl] != 0xff) ? tab->hsp_letter['A' + cl] : 4;
+  }
   __syncthreads();
   const uint32_t units = bv.nq * bv.nstrand;
   const int W = db.word_len;
@@ -1178,6 +1182,28 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
     // ---- query letters (reverse-complemented for strand 1: seqinfo.cpp:292-323)
     for (uint32_t p = lane; p < L; p += 64) s_q[p] = strand == 0 ? bv.qseqs[qo + p] : tab->comp[bv.qseqs[qo + (L - 1 - p)]];
     __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    if (bv.qpk) {
+      // ---- the letters packed for the alignment stage: word k = letters 16 k .. 16 k + 15, 2 bits each (score code & 3), and in the same
+      // layout one bit per letter that is not A/C/G/T/U (pack_codes of ugs_align.hip); zero behind the last letter, three zero words more
+      uint2 *qp = bv.qpk + (uint64_t)unit * bv.qpk_stride;
+      const uint32_t nw = (L + 15) >> 4;
+      for (uint32_t k = lane; k < bv.qpk_stride; k += 64) {
+        uint32_t v = 0, iv = 0;
+        if (k < nw) {
+          const uint4 d4 = *(const uint4 *)(s_q + 16 * k);
+          const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t pos = 16u * k + 4u * (uint32_t)q + (uint32_t)e;
+              const uint32_t sc = pos < L ? (uint32_t)s_sc[(d[q] >> (8 * e)) & 0xffu] : 0u;
+              v |= (sc & 3u) << (2 * (4 * q + e)); iv |= (sc >> 2) << (2 * (4 * q + e));
+            }
+        }
+        qp[k] = make_uint2(v, iv);
+      }
+    }
     for (uint32_t p = lane; p < ((L + 3) & ~3u); p += 64) {
       uint32_t w = UGS_BAD_WORD;
       if (p + W <= L) {
@@ -1931,7 +1957,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   dim3 grid(L.grid), block(64 * L.wpb);
   {   // stage 1: sampled rows of every unit (one wavefront per unit, as many workgroups as fit)
     const uint32_t units = b.nq * b.nstrand, maxq = (b.max_qlen + 15u) & ~15u;
-    const size_t slds = 256 + 4 * ((size_t)maxq * 8 + 2048);
+    const size_t slds = 512 + 4 * ((size_t)maxq * 8 + 2048);
     if (slds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_rank_setup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
     int per_cu = 0, ncu = 0, dev = 0;
     HIPCHK(hipGetDevice(&dev));
