@@ -282,6 +282,7 @@ int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
 /*
  * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the
  * environment ONCE per database handle (at ugs_db_create, never inside a search call) and default to "unset":
+ *   UGS_QPK=1               nt query letters are packed once per unit by the setup kernel (2 bits + other-letter plane) for k_align
  *   UGS_NO_PACKED=1         k_align fetches every target from the byte array instead of the packed letters
  *   UGS_LONGROWS=0|1        force the long-row ranking instantiations off / on
  *   UGS_GSIZE=n UGS_GSHIFT=k  partition size of k_rank (targets, a multiple of 64 / a power of two)

@@ -144,13 +144,13 @@ def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g):
 
 
 def test_gather_kernel_short_protein_queries(aa_small):
-    """queries of 40-70 residues sample <= 15 rows (4-bit counters in k_rank): the gather kernel takes them all the same"""
+    """queries of 12-19 residues have <= 15 words (a 4-bit launch of k_rank): the gather kernel takes them all the same"""
     db, _ = aa_small
     rng = np.random.default_rng(24)
     rows = db.seqs.reshape(db.n, 300)
     parts, offs = [], [0]
     for _ in range(3000):
-        L = int(rng.integers(40, 71)); t = int(rng.integers(0, db.n)); p0 = int(rng.integers(0, 300 - L))
+        L = int(rng.integers(12, 20)); t = int(rng.integers(0, db.n)); p0 = int(rng.integers(0, 300 - L))
         parts.append(rows[t, p0:p0 + L]); offs.append(offs[-1] + L)
     qs = synth.SeqSet(np.concatenate(parts), np.array(offs, dtype=np.uint64), lambda i: "q%d" % i)
     a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=False, id=0.8)[0]
@@ -241,6 +241,21 @@ def test_small_path_short_queries_with_long_row_kernel():
         on, oc, occ = odb.rank(qs.seqs[qi * L:(qi + 1) * L], cap=cand.shape[1])
         m = min(on, cand.shape[1])
         assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
+
+
+def test_packed_query_planes_from_the_setup_kernel(c2_small):
+    """UGS_QPK=1: k_rank_setup packs every unit's letters (2 bits + other-letter plane, strand applied) and k_align reads the planes
+    instead of packing per unit - same hits, both strands, wildcards in the queries"""
+    db, _ = c2_small
+    qs = synth.make_queries(17, db, 3000, 250)
+    q = qs.seqs.copy()
+    rng = np.random.default_rng(17)
+    q[rng.integers(0, len(q), size=400)] = ord("N")
+    q[rng.integers(0, len(q), size=200)] = ord("R")
+    qs = synth.SeqSet(q, qs.offs, lambda i: "q%d" % i)
+    a = _search(db, qs, None, is_nucleo=True, id=0.9, strand_both=1)[0]
+    b = _search(db, qs, {"UGS_QPK": "1"}, is_nucleo=True, id=0.9, strand_both=1)[0]
+    assert a[0] == b[0]
 
 
 def test_wide_offset_instantiations_of_k_rank(c2_small):

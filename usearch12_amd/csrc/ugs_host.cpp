@@ -277,7 +277,7 @@ UgsTune ugs_tune_read()
   t.r2_g = env_int("UGS_R2_G", 8192, 65536, 0); if (t.r2_g % 8192) t.r2_g = 0;
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
-  t.no_qpk = getenv("UGS_NO_QPK") != nullptr;
+  t.qpk = getenv("UGS_QPK") != nullptr;
   return t;
 }
 
@@ -776,11 +776,12 @@ static int plan_launch(ugs_batch *b)
       b->unit_slots_alloc = need;
     }
   }
-  {   // packed query planes (nt searches; not cluster_fast, whose pair stage runs k_align over other views of the batch): 8 bytes per 16 letters
+  {   // packed query planes (nt searches): 8 bytes per 16 letters, written by k_rank_setup, read by k_align.  OFF unless UGS_QPK=1: measured on
+      // C2 it saves k_align 0.06 ms per 1 M queries and costs k_rank_setup 0.25 ms (DESIGN section 3, K-align)
     b->qpk_stride = 0;
     const uint32_t stride = (b->max_qlen + 15u) / 16u + 4u;
     const uint64_t need = units * (uint64_t)stride * 8u;
-    if (p.is_nucleo && !p.local && !db->tune.no_qpk && need <= (1ull << 30)) {
+    if (p.is_nucleo && !p.local && db->tune.qpk && need <= (1ull << 30)) {
       if (!b->d_qpk || need > b->qpk_alloc) {
         if (b->d_qpk) HIPCHK(hipFree(b->d_qpk));
         b->d_qpk = nullptr;

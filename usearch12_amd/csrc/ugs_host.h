@@ -21,7 +21,7 @@ struct UgsTune {
   int phase_clocks;       // UGS_PHASE_CLOCKS    print the kernels' phase clocks with the stats
   int wide_offsets;       // UGS_WIDE_OFFSETS    force the 64-bit-offset instantiations of the Big-path 4-bit ranking kernels
   int rank2;              // UGS_RANK2           -1 unset (= on where eligible), 0 off, 1 on
-  bool no_qpk;                  // UGS_NO_QPK=1               k_align packs the query letters itself (no planes from k_rank_setup)
+  bool qpk;                     // UGS_QPK=1                  nt query letters packed once by k_rank_setup for k_align (off: k_align packs them per unit; measured slower on)
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
 };
 UgsTune ugs_tune_read();
