@@ -271,7 +271,8 @@ int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
  * reached by an oracle-compared test).  out[0] = units ranked by the bitmap kernel (ugs_rank2.hip), out[1] = units it deferred to the
  * general kernel, out[2] = the general kernel's instantiation (big | counter bits << 1 | fast8 << 8 | longrows << 9 | wide offsets << 10), out[3] = 1 if
  * the bitmap kernel was launched; with n >= 6 also out[4] / out[5] = microseconds of the bitmap kernel / of the general kernel behind it
- * (HIP events on the handle's stream).  n >= 4. */
+ * (HIP events on the handle's stream); with n >= 7 also out[6] = candidate pairs k_align rejected through its group filter (pairs without
+ * an HSP, tested four at a time).  n >= 4. */
 int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
 /* Diagnostic: *seen = the ranking kernels this process has launched so far, *compiled = the ones the library holds, one bit each
  * (bits 0-4: Big path - 4-bit counters, its long-row twin, 8/16-bit flattened (sparse index), 8/16-bit dense, 8/16-bit dense + long
@@ -283,6 +284,7 @@ int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
  * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the
  * environment ONCE per database handle (at ugs_db_create, never inside a search call) and default to "unset":
  *   UGS_QPK=1               nt query letters are packed once per unit by the setup kernel (2 bits + other-letter plane) for k_align
+ *   UGS_ALIGN_GROUP=n       k_align tests the candidates of a unit four at a time once n of them were rejected (default 1; 0 = never)
  *   UGS_NO_PACKED=1         k_align fetches every target from the byte array instead of the packed letters
  *   UGS_LONGROWS=0|1        force the long-row ranking instantiations off / on
  *   UGS_GSIZE=n UGS_GSHIFT=k  partition size of k_rank (targets, a multiple of 64 / a power of two)

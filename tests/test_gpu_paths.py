@@ -268,3 +268,55 @@ def test_wide_offset_instantiations_of_k_rank(c2_small):
     for x, y, z in zip(a[2], b[2], c[2]):
         assert np.array_equal(x, y) and np.array_equal(x, z)
     assert a[0] == b[0] == c[0]
+
+
+def _hits_of(db, qs, env, **kw):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k); os.environ[k] = v
+    try:
+        gdb = capi.UgsDB(capi.params(**kw), db.seqs, db.offs, device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs)
+    bat.search(); bat.sync()
+    h, nh, pool = bat.fetch()
+    st = bat.stats()
+    return h, nh, pool, st, bat.kernel_hits()
+
+
+@pytest.mark.parametrize("kw", [dict(id=0.97), dict(id=0.99, max_accepts=3, max_rejects=8, strand_both=1), dict(id=0.9, max_rejects=5)])
+def test_group_filter_of_k_align_equals_the_serial_walk(kw):
+    """k_align tests the candidates of a unit four at a time for "no HSP at all" once the unit has rejected one (UGS_ALIGN_GROUP):
+    same hit tables, same pair and target-letter counts as the walk that takes every pair alone - families (group members WITH an
+    HSP, which go back to the full path), wildcards in targets and queries, targets shorter than two HSP words and longer than 1024"""
+    db, qs = synth.make_hard(91, 160, 14, 2500, lmin=40, lmax=1300)
+    rng = np.random.default_rng(91)
+    d = db.seqs.copy()
+    for t in rng.integers(0, db.n, size=300):                       # wildcards in 300 targets
+        d[int(db.offs[t]) + int(rng.integers(0, int(db.offs[t + 1] - db.offs[t])))] = ord("N")
+    lens = np.diff(db.offs.astype(np.int64))
+    short = np.array([7, 9, 10, 12], dtype=np.int64)                # around 2 x the HSP word length
+    seqs = np.concatenate([d, synth._random_letters(rng, int(short.sum()), synth.NT)])
+    offs = np.concatenate([[0], np.cumsum(np.concatenate([lens, short]))]).astype(np.uint64)
+    db = synth.SeqSet(seqs, offs, lambda i: "t%d" % i)
+    rq = synth.make_db(92, 400, 250)                                # + random queries: every candidate a reject
+    qseqs = np.concatenate([qs.seqs, rq.seqs])
+    qoffs = np.concatenate([qs.offs, rq.offs[1:] + qs.offs[-1]]).astype(np.uint64)
+    qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
+    ref = _hits_of(db, qs, {"UGS_ALIGN_GROUP": "0"}, is_nucleo=True, **kw)
+    assert ref[4]["group_rejects"] == 0 and len(ref[0]) > 200
+    for g in (None, "2", "5"):
+        got = _hits_of(db, qs, None if g is None else {"UGS_ALIGN_GROUP": g}, is_nucleo=True, **kw)
+        assert got[4]["group_rejects"] > 0, g
+        assert np.array_equal(got[1], ref[1]), g
+        for f in ("query", "target", "ids", "mism", "gaps_int", "aln_len", "opens", "qlo", "qhi", "tlo", "thi", "ql", "tl", "strand", "cigar_len", "cols"):
+            assert np.array_equal(got[0][f], ref[0][f]), (g, f)
+        for a, b in zip(got[0][:2000], ref[0][:2000]):                  # (the run pool is handed out in the order the waves finish)
+            assert np.array_equal(got[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])], ref[2][int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])]), g
+        assert got[3]["pairs_aligned"] == ref[3]["pairs_aligned"] and got[3]["target_letters"] == ref[3]["target_letters"], g

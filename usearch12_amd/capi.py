@@ -335,12 +335,12 @@ class UgsBatch:
 
     def kernel_hits(self):
         """which ranking code the last synced search ran: dict(r2_units, deferred, rank_kernel, r2_launched)"""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 7)()
         f = lib().ugs_debug_kernel_hits
         f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]; f.restype = C.c_int
-        _chk(f(self.h, out, 6))
+        _chk(f(self.h, out, 7))
         return {"r2_units": int(out[0]), "deferred": int(out[1]), "rank_kernel": int(out[2]), "r2_launched": int(out[3]),
-                "ms_rank2": out[4] / 1000.0, "ms_rank_deferred": out[5] / 1000.0}
+                "ms_rank2": out[4] / 1000.0, "ms_rank_deferred": out[5] / 1000.0, "group_rejects": int(out[6])}
 
     def candidates(self):
         p = self.db.p

@@ -300,7 +300,7 @@ __device__ __forceinline__ uint64_t read32l(const uint32_t *w, int pos)
 // non-matching pair to the next (a run of matches is consumed at once: the score rises through it, so its best is its end
 // and the x-drop test cannot fire inside it).  Same results as the byte-wise walk of ungappedblast.cpp:91-178.
 template <bool INV>          // INV = false: neither sequence holds a non-ACGTU letter, the "other letter" planes are not read
-__device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int mm2, int X, uint32_t LA, uint32_t LB,
+__device__ __forceinline__ void extend_nt_packed(const uint32_t *A2, const uint32_t *Ai, const uint32_t *B2, const uint32_t *Bi, int m2, int mm2, int X, uint32_t LA, uint32_t LB,
                                                  uint32_t &a1, uint32_t &b1, uint32_t &a2, uint32_t &b2, int &score, int &best,
                                                  uint32_t &bestb1, uint32_t &bestb2)
 {
@@ -310,8 +310,8 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
     bool stop = false;
     while (rem && !stop) {
       const uint32_t n = rem < 32 ? rem : 32;
-      const uint64_t x = read32l(c.A2, (int)a2 + 1) ^ read32l(c.B2, (int)b2 + 1);
-      const uint64_t inv = INV ? (read32l(c.Ai, (int)a2 + 1) | read32l(c.Bi, (int)b2 + 1)) : 0ull;
+      const uint64_t x = read32l(A2, (int)a2 + 1) ^ read32l(B2, (int)b2 + 1);
+      const uint64_t inv = INV ? (read32l(Ai, (int)a2 + 1) | read32l(Bi, (int)b2 + 1)) : 0ull;
       uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
       if (n < 32) bad |= 1ull << (2 * n);                          // sentinel behind the last pair of the block
       uint32_t pos = 0;
@@ -335,8 +335,8 @@ __device__ __forceinline__ void extend_nt_packed(const WaveCtx &c, int m2, int m
     bool stop = false;
     while (rem && !stop) {
       const uint32_t n = rem < 32 ? rem : 32;
-      const uint64_t x = read32l(c.A2, (int)a1 - 32) ^ read32l(c.B2, (int)b1 - 32);     // pair 31 = position -1
-      const uint64_t inv = INV ? (read32l(c.Ai, (int)a1 - 32) | read32l(c.Bi, (int)b1 - 32)) : 0ull;
+      const uint64_t x = read32l(A2, (int)a1 - 32) ^ read32l(B2, (int)b1 - 32);     // pair 31 = position -1
+      const uint64_t inv = INV ? (read32l(Ai, (int)a1 - 32) | read32l(Bi, (int)b1 - 32)) : 0ull;
       uint64_t bad = ((x | (x >> 1)) | inv) & EVEN;
       if (n < 32) bad |= 1ull << (2 * (31 - n));                   // sentinel in front of the first pair of the block
       uint32_t pos = 0;                                            // pairs consumed, from the top
@@ -458,8 +458,8 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
   if (NT) {
-    if (c.a_inv || c.b_inv) extend_nt_packed<true>(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
-    else extend_nt_packed<false>(c, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+    if (c.a_inv || c.b_inv) extend_nt_packed<true>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+    else extend_nt_packed<false>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
   } else {
     {
       uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
@@ -671,6 +671,151 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
   }
   if (lane == 0) c.ws->nhsp = nh;
   lds_sync();
+}
+
+// The quick test of a GROUP of candidates (nt, packed targets): does UngappedBlast find any HSP at all?  A query without a relative in the
+// database walks max_rejects random candidates; each of them lists ~ 15 seeds inside the diagonal window and none extends to an HSP, so a
+// pair on its own keeps a quarter of the wave busy for one extension round and pays the latency of its target fetch alone.  Whether a
+// pair has an HSP does not depend on the order of its seeds (ungappedblast.cpp:62-180: a seed that is not accepted leaves no trace, the
+// BPos = Bhi + 1 skip only ever follows an accepted one), so the seeds of up to UGS_GROUP targets are listed into one list (tagged with
+// the member) and extended together, the targets' letters fetched together.  A member without an accepted seed is what the serial path
+// calls a pair with no HSPs (globalalignmem.cpp:161-166, FailIfNoHSPs): a reject.  Any other member - an accepted seed, a letter that is
+// not A/C/G/T/U, a length outside 2w .. 1024, a full seed list - is reported back ("maybe") and takes the full path, which decides.
+// The members' 2-bit planes live in the target's class / score-code byte arrays (c.B, c.Bs), which hold nothing between two pairs.
+#define UGS_GROUP 4
+struct GroupArgs {           // (by value: the function is not inlined, the wave context stays in the caller's registers)
+  const uint2 *pk; const uint32_t *A2; unsigned char *B, *Bs; const uint16_t *wstart; const uint32_t *qsort; uint32_t *seeds;
+  uint32_t seed_cap, LA, MinLength, gwt, nB; int w, X, m2, mm2, minscore2;
+  unsigned long long *ctr;    // (-DUGS_ALIGN_CLOCKS=5, inlined builds only: the wave's accumulators - T4 fetch + planes, T5 seed listing, T6 extension rounds, T7 groups << 32 | seeds)
+};
+#ifndef UGS_GROUP_INLINE
+#define UGS_GROUP_INLINE __forceinline__      // (as a function of its own, -DUGS_GROUP_INLINE=__noinline__, the call costs the candidate loop 2.5 ms per 1 M C2 queries)
+#endif
+__device__ UGS_GROUP_INLINE uint32_t group_filter(const GroupArgs c, uint32_t k, uint32_t n, uint64_t cto, uint32_t clen)
+{
+  const int lane = (int)(threadIdx.x & 63), w = c.w, X = c.X;
+  const int m2 = c.m2, mm2 = c.mm2;
+  const uint32_t LA = c.LA, MinLength = c.MinLength, gwt = c.gwt, nB = c.nB;
+  uint32_t maybe = 0;
+  uint32_t Lg[UGS_GROUP];
+#if UGS_ALIGN_CLOCKS == 5
+  const unsigned long long tg0 = clock64();
+#endif
+  uint2 lo[UGS_GROUP], hi[UGS_GROUP];
+  uint32_t sh2[UGS_GROUP];
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    Lg[g] = 0; lo[g] = make_uint2(0u, 0u); hi[g] = lo[g]; sh2[g] = 0;
+    if ((uint32_t)g < n) {
+      const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)(k + g)) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)(k + g));
+      const uint32_t L = (uint32_t)rl((int)clen, (int)(k + g));
+      if (L > 1024u || L < 2u * (uint32_t)w) maybe |= 1u << g;
+      else {
+        Lg[g] = L; sh2[g] = ((uint32_t)to & 15u) * 2u;
+        const uint64_t w0 = (to >> 4) + (uint32_t)lane;
+        if ((uint32_t)lane * 16u < L + 16u) { lo[g] = c.pk[w0]; hi[g] = c.pk[w0 + 1]; }
+      }
+    }
+  }
+  auto gbuf = [&](uint32_t g) -> uint32_t * { unsigned char *base = g < nB ? c.B + g * gwt : (c.Bs - 16) + (g - nB) * gwt; return (uint32_t *)base + 2; };
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    if (Lg[g]) {
+      uint32_t *B2 = gbuf((uint32_t)g);
+      const uint32_t LB = Lg[g], nw = (LB + 15) >> 4, j = (uint32_t)lane;
+      uint32_t w2 = __builtin_amdgcn_alignbit(hi[g].x, lo[g].x, sh2[g]), wi = __builtin_amdgcn_alignbit(hi[g].y, lo[g].y, sh2[g]);
+      if (j + 1 == nw && (LB & 15u)) { const uint32_t m = (1u << (2u * (LB & 15u))) - 1u; w2 &= m; wi &= m; }
+      if (j >= nw) { w2 = 0; wi = 0; }
+      if (j < nw + 3) B2[j] = w2;
+      if (nw + 3 > 64 && j < nw + 3 - 64) B2[64 + j] = 0;
+      if (lane < 2) B2[-1 - lane] = 0;
+      if (__ballot(wi != 0)) { maybe |= 1u << g; Lg[g] = 0; }
+    }
+  }
+  lds_sync();
+#if UGS_ALIGN_CLOCKS == 5
+  const unsigned long long tg1 = clock64();
+#endif
+  // ---- the members' seeds, one list: member << 26 | bpos << 16 | apos
+  uint32_t count = 0;
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    if (Lg[g]) {
+      const uint32_t *B2 = gbuf((uint32_t)g);
+      const uint32_t LB = Lg[g], nwB = LB - w + 1;
+      int dlo, dhi;
+      {
+        const int LAi = (int)LA, LBi = (int)LB;
+        if (LAi <= LBi) { const int mg = LAi / 4 + 1; dlo = LAi - LBi - mg; dhi = mg; }
+        else { const int mg = LBi / 4 + 1; dlo = -mg; dhi = mg + LAi - LBi; }
+      }
+      for (uint32_t scan = 0; scan < nwB; scan += 256) {
+        uint32_t bp[4], lo4[4], cn[4], wd[4], okm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bp[e] = scan + (uint32_t)e * 64u + (uint32_t)lane; lo4[e] = 0; cn[e] = 0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wd[e] = bp[e] < nwB ? nt_word(B2, bp[e], w) : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (bp[e] < nwB) { const uint32_t en = c.wstart[wd[e]]; lo4[e] = en & 0xfffu; cn[e] = en >> 12; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          okm[e] = 0;
+          for (uint32_t r = 0; r < cn[e]; ++r) { const int d = (int)(c.qsort[lo4[e] + r] & 0xffffu) - (int)bp[e]; okm[e] |= (d >= dlo && d <= dhi ? 1u : 0u) << r; }
+          cn[e] = (uint32_t)__popc(okm[e]);
+        }
+        const uint32_t c01 = cn[0] | (cn[1] << 16), c23 = cn[2] | (cn[3] << 16);
+        const uint32_t i01 = wave_incl_sum_u32(c01), i23 = wave_incl_sum_u32(c23);
+        const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, 63);
+        const uint32_t tot[4] = {t01 & 0xffffu, t01 >> 16, t23 & 0xffffu, t23 >> 16};
+        const uint32_t total4 = tot[0] + tot[1] + tot[2] + tot[3];
+        if (count + total4 > c.seed_cap) { maybe |= 1u << g; break; }          // (the member's seeds listed so far are extended in vain)
+        const uint32_t inc[4] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
+        uint32_t base = count;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t off = base + inc[e] - cn[e];
+          for (uint32_t m = okm[e]; m; m &= m - 1) { const uint32_t r = (uint32_t)__ffs((int)m) - 1u; c.seeds[off++] = ((uint32_t)g << 26) | (bp[e] << 16) | (c.qsort[lo4[e] + r] & 0xffffu); }
+          base += tot[e];
+        }
+        count += total4;
+      }
+    }
+  }
+  lds_sync();
+#if UGS_ALIGN_CLOCKS == 5
+  const unsigned long long tg2 = clock64();
+#endif
+  // ---- extend them 64 at a time; the seeds of a member that has an accepted seed already are passed over
+  const uint32_t all = (1u << n) - 1u;
+  for (uint32_t idx = 0; idx < count && (maybe & all) != all; idx += 64) {
+    const uint32_t me = idx + (uint32_t)lane;
+    bool ok = false;
+    uint32_t g = 0;
+    if (me < count) {
+      const uint32_t sd = c.seeds[me];
+      g = sd >> 26;
+      if (!((maybe >> g) & 1u)) {
+        const uint32_t bpos = (sd >> 16) & 1023u, apos = sd & 0xffffu;
+        const uint32_t *B2 = gbuf(g);
+        const uint32_t LB = g == 0 ? Lg[0] : g == 1 ? Lg[1] : g == 2 ? Lg[2] : Lg[3];
+        int score = w * m2, best = score;
+        uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
+        uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
+        extend_nt_packed<false>(c.A2, c.A2, B2, B2, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+        const uint32_t Len = bestb2 - bestb1 + 1, Alo = apos - (bpos - bestb1);
+        ok = Len >= MinLength && best >= c.minscore2 && is_global_hsp(Alo, bestb1, LA, LB);
+      }
+    }
+    if (__ballot(ok)) {
+#pragma unroll
+      for (int gi = 0; gi < UGS_GROUP; ++gi) if (__ballot(ok && g == (uint32_t)gi)) maybe |= 1u << gi;
+    }
+  }
+  lds_sync();
+#if UGS_ALIGN_CLOCKS == 5
+  { const unsigned long long tg3 = clock64(); c.ctr[0] += tg1 - tg0; c.ctr[1] += tg2 - tg1; c.ctr[2] += tg3 - tg2; c.ctr[3] += (1ull << 32) | count; }
+#endif
+  return maybe & all;
 }
 
 // chainer.cpp:352-500 on lane 0 (HSP counts are tiny); csc layout: [bp_pos 2n][bp_idxlo 2n][prev n][cscore n][list n]
@@ -1056,7 +1201,8 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   unsigned long long *ctr = bv.counters;
 
   unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0, tq;
-  unsigned long long w_tletters = 0, w_pairs = 0;
+  unsigned long long gclk[4] = {0, 0, 0, 0};
+  unsigned long long w_tletters = 0, w_pairs = 0, w_grouped = 0;
   // units are handed out dynamically: a query without a hit walks all its candidates (32x the work of a query that
   // accepts its first one), so a static stride leaves most waves idle while the unlucky ones finish
   (void)gw; (void)nw;
@@ -1148,8 +1294,47 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       }
     };
     if (ncand) prefetch(0);
+    // the group filter (group_filter above): once a unit has rejected db.group_after candidates, the next ones are tested UGS_GROUP at a time
+    uint32_t pre_k = 0;                                         // the candidate whose letters `pre` holds
+    uint32_t grp_lo = 0, grp_hi = 0, grp_maybe = 0;             // members [grp_lo, grp_hi) are decided: bit set = takes the full path
+    uint32_t gwt = 0, gnB = 0, gmax = 0;
+    bool group_ok = false;
+    if constexpr (!PAIR) {
+      gwt = (uint32_t)((((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15);
+      gnB = maxt / gwt;
+      gmax = gnB + (maxt + 32u) / gwt; if (gmax > UGS_GROUP) gmax = UGS_GROUP;
+      group_ok = db.group_after != 0 && ncand && have_packed && c.use_tab && c.bsh == 0 && !c.a_inv && c.nwA > 0 && gmax >= 2 && LA < 65536u;
+    }
     for (uint32_t k = 0; k < ncand; ++k) {
       tq = ACLK();
+      if constexpr (!PAIR) {
+        if (group_ok && k >= grp_hi && nrej >= db.group_after) {
+          uint32_t n = ncand - k < gmax ? ncand - k : gmax;
+          if (max_rej - nrej < n) n = max_rej - nrej;
+          if (n >= 2) {
+            uint32_t MinL = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
+            if (MinL > LA / 4) MinL = LA / 4;
+            if (MinL < 16) MinL = 16;
+            GroupArgs ga;
+            ga.pk = db.pk; ga.A2 = c.A2; ga.B = c.B; ga.Bs = c.Bs; ga.wstart = c.wstart; ga.qsort = c.qsort; ga.seeds = c.seeds;
+            ga.seed_cap = c.seed_cap; ga.LA = LA; ga.MinLength = MinL; ga.gwt = gwt; ga.nB = gnB;
+            ga.w = db.hsp_w; ga.X = db.xdrop2; ga.m2 = c.s_sub2[0]; ga.mm2 = c.s_sub2[2]; ga.minscore2 = db.minscore2; ga.ctr = gclk;
+            grp_maybe = group_filter(ga, k, n, cto, clen);
+            grp_lo = k; grp_hi = k + n;
+            ta2 += ACLK() - tq; tq = ACLK();
+          }
+        }
+        if (k < grp_hi && !((grp_maybe >> (k - grp_lo)) & 1u)) {
+          // a pair without an HSP: fetched, counted and rejected as the full path would (no chain -> no alignment -> reject)
+          nvis = k + 1;
+          const uint32_t LBq = (uint32_t)rl((int)clen, (int)k);
+          w_tletters += (((LBq + 15u) >> 4) + 1u) * 8u; ++w_pairs; ++w_grouped;
+          ++nrej;
+          if (nrej == max_rej) break;
+          continue;
+        }
+        if (pre_k != k) { prefetch(k); pre_k = k; }
+      }
       nvis = k + 1;
       const uint32_t t = (uint32_t)rl((int)ct, (int)k);
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
@@ -1209,7 +1394,12 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; const uint8_t sc = s_sc[cl & 31]; c.B[p] = cl; c.Bs[p] = sc; anyb = anyb || sc > 3; }
       }
       c.b_inv = c.nt && __ballot(anyb) != 0;
-      if (k + 1 < ncand) prefetch(k + 1);
+      {
+        // (no prefetch for a candidate the group filter has rejected already, or will look at itself)
+        bool want = k + 1 < ncand;
+        if constexpr (!PAIR) want = want && !(k + 1 < grp_hi ? !((grp_maybe >> (k + 1 - grp_lo)) & 1u) : (group_ok && nrej + 1 >= db.group_after && max_rej - nrej > 2 && ncand - k > 2));
+        if (want) { prefetch(k + 1); pre_k = k + 1; }
+      }
       wave_sync();
       if (c.nt && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
       if constexpr (PAIR) if (db.pair_mask) {
@@ -1384,9 +1574,11 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     wave_sync();
     if constexpr (PAIR) if (--strands_left) { ++unit; goto next_strand; }
   }
-  if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs); }
+  if (lane == 0) { atomicAdd(&ctr[UGS_CTR_TLETTERS], w_tletters); atomicAdd(&ctr[UGS_CTR_PAIRS], w_pairs); if (w_grouped) atomicAdd(&ctr[UGS_CTR_GROUPED], w_grouped); }
   if (tid == 0) {
-#if UGS_ALIGN_CLOCKS != 3
+#if UGS_ALIGN_CLOCKS == 5
+    atomicAdd(&ctr[UGS_CTR_T4], gclk[0]); atomicAdd(&ctr[UGS_CTR_T5], gclk[1]); atomicAdd(&ctr[UGS_CTR_T6], gclk[2]); atomicAdd(&ctr[UGS_CTR_T7], gclk[3]);
+#elif UGS_ALIGN_CLOCKS != 3
     atomicAdd(&ctr[UGS_CTR_T4], ta0); atomicAdd(&ctr[UGS_CTR_T5], ta1); atomicAdd(&ctr[UGS_CTR_T6], ta2); atomicAdd(&ctr[UGS_CTR_T7], ta3);
 #endif
   }

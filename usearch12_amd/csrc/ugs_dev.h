@@ -66,6 +66,7 @@ struct UgsDbView {
   const uint32_t *t_key, *t_size;
   uint32_t align_flags;      // UGS_A_FULLDP | UGS_A_GAFORCE | UGS_A_TERMID | UGS_A_TERMIDD
   float termid, termidd;
+  uint32_t group_after;      // k_align: rejects of a unit after which its candidates go through the group filter (0 = never)
 };
 
 struct UgsBatchView {
@@ -116,7 +117,7 @@ struct UgsBatchView {
 #define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited): a walk that reaches the end of a full candidate list is an error
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
-       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
+       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_GROUPED, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
 enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64 };
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates

@@ -278,6 +278,7 @@ UgsTune ugs_tune_read()
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
   t.qpk = getenv("UGS_QPK") != nullptr;
+  t.align_group = env_int("UGS_ALIGN_GROUP", 0, 64, -1);
   return t;
 }
 
@@ -358,6 +359,7 @@ int ugs_db_replan(ugs_db *db)
   UgsDbView &v = db->v;
   v.seqs = db->d_seqs; v.offs = db->d_offs; v.row_off = db->d_row_off; v.postings = db->d_postings; v.part = db->d_part;
   v.part2 = gsize2 ? db->d_part2 : nullptr; v.np2 = np2; v.gsize2 = gsize2;
+  v.group_after = db->tune.align_group < 0 ? 1u : (uint32_t)db->tune.align_group;
   v.pk = db->tune.no_packed ? nullptr : db->d_pk;       // UGS_NO_PACKED: k_align fetches every target from the byte array (A/B, fault isolation)
   v.np = np; v.gsize = gsize; v.big = nseq > db->p.big ? 1 : 0; v.max_tlen = db->max_tlen;
   db->hbm_bytes = db->nletters + ((size_t)nseq + 1) * 8 + ((size_t)slots + 1) * 8 + db->n_postings * 4 +
@@ -1137,6 +1139,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
     if (b->r2_ran) { HIPCHK(hipEventElapsedTime(&a, b->ev0s, b->ev0r)); HIPCHK(hipEventElapsedTime(&c, b->ev0r, b->ev1)); }
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
+  if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];
   return UGS_OK;
 }
 
