@@ -277,7 +277,7 @@ int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
 /* Diagnostic: *seen = the ranking kernels this process has launched so far, *compiled = the ones the library holds, one bit each
  * (bits 0-4: Big path - 4-bit counters, its long-row twin, 8/16-bit flattened (sparse index), 8/16-bit dense, 8/16-bit dense + long
  * rows; bits 5-9: the same five on the small path; 12 / 13: the two Big-path 4-bit kernels with 64-bit offsets; 14: the bitmap kernel,
- * 15: its gather variant for sparse indexes).  The test-suite ends with seen == compiled. */
+ * 15: its gather variant for sparse indexes, 16: its cluster_fast instantiation).  The test-suite ends with seen == compiled. */
 int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
 
 /*

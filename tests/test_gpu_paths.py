@@ -311,7 +311,7 @@ def test_group_filter_of_k_align_equals_the_serial_walk(kw):
     qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
     ref = _hits_of(db, qs, {"UGS_ALIGN_GROUP": "0"}, is_nucleo=True, **kw)
     assert ref[4]["group_rejects"] == 0 and len(ref[0]) > 200
-    for g in (None, "2", "5"):
+    for g in (None, "2", "3"):
         got = _hits_of(db, qs, None if g is None else {"UGS_ALIGN_GROUP": g}, is_nucleo=True, **kw)
         assert got[4]["group_rejects"] > 0, g
         assert np.array_equal(got[1], ref[1]), g

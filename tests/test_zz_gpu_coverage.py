@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 NAMES = {0: "Big 4-bit (HOT)", 1: "Big 4-bit long rows", 2: "Big 8/16-bit flattened (sparse)", 3: "Big 8/16-bit dense", 4: "Big 8/16-bit dense, long rows",
          5: "small 4-bit", 6: "small 4-bit long rows", 7: "small 8/16-bit flattened", 8: "small 8/16-bit dense", 9: "small 8/16-bit dense, long rows",
-         12: "HOT, 64-bit offsets", 13: "long rows, 64-bit offsets", 14: "k_rank2 (bitmap)", 15: "k_rank2g (bitmap, sparse index)"}
+         12: "HOT, 64-bit offsets", 13: "long rows, 64-bit offsets", 14: "k_rank2 (bitmap)", 15: "k_rank2g (bitmap, sparse index)", 16: "k_rank2, cluster_fast instantiation"}
 
 
 def test_every_compiled_ranking_kernel_was_launched_in_this_session(request):

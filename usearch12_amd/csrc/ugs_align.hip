@@ -66,6 +66,7 @@ struct WaveCtx {
   uint32_t *csc;              // chainer scratch
   WaveState *ws;
   const uint8_t *s_cls; const int8_t *s_sub2; const uint64_t *s_match; const uint8_t *s_hl;
+  const uint16_t *xlut;       // the extension table (extend_nt_lut) or null
   // global scratch
   uint8_t *tb; uint32_t *runs; uint32_t runs_cap;
   uint8_t *lds_tb; uint32_t *lds_runs; uint32_t *lds_rt;   // LDS fast copies: small traceback matrices, first LRUNS runs
@@ -356,6 +357,74 @@ __device__ __forceinline__ void extend_nt_packed(const uint32_t *A2, const uint3
   }
 }
 
+// The same extension (no letter outside A/C/G/T/U on either side) driven by a TABLE: the serial rule of ungappedblast.cpp:91-178
+//   score += s; if (score > best) { best = score; pos = here; } else if (best - score > X) stop;
+// depends on the past only through the deficit d = best - score (0 .. X), so four letter pairs at a time are one look-up of
+// xlut[d / 2][mismatch bits of the four pairs] = stop << 15 | step of the last new best (1..4, 0 none) << 12 | rise of the best / 2 << 6 |
+// new deficit / 2, built per workgroup by simulating the rule letter by letter (k_align).  Needs even match / mismatch scores and an
+// even X <= 32 half-units (the reference's defaults: 2, -4, 32); k_align falls back to extend_nt_packed otherwise (c.xlut == null).
+// A random seed stops after ~ 15 letters: four or five look-ups per direction instead of a dozen trips of the mismatch-to-mismatch
+// loop - the seeds of a pair without a relative are where k_align's time goes.
+__device__ __forceinline__ uint32_t compact16(uint32_t y)          // bits 0, 2, .. 30 of y -> bits 0 .. 15
+{
+  y = (y | (y >> 1)) & 0x33333333u;
+  y = (y | (y >> 2)) & 0x0f0f0f0fu;
+  y = (y | (y >> 4)) & 0x00ff00ffu;
+  return (y | (y >> 8)) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t read16l(const uint32_t *w, int pos)    // 16 letters starting at letter `pos` (>= -32)
+{
+  const int k = pos >> 4;
+  return __builtin_amdgcn_alignbit(w[k + 1], w[k], ((uint32_t)pos & 15u) * 2u);
+}
+__device__ __forceinline__ void extend_nt_lut(const uint32_t *A2, const uint32_t *B2, const uint16_t *xlut, uint32_t LA, uint32_t LB,
+                                              uint32_t &a1, uint32_t &b1, uint32_t &a2, uint32_t &b2, int &best,
+                                              uint32_t &bestb1, uint32_t &bestb2)
+{
+  {
+    uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+    uint32_t d = 0;
+    bool stop = false;
+    while (rem && !stop) {
+      const uint32_t n = rem < 16 ? rem : 16;
+      const uint32_t x = read16l(A2, (int)a2 + 1) ^ read16l(B2, (int)b2 + 1);
+      uint32_t m = compact16((x | (x >> 1)) & 0x55555555u);
+      if (n < 16) m |= 0xffffu << n;                                // behind the end: mismatches (they can stop the walk, never raise the best)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!stop && (uint32_t)(4 * q) < n) {
+          const uint32_t e = xlut[(d << 4) | ((m >> (4 * q)) & 15u)];
+          const uint32_t g = (e >> 6) & 63u;
+          if (g) { best += 2 * (int)g; bestb2 = b2 + 4u * q + ((e >> 12) & 7u); }
+          d = e & 63u; stop = (e >> 15) != 0u;
+        }
+      }
+      a2 += n; b2 += n; rem -= n;
+    }
+  }
+  {
+    uint32_t rem = b1 < a1 ? b1 : a1;
+    uint32_t d = 0;
+    bool stop = false;
+    while (rem && !stop) {
+      const uint32_t n = rem < 16 ? rem : 16;
+      const uint32_t x = read16l(A2, (int)a1 - 16) ^ read16l(B2, (int)b1 - 16);        // letter 15 = position -1
+      uint32_t m = __builtin_bitreverse32(compact16((x | (x >> 1)) & 0x55555555u)) >> 16;   // bit j = the pair at position -1 - j
+      if (n < 16) m |= 0xffffu << n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!stop && (uint32_t)(4 * q) < n) {
+          const uint32_t e = xlut[(d << 4) | ((m >> (4 * q)) & 15u)];
+          const uint32_t g = (e >> 6) & 63u;
+          if (g) { best += 2 * (int)g; bestb1 = b1 - 4u * q - ((e >> 12) & 7u); }
+          d = e & 63u; stop = (e >> 15) != 0u;
+        }
+      }
+      a1 -= n; b1 -= n; rem -= n;
+    }
+  }
+}
+
 // wave-wide inclusive prefix maximum (identity INT_MIN)
 __device__ __forceinline__ int coop_incl_max(int v)
 {
@@ -459,6 +528,7 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
   uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
   if (NT) {
     if (c.a_inv || c.b_inv) extend_nt_packed<true>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+    else if (c.xlut) extend_nt_lut(c.A2, c.B2, c.xlut, LA, LB, a1, b1, a2, b2, best, bestb1, bestb2);
     else extend_nt_packed<false>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
   } else {
     {
@@ -684,7 +754,7 @@ __device__ __forceinline__ void ungapped_blast(WaveCtx &c, const UgsDbView &db, 
 // The members' 2-bit planes live in the target's class / score-code byte arrays (c.B, c.Bs), which hold nothing between two pairs.
 #define UGS_GROUP 4
 struct GroupArgs {           // (by value: the function is not inlined, the wave context stays in the caller's registers)
-  const uint2 *pk; const uint32_t *A2; unsigned char *B, *Bs; const uint16_t *wstart; const uint32_t *qsort; uint32_t *seeds;
+  const uint2 *pk; const uint32_t *A2; unsigned char *B, *Bs; const uint16_t *wstart; const uint32_t *qsort; uint32_t *seeds; const uint16_t *xlut;
   uint32_t seed_cap, LA, MinLength, gwt, nB; int w, X, m2, mm2, minscore2;
   unsigned long long *ctr;    // (-DUGS_ALIGN_CLOCKS=5, inlined builds only: the wave's accumulators - T4 fetch + planes, T5 seed listing, T6 extension rounds, T7 groups << 32 | seeds)
 };
@@ -801,7 +871,8 @@ __device__ UGS_GROUP_INLINE uint32_t group_filter(const GroupArgs c, uint32_t k,
         int score = w * m2, best = score;
         uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
         uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
-        extend_nt_packed<false>(c.A2, c.A2, B2, B2, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+        if (c.xlut) extend_nt_lut(c.A2, B2, c.xlut, LA, LB, a1, b1, a2, b2, best, bestb1, bestb2);
+        else extend_nt_packed<false>(c.A2, c.A2, B2, B2, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
         const uint32_t Len = bestb2 - bestb1 + 1, Alo = apos - (bpos - bestb1);
         ok = Len >= MinLength && best >= c.minscore2 && is_global_hsp(Alo, bestb1, LA, LB);
       }
@@ -1143,12 +1214,30 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     if (db.is_nucleo) s_sc[k] = (k < 26 && tab->udb_letter['A' + k] != 0xff) ? tab->hsp_letter['A' + k] : 4;
     else s_sc[k] = (k < 26) ? (uint8_t)k : 31;
   }
+  // the extension table (extend_nt_lut): entry (d / 2, four mismatch bits) by simulating the serial x-drop rule
+  uint16_t *s_xlut = (uint16_t *)(smem + 2112);
+  bool xlut_ok = false;
+  {
+    const int m2 = tab->sub2[0], mm2 = tab->sub2[2], X = db.xdrop2;      // nt: 2 * score(A, A), 2 * score(A, C)
+    xlut_ok = db.is_nucleo && m2 > 0 && mm2 < 0 && !(m2 & 1) && !(mm2 & 1) && !(X & 1) && X >= 0 && X <= 2 * (UGS_XLUT_D - 1) && m2 <= 30;
+    if (xlut_ok)
+      for (int k = tid; k < UGS_XLUT_D * 16; k += blockDim.x) {
+        int cur = -2 * (k >> 4), gain = 0, o = 0; bool stop = false;      // cur = score - best
+        for (int j = 0; j < 4 && !stop; ++j) {
+          cur += ((k >> j) & 1) ? mm2 : m2;
+          if (cur > 0) { gain += cur; cur = 0; o = j + 1; }
+          else if (-cur > X) stop = true;
+        }
+        const int dn = stop ? 0 : (-cur) / 2;
+        s_xlut[k] = (uint16_t)((stop ? 0x8000 : 0) | (o << 12) | ((gain / 2) << 6) | dn);
+      }
+  }
   __syncthreads();
 
   // ---- per-wave carve
   const uint32_t maxq = (bv.max_qlen + 15u) & ~15u, maxt = (db.max_tlen + 15u) & ~15u;
   uint32_t q2 = 64; while (q2 < maxq) q2 <<= 1;
-  unsigned char *wb = smem + 2112 + (size_t)wave * wave_lds;
+  unsigned char *wb = smem + UGS_ALIGN_HDR + (size_t)wave * wave_lds;
   WaveCtx c;
   size_t off = 0;
   c.ws = (WaveState *)(wb + off); off += 32;
@@ -1189,7 +1278,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     c.csc = (uint32_t *)u;
     off += (us + 15) & ~(size_t)15;
   }
-  c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl;
+  c.s_cls = s_cls; c.s_sub2 = s_sub2; c.s_match = s_match; c.s_hl = s_hl; c.xlut = xlut_ok ? s_xlut : nullptr;
   c.lane = lane; c.hsp_cap = hsp_cap;
   const uint32_t gw = blockIdx.x * wpb + wave, nw = gridDim.x * wpb;
   c.tb = bv.tb + (uint64_t)gw * bv.tb_stride;
@@ -1318,7 +1407,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
             GroupArgs ga;
             ga.pk = db.pk; ga.A2 = c.A2; ga.B = c.B; ga.Bs = c.Bs; ga.wstart = c.wstart; ga.qsort = c.qsort; ga.seeds = c.seeds;
             ga.seed_cap = c.seed_cap; ga.LA = LA; ga.MinLength = MinL; ga.gwt = gwt; ga.nB = gnB;
-            ga.w = db.hsp_w; ga.X = db.xdrop2; ga.m2 = c.s_sub2[0]; ga.mm2 = c.s_sub2[2]; ga.minscore2 = db.minscore2; ga.ctr = gclk;
+            ga.w = db.hsp_w; ga.X = db.xdrop2; ga.m2 = c.s_sub2[0]; ga.mm2 = c.s_sub2[2]; ga.minscore2 = db.minscore2; ga.ctr = gclk; ga.xlut = c.xlut;
             grp_maybe = group_filter(ga, k, n, cto, clen);
             grp_lo = k; grp_hi = k + n;
             ta2 += ACLK() - tq; tq = ACLK();
@@ -1594,7 +1683,7 @@ int ugs_align_blocks_per_cu(int threads, size_t lds)
 
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
-  const uint32_t wave_lds = (uint32_t)((L.lds - 2112) / L.wpb);
+  const uint32_t wave_lds = (uint32_t)((L.lds - UGS_ALIGN_HDR) / L.wpb);
   if (db.pair_mask || (db.filter_mask & UGS_F_ABSKEW) || db.align_flags) {
     HIPCHK(hipFuncSetAttribute((const void *)k_align<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
     hipLaunchKernelGGL(k_align<true>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);

@@ -7,6 +7,8 @@
 
 #define UGS_WAVE 64
 #define UGS_MAXREPS 8          // hspfinder.h:10
+#define UGS_XLUT_D 17          // k_align: x-drop deficits (in units of 2 half-units) the extension table covers: X <= 32 half-units
+#define UGS_ALIGN_HDR (2112 + UGS_XLUT_D * 16 * 2)     // workgroup-shared LDS in front of k_align's per-wave regions: letter tables + the extension table
 #define UGS_BAD_WORD 0xffffffffu
 #define UGS_KMAX 64            // max candidates walked per strand (max_accepts+max_rejects-1)
 

@@ -808,16 +808,20 @@ static int plan_launch(ugs_batch *b)
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   } else
-  if (db->v.part2 && !db->r2_gather && bits == 4 && !b->rl.longrows && b->K <= 64) {
+  // (cluster_fast: a centroid index always has long rows - the centroids of an abundant species share their words; the bitmap kernel
+  // reads a long sub-row as several chunks and the units whose window does not fit its chunk list are deferred, so it takes those too)
+  if (db->v.part2 && !db->r2_gather && bits == 4 && (!b->rl.longrows || b->cl_mode) && b->K <= 64) {
     const uint32_t nsm = std::min<uint32_t>(ns_typ, 15u);
-    const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
+    uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
+    if (b->cl_mode) kcap = std::min<uint32_t>(kcap, 508u);               // (the CL instantiation compacts a full list in eight register batches)
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
     // the chunk list of a window: every partition takes its rows' chunks rounded up to a multiple of 4; sized for 16 partitions of
     // the typical query with room for sub-rows of two chunks (the kernel fits each unit's window to the list)
     b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
     b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>(28u, (db->v.np2 + 3u) / 4u * 4u));
+    if (b->cl_mode && b->rl.longrows) b->r2.clcap *= 2;                 // (room for the chunks of long sub-rows)
     b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap);
-    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0), 32));
+    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   }
@@ -837,9 +841,9 @@ static int plan_launch(ugs_batch *b)
   const size_t wave_lds = (32 + ((size_t)maxq + maxt) + ((size_t)maxq + maxt + 64) + packed_b + wstart_b + (size_t)(always_counting ? maxq : q2) * 4 +
                            2 * 32 * 4 + 1024 + (size_t)hsp_cap * (16 + 4) + u_region + 15 + 16) & ~(size_t)15;
   int awpb = 4;
-  while (awpb > 1 && 2112 + awpb * wave_lds > LDS_MAX) awpb >>= 1;
-  if (2112 + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", 2112 + wave_lds); return UGS_E_ENVELOPE; }
-  const size_t alds = 2112 + awpb * wave_lds;
+  while (awpb > 1 && UGS_ALIGN_HDR + awpb * wave_lds > LDS_MAX) awpb >>= 1;
+  if (UGS_ALIGN_HDR + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", UGS_ALIGN_HDR + wave_lds); return UGS_E_ENVELOPE; }
+  const size_t alds = UGS_ALIGN_HDR + awpb * wave_lds;
   int aper_cu = ugs_align_blocks_per_cu(64 * awpb, alds);
   aper_cu = std::max(1, std::min(aper_cu, 8));
   if (db->tune.align_wgs) aper_cu = std::min(aper_cu, db->tune.align_wgs);
@@ -948,7 +952,7 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
-  const bool r2 = b->r2_grid > 0 && !b->v.cand_key && !b->v.cl_ev;
+  const bool r2 = b->r2_grid > 0 && (b->v.cand_key ? (b->cl_mode && !b->r2.gather && b->v.cl_ev && b->v.cl_info) : !b->v.cl_ev);
   if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
   b->r2_ran = r2 && b->nq;
   HIPCHK(hipEventRecord(b->ev1, db->stream));

@@ -81,6 +81,7 @@ struct ugs_batch {
   UgsRankLaunch rl; UgsAlignLaunch al;
   hipEvent_t ev0, ev0s, ev0r, ev1, ev2;   // ev0r: end of the bitmap ranking kernel (before k_rank takes the deferred units)
   bool r2_ran;
+  bool cl_mode;                     // the batch of a cluster_fast loop (ugs_cluster.cpp): its searches leave walk records, the bitmap kernel runs its CL instantiation
   // upload path: H2D copies go through the batch's own copy stream; the search waits for ev_up on the handle's stream,
   // so the upload of one batch overlaps the kernels of another (h_rel: page-locked staging of the relative offsets)
   hipStream_t copy_stream; hipEvent_t ev_up, ev_done; uint64_t *h_rel;   // ev_done: end of the last enqueued search

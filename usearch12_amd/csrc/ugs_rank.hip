@@ -1920,7 +1920,7 @@ static const void *rank_kernel(int big, int bits, int fast8, int longrows, int w
 static std::atomic<unsigned long long> g_rank_seen{0};
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled)
 {
-  if (compiled) *compiled = 0x3ffull | (3ull << 12) | (3ull << 14);
+  if (compiled) *compiled = 0x3ffull | (3ull << 12) | (7ull << 14);
   return g_rank_seen.load();
 }
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
@@ -1979,7 +1979,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   }
   int ordinal = 0;
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide, &ordinal);
-  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather ? 15 : 14)) : 0ull));
+  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather ? 15 : (b.cand_key ? 16 : 14))) : 0ull));
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;

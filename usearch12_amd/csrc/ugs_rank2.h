@@ -15,5 +15,5 @@ struct UgsRank2Params {
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap);
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np);
-int ugs_rank2_blocks_per_cu(size_t lds, int gather);
+int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl = 0);      // cl: the cluster_fast instantiation (walk records)
 int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st);

@@ -103,7 +103,14 @@ template <int K> __device__ __forceinline__ void r2_take(uint32_t (&t)[4])
 // what the emission of a chunk needs after its atomics were issued
 struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 
-template <int D>
+// CL: the instantiation for cluster_fast (ugs_cluster.cpp).  Its host side merges a unit's walk with the centroids founded inside the same
+// batch, so the candidates are chosen WITHOUT the MinValue cut-off and leave their full keys (cand_key), and the strict prefix maxima
+// of the scan go out as cl_ev / cl_info - exactly what k_rank writes in that mode (ugs_rank.hip "cluster_fast").  A centroid index gives
+// a read hundreds of targets with count >= 3 (the centroids of its species), so a full kept-key list is not a reason to defer there:
+// the list is COMPACTED to its K smallest keys (the smallest key of every count value is tracked apart, s_fpk, as the keys are made).
+#define R2_CMAXV 4095u          // ugs_rank.hip make_key: (CMAXV - count) << POS_BITS | first row << 32 | target
+#define R2_POS_BITS 44
+template <int D, bool CL>
 __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,7 +165,13 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
     if (unit >= units) break;
     const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
     bool bad = ns > 15u;                                                  // 4-bit count field of the keys
-    if (ns == 0) { if (lane == 0) bv.cand_n[unit] = 0; continue; }
+#ifdef R2_DEFER_STATS
+    if (bad && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T0], 1ull);
+#endif
+    if (ns == 0) {
+      if (lane == 0) { bv.cand_n[unit] = 0; if constexpr (CL) { bv.cl_info[(uint64_t)unit * 4 + 0] = 0; bv.cl_info[(uint64_t)unit * 4 + 1] = 0; bv.cl_info[(uint64_t)unit * 4 + 2] = 0; } }
+      continue;
+    }
     uint32_t nk = 0, n_stg = 0;
     bool any_posting = false;
     R2_CLK(const unsigned long long tk0 = clock64(); unsigned long long tfin = 0, tpre = 0;)
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         const bool rowlane = lane < ns;
         const uint32_t slot = rowlane ? bv.unit_slots[(uint64_t)unit * ns_max + lane] : 0u;
         const uint64_t rs = rowlane ? db.row_off[slot] : 0ull;            // the row's first posting (element index)
-        if (lane < 16) { s_slots[lane] = slot; s_rs[lane] = rs; s_c2[lane] = 0; s_cum[lane] = 0; }
+        if (lane < 16) { s_slots[lane] = slot; s_rs[lane] = rs; s_c2[lane] = 0; s_cum[lane] = 0; if constexpr (CL) s_fpk[lane] = R2_KEY_INF; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
       // one ds_or_rtn per posting; invalid postings OR a zero into an in-range word
@@ -227,8 +240,36 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
       // ---- a partition is done: group its records by target, make keys, prune, keep (NB register batches of 64 records)
+      // CL: the kept-key list is about to overflow - its K smallest keys stay (all-pairs ranks, keys are distinct), in rank order
+      auto compact_kept = [&]() {
+        constexpr int CB = 8;                                            // register batches of 64 keys (kcap <= 508 in this mode)
+        uint32_t ck[CB], cr[CB];
+        if (lane < 4u) s_kl[nk + lane] = R2_KEY_INF;                     // (padding for the 4-wide loop; nk <= kcap)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          const uint32_t i = (uint32_t)q * 64u + lane;
+          ck[q] = R2_KEY_INF; cr[q] = 0xffffffffu;
+          if ((uint32_t)q * 64u < nk) {
+            ck[q] = i < nk ? s_kl[i] : R2_KEY_INF;
+            uint32_t rank = 0;
+            const uint4 *k4 = (const uint4 *)s_kl;
+            for (uint32_t j = 0; j < nk; j += 4u) {
+              const uint4 x = k4[j >> 2];
+              rank += (x.x < ck[q]) + (x.y < ck[q]) + (x.z < ck[q]) + (x.w < ck[q]);
+            }
+            cr[q] = rank;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int q = 0; q < CB; ++q) if (ck[q] != R2_KEY_INF && cr[q] < K) s_kl[cr[q]] = ck[q];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        nk = nk < K ? nk : K;
+      };
       auto finalize_nb = [&](auto nbc, uint32_t n) {
         constexpr int NB = decltype(nbc)::value;
+        if constexpr (CL) { if (nk + n > kcap) compact_kept(); }
         uint32_t rec[NB], t[NB], row[NB], wofs[NB], hbit[NB], cnt[NB], cumv[NB]; bool act[NB], fl[NB], drop[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -276,6 +317,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const uint32_t key = ((15u - cnt[b]) << 28) | rec[b];
+          if constexpr (CL) { if (act[b] && !drop[b]) atomicMin(&s_fpk[15u - cnt[b]], key); }      // (every target's key, kept or not)
           const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
           const uint64_t m = __ballot(keep);
           uint32_t pos = nk_new + r2_mbcnt(m);
@@ -300,6 +342,9 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         if (n == 0) return;
 #if defined(R2_PROBE_NOFIN)
         return;
+#endif
+#ifdef R2_DEFER_STATS      // (tuning build: why units are deferred - T0 rows > 15, T1 chunk list, T2.. records of the overflowing partition by powers of two)
+        if (n > R2_SCAP && lane == 0) { uint32_t bkt = 0; while (bkt < 5u && (256u << bkt) < n) ++bkt; atomicAdd(&bv.counters[UGS_CTR_T2 + bkt], 1ull); }
 #endif
         if (n > R2_SCAP) { bad = true; return; }
         if (n > 64u) finalize_nb(std::integral_constant<int, 2>{}, n); else finalize_nb(std::integral_constant<int, 1>{}, n);
@@ -353,6 +398,9 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         any_posting = true;
         R2_CLK(tpre = clock64() - tk0;)
         // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
+#ifdef R2_DEFER_STATS
+        if (nch + 2u * (uint32_t)D > clcap && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T1], 1ull);
+#endif
         if (nch + 2u * (uint32_t)D > clcap) { bad = true; break; }     // (a window with more chunks than the list holds: very long rows)
         for (uint32_t i = nch + lane; i < nch + 2u * (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -428,10 +476,10 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
     R2_CLK(const unsigned long long tk1 = clock64();)
     // ---- cut-offs from the smallest key of every count value (countsort.cpp:13-24,114-126)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane < 16u) s_fpk[lane] = R2_KEY_INF;
+    if constexpr (!CL) { if (lane < 16u) s_fpk[lane] = R2_KEY_INF; }
     if (lane < 4u) s_kl[nk + lane] = R2_KEY_INF;                         // (padding for the 4-wide ranking loop; nk <= kcap)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (uint32_t i = lane; i < nk; i += 64u) { const uint32_t key = s_kl[i]; atomicMin(&s_fpk[key >> 28], key); }
+    if constexpr (!CL) for (uint32_t i = lane; i < nk; i += 64u) { const uint32_t key = s_kl[i]; atomicMin(&s_fpk[key >> 28], key); }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t M = 0, nv = 0;
     {
@@ -446,7 +494,40 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         nv = lm ? 63u - (uint32_t)__builtin_clzll(lm) : 0u;
       } else M = any_posting ? 1u : 0u;
     }
-    const uint32_t min_value = nv / 2u;
+    const uint32_t min_value = CL ? 0u : nv / 2u;                         // (cluster_fast: the host applies the cut-off of the merged scan)
+    if constexpr (CL) {
+      // the strict prefix maxima of the scan, as k_rank's cluster mode writes them: for c = M .. 1 the first position of count c where it
+      // lies before the first position of every higher count.  Counts >= 2 come from s_fpk; a count-1 target is only ever an event
+      // (and only ever decides NextValue) as the very FIRST posting of the scan: every posting in front of the first count >= 2 target
+      // has count 1, and if there is none the first count-1 position lies behind that target
+      uint64_t P0 = ~0ull;
+      {
+        const bool rowlane = lane < ns;
+        const uint32_t slot = rowlane ? s_slots[lane] : 0u;
+        const uint64_t ra = rowlane ? db.row_off[slot] : 0ull, rb = rowlane ? db.row_off[slot + 1] : 0ull;
+        const uint64_t ne_rows = __ballot(rowlane && rb > ra);
+        if (ne_rows) {
+          const uint32_t r0 = (uint32_t)__ffsll((long long)ne_rows) - 1u;
+          const uint64_t a0 = r2_readlane64(ra, r0);
+          P0 = ((uint64_t)r0 << 32) | postings[a0];
+        }
+      }
+      if (lane == 0) {
+        uint32_t ne = 0, nv_out = nv;
+        uint64_t sufmin = ~0ull;
+        if (M >= 2u) {
+          for (uint32_t c = M; c >= 2u; --c) {
+            const uint32_t k32 = s_fpk[15u - c];
+            if (k32 == R2_KEY_INF) continue;
+            const uint64_t f = ((uint64_t)((k32 >> 24) & 15u) << 32) | (k32 & 0xffffffu);
+            if (f < sufmin) { if (ne < UGS_CL_EV) bv.cl_ev[(uint64_t)unit * UGS_CL_EV + ne] = ((uint64_t)c << R2_POS_BITS) | f; ++ne; sufmin = f; }
+          }
+          if (nv_out < 2u) nv_out = P0 < sufmin ? 1u : 0u;
+        } else nv_out = 0;
+        if (M >= 1u && P0 < sufmin) { if (ne < UGS_CL_EV) bv.cl_ev[(uint64_t)unit * UGS_CL_EV + ne] = (1ull << R2_POS_BITS) | P0; ++ne; }
+        bv.cl_info[(uint64_t)unit * 4 + 0] = M; bv.cl_info[(uint64_t)unit * 4 + 1] = nv_out; bv.cl_info[(uint64_t)unit * 4 + 2] = ne;
+      }
+    }
     const uint32_t cmin = min_value > 2u ? min_value : 2u;
     const uint32_t limit = (16u - cmin) << 28;                            // keys below it have count >= cmin
     // ---- rank the kept keys all-pairs (nk is small: ~K + the targets with count >= 3)
@@ -468,6 +549,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           const uint32_t tg = key & 0xffffffu;
           bv.cand[(uint64_t)unit * K + rank] = tg;
           bv.cand_cnt[(uint64_t)unit * K + rank] = 15u - (key >> 28);
+          if constexpr (CL) bv.cand_key[(uint64_t)unit * K + rank] = ((uint64_t)(R2_CMAXV - (15u - (key >> 28))) << R2_POS_BITS) | ((uint64_t)((key >> 24) & 15u) << 32) | tg;
           s_sel[rank] = tg;
         }
       }
@@ -491,7 +573,10 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           const bool e = on && !in_set;
           const uint64_t m = __ballot(e);
           const uint32_t rank = r2_mbcnt(m);
-          if (e && filled + rank < K) { bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u; }
+          if (e && filled + rank < K) {
+            bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u;
+            if constexpr (CL) bv.cand_key[(uint64_t)unit * K + filled + rank] = ((uint64_t)(R2_CMAXV - 1u) << R2_POS_BITS) | ((uint64_t)r << 32) | t;
+          }
           const uint32_t n = (uint32_t)__popcll(m);
           filled = filled + n < K ? filled + n : K;
         }
@@ -918,7 +1003,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
 }
 
-static const void *rank2_kernel(int gather = 0) { return gather ? (const void *)k_rank2g : (const void *)k_rank2<UGS_R2_DEPTH>; }
+static const void *rank2_kernel(int gather = 0, int cl = 0) { return gather ? (const void *)k_rank2g : cl ? (const void *)k_rank2<UGS_R2_DEPTH, true> : (const void *)k_rank2<UGS_R2_DEPTH, false>; }
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
 {
@@ -930,10 +1015,10 @@ size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
   return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + 2 * (R2G_HB_BITS / 32) + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
 }
 
-int ugs_rank2_blocks_per_cu(size_t lds, int gather)
+int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl)
 {
   int n = 0;
-  const void *fn = rank2_kernel(gather);
+  const void *fn = rank2_kernel(gather, cl);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess || n < 1) n = 1;
   return n;
@@ -941,7 +1026,9 @@ int ugs_rank2_blocks_per_cu(size_t lds, int gather)
 
 int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st)
 {
-  const void *fn = rank2_kernel((int)prm.gather);
+  const bool cl = b.cand_key != nullptr;                               // cluster_fast's walk records (ugs_cluster.cpp)
+  if (cl && (prm.gather || !b.cl_ev || !b.cl_info || prm.kcap > 508u)) { ugs_set_error("bitmap ranking kernel: cluster mode outside its envelope"); return UGS_E_ENVELOPE; }
+  const void *fn = rank2_kernel((int)prm.gather, cl ? 1 : 0);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));
   UgsDbView a0 = db; UgsBatchView a1 = b; UgsRank2Params a2 = prm;
   void *args[] = {&a0, &a1, &a2};
