@@ -112,8 +112,13 @@ def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
     scratch access (a scratch store or load would sit in the same in-order VMEM queue), and (4) the ring is drained (vmcnt(0))
     before the slots are used again."""
     isa = _isa_of("ugs_rank2.hip")
-    body = _kernel_body(isa, "k_rank2ILi")
-    meta = isa[isa.index(".name:           _Z7k_rank2"):]
+    for inst in ("k_rank2ILi4ELb0EE", "k_rank2ILi4ELb1EE"):          # the search kernel and its cluster_fast instantiation
+        _check_rank2_ring(isa, inst)
+
+
+def _check_rank2_ring(isa, inst):
+    body = _kernel_body(isa, inst)
+    meta = isa[isa.index(".name:           _Z7" + inst):]
     assert re.search(r"\.vgpr_spill_count:\s*0\b", meta[:2000]), "k_rank2 spills vector registers"
     assert re.search(r"\.agpr_count:\s*16\b", meta[:2000]) or re.search(r"\.agpr_count:\s*16\b[^\n]*(\n[^\n]*){0,25}_Z7k_rank2", isa), "the ring's 16 accumulator registers"
     assert "scratch_" not in body
@@ -121,8 +126,16 @@ def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
     assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) == 8, loads      # prologue + ring, one slot each
     assert not re.search(r"global_load_dwordx4 v\[", body), "a posting load with a VGPR destination"
     reads = re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", body)
-    assert len(reads) == 16 and sorted(set(reads), key=lambda a: int(a[1:])) == ["a%d" % i for i in range(16)], reads
-    assert "v_accvgpr_write" not in body and "v_accvgpr_mov" not in body
+    ring = [a for a in reads if int(a[1:]) < 16]
+    assert len(ring) == 16 and sorted(set(ring), key=lambda a: int(a[1:])) == ["a%d" % i for i in range(16)], reads
+    if inst.endswith("Lb0EE"):
+        assert len(reads) == 16 and "v_accvgpr_write" not in body and "v_accvgpr_mov" not in body
+    else:
+        # the cluster_fast instantiation: the compiler parks a few spilled values in accumulator registers of its own - never in
+        # the ring's a0 .. a15 (a load may still be in flight to those after the statement that names them as clobbered)
+        for m in re.finditer(r"v_accvgpr_(?:write_b32 (a\d+)|mov_b32 (a\d+), (a\d+))", body):
+            for a in m.groups():
+                assert a is None or int(a[1:]) >= 16, m.group(0)
     # every block of four reads follows its own counted wait inside one asm statement
     assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == 4
     # the atomics of the bitmap are LDS instructions (not flat), with return

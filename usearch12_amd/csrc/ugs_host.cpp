@@ -813,14 +813,14 @@ static int plan_launch(ugs_batch *b)
   if (db->v.part2 && !db->r2_gather && bits == 4 && (!b->rl.longrows || b->cl_mode) && b->K <= 64) {
     const uint32_t nsm = std::min<uint32_t>(ns_typ, 15u);
     uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
-    if (b->cl_mode) kcap = std::min<uint32_t>(kcap, 508u);               // (the CL instantiation compacts a full list in eight register batches)
+    if (b->cl_mode) kcap = std::min<uint32_t>(std::max<uint32_t>(kcap, db->tune.r2_kcap ? 0u : b->K + 260u), 508u);   // (the CL instantiation compacts a full list - to K keys, in eight register batches - before a partition's <= 256 keys are added)
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
     // the chunk list of a window: every partition takes its rows' chunks rounded up to a multiple of 4; sized for 16 partitions of
     // the typical query with room for sub-rows of two chunks (the kernel fits each unit's window to the list)
     b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
     b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>(28u, (db->v.np2 + 3u) / 4u * 4u));
     if (b->cl_mode && b->rl.longrows) b->r2.clcap *= 2;                 // (room for the chunks of long sub-rows)
-    b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap);
+    b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap, b->cl_mode ? 1 : 0);
     int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));

@@ -13,7 +13,7 @@ struct UgsRank2Params {
   uint32_t gather;     // 1: k_rank2g (sparse index: one chunk = the sub-rows of all sampled rows of a partition)
 };
 
-size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap);
+size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl = 0);
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np);
 int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl = 0);      // cl: the cluster_fast instantiation (walk records)
 int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st);

@@ -44,6 +44,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define R2_SCAP 128u            // records of one partition the grouping handles (two register batches)
+#define R2_SCAP_CL 256u         // ... of the cluster_fast instantiation (four: a read's species has many centroids)
 #ifndef R2_HB_BITS
 #define R2_HB_BITS 2048u        // bits of each of the two hash filters
 #endif
@@ -111,7 +112,7 @@ struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 #define R2_CMAXV 4095u          // ugs_rank.hip make_key: (CMAXV - count) << POS_BITS | first row << 32 | target
 #define R2_POS_BITS 44
 template <int D, bool CL>
-__global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
+__global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x;
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
   // ---- LDS carve (the bitmap sits at offset 0 so that a posting's word address needs no add)
   const uint32_t G = prm.G, np = prm.np, K = bv.K, kcap = prm.kcap;
   const uint32_t bm_bytes = G / 8u;
-  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP] records of the partition being scanned
-  uint32_t *s_hba = s_stg + R2_SCAP;                                    // [64] hash filter A
+  constexpr uint32_t SCAP = CL ? R2_SCAP_CL : R2_SCAP;                 // records of one partition the grouping handles
+  uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [SCAP] records of the partition being scanned
+  uint32_t *s_hba = s_stg + SCAP;                                       // [64] hash filter A
   uint32_t *s_hbb = s_hba + R2_HB_BITS / 32;                            // [64] hash filter B
   uint32_t *s_c2 = s_hbb + R2_HB_BITS / 32;                             // [16] kept count-2 keys per row
   uint32_t *s_cum = s_c2 + 16;                                          // [16] ... with that row or a lower one
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
     const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
     bool bad = ns > 15u;                                                  // 4-bit count field of the keys
 #ifdef R2_DEFER_STATS
-    if (bad && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T0], 1ull);
+    if (bad && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T4], 1ull);
 #endif
     if (ns == 0) {
       if (lane == 0) { bv.cand_n[unit] = 0; if constexpr (CL) { bv.cl_info[(uint64_t)unit * 4 + 0] = 0; bv.cl_info[(uint64_t)unit * 4 + 1] = 0; bv.cl_info[(uint64_t)unit * 4 + 2] = 0; } }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           const uint64_t m = __ballot(hit);
           if (m) {
             uint32_t pos = n_stg + r2_mbcnt(m);
-            pos = pos < R2_SCAP - 1u ? pos : R2_SCAP - 1u;             // (beyond the capacity the unit is deferred: n_stg tells)
+            pos = pos < SCAP - 1u ? pos : SCAP - 1u;                   // (beyond the capacity the unit is deferred: n_stg tells)
             if (hit) s_stg[pos] = S.t[j] | rtag;
             n_stg += (uint32_t)__popcll(m);
           }
@@ -294,6 +296,32 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int b = 0; b < NB; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }     // both filters clean again
+        if constexpr (CL) {
+          // cluster_fast: most records share their target with others (the centroids of the read's species are hit by every sampled
+          // word), so the flagged records are taken a TARGET at a time: the records were staged in scan order = descending rows, a
+          // target's LAST record carries its first-touch row; count = its records + 1, every other record of it is dropped
+          uint64_t fm[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) fm[b] = __ballot(fl[b]);
+#pragma unroll
+          for (int bb = 0; bb < NB; ++bb) {
+            while (fm[bb]) {
+              const int L = __ffsll((long long)fm[bb]) - 1;
+              const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L);
+              uint32_t nsame = 0; int lastb = 0; uint64_t lastm = 0;
+#pragma unroll
+              for (int b = 0; b < NB; ++b) {
+                const uint64_t mb = __ballot(act[b] && t[b] == tL);
+                nsame += (uint32_t)__popcll(mb);
+                if (mb) { lastb = b; lastm = mb; }
+                fm[b] &= ~mb;
+              }
+              const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(lastm);
+#pragma unroll
+              for (int b = 0; b < NB; ++b) if (act[b] && t[b] == tL) { cnt[b] = nsame + 1u; drop[b] = !(b == lastb && lane == lastl); }
+            }
+          }
+        } else
         // the flagged records (a handful) against all records: count = records of the target + 1, first row = the lowest row
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
@@ -343,10 +371,11 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
 #if defined(R2_PROBE_NOFIN)
         return;
 #endif
-#ifdef R2_DEFER_STATS      // (tuning build: why units are deferred - T0 rows > 15, T1 chunk list, T2.. records of the overflowing partition by powers of two)
-        if (n > R2_SCAP && lane == 0) { uint32_t bkt = 0; while (bkt < 5u && (256u << bkt) < n) ++bkt; atomicAdd(&bv.counters[UGS_CTR_T2 + bkt], 1ull); }
+#ifdef R2_DEFER_STATS      // (tuning build: why units are deferred - two 32-bit counts per word: T4 rows > 15 | chunk list, T5 .. T7 records of the overflowing partition: <= 256 | <= 512, <= 1024 | <= 2048, <= 4096 | more)
+        if (n > SCAP && lane == 0) { uint32_t bkt = 0; while (bkt < 5u && (256u << bkt) < n) ++bkt; atomicAdd(&bv.counters[UGS_CTR_T5 + (bkt >> 1)], 1ull << (32u * (bkt & 1u))); }
 #endif
-        if (n > R2_SCAP) { bad = true; return; }
+        if (n > SCAP) { bad = true; return; }
+        if constexpr (CL) { if (n > 128u) { finalize_nb(std::integral_constant<int, 4>{}, n); return; } }
         if (n > 64u) finalize_nb(std::integral_constant<int, 2>{}, n); else finalize_nb(std::integral_constant<int, 1>{}, n);
       };
 
@@ -354,7 +383,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
       // (as many partitions per window as the chunk list holds for this unit's row count: a multiple of 4)
       uint32_t W = ((clcap - 16u) / ((ns + 4u) & ~3u)) & ~3u;
       W = W < 4u ? 4u : (W > prm.W ? prm.W : W);
-      for (uint32_t p0 = 0; p0 < np && !bad; p0 += W) {
+      for (uint32_t p0 = 0; p0 < np && !bad; ) {
         const uint32_t Wn = np - p0 < W ? np - p0 : W;
         // (1) the window's chunk list -> LDS.  Lane = (partition of the window: lane >> 4, row: ns - 1 - (lane & 15)), so lane order is the
         // scan order (partition ascending, row DESCENDING); a sub-row's bounds are two adjacent words of the row's partition-table
@@ -394,14 +423,17 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
           if (rr == 15u && pl < 32u) s_pe[pl] = mybase + mypad;           // list index at which this partition ends
           nch = gbase;
         }
-        if (nch == 0) continue;
+        if (nch == 0) { p0 += Wn; continue; }
         any_posting = true;
         R2_CLK(tpre = clock64() - tk0;)
         // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
 #ifdef R2_DEFER_STATS
-        if (nch + 2u * (uint32_t)D > clcap && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T1], 1ull);
+        if (nch + 2u * (uint32_t)D > clcap && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T4], 1ull << 32);
 #endif
-        if (nch + 2u * (uint32_t)D > clcap) { bad = true; break; }     // (a window with more chunks than the list holds: very long rows)
+        if (nch + 2u * (uint32_t)D > clcap) {                          // a window with more chunks than the list holds: very long rows
+          if constexpr (CL) { if (W > 1u) { W = W > 4u ? 4u : W >> 1; continue; } }     // (cluster_fast: the window is cut down to one partition before the unit is given up)
+          bad = true; break;
+        }
         for (uint32_t i = nch + lane; i < nch + 2u * (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // (2) the ring: D = 4 chunk slots, three posting loads in flight behind the chunk being counted (r2_issue / r2_take above).  A
@@ -459,6 +491,7 @@ __global__ __launch_bounds__(64, 4) void k_rank2(UgsDbView db, UgsBatchView bv, 
         }
         // every load of the ring has landed before the next window (or unit) issues into the same slots
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        p0 += Wn;
       }
     }
     if (bad) {
@@ -1005,9 +1038,9 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
 
 static const void *rank2_kernel(int gather = 0, int cl = 0) { return gather ? (const void *)k_rank2g : cl ? (const void *)k_rank2<UGS_R2_DEPTH, true> : (const void *)k_rank2<UGS_R2_DEPTH, false>; }
 
-size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap)
+size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl)
 {
-  return (size_t)G / 8 + (R2_SCAP + 2 * (R2G_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
+  return (size_t)G / 8 + ((cl ? R2_SCAP_CL : R2_SCAP) + 2 * (R2G_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
 }
 
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
