@@ -170,16 +170,32 @@ __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
     // only the positions of words that occur more than once need a rank (about a fifth of a random query): they are listed
     // densely first, so that the O(L) rank scans fill whole wavefronts
     uint32_t *dup = c.qsort;                               // (free until the final scatter)
+    // ... and their words (buckets) densely behind the rank array when the union region has the room: a position's rank is then
+    // counted among the EARLIER LISTED positions only (a quarter of the scan over all earlier positions)
+    uint32_t *dw = c.seeds + ((((nwA + 3) & ~3u) * 3u / 2u + 3u) & ~3u);
+    const bool dense = (uint64_t)((((nwA + 3) & ~3u) * 3u / 2u + 3u) & ~3u) + nwA + 4u <= c.union_words;
     uint32_t ndup = 0;
     for (uint32_t p0 = 0; p0 < nwA; p0 += 64) {
       const uint32_t p = p0 + lane;
-      const bool need = p < nwA && c.wstart[tw[p < nwA ? p : 0] >> bsh] > 1;
+      const uint32_t wd = tw[p < nwA ? p : 0] >> bsh;
+      const bool need = p < nwA && c.wstart[wd] > 1;
       if (p < nwA) tr[p] = 0;
       const uint64_t m = __ballot(need);
-      if (need) dup[ndup + __popcll(m & ((1ull << lane) - 1ull))] = p;
+      if (need) { const uint32_t k = ndup + __popcll(m & ((1ull << lane) - 1ull)); dup[k] = p; if (dense) dw[k] = wd; }
       ndup += (uint32_t)__popcll(m);
     }
     lds_sync();
+    if (dense) {
+      for (uint32_t i = lane; i < ndup; i += 64) {
+        const uint32_t wd = dw[i];
+        const uint4 *v4 = (const uint4 *)dw;
+        uint32_t rank = 0;
+        const uint32_t nq4 = i >> 2;
+        for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; rank += (x.x == wd) + (x.y == wd) + (x.z == wd) + (x.w == wd); }
+        for (uint32_t q = nq4 << 2; q < i; ++q) rank += dw[q] == wd;
+        tr[dup[i]] = (uint16_t)rank;
+      }
+    } else
     for (uint32_t i = lane; i < ndup; i += 64) {
       const uint32_t p = dup[i], wd = tw[p] >> bsh;
       const uint4 *v4 = (const uint4 *)tw;
@@ -1190,7 +1206,9 @@ __device__ __forceinline__ void align_hole(WaveCtx &c, const UgsDbView &db, uint
 // (-DUGS_ALIGN_CLOCKS=4: inside ungapped_blast - T4 seed listing, T5 extension rounds, T6 rounds, T7 seeds extended; the per-round atomics slow the kernel several times: ratios only)
 #define ACLK() (UGS_ALIGN_CLOCKS == 1 ? clock64() : 0ull)
 #define ACLK2() (UGS_ALIGN_CLOCKS == 2 ? clock64() : 0ull)      // finer clocks inside the post-HSP part: T4 chain, T5 classes + HSP identity, T6 holes, T7 FillLo + hit
-template <bool PAIR>
+// NT: nucleotide / amino-acid databases have instantiations of their own - the packed-letter paths, the group filter and the extension
+// table exist only in the first, the bucketed word table and the BLOSUM look-ups only in the second, and neither carries the other's registers
+template <bool PAIR, bool NT>
 #ifndef UGS_ALIGN_WGS
 #define UGS_ALIGN_WGS 4
 #endif
@@ -1211,7 +1229,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   for (int k = tid; k < 64; k += blockDim.x) s_match[k] = tab->match[k];
   for (int k = tid; k < 32; k += blockDim.x) {
     s_hl[k] = (k < 26) ? tab->hsp_letter['A' + k] : 0;
-    if (db.is_nucleo) s_sc[k] = (k < 26 && tab->udb_letter['A' + k] != 0xff) ? tab->hsp_letter['A' + k] : 4;
+    if (NT) s_sc[k] = (k < 26 && tab->udb_letter['A' + k] != 0xff) ? tab->hsp_letter['A' + k] : 4;
     else s_sc[k] = (k < 26) ? (uint8_t)k : 31;
   }
   // the extension table (extend_nt_lut): entry (d / 2, four mismatch bits) by simulating the serial x-drop rule
@@ -1219,7 +1237,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   bool xlut_ok = false;
   {
     const int m2 = tab->sub2[0], mm2 = tab->sub2[2], X = db.xdrop2;      // nt: 2 * score(A, A), 2 * score(A, C)
-    xlut_ok = db.is_nucleo && m2 > 0 && mm2 < 0 && !(m2 & 1) && !(mm2 & 1) && !(X & 1) && X >= 0 && X <= 2 * (UGS_XLUT_D - 1) && m2 <= 30;
+    xlut_ok = NT && m2 > 0 && mm2 < 0 && !(m2 & 1) && !(mm2 & 1) && !(X & 1) && X >= 0 && X <= 2 * (UGS_XLUT_D - 1) && m2 <= 30;
     if (xlut_ok)
       for (int k = tid; k < UGS_XLUT_D * 16; k += blockDim.x) {
         int cur = -2 * (k >> 4), gain = 0, o = 0; bool stop = false;      // cur = score - best
@@ -1257,7 +1275,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   c.lds_runs = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_rt = (uint32_t *)(wb + off); off += LRUNS * 4;
   c.lds_tb = wb + off; off += LTB;
-  c.nt = db.is_nucleo != 0;
+  c.nt = NT;
   c.a_inv = false; c.b_inv = false;
   // union region: the seed list lives only inside UngappedBlast, the chainer scratch only inside the chainer, the DP
   // rows only in the holes after it
@@ -1322,7 +1340,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     uint32_t nacc = 0, nrej = 0;
     if (ncand) {
       // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
-      bool planes = c.nt && bv.qpk != nullptr;
+      bool planes = NT && bv.qpk != nullptr;
       if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
       for (uint32_t p = lane; p < LA; p += 64) {
         uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
@@ -1339,7 +1357,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         c.a_inv = __ballot(any) != 0;
       }
       wave_sync();
-      if (c.nt && !planes) {
+      if (NT && !planes) {
         pack_codes(c.As, LA, c.A2, c.Ai, lane);
         bool any = false;
         for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;
@@ -1362,7 +1380,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     // queries without a hit and never do.  Everything else (aa, longer targets, the in-batch pair stage of cluster_fast whose targets
     // are query letters): 4 x 4 letters per lane from the byte array as before.
     uint32_t pre[4] = {0, 0, 0, 0};
-    const bool have_packed = c.nt && db.pk != nullptr;
+    const bool have_packed = NT && db.pk != nullptr;
     auto prefetch = [&](uint32_t k2) {
       const uint64_t to2 = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k2) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k2);
       const uint32_t L2 = (uint32_t)rl((int)clen, (int)k2);
@@ -1388,7 +1406,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     uint32_t grp_lo = 0, grp_hi = 0, grp_maybe = 0;             // members [grp_lo, grp_hi) are decided: bit set = takes the full path
     uint32_t gwt = 0, gnB = 0, gmax = 0;
     bool group_ok = false;
-    if constexpr (!PAIR) {
+    if constexpr (!PAIR && NT) {
       gwt = (uint32_t)((((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15);
       gnB = maxt / gwt;
       gmax = gnB + (maxt + 32u) / gwt; if (gmax > UGS_GROUP) gmax = UGS_GROUP;
@@ -1396,7 +1414,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     }
     for (uint32_t k = 0; k < ncand; ++k) {
       tq = ACLK();
-      if constexpr (!PAIR) {
+      if constexpr (!PAIR && NT) {
         if (group_ok && k >= grp_hi && nrej >= db.group_after) {
           uint32_t n = ncand - k < gmax ? ncand - k : gmax;
           if (max_rej - nrej < n) n = max_rej - nrej;
@@ -1429,7 +1447,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
       c.LB = LB;
-      const bool pack_direct = c.nt && LB <= 1024;             // nt: a lane's 4 letters are one byte of the packed arrays
+      const bool pack_direct = NT && LB <= 1024;             // nt: a lane's 4 letters are one byte of the packed arrays
       const bool from_packed = have_packed && LB <= 1024;
       bool classes_loaded = !from_packed;
       // the target's class bytes (c.B) for a pair fetched from the packed arrays: loaded when the pair first needs them
@@ -1482,15 +1500,15 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       }
       for (uint32_t p = 1024 + lane; p < LB; p += 64) { const uint8_t cl = s_cls[db.seqs[to + p]]; const uint8_t sc = s_sc[cl & 31]; c.B[p] = cl; c.Bs[p] = sc; anyb = anyb || sc > 3; }
       }
-      c.b_inv = c.nt && __ballot(anyb) != 0;
+      c.b_inv = NT && __ballot(anyb) != 0;
       {
         // (no prefetch for a candidate the group filter has rejected already, or will look at itself)
         bool want = k + 1 < ncand;
-        if constexpr (!PAIR) want = want && !(k + 1 < grp_hi ? !((grp_maybe >> (k + 1 - grp_lo)) & 1u) : (group_ok && nrej + 1 >= db.group_after && max_rej - nrej > 2 && ncand - k > 2));
+        if constexpr (!PAIR && NT) want = want && !(k + 1 < grp_hi ? !((grp_maybe >> (k + 1 - grp_lo)) & 1u) : (group_ok && nrej + 1 >= db.group_after && max_rej - nrej > 2 && ncand - k > 2));
         if (want) { prefetch(k + 1); pre_k = k + 1; }
       }
       wave_sync();
-      if (c.nt && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
+      if (NT && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
       if constexpr (PAIR) if (db.pair_mask) {
         // Accepter::RejectPair accepter.cpp:140-197.  Big path: the pair is a reject for the terminator
         // (udbusortedsearcherbig.cpp:118-127); small path: it is passed over without a trace (searcher.cpp:63-67)
@@ -1532,7 +1550,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       const bool fulldp = PAIR ? (db.align_flags & UGS_A_FULLDP) != 0 : false;
       const bool force_all = PAIR ? (db.align_flags & (UGS_A_FULLDP | UGS_A_GAFORCE)) != 0 : false;
       if (!fulldp) {
-        if (c.nt) ungapped_blast<true>(c, db, MinHSPLength, ctr); else ungapped_blast<false>(c, db, MinHSPLength, ctr);
+        ungapped_blast<NT>(c, db, MinHSPLength, ctr);
       }
       ta2 += ACLK() - tq; tq = ACLK();
       unsigned long long tq2 = ACLK2();
@@ -1673,24 +1691,28 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
   }
 }
 
-int ugs_align_blocks_per_cu(int threads, size_t lds)
+static const void *align_kernel(bool pair, bool nt)
+{
+  return pair ? (nt ? (const void *)k_align<true, true> : (const void *)k_align<true, false>) : (nt ? (const void *)k_align<false, true> : (const void *)k_align<false, false>);
+}
+
+int ugs_align_blocks_per_cu(int threads, size_t lds, int is_nucleo)
 {
   int n = 0;
-  if (hipFuncSetAttribute((const void *)k_align<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_align<false>, threads, lds) != hipSuccess || n < 1) n = 1;
+  const void *fn = align_kernel(false, is_nucleo != 0);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds) != hipSuccess || n < 1) n = 1;
   return n;
 }
 
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st)
 {
-  const uint32_t wave_lds = (uint32_t)((L.lds - UGS_ALIGN_HDR) / L.wpb);
-  if (db.pair_mask || (db.filter_mask & UGS_F_ABSKEW) || db.align_flags) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_align<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_align<true>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
-  } else {
-    HIPCHK(hipFuncSetAttribute((const void *)k_align<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
-    hipLaunchKernelGGL(k_align<false>, dim3(L.grid), dim3(64 * L.wpb), L.lds, st, db, b, L.hsp_cap, wave_lds, L.seed_cap);
-  }
+  uint32_t wave_lds = (uint32_t)((L.lds - UGS_ALIGN_HDR) / L.wpb);
+  const void *fn = align_kernel(db.pair_mask || (db.filter_mask & UGS_F_ABSKEW) || db.align_flags, db.is_nucleo != 0);
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+  UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.hsp_cap, a4 = L.seed_cap;
+  void *args[] = {&a0, &a1, &a2, &wave_lds, &a4};
+  HIPCHK(hipLaunchKernel(fn, dim3(L.grid), dim3(64 * L.wpb), args, L.lds, st));
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

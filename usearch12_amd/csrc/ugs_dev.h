@@ -151,7 +151,7 @@ int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32
 int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows, int wide);
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows);
-int ugs_align_blocks_per_cu(int threads, size_t lds);
+int ugs_align_blocks_per_cu(int threads, size_t lds, int is_nucleo);
 size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words, int hot);
 int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma,
                      uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, uint32_t query_base,

@@ -844,7 +844,7 @@ static int plan_launch(ugs_batch *b)
   while (awpb > 1 && UGS_ALIGN_HDR + awpb * wave_lds > LDS_MAX) awpb >>= 1;
   if (UGS_ALIGN_HDR + awpb * wave_lds > LDS_MAX) { ugs_set_error("alignment LDS footprint %zu exceeds 160 KiB (sequences too long)", UGS_ALIGN_HDR + wave_lds); return UGS_E_ENVELOPE; }
   const size_t alds = UGS_ALIGN_HDR + awpb * wave_lds;
-  int aper_cu = ugs_align_blocks_per_cu(64 * awpb, alds);
+  int aper_cu = ugs_align_blocks_per_cu(64 * awpb, alds, p.is_nucleo);
   aper_cu = std::max(1, std::min(aper_cu, 8));
   if (db->tune.align_wgs) aper_cu = std::min(aper_cu, db->tune.align_wgs);
   b->al.wpb = awpb; b->al.lds = alds; b->al.hsp_cap = hsp_cap; b->al.seed_cap = seed_cap;
