@@ -1240,6 +1240,22 @@ __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView b
       ndup += (uint32_t)__popcll(m);
     }
     __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    if (ndup <= 512u) {
+      // every earlier occurrence of a listed position's word is listed too (same bucket): the listed words, densely (in the hash
+      // counters' array, which is done), are all a listed position is compared with - a fifth of the scan over all earlier positions
+      uint32_t *s_dw = s_hc;
+      for (uint32_t i = lane; i < ndup; i += 64) s_dw[i] = s_words[s_dup[i]];
+      __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+      for (uint32_t i = lane; i < ndup; i += 64) {
+        const uint32_t w = s_dw[i];
+        const uint4 *v4 = (const uint4 *)s_dw;
+        const uint32_t nq4 = i >> 2;
+        bool dupf = false;
+        for (uint32_t q4 = 0; q4 < nq4; ++q4) { const uint4 x = v4[q4]; dupf = dupf | (x.x == w) | (x.y == w) | (x.z == w) | (x.w == w); }
+        for (uint32_t q = nq4 << 2; q < i; ++q) dupf = dupf | (s_dw[q] == w);
+        if (dupf) s_first[s_dup[i]] = 0;
+      }
+    } else
     for (uint32_t i = lane; i < ndup; i += 64) {
       const uint32_t p = s_dup[i], w = s_words[p];
       const uint4 *v4 = (const uint4 *)s_words;
