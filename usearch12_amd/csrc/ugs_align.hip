@@ -1338,34 +1338,8 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     uint32_t nvis = 0;
     bool walk_ended = false;          // the terminator ended the walk (not the end of the list)
     uint32_t nacc = 0, nrej = 0;
-    if (ncand) {
-      // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
-      bool planes = NT && bv.qpk != nullptr;
-      if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
-      for (uint32_t p = lane; p < LA; p += 64) {
-        uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
-        const uint8_t cl = s_cls[ch];
-        c.A[p] = cl;
-        if (!planes) c.As[p] = s_sc[cl & 31];
-      }
-      if (planes) {
-        const uint2 *qp = bv.qpk + (uint64_t)unit * bv.qpk_stride;
-        const uint32_t nw = (LA + 15) >> 4;
-        bool any = false;
-        for (uint32_t k = lane; k < nw + 3; k += 64) { const uint2 e = qp[k]; c.A2[k] = e.x; c.Ai[k] = e.y; any = any || e.y != 0u; }
-        if (lane < 2) { c.A2[-1 - lane] = 0; c.Ai[-1 - lane] = 0; }
-        c.a_inv = __ballot(any) != 0;
-      }
-      wave_sync();
-      if (NT && !planes) {
-        pack_codes(c.As, LA, c.A2, c.Ai, lane);
-        bool any = false;
-        for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;
-        c.a_inv = __ballot(any) != 0;
-      }
-      build_query_words(c, db.hsp_w, db.alpha);
-    }
-    ta0 += ACLK() - tq;
+    // (the candidates' offsets and the first target's letters are asked for BEFORE the query set-up: three dependent trips to HBM that
+    // used to stand between the set-up and the first pair now travel behind it)
     // one lane per candidate: id, offset and length fetched once for the whole unit
     uint32_t ct = 0, clen = 0; uint64_t cto = 0;
     if ((uint32_t)lane < ncand) {
@@ -1401,6 +1375,34 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       }
     };
     if (ncand) prefetch(0);
+    if (ncand) {
+      // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
+      bool planes = NT && bv.qpk != nullptr;
+      if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
+      for (uint32_t p = lane; p < LA; p += 64) {
+        uint8_t ch = (strand == 0) ? bv.qseqs[qo + p] : s_comp[bv.qseqs[qo + (LA - 1 - p)]];
+        const uint8_t cl = s_cls[ch];
+        c.A[p] = cl;
+        if (!planes) c.As[p] = s_sc[cl & 31];
+      }
+      if (planes) {
+        const uint2 *qp = bv.qpk + (uint64_t)unit * bv.qpk_stride;
+        const uint32_t nw = (LA + 15) >> 4;
+        bool any = false;
+        for (uint32_t k = lane; k < nw + 3; k += 64) { const uint2 e = qp[k]; c.A2[k] = e.x; c.Ai[k] = e.y; any = any || e.y != 0u; }
+        if (lane < 2) { c.A2[-1 - lane] = 0; c.Ai[-1 - lane] = 0; }
+        c.a_inv = __ballot(any) != 0;
+      }
+      wave_sync();
+      if (NT && !planes) {
+        pack_codes(c.As, LA, c.A2, c.Ai, lane);
+        bool any = false;
+        for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;
+        c.a_inv = __ballot(any) != 0;
+      }
+      build_query_words(c, db.hsp_w, db.alpha);
+    }
+    ta0 += ACLK() - tq;
     // the group filter (group_filter above): once a unit has rejected db.group_after candidates, the next ones are tested UGS_GROUP at a time
     uint32_t pre_k = 0;                                         // the candidate whose letters `pre` holds
     uint32_t grp_lo = 0, grp_hi = 0, grp_maybe = 0;             // members [grp_lo, grp_hi) are decided: bit set = takes the full path
