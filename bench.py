@@ -468,6 +468,9 @@ def main():
                            "issue_roofline": issue_roofline("k_rank", ms_rank)},
                 "k_rank_setup": {"bound": "latency (dependent loads, one wavefront per query)", "kernel_ms": ms_setup},
                 "k_align": {"bound": "valu-issue (integer ALU / LDS, not a bandwidth kernel)", "algorithmic_bytes_per_launch": b_align,
+                            # SURVEY.md 8(d)'s rule, one byte per letter of the query and of every candidate visited (the synthetic targets all
+                            # have the query length); algorithmic_bytes_per_launch above = the bytes k_align fetches (packed planes)
+                            "algorithmic_bytes_per_launch_8d": st["query_letters"] + st["pairs_aligned"] * (st["query_letters"] // max(qs.n, 1)),
                             "kernel_ms": ms_align, "achieved_GBps": b_align / (ms_align * 1e-3) / 1e9,
                             "pair_alignments_per_s": st["pairs_aligned"] / (ms_align * 1e-3),
                             "valu_per_pair": (mix["k_align"]["SQ_INSTS_VALU"] / max(st["pairs_aligned"], 1)) if "k_align" in mix else None,

@@ -320,3 +320,34 @@ def test_group_filter_of_k_align_equals_the_serial_walk(kw):
         for a, b in zip(got[0][:2000], ref[0][:2000]):                  # (the run pool is handed out in the order the waves finish)
             assert np.array_equal(got[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])], ref[2][int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])]), g
         assert got[3]["pairs_aligned"] == ref[3]["pairs_aligned"] and got[3]["target_letters"] == ref[3]["target_letters"], g
+
+
+@pytest.mark.parametrize("kw", [dict(id=0.8), dict(id=0.9, max_accepts=2, max_rejects=6)])
+def test_group_filter_of_k_align_amino_acid_targets(kw):
+    """the same for a protein database (targets kept as bytes, bucketed word table, BLOSUM extension): UGS_ALIGN_GROUP 0 / 1 / 2 give the
+    same hit tables and counters - families, wildcards (X, B, Z) in targets and queries, targets around two HSP words and beyond 1024"""
+    db, qs = synth.make_hard(93, 120, 12, 1800, lmin=40, lmax=1200, aa=True)
+    rng = np.random.default_rng(93)
+    d = db.seqs.copy()
+    for t in rng.integers(0, db.n, size=200):
+        d[int(db.offs[t]) + int(rng.integers(0, int(db.offs[t + 1] - db.offs[t])))] = ord("X")
+    lens = np.diff(db.offs.astype(np.int64))
+    short = np.array([4, 5, 6, 7, 9], dtype=np.int64)
+    seqs = np.concatenate([d, synth._random_letters(rng, int(short.sum()), synth.AA, synth.RR_FREQ)])
+    offs = np.concatenate([[0], np.cumsum(np.concatenate([lens, short]))]).astype(np.uint64)
+    db = synth.SeqSet(seqs, offs, lambda i: "t%d" % i)
+    rq = synth.make_db(94, 400, 300, aa=True)
+    qseqs = np.concatenate([qs.seqs, rq.seqs])
+    qoffs = np.concatenate([qs.offs, rq.offs[1:] + qs.offs[-1]]).astype(np.uint64)
+    qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
+    ref = _hits_of(db, qs, {"UGS_ALIGN_GROUP": "0"}, is_nucleo=False, **kw)
+    assert ref[4]["group_rejects"] == 0 and len(ref[0]) > 200
+    for g in (None, "2"):
+        got = _hits_of(db, qs, None if g is None else {"UGS_ALIGN_GROUP": g}, is_nucleo=False, **kw)
+        assert got[4]["group_rejects"] > 0, g
+        assert np.array_equal(got[1], ref[1]), g
+        for f in ("query", "target", "ids", "mism", "gaps_int", "aln_len", "opens", "qlo", "qhi", "tlo", "thi", "ql", "tl", "strand", "cigar_len", "cols"):
+            assert np.array_equal(got[0][f], ref[0][f]), (g, f)
+        for a, b in zip(got[0][:2000], ref[0][:2000]):
+            assert np.array_equal(got[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])], ref[2][int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])]), g
+        assert got[3]["pairs_aligned"] == ref[3]["pairs_aligned"] and got[3]["target_letters"] == ref[3]["target_letters"], g

@@ -519,6 +519,50 @@ __device__ __forceinline__ bool extend_seed_coop(const WaveCtx &c, const UgsDbVi
   return Len >= MinLength && best >= db.minscore2 && is_global_hsp(Alo, Blo, LA, LB);
 }
 
+// The amino-acid extension (ungappedblast.cpp:91-178) on score-code bytes: 8 letter pairs per LDS round trip, consumed strictly in order
+__device__ __forceinline__ void extend_aa_bytes(const int8_t *sub2, const uint8_t *As, const uint8_t *Bs, int X, uint32_t LA, uint32_t LB,
+                                                uint32_t &a1, uint32_t &b1, uint32_t &a2, uint32_t &b2, int &score, int &best,
+                                                uint32_t &bestb1, uint32_t &bestb2)
+{
+  {
+    uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
+    bool stop = false;
+    while (rem && !stop) {
+      uint32_t av[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = As[a2 + o]; bv[k] = Bs[b2 + o]; }
+      const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < n && !stop) {
+          score += (int)sub2[(av[k] << 5) | bv[k]];
+          if (score > best) { best = score; bestb2 = b2 + k + 1; }
+          else if (best - score > X) stop = true;
+        }
+      a2 += n; b2 += n; rem -= n;
+    }
+  }
+  score = best;
+  {
+    uint32_t rem = b1 < a1 ? b1 : a1;
+    bool stop = false;
+    while (rem && !stop) {
+      uint32_t av[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = As[a1 - o]; bv[k] = Bs[b1 - o]; }
+      const uint32_t n = rem < 8 ? rem : 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < n && !stop) {
+          score += (int)sub2[(av[k] << 5) | bv[k]];
+          if (score > best) { best = score; bestb1 = b1 - k - 1; }
+          else if (best - score > X) stop = true;
+        }
+      a1 -= n; b1 -= n; rem -= n;
+    }
+  }
+}
+
 // One seed of UngappedBlast (ungappedblast.cpp:62-180): seed score, x-drop extension right then
 // left, acceptance test.  nt: byte-SWAR - a run of matching letters is consumed per step (a match
 // always raises the score, so inside a run the best is the run's end and the x-drop test cannot
@@ -546,45 +590,7 @@ __device__ __forceinline__ bool extend_seed(const WaveCtx &c, const UgsDbView &d
     if (c.a_inv || c.b_inv) extend_nt_packed<true>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
     else if (c.xlut) extend_nt_lut(c.A2, c.B2, c.xlut, LA, LB, a1, b1, a2, b2, best, bestb1, bestb2);
     else extend_nt_packed<false>(c.A2, c.Ai, c.B2, c.Bi, m2, mm2, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
-  } else {
-    {
-      uint32_t rem = (LB - 1 - b2) < (LA - 1 - a2) ? (LB - 1 - b2) : (LA - 1 - a2);
-      bool stop = false;
-      while (rem && !stop) {
-        uint32_t av[8], bv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a2 + o]; bv[k] = c.Bs[b2 + o]; }
-        const uint32_t n = rem < 8 ? rem : 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if ((uint32_t)k < n && !stop) {
-            score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
-            if (score > best) { best = score; bestb2 = b2 + k + 1; }
-            else if (best - score > X) stop = true;
-          }
-        a2 += n; b2 += n; rem -= n;
-      }
-    }
-    score = best;
-    {
-      uint32_t rem = b1 < a1 ? b1 : a1;
-      bool stop = false;
-      while (rem && !stop) {
-        uint32_t av[8], bv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint32_t o = (uint32_t)(k + 1) <= rem ? (uint32_t)(k + 1) : rem; av[k] = c.As[a1 - o]; bv[k] = c.Bs[b1 - o]; }
-        const uint32_t n = rem < 8 ? rem : 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if ((uint32_t)k < n && !stop) {
-            score += sscore<NT>(c, m2, mm2, av[k], bv[k]);
-            if (score > best) { best = score; bestb1 = b1 - k - 1; }
-            else if (best - score > X) stop = true;
-          }
-        a1 -= n; b1 -= n; rem -= n;
-      }
-    }
-  }
+  } else extend_aa_bytes(c.s_sub2, c.As, c.Bs, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
   const uint32_t Blo = bestb1, Bhi = bestb2, Len = Bhi - Blo + 1;
   const uint32_t Alo = apos - (bpos - bestb1);
   oAlo = Alo; oBlo = Blo; oLen = Len; oBest = best;
@@ -902,6 +908,135 @@ __device__ UGS_GROUP_INLINE uint32_t group_filter(const GroupArgs c, uint32_t k,
 #if UGS_ALIGN_CLOCKS == 5
   { const unsigned long long tg3 = clock64(); c.ctr[0] += tg1 - tg0; c.ctr[1] += tg2 - tg1; c.ctr[2] += tg3 - tg2; c.ctr[3] += (1ull << 32) | count; }
 #endif
+  return maybe & all;
+}
+
+// The same filter for amino-acid databases (and any target kept as bytes): a member's letters are fetched from the byte array and kept as
+// score codes (member 0 in the score-code array of the serial path, the others in the tail of the union region, where the filter's seed
+// list then ends); words through the HSP letter of a score code, the bucketed word table as in ungapped_blast, extension by extend_aa_bytes.
+struct GroupArgsAA {
+  const uint8_t *seqs; const uint8_t *As; uint8_t *Bs0; uint8_t *tail; const uint16_t *wstart; const uint32_t *qsort; uint32_t *seeds;
+  const uint8_t *s_cls, *s_sc, *s_hl; const int8_t *sub2;
+  uint32_t seed_cap, LA, MinLength, gstride, bsh; int w, alpha, X, minscore2;
+};
+__device__ UGS_GROUP_INLINE uint32_t group_filter_aa(const GroupArgsAA c, uint32_t k, uint32_t n, uint64_t cto, uint32_t clen)
+{
+  const int lane = (int)(threadIdx.x & 63), w = c.w, X = c.X;
+  const uint32_t LA = c.LA, MinLength = c.MinLength;
+  uint32_t maybe = 0;
+  uint32_t Lg[UGS_GROUP];
+  uint32_t v[UGS_GROUP][4];
+  auto gbuf = [&](uint32_t g) -> uint8_t * { return g == 0 ? c.Bs0 : c.tail + (g - 1u) * c.gstride; };
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    Lg[g] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[g][e] = 0;
+    if ((uint32_t)g < n) {
+      const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)(k + g)) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)(k + g));
+      const uint32_t L = (uint32_t)rl((int)clen, (int)(k + g));
+      if (L > 1024u || L < 2u * (uint32_t)w) maybe |= 1u << g;
+      else {
+        Lg[g] = L;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
+          if (o < L) __builtin_memcpy(&v[g][e], c.seqs + to + o, 4);       // unaligned dword load (the DB buffer is padded)
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    if (Lg[g]) {
+      uint8_t *Bs = gbuf((uint32_t)g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t o = (uint32_t)(e * 64 + lane) * 4;
+        if (o < Lg[g]) {
+          uint32_t sc4 = 0;
+#pragma unroll
+          for (uint32_t b = 0; b < 4; ++b) sc4 |= (uint32_t)c.s_sc[c.s_cls[(v[g][e] >> (8 * b)) & 0xffu] & 31] << (8 * b);
+          *(uint32_t *)(Bs + o) = sc4;                                   // (codes behind the last letter are never read)
+        }
+      }
+    }
+  }
+  lds_sync();
+  // ---- the members' seeds, one list: member << 26 | bpos << 16 | apos
+  uint32_t count = 0;
+#pragma unroll
+  for (int g = 0; g < UGS_GROUP; ++g) {
+    if (Lg[g]) {
+      const uint8_t *Bs = gbuf((uint32_t)g);
+      const uint32_t LB = Lg[g], nwB = LB - w + 1;
+      int dlo, dhi;
+      {
+        const int LAi = (int)LA, LBi = (int)LB;
+        if (LAi <= LBi) { const int mg = LAi / 4 + 1; dlo = LAi - LBi - mg; dhi = mg; }
+        else { const int mg = LBi / 4 + 1; dlo = -mg; dhi = mg + LAi - LBi; }
+      }
+      for (uint32_t scan = 0; scan < nwB; scan += 64) {
+        const uint32_t bpos = scan + (uint32_t)lane;
+        uint32_t lo = 0, cnt = 0, word = 0;
+        if (bpos < nwB) {
+          for (int q = 0; q < w; ++q) word = word * c.alpha + c.s_hl[Bs[bpos + q]];
+          const uint32_t e = c.wstart[word >> c.bsh]; lo = e & 0xfffu; cnt = e >> 12;
+        }
+        uint32_t okm = 0;
+        if (c.bsh) {
+          // a bucket's entries in query-position order: the first MaxReps of THIS word are the word's positions (HSPFinder::SetA)
+          uint32_t nm = 0;
+          for (uint32_t r = 0; r < cnt; ++r) {
+            const uint32_t e = c.qsort[lo + r];
+            if ((e >> 16) == word) {
+              const int d = (int)(e & 0xffffu) - (int)bpos;
+              if (nm < UGS_MAXREPS) okm |= (d >= dlo && d <= dhi ? 1u : 0u) << r;
+              ++nm;
+            }
+          }
+        } else
+          for (uint32_t r = 0; r < cnt; ++r) { const int d = (int)(c.qsort[lo + r] & 0xffffu) - (int)bpos; okm |= (d >= dlo && d <= dhi ? 1u : 0u) << r; }
+        const uint32_t cn = (uint32_t)__popc(okm);
+        const uint32_t incl = wave_incl_sum_u32(cn);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (count + total > c.seed_cap) { maybe |= 1u << g; break; }
+        uint32_t off = count + incl - cn;
+        for (uint32_t m = okm; m; m &= m - 1) { const uint32_t r = (uint32_t)__ffs((int)m) - 1u; c.seeds[off++] = ((uint32_t)g << 26) | (bpos << 16) | (c.qsort[lo + r] & 0xffffu); }
+        count += total;
+      }
+    }
+  }
+  lds_sync();
+  // ---- extend them 64 at a time; the seeds of a member that has an accepted seed already are passed over
+  const uint32_t all = (1u << n) - 1u;
+  for (uint32_t idx = 0; idx < count && (maybe & all) != all; idx += 64) {
+    const uint32_t me = idx + (uint32_t)lane;
+    bool ok = false;
+    uint32_t g = 0;
+    if (me < count) {
+      const uint32_t sd = c.seeds[me];
+      g = sd >> 26;
+      if (!((maybe >> g) & 1u)) {
+        const uint32_t bpos = (sd >> 16) & 1023u, apos = sd & 0xffffu;
+        const uint8_t *Bs = gbuf(g);
+        const uint32_t LB = g == 0 ? Lg[0] : g == 1 ? Lg[1] : g == 2 ? Lg[2] : Lg[3];
+        int score = 0;
+        for (int q = 0; q < w; ++q) score += (int)c.sub2[((uint32_t)c.As[apos + q] << 5) | Bs[bpos + q]];
+        int best = score;
+        uint32_t b2 = bpos + w - 1, a2 = apos + w - 1, bestb2 = b2;
+        uint32_t a1 = apos, b1 = bpos, bestb1 = b1;
+        extend_aa_bytes(c.sub2, c.As, Bs, X, LA, LB, a1, b1, a2, b2, score, best, bestb1, bestb2);
+        const uint32_t Len = bestb2 - bestb1 + 1, Alo = apos - (bpos - bestb1);
+        ok = Len >= MinLength && best >= c.minscore2 && is_global_hsp(Alo, bestb1, LA, LB);
+      }
+    }
+    if (__ballot(ok)) {
+#pragma unroll
+      for (int gi = 0; gi < UGS_GROUP; ++gi) if (__ballot(ok && g == (uint32_t)gi)) maybe |= 1u << gi;
+    }
+  }
+  lds_sync();
   return maybe & all;
 }
 
@@ -1408,6 +1543,13 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     uint32_t grp_lo = 0, grp_hi = 0, grp_maybe = 0;             // members [grp_lo, grp_hi) are decided: bit set = takes the full path
     uint32_t gwt = 0, gnB = 0, gmax = 0;
     bool group_ok = false;
+    uint8_t *gtail = nullptr; uint32_t gcap = 0;                // (aa: the score codes of group members 1 .. 3, where the filter's seed list ends)
+    if constexpr (!PAIR && !NT) {
+      const uint32_t ub = (c.union_words * 4u) & ~15u;
+      gmax = UGS_GROUP;
+      if (ub >= 3u * maxt + 1024u) { gtail = (uint8_t *)c.seeds + (ub - 3u * maxt); gcap = (ub - 3u * maxt) / 4u; if (gcap > c.seed_cap) gcap = c.seed_cap; }
+      group_ok = db.group_after != 0 && ncand && gtail != nullptr && c.use_tab && c.nwA > 0 && LA < 65536u;
+    }
     if constexpr (!PAIR && NT) {
       gwt = (uint32_t)((((size_t)maxt / 16 + 6) * 4 + 15) & ~(size_t)15);
       gnB = maxt / gwt;
@@ -1416,7 +1558,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     }
     for (uint32_t k = 0; k < ncand; ++k) {
       tq = ACLK();
-      if constexpr (!PAIR && NT) {
+      if constexpr (!PAIR) {
         if (group_ok && k >= grp_hi && nrej >= db.group_after) {
           uint32_t n = ncand - k < gmax ? ncand - k : gmax;
           if (max_rej - nrej < n) n = max_rej - nrej;
@@ -1424,11 +1566,20 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
             uint32_t MinL = db.min_hsp_len_opt == 0 ? 32u : (uint32_t)db.min_hsp_len_opt;
             if (MinL > LA / 4) MinL = LA / 4;
             if (MinL < 16) MinL = 16;
+            if constexpr (!NT) {
+              GroupArgsAA ga;
+              ga.seqs = db.seqs; ga.As = c.As; ga.Bs0 = c.Bs; ga.tail = gtail; ga.wstart = c.wstart; ga.qsort = c.qsort; ga.seeds = c.seeds;
+              ga.s_cls = s_cls; ga.s_sc = s_sc; ga.s_hl = s_hl; ga.sub2 = s_sub2;
+              ga.seed_cap = gcap; ga.LA = LA; ga.MinLength = MinL; ga.gstride = maxt; ga.bsh = c.bsh;
+              ga.w = db.hsp_w; ga.alpha = db.alpha; ga.X = db.xdrop2; ga.minscore2 = db.minscore2;
+              grp_maybe = group_filter_aa(ga, k, n, cto, clen);
+            } else {
             GroupArgs ga;
             ga.pk = db.pk; ga.A2 = c.A2; ga.B = c.B; ga.Bs = c.Bs; ga.wstart = c.wstart; ga.qsort = c.qsort; ga.seeds = c.seeds;
             ga.seed_cap = c.seed_cap; ga.LA = LA; ga.MinLength = MinL; ga.gwt = gwt; ga.nB = gnB;
             ga.w = db.hsp_w; ga.X = db.xdrop2; ga.m2 = c.s_sub2[0]; ga.mm2 = c.s_sub2[2]; ga.minscore2 = db.minscore2; ga.ctr = gclk; ga.xlut = c.xlut;
             grp_maybe = group_filter(ga, k, n, cto, clen);
+            }
             grp_lo = k; grp_hi = k + n;
             ta2 += ACLK() - tq; tq = ACLK();
           }
@@ -1437,7 +1588,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           // a pair without an HSP: fetched, counted and rejected as the full path would (no chain -> no alignment -> reject)
           nvis = k + 1;
           const uint32_t LBq = (uint32_t)rl((int)clen, (int)k);
-          w_tletters += (((LBq + 15u) >> 4) + 1u) * 8u; ++w_pairs; ++w_grouped;
+          w_tletters += NT ? (((LBq + 15u) >> 4) + 1u) * 8u : LBq; ++w_pairs; ++w_grouped;
           ++nrej;
           if (nrej == max_rej) break;
           continue;
@@ -1506,7 +1657,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       {
         // (no prefetch for a candidate the group filter has rejected already, or will look at itself)
         bool want = k + 1 < ncand;
-        if constexpr (!PAIR && NT) want = want && !(k + 1 < grp_hi ? !((grp_maybe >> (k + 1 - grp_lo)) & 1u) : (group_ok && nrej + 1 >= db.group_after && max_rej - nrej > 2 && ncand - k > 2));
+        if constexpr (!PAIR) want = want && !(k + 1 < grp_hi ? !((grp_maybe >> (k + 1 - grp_lo)) & 1u) : (group_ok && nrej + 1 >= db.group_after && max_rej - nrej > 2 && ncand - k > 2));
         if (want) { prefetch(k + 1); pre_k = k + 1; }
       }
       wave_sync();
