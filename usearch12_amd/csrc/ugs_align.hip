@@ -1200,9 +1200,17 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
       TB = (uint8_t *)(Mrow - 4) + tb_off;
     } else TB = c.tb;
   }
+  // the traceback bytes are addressed as LDS where they are LDS (a generic pointer makes every store of the row sweep and every load of
+  // the single-lane traceback a flat instruction, whose latency the fences of the sweep and the traceback's dependent chain then expose)
+  const bool tb_lds = TB != c.tb;
+  typedef uint8_t __attribute__((address_space(3))) *lds8;
+  const lds8 TBl = (lds8)(uintptr_t)(uint32_t)(uintptr_t)TB;
+  auto tb_st = [&](uint64_t off, uint8_t v) { if (tb_lds) TBl[(uint32_t)off] = v; else c.tb[off] = v; };
+  auto tb_ld = [&](uint64_t off) -> uint8_t { return tb_lds ? TBl[(uint32_t)off] : c.tb[off]; };
   for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
   wave_sync();
   unsigned long long cells = 0;
+  int dEnd = NEG;                                                  // Drow[LB]: touched by the end-of-row special case only - a wave-uniform register
   for (uint32_t i = 0; i < LA; ++i) {
     uint32_t Startj, Endj;
     get_range_j(LA, LB, dlo, dhi, i, Startj, Endj);
@@ -1211,8 +1219,8 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     const int OpenA = i == 0 ? P.LOpenA : P.OpenA, ExtA = i == 0 ? P.LExtA : P.ExtA;
     int carryM = (i == 0) ? 0 : (Startj == 0 ? NEG : Mrow[(int)Startj - 1]);
     int carryI = NEG;
-    uint8_t *TBrow = TB + (uint64_t)i * stride;
-    if (Startj > 0 && lane == 0) TBrow[0] = TB_IM;               // TBrow[Startj-1]
+    const uint64_t rowo = (uint64_t)i * stride;
+    if (Startj > 0 && lane == 0) tb_st(rowo, TB_IM);             // (the entry of column Startj - 1)
     cells += Endj - Startj;
     for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
       const uint32_t j = j0 + lane;
@@ -1240,25 +1248,25 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
       if (md >= nd) { nd = md; bits |= TB_MD; }
       const int iext = sat_add(Iprev, ExtA);
       if (mi >= iext) bits |= TB_MI;
-      if (act) { Mrow[j] = newM; Drow[j] = nd; TBrow[j - Startj + 1] = bits; }
+      if (act) { Mrow[j] = newM; Drow[j] = nd; tb_st(rowo + (j - Startj + 1), bits); }
       const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
       carryM = rl(oldM, lastl);
       carryI = rl(Iout, lastl);
       wave_sync();
     }
-    if (lane == 0) {                                              // "Special case for end of Drow[]"
+    {                                                             // "Special case for end of Drow[]" (scalar: no LDS round trip, no second fence per row)
       uint8_t tbe = 0;
       const int md = sat_add(carryM, P.ROpenB);
-      int dl = sat_add(Drow[LB], P.RExtB);
+      int dl = sat_add(dEnd, P.RExtB);
       if (md >= dl) { dl = md; tbe = TB_MD; }
-      Drow[LB] = dl; TBrow[stride - 1] = tbe;
+      dEnd = dl;
+      if (lane == 0) tb_st(rowo + stride - 1, tbe);
     }
-    wave_sync();
   }
   // last row of DPI (viterbifastbandmem.cpp:186-204), strict '>'
   uint32_t Startj, Endj;
   get_range_j(LA, LB, dlo, dhi, LA - 1, Startj, Endj);
-  uint8_t *TBlast = TB + (uint64_t)LA * stride;
+  const uint64_t lasto = (uint64_t)LA * stride;
   if (lane == 0) Mrow[(int)Startj - 1] = NEG;
   wave_sync();
   cells += LB;
@@ -1274,7 +1282,7 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
     const int Iprev = wave_shr1(Iout, carryI);
     const int iext = sat_add(Iprev, P.RExtA);
-    if (act) TBlast[j - Startj + 1] = (mi > iext) ? TB_MI : 0;
+    if (act) tb_st(lasto + (j - Startj + 1), (mi > iext) ? TB_MI : 0);
     const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
     carryI = rl(Iout, lastl);
   }
@@ -1282,9 +1290,12 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
 #if UGS_ALIGN_CLOCKS == 3
   const unsigned long long tv1 = clock64();
 #endif
-  if (lane == 0) {
-    atomicAdd(&counters[UGS_CTR_CELLS], cells);
-    const int FinalM = Mrow[LB - 1], FinalD = Drow[LB], FinalI = carryI;
+  {
+    // The traceback is one dependent chain.  Every lane walks it (the same bytes: LDS broadcast reads, made wave-uniform with
+    // readfirstlane), so the state and the index arithmetic live in SCALAR registers and issue on the scalar unit - as lane-0-only code it
+    // was a chain of ~ 40 vector instructions per step (1 000 cycles a step, a third of an amino-acid pair's time); lane 0 alone writes the runs
+    if (lane == 0) atomicAdd(&counters[UGS_CTR_CELLS], cells);
+    const int FinalM = rl(Mrow[LB - 1], 0), FinalD = dEnd, FinalI = carryI;
     int Score = FinalM; uint32_t State = 0;                       // 0=M 1=D 2=I
     if (FinalD > Score) { Score = FinalD; State = 1; }
     if (FinalI > Score) { Score = FinalI; State = 2; }
@@ -1293,24 +1304,24 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     uint32_t i = LA, j = LB;
     const uint32_t sLast = Startj;
     auto tbget = [&](uint32_t ti, uint32_t tj) -> uint8_t {
-      if (tj == LB && ti < LA) return TB[(uint64_t)ti * stride + stride - 1];
+      if (tj == LB && ti < LA) return (uint8_t)__builtin_amdgcn_readfirstlane((int)tb_ld((uint64_t)ti * stride + stride - 1));
       uint32_t s, e;
       if (ti >= LA) s = sLast; else get_range_j(LA, LB, dlo, dhi, ti, s, e);
       const int idx = (int)tj - (int)s + 1;
       if (idx < 0 || idx >= (int)stride - 1) return 0;
-      return TB[(uint64_t)ti * stride + idx];
+      return (uint8_t)__builtin_amdgcn_readfirstlane((int)tb_ld((uint64_t)ti * stride + idx));
     };
     while (i != 0 || j != 0) {
       if (State == curop) ++curlen;
-      else { if (curlen) { put_rt(c, nrt, (curlen << 2) | curop); ++nrt; } curop = State; curlen = 1; }
+      else { if (curlen) { if (lane == 0) put_rt(c, nrt, (curlen << 2) | curop); ++nrt; } curop = State; curlen = 1; }
       uint8_t t;
       if (State == 0) { t = tbget(i - 1, j - 1); State = (t & TB_DM) ? 1 : ((t & TB_IM) ? 2 : 0); --i; --j; }
       else if (State == 1) { t = tbget(i - 1, j); State = (t & TB_MD) ? 0 : 1; --i; }
       else { t = tbget(i, j - 1); State = (t & TB_MI) ? 0 : 2; --j; }
     }
-    if (curlen) { put_rt(c, nrt, (curlen << 2) | curop); ++nrt; }
+    if (curlen) { if (lane == 0) put_rt(c, nrt, (curlen << 2) | curop); ++nrt; }
     if (nrt > c.runs_cap) nrt = c.runs_cap;
-    for (int k = (int)nrt - 1; k >= 0; --k) { const uint32_t r = get_rt(c, (uint32_t)k); push_run(c, r & 3, r >> 2); }
+    if (lane == 0) for (int k = (int)nrt - 1; k >= 0; --k) { const uint32_t r = get_rt(c, (uint32_t)k); push_run(c, r & 3, r >> 2); }
   }
   wave_sync();
 #if UGS_ALIGN_CLOCKS == 3
