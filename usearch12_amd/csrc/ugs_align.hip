@@ -1207,86 +1207,159 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
   const lds8 TBl = (lds8)(uintptr_t)(uint32_t)(uintptr_t)TB;
   auto tb_st = [&](uint64_t off, uint8_t v) { if (tb_lds) TBl[(uint32_t)off] = v; else c.tb[off] = v; };
   auto tb_ld = [&](uint64_t off) -> uint8_t { return tb_lds ? TBl[(uint32_t)off] : c.tb[off]; };
-  for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
-  wave_sync();
   unsigned long long cells = 0;
   int dEnd = NEG;                                                  // Drow[LB]: touched by the end-of-row special case only - a wave-uniform register
-  for (uint32_t i = 0; i < LA; ++i) {
-    uint32_t Startj, Endj;
-    get_range_j(LA, LB, dlo, dhi, i, Startj, Endj);
-    if (Endj == 0) continue;
-    const uint8_t a = c.A[a0 + i];
-    const int OpenA = i == 0 ? P.LOpenA : P.OpenA, ExtA = i == 0 ? P.LExtA : P.ExtA;
-    int carryM = (i == 0) ? 0 : (Startj == 0 ? NEG : Mrow[(int)Startj - 1]);
-    int carryI = NEG;
-    const uint64_t rowo = (uint64_t)i * stride;
-    if (Startj > 0 && lane == 0) tb_st(rowo, TB_IM);             // (the entry of column Startj - 1)
-    cells += Endj - Startj;
-    for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      const bool act = j < Endj;
-      const int oldM = act ? Mrow[j] : NEG;
-      const int oldD = act ? Drow[j] : NEG;
-      const int saved = wave_shr1(oldM, carryM);
+  uint32_t Startj = 0, Endj = 0;                                   // (after the sweep: the range of the last row)
+  int carryI = NEG, FinalM = NEG;
+  if (LB <= 64u) {
+    // ---- a hole at most 64 columns wide (the usual one): lane = COLUMN for the whole hole.  The two DP rows are registers (no LDS round
+    // trip and no fence per row), the column's target letter is read once, the score look-up of a row is issued before the row's
+    // recurrences (it depends on the letters only) and the next row's query letter travels a row ahead.  Same recurrences, same traceback
+    // bytes in the same layout as the general sweep below (viterbifastbandmem.cpp:12-204).
+    const uint32_t jc = (uint32_t)lane;
+    int M = NEG, D = NEG;                                          // Mrow[jc], Drow[jc]
+    const uint8_t bl = jc < LB ? c.B[b0 + jc] : (uint8_t)0;
+    uint8_t a_next = c.A[a0];
+    for (uint32_t i = 0; i < LA; ++i) {
+      const uint8_t a = a_next;
+      if (i + 1 < LA) a_next = c.A[a0 + i + 1];
+      get_range_j(LA, LB, dlo, dhi, i, Startj, Endj);
+      if (Endj == 0) continue;
+      const bool act = jc >= Startj && jc < Endj;
+      const int sc = act ? score2(c, a, bl) : 0;
+      const int OpenA = i == 0 ? P.LOpenA : P.OpenA, ExtA = i == 0 ? P.LExtA : P.ExtA;
+      const uint64_t rowo = (uint64_t)i * stride;
+      if (Startj > 0 && lane == 0) tb_st(rowo, TB_IM);           // (the entry of column Startj - 1)
+      cells += Endj - Startj;
+      const int oldM = act ? M : NEG;
+      const int oldD = act ? D : NEG;
+      int saved = wave_shr1(M, NEG);                             // Mrow[jc - 1] as the previous row left it
+      if (i == 0 && jc == Startj) saved = 0;
       const int mi = act ? sat_add(saved, OpenA) : NEG;
-      // in-row insert recurrence I[k] = max(mi[k], I[k-1]+ExtA) as a max-plus prefix scan
       int v = mi <= NEGT ? NEG : mi - lane * ExtA;
       v = wave_incl_max_i32(v);
-      const int fromscan = v <= NEGT ? NEG : v + lane * ExtA;
-      const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * ExtA;
-      const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
-      const int Iprev = wave_shr1(Iout, carryI);
+      const int Iout = v <= NEGT ? NEG : v + lane * ExtA;
+      const int Iprev = wave_shr1(Iout, NEG);
       uint8_t bits = 0;
       int xM = saved;
       if (oldD > xM) { xM = oldD; bits = TB_DM; }
       if (Iprev > xM) { xM = Iprev; bits = TB_IM; }
-      const int sc = act ? score2(c, a, c.B[b0 + j]) : 0;
       const int newM = sat_add(xM, sc);
-      const int ob = (j == 0) ? P.LOpenB : P.OpenB, eb = (j == 0) ? P.LExtB : P.ExtB;
+      const int ob = (jc == 0) ? P.LOpenB : P.OpenB, eb = (jc == 0) ? P.LExtB : P.ExtB;
       const int md = sat_add(saved, ob);
       int nd = sat_add(oldD, eb);
       if (md >= nd) { nd = md; bits |= TB_MD; }
       const int iext = sat_add(Iprev, ExtA);
       if (mi >= iext) bits |= TB_MI;
-      if (act) { Mrow[j] = newM; Drow[j] = nd; tb_st(rowo + (j - Startj + 1), bits); }
+      if (act) { M = newM; D = nd; tb_st(rowo + (jc - Startj + 1), bits); }
+      const int carryM = rl(oldM, (int)Endj - 1);
+      {                                                           // "Special case for end of Drow[]"
+        uint8_t tbe = 0;
+        const int mdl = sat_add(carryM, P.ROpenB);
+        int dl = sat_add(dEnd, P.RExtB);
+        if (mdl >= dl) { dl = mdl; tbe = TB_MD; }
+        dEnd = dl;
+        if (lane == 0) tb_st(rowo + stride - 1, tbe);
+      }
+    }
+    // last row of DPI (viterbifastbandmem.cpp:186-204), strict '>'
+    get_range_j(LA, LB, dlo, dhi, LA - 1, Startj, Endj);
+    const uint64_t lasto = (uint64_t)LA * stride;
+    cells += LB;
+    {
+      const bool act = jc >= Startj && jc < Endj;
+      int Ms = wave_shr1(M, NEG);
+      if (jc == Startj) Ms = NEG;                                 // (Mrow[Startj - 1] = NEG)
+      const int mi = act ? sat_add(Ms, P.ROpenA) : NEG;
+      int v = mi <= NEGT ? NEG : mi - lane * P.RExtA;
+      v = wave_incl_max_i32(v);
+      const int Iout = v <= NEGT ? NEG : v + lane * P.RExtA;
+      const int Iprev = wave_shr1(Iout, NEG);
+      const int iext = sat_add(Iprev, P.RExtA);
+      if (act) tb_st(lasto + (jc - Startj + 1), (mi > iext) ? TB_MI : 0);
+      if (Endj > Startj) carryI = rl(Iout, (int)Endj - 1);
+    }
+    FinalM = rl(M, (int)LB - 1);
+    wave_sync();
+  } else {
+    for (uint32_t j = lane; j <= LB + 1; j += 64) { Mrow[(int)j - 1] = NEG; if (j <= LB) Drow[j] = NEG; }
+    wave_sync();
+    for (uint32_t i = 0; i < LA; ++i) {
+      uint32_t Startj, Endj;
+      get_range_j(LA, LB, dlo, dhi, i, Startj, Endj);
+      if (Endj == 0) continue;
+      const uint8_t a = c.A[a0 + i];
+      const int OpenA = i == 0 ? P.LOpenA : P.OpenA, ExtA = i == 0 ? P.LExtA : P.ExtA;
+      int carryM = (i == 0) ? 0 : (Startj == 0 ? NEG : Mrow[(int)Startj - 1]);
+      int carryI = NEG;
+      const uint64_t rowo = (uint64_t)i * stride;
+      if (Startj > 0 && lane == 0) tb_st(rowo, TB_IM);             // (the entry of column Startj - 1)
+      cells += Endj - Startj;
+      for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool act = j < Endj;
+        const int oldM = act ? Mrow[j] : NEG;
+        const int oldD = act ? Drow[j] : NEG;
+        const int saved = wave_shr1(oldM, carryM);
+        const int mi = act ? sat_add(saved, OpenA) : NEG;
+        // in-row insert recurrence I[k] = max(mi[k], I[k-1]+ExtA) as a max-plus prefix scan
+        int v = mi <= NEGT ? NEG : mi - lane * ExtA;
+        v = wave_incl_max_i32(v);
+        const int fromscan = v <= NEGT ? NEG : v + lane * ExtA;
+        const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * ExtA;
+        const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
+        const int Iprev = wave_shr1(Iout, carryI);
+        uint8_t bits = 0;
+        int xM = saved;
+        if (oldD > xM) { xM = oldD; bits = TB_DM; }
+        if (Iprev > xM) { xM = Iprev; bits = TB_IM; }
+        const int sc = act ? score2(c, a, c.B[b0 + j]) : 0;
+        const int newM = sat_add(xM, sc);
+        const int ob = (j == 0) ? P.LOpenB : P.OpenB, eb = (j == 0) ? P.LExtB : P.ExtB;
+        const int md = sat_add(saved, ob);
+        int nd = sat_add(oldD, eb);
+        if (md >= nd) { nd = md; bits |= TB_MD; }
+        const int iext = sat_add(Iprev, ExtA);
+        if (mi >= iext) bits |= TB_MI;
+        if (act) { Mrow[j] = newM; Drow[j] = nd; tb_st(rowo + (j - Startj + 1), bits); }
+        const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
+        carryM = rl(oldM, lastl);
+        carryI = rl(Iout, lastl);
+        wave_sync();
+      }
+      {                                                             // "Special case for end of Drow[]" (scalar: no LDS round trip, no second fence per row)
+        uint8_t tbe = 0;
+        const int md = sat_add(carryM, P.ROpenB);
+        int dl = sat_add(dEnd, P.RExtB);
+        if (md >= dl) { dl = md; tbe = TB_MD; }
+        dEnd = dl;
+        if (lane == 0) tb_st(rowo + stride - 1, tbe);
+      }
+    }
+    // last row of DPI (viterbifastbandmem.cpp:186-204), strict '>'
+    get_range_j(LA, LB, dlo, dhi, LA - 1, Startj, Endj);
+    const uint64_t lasto = (uint64_t)LA * stride;
+    if (lane == 0) Mrow[(int)Startj - 1] = NEG;
+    wave_sync();
+    cells += LB;
+    for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool act = j < Endj;
+      const int mi = act ? sat_add(Mrow[(int)j - 1], P.ROpenA) : NEG;
+      int v = mi <= NEGT ? NEG : mi - lane * P.RExtA;
+      v = wave_incl_max_i32(v);
+      const int fromscan = v <= NEGT ? NEG : v + lane * P.RExtA;
+      const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * P.RExtA;
+      const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
+      const int Iprev = wave_shr1(Iout, carryI);
+      const int iext = sat_add(Iprev, P.RExtA);
+      if (act) tb_st(lasto + (j - Startj + 1), (mi > iext) ? TB_MI : 0);
       const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
-      carryM = rl(oldM, lastl);
       carryI = rl(Iout, lastl);
-      wave_sync();
     }
-    {                                                             // "Special case for end of Drow[]" (scalar: no LDS round trip, no second fence per row)
-      uint8_t tbe = 0;
-      const int md = sat_add(carryM, P.ROpenB);
-      int dl = sat_add(dEnd, P.RExtB);
-      if (md >= dl) { dl = md; tbe = TB_MD; }
-      dEnd = dl;
-      if (lane == 0) tb_st(rowo + stride - 1, tbe);
-    }
+    wave_sync();
+    FinalM = rl(Mrow[LB - 1], 0);
   }
-  // last row of DPI (viterbifastbandmem.cpp:186-204), strict '>'
-  uint32_t Startj, Endj;
-  get_range_j(LA, LB, dlo, dhi, LA - 1, Startj, Endj);
-  const uint64_t lasto = (uint64_t)LA * stride;
-  if (lane == 0) Mrow[(int)Startj - 1] = NEG;
-  wave_sync();
-  cells += LB;
-  int carryI = NEG;
-  for (uint32_t j0 = Startj; j0 < Endj; j0 += 64) {
-    const uint32_t j = j0 + lane;
-    const bool act = j < Endj;
-    const int mi = act ? sat_add(Mrow[(int)j - 1], P.ROpenA) : NEG;
-    int v = mi <= NEGT ? NEG : mi - lane * P.RExtA;
-    v = wave_incl_max_i32(v);
-    const int fromscan = v <= NEGT ? NEG : v + lane * P.RExtA;
-    const int fromcarry = carryI <= NEGT ? NEG : carryI + (lane + 1) * P.RExtA;
-    const int Iout = fromscan > fromcarry ? fromscan : fromcarry;
-    const int Iprev = wave_shr1(Iout, carryI);
-    const int iext = sat_add(Iprev, P.RExtA);
-    if (act) tb_st(lasto + (j - Startj + 1), (mi > iext) ? TB_MI : 0);
-    const int lastl = (Endj - j0) >= 64 ? 63 : (int)(Endj - j0) - 1;
-    carryI = rl(Iout, lastl);
-  }
-  wave_sync();
 #if UGS_ALIGN_CLOCKS == 3
   const unsigned long long tv1 = clock64();
 #endif
@@ -1295,7 +1368,7 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
     // readfirstlane), so the state and the index arithmetic live in SCALAR registers and issue on the scalar unit - as lane-0-only code it
     // was a chain of ~ 40 vector instructions per step (1 000 cycles a step, a third of an amino-acid pair's time); lane 0 alone writes the runs
     if (lane == 0) atomicAdd(&counters[UGS_CTR_CELLS], cells);
-    const int FinalM = rl(Mrow[LB - 1], 0), FinalD = dEnd, FinalI = carryI;
+    const int FinalD = dEnd, FinalI = carryI;
     int Score = FinalM; uint32_t State = 0;                       // 0=M 1=D 2=I
     if (FinalD > Score) { Score = FinalD; State = 1; }
     if (FinalI > Score) { Score = FinalI; State = 2; }
