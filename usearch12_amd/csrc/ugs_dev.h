@@ -111,6 +111,12 @@ struct UgsBatchView {
   uint32_t *cl_info;         // [units*4] M, NextValue, number of prefix maxima, -
   uint32_t *walk_n;          // [units] candidates the alignment walk visited
   const uint32_t *unit_map;  // [units] pair stage: unit -> query << 1 | strand (several units per query)
+  // cluster_fast: the ranking kernels take the units in descending order of their postings (a batch of reads holds a few units a hundred
+  // times heavier than the rest: started last they are the tail of the launch).  k_unit_cost writes unit_cost and a histogram of cost
+  // classes, k_unit_order the order; all null outside cluster_fast
+  uint32_t *unit_cost;       // [units] sampled postings of the unit (saturated)
+  uint32_t *unit_order;      // [units] units by descending cost class
+  uint32_t *order_hist;      // [512] units per cost class | cursors (zeroed by the launcher)
   uint32_t *defer_list;      // [units] units the bitmap ranking kernel (ugs_rank2.hip) hands on to k_rank; counters[UGS_CTR_DEFER] of them
   uint32_t use_defer;        // k_rank (HOT instantiation): take the units from defer_list instead of 0 .. units-1
 };

@@ -1143,6 +1143,42 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, RankShared *sh, in
 // (GetWordCountingParams wordparams.cpp:179-191 via the host's step table).  One wavefront per unit, no block barriers:
 // this stage is a chain of dependent loads with little arithmetic, so it runs at full occupancy in its own launch
 // instead of stalling a 128-VGPR scan workgroup.
+// cost class of a unit, heaviest first: 255 - ~9 classes per doubling of its postings
+__device__ __forceinline__ uint32_t ugs_unit_cost_class(uint32_t cost)
+{
+  const uint32_t c = (uint32_t)(__log2f((float)cost + 1.0f) * 9.0f);
+  return 255u - (c < 255u ? c : 255u);
+}
+// a unit's cost = the postings of its sampled rows (one thread per unit: at most a few dozen row lengths), and the histogram of the classes
+__global__ __launch_bounds__(256) void k_unit_cost(UgsDbView db, UgsBatchView bv, uint32_t units, uint32_t ns_max)
+{
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x) {
+    const uint32_t ns = bv.unit_ns[u];
+    unsigned long long sum = 0;
+    for (uint32_t r = 0; r < ns; ++r) { const uint32_t slot = bv.unit_slots[(uint64_t)u * ns_max + r]; sum += db.row_off[slot + 1] - db.row_off[slot]; }
+    const uint32_t cost = sum > 0xffffffffull ? 0xffffffffu : (uint32_t)sum;
+    bv.unit_cost[u] = cost;
+    atomicAdd(&bv.order_hist[ugs_unit_cost_class(cost)], 1u);
+  }
+}
+// units by descending cost class (a counting sort: every workgroup sums the histogram for itself, positions inside a class by atomics -
+// the order inside a class does not matter)
+__global__ __launch_bounds__(256) void k_unit_order(UgsBatchView bv, uint32_t units)
+{
+  __shared__ uint32_t s_base[256];
+  {
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < threadIdx.x; ++k) sum += bv.order_hist[k];
+    s_base[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x) {
+    const uint32_t b = ugs_unit_cost_class(bv.unit_cost[u]);
+    const uint32_t pos = s_base[b] + atomicAdd(&bv.order_hist[256 + b], 1u);
+    bv.unit_order[pos] = u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_rank_setup(UgsDbView db, UgsBatchView bv, uint32_t ns_max)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1409,7 +1445,10 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !WIDE) ? (LONG 
   if (tid == 0) sh->pad1 = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK], 1ull);
   __syncthreads();
   for (uint32_t uq = sh->pad1; uq < units; uq = sh->pad1) {
-    const uint32_t unit = deferred ? bv.defer_list[uq] : uq;
+    // (the list is taken from its END: the bitmap kernel appends a unit when it gives it up, the units it worked on longest - the heaviest,
+    // the ones that should not be started last - come last)
+    // (... unless the units were handed out heaviest first, cluster_fast: then the list starts with the heavy ones)
+    const uint32_t unit = deferred ? (bv.unit_order ? bv.defer_list[uq] : bv.defer_list[units - 1u - uq]) : (bv.unit_order ? bv.unit_order[uq] : uq);
     __syncthreads();                     // everyone has read sh->pad1
     const unsigned long long tk0 = clock64();
     // ---- the sampled index rows of this unit were chosen by k_rank_setup
@@ -1980,8 +2019,14 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_rank_setup, 256, slds) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint32_t sgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)ncu * per_cu));
+    if (units && b.unit_cost) HIPCHK(hipMemsetAsync(b.order_hist, 0, 512 * sizeof(uint32_t), st));
     if (units) hipLaunchKernelGGL(k_rank_setup, dim3(sgrid), dim3(256), slds, st, db, b, L.ns_max);
     HIPCHK(hipGetLastError());
+    if (units && b.unit_cost) {
+      hipLaunchKernelGGL(k_unit_cost, dim3(std::min<uint32_t>((units + 255) / 256, 256u)), dim3(256), 0, st, db, b, units, L.ns_max);
+      hipLaunchKernelGGL(k_unit_order, dim3(std::min<uint32_t>((units + 255) / 256, 64u)), dim3(256), 0, st, b, units);
+      HIPCHK(hipGetLastError());
+    }
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
     if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }

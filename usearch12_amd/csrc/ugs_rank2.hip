@@ -162,9 +162,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
       ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
       uidx = 0;
     }
-    const uint32_t unit = ubase + uidx;
+    uint32_t unit = ubase + uidx;
     ++uidx;
     if (unit >= units) break;
+    if constexpr (CL) { if (bv.unit_order) unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_order[unit]); }     // (heaviest first)
     const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
     bool bad = ns > 15u;                                                  // 4-bit count field of the keys
 #ifdef R2_DEFER_STATS
