@@ -279,6 +279,9 @@ int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
  * rows; bits 5-9: the same five on the small path; 12 / 13: the two Big-path 4-bit kernels with 64-bit offsets; 14: the bitmap kernel,
  * 15: its gather variant for sparse indexes, 16: its cluster_fast instantiation).  The test-suite ends with seen == compiled. */
 int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
+/* Diagnostic: the name of the ranking kernel behind bit `bit` of those masks (a static string), or NULL if the library holds no such
+ * instantiation - the library's own table, so that a test or tool keeps no list of its own. */
+const char *ugs_debug_rank_instance_name(int bit);
 
 /*
  * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the

@@ -116,3 +116,21 @@ def test_options_outside_the_envelope_are_refused_at_create():
                dict(band=-1)):
         with pytest.raises(capi.UgsError):
             capi.UgsDB(capi.params(is_nucleo=True, id=0.9, **kw), db.seqs, db.offs, device=0)
+
+
+@pytest.mark.parametrize("limit", [None, "1"])
+def test_fully_redundant_database_in_one_partition(limit, monkeypatch):
+    """N copies of a sequence in a database of one partition (np = 1 < waves per workgroup): ONE wave of k_rank emits every posting of
+    the unit's rows, so its share of the candidate buffer must be able to grow to the whole unit (the regrow was capped
+    per workgroup and such a search failed after six identical retries).  UGS_EMIT_LIMIT=1 starts from a one-key buffer."""
+    if limit:
+        monkeypatch.setenv("UGS_EMIT_LIMIT", limit)
+    rng = np.random.default_rng(77)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    t = rnd(400)
+    fam = [t] * 700 + [t[:200] + rnd(1) + t[201:] for _ in range(100)]
+    db = fam + [rnd(400) for _ in range(50)]
+    qs = [t, t[:150] + "A" + t[151:], t[20:380], db[-1]]
+    for big in (0, 100):
+        g = both(db, qs, ident=0.97, big=big, max_accepts=4, max_rejects=8)
+        assert g[1][0] == 4

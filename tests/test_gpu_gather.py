@@ -121,8 +121,9 @@ def test_rccl_gather_over_every_device_of_the_box():
     8-GPU node it is the first thing that runs RCCL between devices - and it must equal one fetch over all queries."""
     ndev = capi.device_count() if hasattr(capi, "device_count") else int(capi.lib().ugs_device_count())
     assert ndev >= 1
-    db = synth.make_db(33, 3000, 220)
-    qs = synth.make_queries(33, db, 1200, 220)
+    # real multi-MB tables (VERDICT r04 item 1): ~ 110 k hit records of 80 bytes + their paths, not a golden's few hundred
+    db = synth.make_db(33, 100_000, 220)
+    qs = synth.make_queries(33, db, 120_000, 220)
     p = capi.params(is_nucleo=True, id=0.9, max_accepts=3, max_rejects=16)
     g0 = capi.UgsDB(p, db.seqs, db.offs, device=0)
     b0 = capi.UgsBatch(g0, qs.n, int(qs.offs[-1]))
@@ -147,5 +148,6 @@ def test_rccl_gather_over_every_device_of_the_box():
     th = [threading.Thread(target=run, args=(r,)) for r in range(ndev)]
     [t.start() for t in th]; [t.join(300) for t in th]
     assert not err, err
+    assert want[0].nbytes > 6_000_000
     _same(res[0], want)
     [c.close() for c in comms]

@@ -82,6 +82,49 @@ def test_bitmap_kernel_with_small_partitions_and_several_windows(c2_small):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("g", ["8192", "16384", None])
+def test_bitmap_kernel_with_a_nearly_full_kept_key_list(c2_small, g):
+    """families of 200-250 near-identical targets spread over the partitions: every member keeps a key (count >= 3 keys are never
+    pruned), so the kept-key list - the LAST region of the wave's LDS carve - fills to just under its capacity of 252.  ADVICE r04:
+    the host sized the carve with the gather kernel's smaller hash filters, the top of the list lay outside the allocation
+    (dropped writes, reads of 0 = a key of count 15 / row 0 / target 0) wherever the 1280-byte LDS granule did not cover it."""
+    base, _ = c2_small
+    rng = np.random.default_rng(31)
+    L = 250
+    seqs = base.seqs.reshape(base.n, L).copy()
+    members = []
+    for f, size in enumerate((200, 224, 236, 244, 250)):
+        proto = seqs[1000 + f].copy()
+        idx = rng.choice(base.n - 5000, size=size, replace=False) + 2000
+        for t in idx:
+            row = proto.copy()
+            pos = rng.integers(0, L, size=2)
+            row[pos] = seqs[t][pos]
+            seqs[t] = row
+        members.append(idx)
+    db = synth.SeqSet(seqs.reshape(-1), base.offs, lambda i: "t%d" % i)
+    q = []
+    for idx in members:
+        for t in idx[::10]:
+            row = seqs[t].copy()
+            pos = rng.integers(0, L, size=3)
+            row[pos] = seqs[(t + 7) % base.n][pos]
+            q.append(row)
+    qs0 = synth.make_queries(31, db, 500, L)
+    qseqs = np.concatenate([qs0.seqs] + q)
+    qoffs = np.concatenate([qs0.offs, qs0.offs[-1] + np.arange(1, len(q) + 1, dtype=np.uint64) * np.uint64(L)])
+    qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
+    env = {"UGS_RANK2": "1"}
+    if g:
+        env["UGS_R2_G"] = g
+    a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=True, id=0.97)[0]
+    b = _search(db, qs, env, is_nucleo=True, id=0.97)[0]
+    assert b[1]["r2_launched"] == 1 and b[1]["r2_units"] >= 500 + len(q) * 3 // 5         # (the 250-member family may defer)
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0]
+
+
 def test_bitmap_kernel_both_strands_and_oracle(c2_small):
     db, _ = c2_small
     qs = synth.make_queries(13, db, 600, 250)

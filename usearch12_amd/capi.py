@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -115,6 +115,13 @@ def rank_instances():
     f.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; f.restype = C.c_int
     _chk(f(C.byref(a), C.byref(b)))
     return int(a.value), int(b.value)
+
+
+def rank_instance_names():
+    """{bit: name} of every ranking kernel the library holds (its own table: ugs_dev.h UGS_RANK_INST_TABLE)"""
+    f = lib().ugs_debug_rank_instance_name
+    f.argtypes = [C.c_int]; f.restype = C.c_char_p
+    return {i: f(i).decode() for i in range(64) if f(i)}
 
 
 def params(is_nucleo=True, id=0.97, local_evalue=None, **kw):

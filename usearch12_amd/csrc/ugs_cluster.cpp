@@ -434,6 +434,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
   ugs_db *db = G.db;
   db->max_tlen = maxlen; db->v.max_tlen = maxlen;           // every centroid is one of the input sequences: plan the kernels for the longest
   if (maxlen >= (uint32_t)p.word_len + 255u) db->gsize_limit = 2048;   // > 255 query words: 16-bit counters on the small path
+  const bool profile = getenv("UGS_CLUSTER_PROFILE") != nullptr;       // (debug switches are read once per call, never inside the batch loop)
   uint32_t Bmax = 32768;            // (C3: 16 384 -> 32 768 takes 0.1 s off: fewer, fuller launches; 65 536 loses it again to the in-batch stage)
   if (const char *e = getenv("UGS_CLUSTER_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) Bmax = (uint32_t)v; }
   Bmax = std::min<uint32_t>(Bmax, std::max<uint32_t>(nu, 1));
@@ -479,14 +480,14 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
       stage_off.push_back(stage.size());
     }
     RCCHK(ugs_batch_upload(b, stage.data(), stage_off.data(), B));
-    if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: n0 %u B %u stage+upload %.4f s\n", C->st.batches, n0, B, now_s() - tq);
+    if (profile) fprintf(stderr, "[ugs] batch %u: n0 %u B %u stage+upload %.4f s\n", C->st.batches, n0, B, now_s() - tq);
     const uint32_t units = B * ns;
     b->v.unit_cost = (uint32_t *)d_ucost.p; b->v.unit_order = (uint32_t *)d_uorder.p; b->v.order_hist = (uint32_t *)d_ohist.p;
     b->v.cand_key = (uint64_t *)d_ckey.p; b->v.cl_ev = (uint64_t *)d_clev.p; b->v.cl_info = (uint32_t *)d_clinfo.p; b->v.walk_n = (uint32_t *)d_walk.p;
     b->v.unit_map = nullptr;
     RCCHK(ugs_batch_search(b));
     RCCHK(ugs_batch_sync(b));
-    if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: search done %.4f s\n", C->st.batches, now_s() - tq);
+    if (profile) fprintf(stderr, "[ugs] batch %u: search done %.4f s\n", C->st.batches, now_s() - tq);
     const bool small_path = !db->v.big;
     C->st.s_search += (float)(now_s() - tq); tq = now_s();
     // ---- the batch's own index and the in-batch word counts (count, scan, write)
@@ -700,7 +701,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
     ++C->st.batches; C->st.pairs_in_batch += n_pairs; C->st.inbatch_entries += n_ent; C->st.queries_redone += B - done;
     C->st.max_batch = std::max<uint32_t>(C->st.max_batch, B);
     ugs_batch_stats bs;
-    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { uint64_t kh[6] = {0, 0, 0, 0, 0, 0}; if (getenv("UGS_CLUSTER_PROFILE")) { (void)ugs_debug_kernel_hits(b, kh, 6); fprintf(stderr, "[ugs] batch %u: bitmap kernel %.3f ms, k_rank behind it %.3f ms ; T0..T7 %llu %llu %llu %llu %llu %llu %llu %llu\n", C->st.batches, kh[4] / 1000.0, kh[5] / 1000.0, b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5], b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]); } if (getenv("UGS_CLUSTER_PROFILE")) fprintf(stderr, "[ugs] batch %u: n0 %u B %u done %u path %s ms_setup %.3f ms_rank %.3f ms_align %.3f pairs %llu | bitmap kernel: %s units %llu deferred %llu\n", C->st.batches, n0, B, done, small_path ? "small" : "big", bs.ms_rank_setup, bs.ms_rank, bs.ms_align, (unsigned long long)n_pairs, b->r2_ran ? "ran" : "-", b->ctr[UGS_CTR_R2_DONE], b->ctr[UGS_CTR_DEFER]);
+    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { uint64_t kh[6] = {0, 0, 0, 0, 0, 0}; if (profile) { (void)ugs_debug_kernel_hits(b, kh, 6); fprintf(stderr, "[ugs] batch %u: bitmap kernel %.3f ms, k_rank behind it %.3f ms ; T0..T7 %llu %llu %llu %llu %llu %llu %llu %llu\n", C->st.batches, kh[4] / 1000.0, kh[5] / 1000.0, b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5], b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]); } if (profile) fprintf(stderr, "[ugs] batch %u: n0 %u B %u done %u path %s ms_setup %.3f ms_rank %.3f ms_align %.3f pairs %llu | bitmap kernel: %s units %llu deferred %llu\n", C->st.batches, n0, B, done, small_path ? "small" : "big", bs.ms_rank_setup, bs.ms_rank, bs.ms_align, (unsigned long long)n_pairs, b->r2_ran ? "ran" : "-", b->ctr[UGS_CTR_R2_DONE], b->ctr[UGS_CTR_DEFER]);
       C->st.ms_rank += bs.ms_rank + bs.ms_rank_setup; C->st.ms_align += bs.ms_align; C->st.postings += bs.postings; C->st.pairs_frozen += bs.pairs_aligned; }
     next += done;
     B_prev = B; pairs_prev = n_pairs;

@@ -143,7 +143,7 @@ struct UgsLocalView {
 };
 
 // launch descriptors computed on the host
-struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; int fast8; int longrows; int wide; };
+struct UgsRankLaunch { int bits; int wpb; int grid; size_t lds; uint32_t ns_max; uint32_t part_words; int fast8; int longrows; int wide; int debug_sync; };
 struct UgsAlignLaunch { int wpb; int grid; size_t lds; uint32_t hsp_cap; uint32_t seed_cap; };
 
 // kernels' host-callable launchers (defined in the .hip files)
@@ -155,7 +155,19 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
 int ugs_build_part(const uint64_t *d_row_off, const uint32_t *d_postings, uint32_t slots, uint32_t np,
                    uint32_t gsize, uint32_t *d_part, hipStream_t st);
 int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8, int longrows, int wide);
+// The ranking kernels' instantiations: ONE table for rank_kernel()'s ordinals, the "compiled" mask of ugs_rank_instances_seen, the names
+// ugs_debug_rank_instance_name hands to the test-suite (tests/test_zz_gpu_coverage.py holds no list of its own).
+#define UGS_RANK_INST_TABLE(X) \
+  X(0, BIG4, "Big 4-bit (HOT)") X(1, BIG4_LONG, "Big 4-bit long rows") X(2, BIG_FLAT, "Big 8/16-bit flattened (sparse)") \
+  X(3, BIG_DENSE, "Big 8/16-bit dense") X(4, BIG_DENSE_LONG, "Big 8/16-bit dense, long rows") \
+  X(5, SMALL4, "small 4-bit") X(6, SMALL4_LONG, "small 4-bit long rows") X(7, SMALL_FLAT, "small 8/16-bit flattened") \
+  X(8, SMALL_DENSE, "small 8/16-bit dense") X(9, SMALL_DENSE_LONG, "small 8/16-bit dense, long rows") \
+  X(12, BIG4_WIDE, "HOT, 64-bit offsets") X(13, BIG4_LONG_WIDE, "long rows, 64-bit offsets") \
+  X(14, R2, "k_rank2 (bitmap)") X(15, R2G, "k_rank2g (bitmap, sparse index)") X(16, R2_CL, "k_rank2, cluster_fast instantiation")
+#define UGS_RANK_INST_ENUM(i, n, s) UGS_RI_##n = i,
+enum { UGS_RANK_INST_TABLE(UGS_RANK_INST_ENUM) UGS_RI_END };
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);
+const char *ugs_rank_instance_name(int ordinal);          // null: no such instantiation
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows);
 int ugs_align_blocks_per_cu(int threads, size_t lds, int is_nucleo);
 size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_words, int hot);

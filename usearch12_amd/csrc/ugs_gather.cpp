@@ -1,6 +1,7 @@
 // ugs_gather.cpp - include/ugs_comm.h: the gather of the ranks' device-resident hit tables to one rank over RCCL
 // (BASELINE config C4).  Built into libugs_rccl.so (links librccl + libugs); libugs.so itself has no RCCL
-// dependency.  Host C++ only: the tables are moved as bytes, the path offsets are rebased on the host copy.
+// dependency.  The tables are moved as bytes; every rank's path offsets are rebased to the concatenated pool by a kernel over the
+// staged table on the destination (k_rebase_paths), so that rank 0's host does no per-hit work before HitMgr::Sort.
 #include "ugs_host.h"
 #include "../../include/ugs_comm.h"
 #include <rccl/rccl.h>
@@ -44,6 +45,13 @@ struct ugs_comm {
   bool have_last = false; int last_local = 0; bool last_sort = false;
   double s_exchange = 0, s_fetch = 0;
 };
+
+// hits [0, n) of one source rank in the staged table: their paths start `base` runs further into the concatenated pool
+__global__ void k_rebase_paths(ugs_hit *hits, uint64_t n, uint64_t base)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hits[i].cigar_off += base;
+}
 
 static int comm_common_init(ugs_comm *c)
 {
@@ -113,7 +121,7 @@ extern "C" void ugs_comm_destroy(ugs_comm *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipDeviceSynchronize();        // (as ugs_db_destroy: nothing in flight when streams go)
+  if (c->st) (void)hipStreamSynchronize(c->st);        // (as ugs_db_destroy: nothing of this handle in flight when its stream goes)
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (int k = 0; k < 3; ++k) if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
   if (c->d_my) (void)hipFree(c->d_my);
@@ -145,13 +153,6 @@ extern "C" int ugs_gather_refetch(ugs_comm *c, ugs_hit *hits, uint64_t hits_cap,
   if (tot[1]) HIPCHK(hipMemcpyAsync(nhits_per_query, c->d_stage[1], tot[1], hipMemcpyDeviceToHost, c->st));
   if (tot[2]) HIPCHK(hipMemcpyAsync(cigar_pool, c->d_stage[2], tot[2], hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
-  // every rank's path offsets point into its own pool: rebase them to the concatenated one
-  uint64_t h0 = 0, pool_base = 0;
-  for (int r = 0; r < c->world; ++r) {
-    const uint64_t n = c->all[(size_t)r * 3] / sizeof(ugs_hit);
-    if (pool_base) for (uint64_t i = h0; i < h0 + n; ++i) hits[i].cigar_off += pool_base;
-    h0 += n; pool_base += c->all[(size_t)r * 3 + 2] / 4;
-  }
   c->s_fetch = now_s() - t0;
   if (c->last_sort && nq) return ugs_hits_sort(hits, nhits_per_query, (uint32_t)nq, c->last_local);     // HitMgr::Sort, as ugs_batch_fetch does
   return UGS_OK;
@@ -252,6 +253,19 @@ extern "C" int ugs_gather_results(ugs_comm *c, ugs_batch *b, uint32_t query_base
     if (herr != hipSuccess) { ugs_set_error("gather: device copy failed: %s", hipGetErrorString(herr)); return UGS_E_HIP; }
     if (gerr != ncclSuccess || eerr != ncclSuccess) { ugs_set_error("gather: RCCL exchange failed: %s", ncclGetErrorString(gerr != ncclSuccess ? gerr : eerr)); return UGS_E_HIP; }
     HIPCHK(hipStreamSynchronize(c->st));
+  }
+  if (R == dst) {
+    // every rank's path offsets point into its own pool: rebase them to the concatenated one - ONCE, on the staged table (a later
+    // ugs_gather_refetch copies the same staged bytes again)
+    uint64_t h0 = 0, pool_base = 0;
+    for (int r = 0; r < W; ++r) {
+      const uint64_t n = c->all[(size_t)r * 3] / sizeof(ugs_hit);
+      if (pool_base && n) {
+        k_rebase_paths<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>((ugs_hit *)c->d_stage[0] + h0, n, pool_base);
+        HIPCHK(hipGetLastError());
+      }
+      h0 += n; pool_base += c->all[(size_t)r * 3 + 2] / 4;
+    }
   }
   c->s_exchange = now_s() - t0;
   c->s_fetch = 0;

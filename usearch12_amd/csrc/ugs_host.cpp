@@ -227,9 +227,10 @@ extern "C" void ugs_db_destroy(ugs_db *db)
 {
   if (!db) return;
   (void)hipSetDevice(db->device);
-  // no stream or event is destroyed while anything of this device is in flight (a completion signal is a 64-bit word the runtime
-  // DECREMENTS: DESIGN section 4, "host heap"): hipFree would wait as well, this makes it independent of the order below
-  (void)hipDeviceSynchronize();
+  // no stream or event of THIS handle is destroyed while any of its work is in flight (a completion signal is a 64-bit word the
+  // runtime DECREMENTS: DESIGN section 4, "host heap").  Scoped to the handle's own stream: other handles and other libraries on
+  // the same GPU keep running; hipFree of memory still in use by another stream waits by itself.
+  if (db->stream) (void)hipStreamSynchronize(db->stream);
   (void)hipFree(db->d_pk);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part); (void)hipFree(db->d_part2);
   (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
@@ -579,7 +580,11 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
 {
   if (!b) return;
   (void)hipSetDevice(b->db->device);
-  (void)hipDeviceSynchronize();        // (as ugs_db_destroy)
+  // (as ugs_db_destroy: the handle's own streams and events only)
+  if (b->db->stream) (void)hipStreamSynchronize(b->db->stream);
+  if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+  if (b->ev_done) (void)hipEventSynchronize(b->ev_done);
+  if (b->ev_up) (void)hipEventSynchronize(b->ev_up);
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
   (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer); (void)hipFree(b->d_qpk);
@@ -688,11 +693,13 @@ static std::atomic<uint64_t> g_emit_regrows{0};
 extern "C" uint64_t ugs_debug_emit_regrows(void) { return g_emit_regrows.load(); }    // diagnostic: searches re-run with a larger candidate buffer
 
 // keys per workgroup of k_rank's candidate buffer: what earlier searches of this batch object demanded (emit_limit), never more than the
-// worst case (every posting of a unit's longest rows); one rule for the first sizing and for the regrow in ugs_batch_sync
+// worst case.  The buffer is cut into wpb equal per-wave shares and partitions go to waves round-robin, so ONE wave may emit every
+// posting of a unit's longest rows (np < wpb, or a family of near-identical targets inside one partition): the bound is per WAVE, i.e.
+// wpb times that per workgroup.  One rule for the first sizing and for the regrow in ugs_batch_sync.
 static uint64_t emit_cap_for(const ugs_batch *b, uint32_t ns_max)
 {
   const ugs_db *db = b->db;
-  const uint64_t worst = (uint64_t)ns_max * db->max_row + 1;
+  const uint64_t worst = ((uint64_t)ns_max * db->max_row + 1) * (uint64_t)std::max(1, b->rl.wpb);
   return std::min<uint64_t>(worst, b->emit_limit) + (db->tune.emit_limit ? 0 : (uint64_t)db->v.np * 4 * b->K) + 64;
 }
 
@@ -746,7 +753,7 @@ static int plan_launch(ugs_batch *b)
   int per_cu = ugs_rank_blocks_per_cu(64 * wpb, rlds, db->v.big, bits, b->rl.fast8, b->rl.longrows, b->rl.wide);      // real residency (VGPRs, LDS, wave slots)
   per_cu = std::max(1, std::min(per_cu, 8));
   if (db->tune.rank_wgs) per_cu = std::min(per_cu, db->tune.rank_wgs);
-  b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words;
+  b->rl.bits = bits; b->rl.wpb = wpb; b->rl.lds = rlds; b->rl.ns_max = ns_max; b->rl.part_words = part_words; b->rl.debug_sync = db->tune.debug_sync ? 1 : 0;
   b->rl.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * per_cu));
   // every target is emitted at most once per unit; bound by postings/2 as well
   // a target with count c is emitted c times (deduplicated at selection): bounded by the postings read
@@ -986,6 +993,11 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
       const uint64_t wpb = (uint64_t)b->rl.wpb, demand = b->ctr[UGS_CTR_EMIT_MAX] * wpb;
       b->emit_limit = std::max<uint64_t>(b->emit_limit, demand + demand / 4 + 4096);      // (to the reported demand, not doubling blindly)
       const uint64_t ecap = emit_cap_for(b, b->rl.ns_max), want = ecap * (uint64_t)b->rl.grid;
+      if (ecap <= b->v.emit_cap) {      // the buffer already holds the worst case per wave: running the search again cannot help
+        ugs_set_error("candidate buffer of the ranking kernel: a wave emitted %llu keys for one unit with %llu keys per workgroup in place, which is the bound of this index (%u sampled rows x longest row %llu x %d waves)",
+                      (unsigned long long)b->ctr[UGS_CTR_EMIT_MAX], (unsigned long long)b->v.emit_cap, b->rl.ns_max, (unsigned long long)db->max_row, b->rl.wpb);
+        return UGS_E_ENVELOPE;
+      }
       if (want > b->emit_cap_alloc) {
         HIPCHK(hipFree(b->d_emit)); b->d_emit = nullptr;
         HIPCHK(hipMalloc(&b->d_emit, want * 8));
@@ -1129,6 +1141,8 @@ extern "C" int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled)
   return UGS_OK;
 }
 
+extern "C" const char *ugs_debug_rank_instance_name(int bit) { return ugs_rank_instance_name(bit); }
+
 // diagnostic (tests/test_gpu_paths.py): which ranking code the last synced search of this batch ran.
 //   out[0] units ranked by the bitmap kernel (ugs_rank2.hip)   out[1] units it deferred to k_rank
 //   out[2] k_rank instantiation: big | bits << 1 | fast8 << 8 | longrows << 9      out[3] 1 if the bitmap kernel was launched
@@ -1140,7 +1154,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
   out[3] = b->r2_ran ? 1 : 0;
   if (n >= 6) {
     float a = 0, c = 0;
-    if (b->r2_ran) { HIPCHK(hipEventElapsedTime(&a, b->ev0s, b->ev0r)); HIPCHK(hipEventElapsedTime(&c, b->ev0r, b->ev1)); }
+    if (b->r2_ran) { if (hipEventElapsedTime(&a, b->ev0s, b->ev0r) != hipSuccess) a = 0; if (hipEventElapsedTime(&c, b->ev0r, b->ev1) != hipSuccess) c = 0; (void)hipGetLastError(); }    // (a diagnostic: an event not yet complete reads as 0, never an error)
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
   if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];

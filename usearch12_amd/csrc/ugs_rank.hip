@@ -1953,30 +1953,42 @@ static const void *rank_kernel(int big, int bits, int fast8, int longrows, int w
   int dummy; int &id = ordinal ? *ordinal : dummy;
 #ifdef UGS_ONLY_HOT               // tuning builds (tools/build_variant.sh): only the C2 instantiation, compiles in seconds
   (void)big; (void)mode; (void)longrows; (void)wide;
-  id = 0;
+  id = UGS_RI_BIG4;
   return (const void *)k_rank<false, false, false, false>;
 #else
   if (wide && big && mode == 0) {  // (only the two Big-path 4-bit kernels have 32-bit offsets to outgrow)
-    id = longrows ? 13 : 12;
+    id = longrows ? UGS_RI_BIG4_LONG_WIDE : UGS_RI_BIG4_WIDE;
     return longrows ? (const void *)k_rank<false, false, false, true, true> : (const void *)k_rank<false, false, false, false, true>;
   }
   if (longrows) {
-    id = big ? (mode == 0 ? 1 : mode == 1 ? 2 : 4) : (mode == 0 ? 6 : mode == 1 ? 7 : 9);
+    id = big ? (mode == 0 ? UGS_RI_BIG4_LONG : mode == 1 ? UGS_RI_BIG_FLAT : UGS_RI_BIG_DENSE_LONG) : (mode == 0 ? UGS_RI_SMALL4_LONG : mode == 1 ? UGS_RI_SMALL_FLAT : UGS_RI_SMALL_DENSE_LONG);
     return big ? (mode == 0 ? (const void *)k_rank<false, false, false, true> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, true>)
                : (mode == 0 ? (const void *)k_rank<true, false, false, true> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, true>);
   }
-  id = big ? (mode == 0 ? 0 : mode == 1 ? 2 : 3) : (mode == 0 ? 5 : mode == 1 ? 7 : 8);
+  id = big ? (mode == 0 ? UGS_RI_BIG4 : mode == 1 ? UGS_RI_BIG_FLAT : UGS_RI_BIG_DENSE) : (mode == 0 ? UGS_RI_SMALL4 : mode == 1 ? UGS_RI_SMALL_FLAT : UGS_RI_SMALL_DENSE);
   return big ? (mode == 0 ? (const void *)k_rank<false, false, false, false> : mode == 1 ? (const void *)k_rank<false, true, false, false> : (const void *)k_rank<false, true, true, false>)
              : (mode == 0 ? (const void *)k_rank<true, false, false, false> : mode == 1 ? (const void *)k_rank<true, true, false, false> : (const void *)k_rank<true, true, true, false>);
 #endif
 }
-// bit i: instantiation i was launched by this process (0 HOT, 1 its LONG twin, 2 Big 8/16-bit flattened, 3 / 4 Big 8/16-bit dense /
-// long rows, 5-9 the same five of the small path, 12 / 13 HOT / LONG with 64-bit offsets, 14 k_rank2, 15 k_rank2g)
+// bit i: instantiation i (UGS_RANK_INST_TABLE, ugs_dev.h) was launched by this process
 static std::atomic<unsigned long long> g_rank_seen{0};
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled)
 {
-  if (compiled) *compiled = 0x3ffull | (3ull << 12) | (7ull << 14);
+#define UGS_RI_BIT(i, n, s) | (1ull << (i))
+#ifdef UGS_ONLY_HOT
+  if (compiled) *compiled = (1ull << UGS_RI_BIG4) | (1ull << UGS_RI_R2) | (1ull << UGS_RI_R2G) | (1ull << UGS_RI_R2_CL);
+#else
+  if (compiled) *compiled = 0ull UGS_RANK_INST_TABLE(UGS_RI_BIT);
+#endif
+#undef UGS_RI_BIT
   return g_rank_seen.load();
+}
+const char *ugs_rank_instance_name(int ordinal)
+{
+#define UGS_RI_NAME(i, n, s) if (ordinal == (i)) return s;
+  UGS_RANK_INST_TABLE(UGS_RI_NAME)
+#undef UGS_RI_NAME
+  return nullptr;
 }
 // the instantiation with five workgroups per CU and a smaller LDS key segment (must mirror k_rank's HOT)
 int ugs_rank_is_hot(int big, int bits, int fast8, int longrows) { (void)fast8; return bits != 4 ? 3 : (big ? (longrows ? 2 : 1) : 0); }   // 1 = HOT, 2 = its LONG twin, 3 = wider counters (BATCH kernels)
@@ -2028,7 +2040,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
       HIPCHK(hipGetLastError());
     }
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
-    if (getenv("UGS_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
+    if (L.debug_sync) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
 #ifdef UGS_ONLY_HOT
   if (!(db.big && L.bits == 4 && !L.longrows)) { ugs_set_error("UGS_ONLY_HOT build"); return UGS_E_ENVELOPE; }
@@ -2040,7 +2052,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   }
   int ordinal = 0;
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide, &ordinal);
-  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather ? 15 : (b.cand_key ? 16 : 14))) : 0ull));
+  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather ? UGS_RI_R2G : (b.cand_key ? UGS_RI_R2_CL : UGS_RI_R2))) : 0ull));
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;

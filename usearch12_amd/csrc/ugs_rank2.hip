@@ -49,6 +49,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define R2_HB_BITS 2048u        // bits of each of the two hash filters
 #endif
 #define R2_KEY_INF 0xffffffffu
+// 32-bit words of k_rank2's LDS carve between the bitmap and the chunk list: staging records, the two hash filters, s_c2 / s_cum / s_fpk /
+// s_slots (16 each), s_rs (16 x u64), s_pe (32).  ONE definition for the kernel's carve and the host's size (ugs_rank2_lds).
+__host__ __device__ constexpr uint32_t r2_fixed_words(bool cl) { return (cl ? R2_SCAP_CL : R2_SCAP) + 2u * (R2_HB_BITS / 32u) + 16u * 4u + 32u + 32u; }
 #ifndef UGS_R2_DEPTH
 #define UGS_R2_DEPTH 4          // ring slots: posting chunks in flight per wave (3 behind the one being counted)
 #endif
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
   uint32_t *s_sel = s_stg;                                              // [64] selected targets for the fill (the staging area is idle by then)
   uint64_t *s_rs = (uint64_t *)(s_slots + 16);                            // [16] first posting (element index) of the unit's rows
   uint32_t *s_pe = (uint32_t *)(s_rs + 16);                             // [32] chunk index at which each partition of the window ends (W <= 28)
-  uint2 *s_cl = (uint2 *)(s_pe + 32);                                   // [clcap] chunk list of the window being scanned
+  uint2 *s_cl = (uint2 *)(s_stg + r2_fixed_words(CL));                  // [clcap] chunk list of the window being scanned (== s_pe + 32)
   const uint32_t clcap = prm.clcap;
   uint32_t *s_kl = (uint32_t *)(s_cl + clcap);                          // [kcap + 4] kept keys
   const uint32_t amax = bm_bytes - 4u;                                  // last word of the bitmap (G need not be a power of two)
@@ -1041,7 +1044,7 @@ static const void *rank2_kernel(int gather = 0, int cl = 0) { return gather ? (c
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl)
 {
-  return (size_t)G / 8 + ((cl ? R2_SCAP_CL : R2_SCAP) + 2 * (R2G_HB_BITS / 32) + 16 * 4 + 32 + 32) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;
+  return (size_t)G / 8 + (size_t)r2_fixed_words(cl != 0) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;       // (the kernel's own carve)
 }
 
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
@@ -1063,6 +1066,8 @@ int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2P
   const bool cl = b.cand_key != nullptr;                               // cluster_fast's walk records (ugs_cluster.cpp)
   if (cl && (prm.gather || !b.cl_ev || !b.cl_info || prm.kcap > 508u)) { ugs_set_error("bitmap ranking kernel: cluster mode outside its envelope"); return UGS_E_ENVELOPE; }
   const void *fn = rank2_kernel((int)prm.gather, cl ? 1 : 0);
+  const size_t need = prm.gather ? ugs_rank2g_lds(prm.G, prm.kcap, prm.np) : ugs_rank2_lds(prm.G, prm.kcap, prm.clcap, cl ? 1 : 0);
+  if (prm.lds < need) { ugs_set_error("bitmap ranking kernel: %u bytes of LDS per wave, its carve needs %zu", prm.lds, need); return UGS_E_ENVELOPE; }
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));
   UgsDbView a0 = db; UgsBatchView a1 = b; UgsRank2Params a2 = prm;
   void *args[] = {&a0, &a1, &a2};
