@@ -45,46 +45,140 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-def cpu_baseline(kind, db, qs, ident, sample_q, threads):
-    """Time the CPU path on a bounded sample of the same workload on this host's cores."""
+def blast6_lines(capi, hits, qlabel, tlabel):
+    """-blast6out text of a hit table through the product's own formatter (ugs_format_blast6 = blast6out.cpp:27-80), one bytes line per hit"""
+    L = capi.lib()
+    buf = ctypes.create_string_buffer(1024)
+    out = []
+    rec = hits.dtype.itemsize
+    base = hits.ctypes.data
+    for i in range(len(hits)):
+        n = L.ugs_format_blast6(base + i * rec, qlabel(int(hits["query"][i])).encode(), tlabel(int(hits["target"][i])).encode(), buf, 1024)
+        out.append(buf.raw[:n])
+    return out
+
+
+def cpu_baseline(kind, db, qs, ident, sweep_q, parity_q, nproc):
+    """The CPU path on bounded samples of the same workload on this host's cores (checker / baseline leg: nothing here is inside the
+    timed region or on the product path).  kind "reference" = the unmodified usearch12 binary (oracle/_ref):
+      * the database is indexed ONCE (-makeudb_usearch), so that a search run is file load + search, and the load is what a 1-query run takes;
+      * a thread sweep (-threads 16 / 32 / 64 / 128 / all) over the first `sweep_q` queries: the reference's shared FASTA reader and output
+        lock put its best point far below "all threads" (VERDICT r04) - `value` is the best point of the sweep;
+      * one run over the first `parity_q` queries at the best thread count whose -blast6out is KEPT: main() compares it with the GPU's hits.
+    Returns (cpu_baseline object, reference blast6 lines or None, queries of that run)."""
     if kind == "none":
-        return None
-    sample = qs.slice(0, min(sample_q, qs.n))
+        return None, None, 0
     if kind == "reference":
         ref = os.path.join(ROOT, "oracle", "_ref", "usearch12")
         if not os.path.exists(ref):
             kind = "port"
     if kind == "reference":
         with tempfile.TemporaryDirectory() as tmp:
-            dbfa, qfa, q1 = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa"), os.path.join(tmp, "q1.fa")
+            dbfa, q1 = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q1.fa")
             db.write_fasta(dbfa)
-            sample.write_fasta(qfa)
-            sample.slice(0, 1).write_fasta(q1)
+            qs.slice(0, 1).write_fasta(q1)
+            t0 = time.time()
+            udb = os.path.join(tmp, "db.udb")
+            rc = subprocess.call([ref, "-makeudb_usearch", dbfa, "-output", udb], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t_makeudb = time.time() - t0
+            dbarg = udb if rc == 0 and os.path.exists(udb) else dbfa
 
-            def run(q):
+            def run(q, threads, out):
                 t0 = time.time()
-                subprocess.check_call([ref, "-usearch_global", q, "-db", dbfa, "-id", str(ident), "-strand", "plus",
-                                       "-blast6out", os.path.join(tmp, "o.b6"), "-threads", str(threads)],
-                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                subprocess.check_call([ref, "-usearch_global", q, "-db", dbarg, "-id", str(ident), "-strand", "plus",
+                                       "-blast6out", out, "-threads", str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 return time.time() - t0
-            t_load = run(q1)          # DB load + mask + index build + 1 query
-            t_full = run(qfa)
-        t_search = max(t_full - t_load, 1e-3)
-        return {"value": sample.n / t_search, "unit": "query-seqs/s", "cores": threads, "kind": "reference",
-                "sample": "%d of the same C2 queries vs the full %d-seq DB, unmodified usearch12 sources -threads %d "
-                          "(built by oracle/build_ref.sh with g++ -O3 -march=x86-64-v2, not the reference Makefile's -march=native); "
-                          "search wall = full run %.1fs minus a 1-query run %.1fs (DB load+index)" %
-                          (sample.n, db.n, threads, t_full, t_load)}
+            sweep_n = min(sweep_q, qs.n)
+            qsw = os.path.join(tmp, "qsweep.fa")
+            qs.slice(0, sweep_n).write_fasta(qsw)
+            points = []
+            for T in sorted({t for t in (16, 32, 64, 128, nproc) if 1 <= t <= nproc}):
+                t_load = run(q1, T, os.path.join(tmp, "o1.b6"))
+                t_full = run(qsw, T, os.path.join(tmp, "osw.b6"))
+                points.append({"threads": T, "queries": sweep_n, "run_s": round(t_full, 3), "load_s": round(t_load, 3),
+                               "query_seqs_per_s": sweep_n / max(t_full - t_load, 1e-3)})
+            best = max(points, key=lambda x: x["query_seqs_per_s"])
+            par_n = min(parity_q, qs.n)
+            lines = None
+            if par_n:
+                qpar = os.path.join(tmp, "qpar.fa")
+                qs.slice(0, par_n).write_fasta(qpar)
+                t_load = run(q1, best["threads"], os.path.join(tmp, "o1.b6"))
+                t_full = run(qpar, best["threads"], os.path.join(tmp, "opar.b6"))
+                points.append({"threads": best["threads"], "queries": par_n, "run_s": round(t_full, 3), "load_s": round(t_load, 3),
+                               "query_seqs_per_s": par_n / max(t_full - t_load, 1e-3), "blast6out_kept_for_parity_sample": True})
+                lines = open(os.path.join(tmp, "opar.b6"), "rb").read().splitlines(keepends=True)
+                best = max(points, key=lambda x: x["query_seqs_per_s"])
+        return ({"value": best["query_seqs_per_s"], "unit": "query-seqs/s", "cores": best["threads"], "kind": "reference",
+                 "host_threads_available": nproc, "sweep": points,
+                 "sample": "best point of a -threads sweep of the unmodified usearch12 binary (oracle/build_ref.sh: g++ -O3 -march=x86-64-v2 on the "
+                           "reference's own sources, not its Makefile's -march=native) over the first %d of the same C2 queries vs the full %d-seq DB "
+                           "(indexed once with -makeudb_usearch, %.1f s); search wall of a point = its run minus a 1-query run at the same thread "
+                           "count (file load); %d queries at the best thread count for the parity sample" % (sweep_n, db.n, t_makeudb, par_n)},
+                lines, par_n)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc   # the CPU restatement: checker / baseline only, never the product path
+    sample = qs.slice(0, min(sweep_q, qs.n))
     p = orc.params(is_nucleo=True, id=ident)
     odb = orc.OrcDB(p, db.seqs, db.offs)
     t0 = time.time()
-    odb.search(sample.seqs, sample.offs, nthreads=threads)
+    odb.search(sample.seqs, sample.offs, nthreads=nproc)
     t = time.time() - t0
-    return {"value": sample.n / t, "unit": "query-seqs/s", "cores": threads, "kind": "port",
-            "sample": "%d of the same C2 queries vs the full %d-seq DB, oracle/ugs_oracle.c with %d threads" %
-                      (sample.n, db.n, threads)}
+    return ({"value": sample.n / t, "unit": "query-seqs/s", "cores": nproc, "kind": "port",
+             "sample": "%d of the same C2 queries vs the full %d-seq DB, oracle/ugs_oracle.c with %d threads" % (sample.n, db.n, nproc)}, None, 0)
+
+
+def other_config(capi, synth, name, device):
+    """One of BASELINE.json's other configurations, once, on this GPU (driver-visible numbers for what DESIGN.md section 4 quotes; VERDICT
+    r04 item 2).  Same step as the bench line: upload + kernels + fetch; 1 warm-up + 3 timed steps of one batch."""
+    t0 = time.time()
+    if name == "C3":
+        r = synth.make_reads(3, 5_000_000, length=300)
+        gen_s = time.time() - t0
+        p = capi.cluster_params(0.97)
+        capi.UgsCluster(p, r.slice(0, 2000).seqs, r.slice(0, 2000).offs).close()           # (module load)
+        t0 = time.time()
+        res = capi.UgsCluster(p, r.seqs, r.offs, device=device)
+        dt = time.time() - t0
+        st = res.stats
+        out = {"workload": "C3: cluster_fast 5000000 x 300 nt reads -id 0.97 (UCLUST centroid path), one MI355X", "value": r.n / dt, "unit": "reads/s",
+               "seconds": dt, "clusters": int(res.n_clusters), "uniques": int(res.n_unique),
+               "kernel_ms": {"ranking (all batches)": st.ms_rank, "k_align (all batches)": st.ms_align},
+               "kernel": "k_rank2<cluster_fast> + k_rank over its deferred units", "algorithmic_bytes": 4 * int(st.postings),
+               "frac": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
+        res.close()
+        return out
+    if name == "C5":
+        db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 1_000_000, 300, aa=True)
+        p = capi.params(is_nucleo=False, id=0.8)
+        wl = "C5: usearch_global protein 1000000 x 300 aa queries vs 2000000-seq aa DB, -id 0.8, one MI355X"
+    else:
+        db = synth.make_db(4, 5_000_000, 250)
+        (qs,) = make_query_sets(synth, 4, db, 0, 1_250_000, 250, 1)
+        p = capi.params(is_nucleo=True, id=0.97)
+        wl = "C4, one GPU's shard: queries [0, 1250000) of the 10000000 x 250 nt stream vs the 5000000-seq DB, -id 0.97"
+    gen_s = time.time() - t0
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=device)
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    capi._chk(capi.lib().ugs_host_register(qs.seqs.ctypes.data, qs.seqs.nbytes))
+    times, st, kh, nh = [], None, None, 0
+    for i in range(4):
+        t1 = time.time()
+        bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+        hits = bat.fetch(reuse=True)[0]
+        if i:
+            times.append(time.time() - t1)
+        st, kh, nh = bat.stats(), bat.kernel_hits(), len(hits)
+    capi.lib().ugs_host_unregister(qs.seqs.ctypes.data)
+    dt = float(np.mean(times))
+    b_rank = 4 * st["postings"] + st["query_letters"]
+    kern = ("k_rank2g" if name == "C5" else "k_rank2") if kh["r2_launched"] else "k_rank"
+    out = {"workload": wl, "value": qs.n / dt, "unit": "query-seqs/s", "ms_per_step": 1000 * dt, "hits_per_step": int(nh),
+           "kernel_ms": {"ranking": st["ms_rank"], "k_align": st["ms_align"], "k_rank_setup": st["ms_rank_setup"]},
+           "kernel": kern + " + k_rank over %d deferred units" % kh["deferred"], "algorithmic_bytes": int(b_rank),
+           "frac": b_rank / (st["ms_rank"] * 1e-3) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
+    bat.close(); gdb.close()
+    return out
 
 
 def free_port():
@@ -139,7 +233,13 @@ def main():
     ap.add_argument("--length", type=int, default=250)
     ap.add_argument("--id", type=float, default=0.97)
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-sample", type=int, default=48_000, help="queries of every point of the CPU thread sweep")
+    ap.add_argument("--parity-sample", type=int, default=384_000, help="queries the reference binary searches with its -blast6out kept: the GPU's "
+                    "hits for the same queries are formatted and compared with it (0 = off)")
+    ap.add_argument("--other-configs", default="auto", help="comma list of C5,C4,C3 run once each after the timed region (detail.other_configs); "
+                    "auto = all three on a default one-GPU C2 run, none otherwise")
+    ap.add_argument("--emulate-world", type=int, default=8, help="one-GPU C2 runs: strong-scaling proxy - rank 0's step at 1/N of the batch with the "
+                    "N-rank gather (loopback transport), detail.strong_scaling_proxy; 0 = off")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, "
                          "tables travel through the host) - not a measurement")
@@ -181,6 +281,8 @@ def main():
     cdev = "cpu" if args.backend == "gloo" else "cuda"
 
     from usearch12_amd import capi, synth, multigpu
+    from usearch12_amd.build import csrc_hash
+    csrc_sha = csrc_hash()
 
     workload = args.workload if args.workload != "auto" else "C2"
     seed = 2 if workload == "C2" else 4
@@ -331,27 +433,31 @@ def main():
         state["pending"] = cur
         return out, cur
 
-    # the pipeline is primed so that step 0 finds its batch uploaded
-    bats[0].upload(qsets[0].seqs, qsets[0].offs)
-    for _ in range(args.warmup):
-        step()
-    if state.get("pending") is not None:
-        collect(state["pending"])
+    def timed_steps(n_steps, n_warm):
+        """prime the pipeline, n_warm untimed steps, then EXACTLY n_steps steps between barriers; returns (seconds, stats, kernel hits, last table)"""
+        state.clear(); state["i"] = 0
+        bats[0].upload(qsets[0].seqs, qsets[0].offs)            # step 0 finds its batch uploaded
+        for _ in range(n_warm):
+            step()
+        if state.get("pending") is not None:
+            collect(state["pending"])
+            state["pending"] = None
+        for k in t_parts:
+            t_parts[k] = 0.0
+        barrier()
+        t0 = time.time()
+        stats, khits = [], []
+        for _ in range(n_steps):
+            _, cur = step()
+            stats.append(cur.stats())
+            khits.append(cur.kernel_hits())
+        out = collect(state["pending"])                         # drain: the last step's hit table
         state["pending"] = None
-    for k in t_parts:
-        t_parts[k] = 0.0
-    barrier()
-    t0 = time.time()
-    stats = []
-    khits = []
-    out = None
-    for _ in range(args.steps):
-        out, cur = step()
-        stats.append(cur.stats())
-        khits.append(cur.kernel_hits())
-    out = collect(state["pending"])                             # drain: the last step's hit table
-    barrier()
-    elapsed = time.time() - t0
+        barrier()
+        return time.time() - t0, stats, khits, out
+
+    elapsed, stats, khits, out = timed_steps(args.steps, args.warmup)
+    n_hits_main = int(len(out[0])) if out is not None else 0    # (the table lives in buffers the batch objects own)
     per_rank = None
     if dist is not None:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -372,6 +478,103 @@ def main():
     steps = max(args.steps, 1)
     value = total_q * steps / elapsed
     qs = qsets[0]
+    t_main = dict(t_parts)                                        # (the legs below run more steps through the same closures)
+    db_hbm_bytes = gdb.stats()["hbm_bytes"]
+    nproc = os.cpu_count() or 1
+    one_gpu_c2 = world == 1 and workload == "C2" and not strong_c2 and not args.force_gather
+    cb, parity, proxy, others = None, None, None, None
+    if one_gpu_c2:
+        # ---- checker leg 1: the reference binary on this box's host cores (thread sweep) and ITS OWN -blast6out for the first
+        # parity_sample queries against the GPU's hits for the same queries.  Nothing of it is inside the timed region above.
+        cb, ref_lines, par_n = cpu_baseline(args.cpu_baseline, db, qs, args.id, args.cpu_sample, args.parity_sample, nproc)
+        if ref_lines is not None and par_n:
+            sub = qs.slice(0, par_n)
+            bats[0].upload(sub.seqs, sub.offs); bats[0].search(); bats[0].sync()
+            h, nh, _pool = bats[0].fetch()
+            mine = sorted(blast6_lines(capi, h, lambda i: "q%d" % i, lambda t: "t%d" % t))
+            theirs = sorted(ref_lines)                            # (the reference's threads write in completion order: compare as multisets)
+            same = mine == theirs
+            parity = {"queries": par_n, "hits_gpu": len(mine), "hits_reference": len(theirs), "identical": bool(same),
+                      "what": "every -blast6out line (blast6out.cpp:27-80) of the unmodified reference binary for the first %d queries of this run's "
+                              "batch vs ugs_format_blast6 of the GPU hit table for the same queries, as sorted multisets of lines" % par_n}
+            if not same:
+                diff = sorted(set(mine) ^ set(theirs))[:4]
+                parity["first_differences"] = [x.decode(errors="replace") for x in diff]
+        # ---- strong-scaling proxy: what rank 0 of an N-GPU strong-scaling run does per step - search 1/N of the batch,
+        # take part in the N-rank gather (loopback transport: device-to-device copies stand in for ncclSend/ncclRecv over xGMI), fetch
+        # the WHOLE table - against the one-GPU step of the whole batch.  Ranks 1..N-1 are host threads that hold their searched shards.
+        N = args.emulate_world
+        if N and N > 1 and shard_n >= N:
+            import threading
+            n8 = shard_n // N
+            sub_sets = [q.slice(0, n8) for q in qsets]
+            full_bats, full_sets = list(bats), list(qsets)
+            comms = capi.UgsComm.init_loopback(N, local_rank)
+            peers = []
+            for r in range(1, N):                                  # the other ranks' shards: searched once, then only gathered
+                pq = qsets[0].slice(r * n8, (r + 1) * n8)
+                pb = capi.UgsBatch(gdb, pq.n, int(pq.offs[-1]))
+                pb.upload(pq.seqs, pq.offs); pb.search(); pb.sync()
+                pb.set_query_base(r * n8)
+                peers.append(pb)
+            psteps, pwarm = max(args.steps, 10), 2
+            small = [capi.UgsBatch(gdb, n8, max(int(q.offs[-1]) for q in sub_sets)) for _ in range(2)]
+            # (the shard's letters are views of the page-locked full batches)
+            from usearch12_amd.abi import HIT_DTYPE
+            cap_h = shard_n * (p.max_accepts or 64) + 1
+            gbuf = [np.zeros(cap_h, HIT_DTYPE), np.zeros(shard_n + 1, np.uint32), np.zeros(16 * shard_n + 4096, np.uint32)]
+            for a in gbuf:
+                capi._chk(capi.lib().ugs_host_register(a.ctypes.data, a.nbytes))
+            perr = []
+
+            def peer(r):
+                try:
+                    dummy = (np.zeros(1, np.uint8),) * 3
+                    for _ in range(pwarm + psteps):
+                        comms[r].gather_into(peers[r - 1], r * n8, 0, *dummy)
+                except Exception as e:
+                    perr.append(e)
+            th = [threading.Thread(target=peer, args=(r,)) for r in range(1, N)]
+            [t.start() for t in th]
+            bats[:] = small; qsets[:] = sub_sets; comm = comms[0]
+            for b in small:
+                b.set_query_base(0)
+            t_small, st_s, _kh, got = timed_steps(psteps, pwarm)
+            [t.join(600) for t in th]
+            t_s = dict(t_parts)
+            comm = None
+            bats[:] = full_bats; qsets[:] = full_sets
+            ms_full, ms_small = 1000.0 * elapsed / steps, 1000.0 * t_small / psteps
+            kern_small = float(np.mean([x["ms_rank"] + x["ms_align"] + x["ms_rank_setup"] for x in st_s]))
+            proxy = {"emulated_world": N, "queries_per_rank": n8, "steps": psteps,
+                     "ms_step_whole_batch_one_gpu": ms_full, "ms_step_rank0_at_1_over_N": ms_small,
+                     "predicted_speedup_%d" % N: ms_full / ms_small,
+                     "ms_kernels_rank0": kern_small, "ms_fixed_cost_rank0": ms_small - kern_small,
+                     "ms_gather_call": 1000.0 * t_s["gather"] / psteps, "ms_gather_exchange": 1000.0 * t_s["gather_exchange"] / psteps,
+                     "ms_gather_d2h": 1000.0 * t_s["gather_d2h"] / psteps, "ms_sync_wait_after_gather": 1000.0 * t_s["sync_wait"] / psteps,
+                     "gathered_hits_per_step": int(len(got[0])) if got else 0, "peer_errors": [str(e) for e in perr],
+                     "note": "one GPU: rank 0's kernels run alone (peers only gather), the %d-rank exchange is device-to-device copies instead of "
+                             "xGMI transfers (7 x ~%d KB in parallel over separate links at ~153 GB/s each: < 0.2 ms); the gather of step i runs beside "
+                             "the kernels of step i+1, so only ms_sync_wait_after_gather == 0 would expose it" % (N, int(len(got[0]) * 80 / N / 1000) if got else 0)}
+            for pb in peers + small:
+                pb.close()
+            for a in gbuf:
+                capi.lib().ugs_host_unregister(a.ctypes.data)
+            gbuf = None
+            for c in comms:
+                c.close()
+        # ---- the other named configurations, once each (driver-visible)
+        which = [] if args.other_configs == "none" else (["C5", "C4", "C3"] if args.other_configs == "auto" else [x for x in args.other_configs.split(",") if x])
+        if which:
+            for b in bats:
+                b.close()
+            gdb.close()
+            others = []
+            for name in which:
+                try:
+                    others.append(other_config(capi, synth, name, local_rank))
+                except Exception as e:                              # (reported, never hidden: the C2 line above is already measured)
+                    others.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
 
     if rank == 0:
         st = stats[-1]
@@ -404,8 +607,12 @@ def main():
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
                 if pm.get("db_seqs") == db.n and pm.get("queries") == qs.n and dom in pm.get("traffic_bytes_per_launch", {}):
+                    if pm.get("csrc_sha16") != csrc_sha:        # counters of ANOTHER build say nothing about this one: no traffic rather than a stale ratio
+                        traffic_source = traffic_source or ("none: the newest PMC passes of this shape (profiles/%s) were taken on source hash %s, this build is %s" %
+                                                            (pmc_name, pm.get("csrc_sha16"), csrc_sha))
+                        continue
                     traffic = pm["traffic_bytes_per_launch"][dom]
-                    traffic_source = "profiles/" + pmc_name + " (PMC passes of this command, not measured in this run)"
+                    traffic_source = "profiles/" + pmc_name + " (rocprofv3 --pmc passes of this command on this same source hash, not measured in this run)"
                     mix = pm.get("instruction_mix_per_launch", {})
                     break
             except (OSError, ValueError):
@@ -428,11 +635,8 @@ def main():
                 out["wave_time_waiting_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
             return out
         achieved = b_dom / (ms_dom * 1e-3) / 1e9
-        n_hits = int(len(out[0]))
-        threads = os.cpu_count() or 1
-        sample_q = args.cpu_sample or max(2000, min(qs.n, 1500 * threads))
-        # the CPU baseline is a single-GPU-run item (rank 0 at N=1): the other ranks of a multi-GPU run would only wait for it
-        cb = cpu_baseline(args.cpu_baseline if (world == 1 and workload == "C2") else "none", db, qs, args.id, sample_q, threads)
+        n_hits = n_hits_main
+        # (the CPU baseline is a single-GPU-run item - rank 0 at N=1, measured above: the other ranks of a multi-GPU run would only wait for it)
         how = ("ugs_gather_results (libugs_rccl.so: ncclAllGather of sizes + grouped ncclSend/ncclRecv), issued beside the next step's kernels"
                if comm is not None else (gather_note or ("torch.distributed gloo through the host (dry run)" if dist is not None else "none (one GPU: plain fetch)")))
         if workload == "C2":
@@ -476,18 +680,20 @@ def main():
                             "valu_per_pair": (mix["k_align"]["SQ_INSTS_VALU"] / max(st["pairs_aligned"], 1)) if "k_align" in mix else None,
                             "issue_roofline": issue_roofline("k_align", ms_align)}},
             "cpu_baseline": cb,
-            "detail": {"ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
+            "parity_sample": parity,
+            "detail": {"csrc_sha16": csrc_sha, "other_configs": others, "strong_scaling_proxy": proxy,
+                       "ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),
                        "pairs_aligned_per_query": st["pairs_aligned"] / max(qs.n, 1),
                        "dp_gcells_per_s": st["dp_cells"] / max(ms_align * 1e-3, 1e-9) / 1e9,
-                       "host_ms_search_sync": 1000.0 * t_parts["search_sync"] / steps,
-                       "host_ms_upload_issue": 1000.0 * t_parts["upload_issue"] / steps,
-                       "host_ms_fetch": 1000.0 * t_parts["fetch"] / steps,
-                       "host_ms_gather": 1000.0 * t_parts["gather"] / (steps + 1),
-                       "host_ms_sync_wait_after_collect": 1000.0 * t_parts["sync_wait"] / steps,
+                       "host_ms_search_sync": 1000.0 * t_main["search_sync"] / steps,
+                       "host_ms_upload_issue": 1000.0 * t_main["upload_issue"] / steps,
+                       "host_ms_fetch": 1000.0 * t_main["fetch"] / steps,
+                       "host_ms_gather": 1000.0 * t_main["gather"] / (steps + 1),
+                       "host_ms_sync_wait_after_collect": 1000.0 * t_main["sync_wait"] / steps,
                        "per_rank": per_rank,
                        "index_build_s": t_index, "first_upload_search_s": t_upload, "gen_s": t_gen,
-                       "db_hbm_bytes": gdb.stats()["hbm_bytes"],
+                       "db_hbm_bytes": db_hbm_bytes,
                        "gpu_over_cpu": (value / world / cb["value"]) if cb else None},
         }
         sys.stdout.flush()

@@ -115,7 +115,12 @@ def test_c4_as_named_eight_shards_gathered_to_rank_0():
     assert ident_f.min() >= float(np.float32(0.97)) - 1e-12
     assert np.all(hits["target"] < db.n) and np.all(np.diff(hits["query"].astype(np.int64)) > 0)      # global ids, rank order = query order
     assert np.array_equal(np.flatnonzero(nh), hits["query"])
-    assert int(hits["cigar_off"][-1]) + int(hits["cigar_len"][-1]) <= len(pool) and np.all(np.diff(hits["cigar_off"].astype(np.int64)) >= 0)   # paths rebased into ONE pool
+    # paths rebased into ONE pool: shard r's offsets lie in the r-th segment of it (inside a shard the pool is filled in completion order)
+    ends = hits["cigar_off"].astype(np.int64) + hits["cigar_len"]
+    assert int(ends.max()) <= len(pool) and int(ends.sum() - hits["cigar_off"].astype(np.int64).sum()) == int(hits["cigar_len"].sum())
+    shard_of = np.searchsorted(np.array([b[1] for b in bounds]), hits["query"], side="right")
+    seg_lo = np.array([hits["cigar_off"][shard_of == r].min() for r in range(world)]); seg_hi = np.array([ends[shard_of == r].max() for r in range(world)])
+    assert np.all(seg_hi[:-1] <= seg_lo[1:])
     # ---- the oracle on 300 queries of every shard (its first and last 150: both sides of every boundary)
     ids = np.array(sorted(samples))
     assert len(ids) == world * 300

@@ -67,6 +67,20 @@ def _newest(src):
     return max([_mtime(d) for d in _deps(src)] + [_mtime(os.path.abspath(__file__))])          # (the flags live in this file)
 
 
+def csrc_hash():
+    """16 hex digits over the product's source text (csrc/*.hip|cpp|h + include/*.h, names and bytes, sorted): what ties a PMC profile
+    under profiles/ to the build that produced it (bench.py attaches counter traffic only when the hashes agree)"""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(HERE, "..", "include")
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))] + \
+            [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    for f in sorted(files, key=os.path.basename):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
