@@ -128,10 +128,75 @@ def cpu_baseline(kind, db, qs, ident, sweep_q, parity_q, nproc):
              "sample": "%d of the same C2 queries vs the full %d-seq DB, oracle/ugs_oracle.c with %d threads" % (sample.n, db.n, nproc)}, None, 0)
 
 
+def c4_on_one_device(capi, synth, device, world=8, total_q=10_000_000, db_n=5_000_000, length=250):
+    """BASELINE.json configs[3] on the ONE GPU the driver's bench box has: the 10 M-query stream in `world` contiguous shards, one rank
+    (batch object + communicator rank + host thread for the collective) per shard, the shards searched one after the other against the
+    5 M-sequence index, then ONE gather of the eight device-resident hit tables to rank 0 (ugs_gather_results, loopback transport:
+    device-to-device copies where the 8-GPU job has ncclSend / ncclRecv).  value = 10 M / (first upload -> merged table on the host)."""
+    import threading
+    from usearch12_amd import multigpu
+    t0 = time.time()
+    db = synth.make_db(4, db_n, length)
+    p = capi.params(is_nucleo=True, id=0.97)
+    gdb = capi.UgsDB(p, db.seqs, db.offs, device=device)
+    bounds = [multigpu.shard_range(total_q, world, r) for r in range(world)]
+    shards = [make_query_sets(synth, 4, db, lo, hi - lo, length, 1)[0] for lo, hi in bounds]
+    gen_s = time.time() - t0
+    bats = []
+    for q in shards:
+        capi._chk(capi.lib().ugs_host_register(q.seqs.ctypes.data, q.seqs.nbytes))
+        bats.append(capi.UgsBatch(gdb, q.n, int(q.offs[-1])))
+    comms = capi.UgsComm.init_loopback(world, device)
+    best = None
+    for rep in range(2):                                          # (the first pass sizes every scratch buffer)
+        res, err = [None] * world, []
+        t1 = time.time()
+        for b, q in zip(bats, shards):
+            b.upload(q.seqs, q.offs); b.search()
+        for b in bats:
+            b.sync()
+        t2 = time.time()
+
+        def run(r):
+            try:
+                res[r] = comms[r].gather(bats[r], bounds[r][0], dst=0)
+            except Exception as e:
+                err.append("%d: %s" % (r, e))
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join(600) for t in th]
+        t3 = time.time()
+        if err:
+            raise RuntimeError("; ".join(err))
+        best = (t3 - t1, t2 - t1, t3 - t2)
+    hits, nh, pool = res[0]
+    sts = [b.stats() for b in bats]
+    khs = [b.kernel_hits() for b in bats]
+    ms_rank = sum(x["ms_rank"] for x in sts)
+    b_rank = sum(4 * x["postings"] + x["query_letters"] for x in sts)
+    ok = len(nh) == total_q and int(nh.sum()) == len(hits) and bool(np.all(np.diff(hits["query"].astype(np.int64)) > 0))
+    out = {"workload": "C4: usearch_global %d x %d nt queries in %d contiguous shards (one rank each, all on this one GPU, searched one after the other) vs the "
+                       "%d-seq DB, -id 0.97, one gather of the %d hit tables to rank 0 through ugs_gather_results (loopback transport)" % (total_q, length, world, db_n, world),
+           "value": total_q / best[0], "unit": "query-seqs/s", "seconds": best[0], "seconds_search": best[1], "seconds_gather_to_host": best[2],
+           "hits": int(len(hits)), "merged_table_consistent": bool(ok),
+           "kernel_ms": {"ranking (8 shards)": ms_rank, "k_align (8 shards)": sum(x["ms_align"] for x in sts), "k_rank_setup (8 shards)": sum(x["ms_rank_setup"] for x in sts)},
+           "kernel": "k_rank2 + k_rank over %d deferred units" % sum(k["deferred"] for k in khs), "algorithmic_bytes": int(b_rank),
+           "frac": b_rank / (ms_rank * 1e-3) / (HBM_PEAK_GBS * 1e9), "predicted_8_gpu_value": total_q / (best[1] / world + best[2]), "gen_s": gen_s}
+    for q in shards:
+        capi.lib().ugs_host_unregister(q.seqs.ctypes.data)
+    for b in bats:
+        b.close()
+    for c in comms:
+        c.close()
+    gdb.close()
+    return out
+
+
 def other_config(capi, synth, name, device):
     """One of BASELINE.json's other configurations, once, on this GPU (driver-visible numbers for what DESIGN.md section 4 quotes; VERDICT
     r04 item 2).  Same step as the bench line: upload + kernels + fetch; 1 warm-up + 3 timed steps of one batch."""
     t0 = time.time()
+    if name == "C4":
+        return c4_on_one_device(capi, synth, device)
     if name == "C3":
         r = synth.make_reads(3, 5_000_000, length=300)
         gen_s = time.time() - t0
@@ -148,15 +213,11 @@ def other_config(capi, synth, name, device):
                "frac": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
         res.close()
         return out
-    if name == "C5":
-        db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 1_000_000, 300, aa=True)
-        p = capi.params(is_nucleo=False, id=0.8)
-        wl = "C5: usearch_global protein 1000000 x 300 aa queries vs 2000000-seq aa DB, -id 0.8, one MI355X"
-    else:
-        db = synth.make_db(4, 5_000_000, 250)
-        (qs,) = make_query_sets(synth, 4, db, 0, 1_250_000, 250, 1)
-        p = capi.params(is_nucleo=True, id=0.97)
-        wl = "C4, one GPU's shard: queries [0, 1250000) of the 10000000 x 250 nt stream vs the 5000000-seq DB, -id 0.97"
+    if name != "C5":
+        raise ValueError("unknown configuration %r" % name)
+    db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 1_000_000, 300, aa=True)
+    p = capi.params(is_nucleo=False, id=0.8)
+    wl = "C5: usearch_global protein 1000000 x 300 aa queries vs 2000000-seq aa DB, -id 0.8, one MI355X"
     gen_s = time.time() - t0
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=device)
     bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
@@ -172,7 +233,7 @@ def other_config(capi, synth, name, device):
     capi.lib().ugs_host_unregister(qs.seqs.ctypes.data)
     dt = float(np.mean(times))
     b_rank = 4 * st["postings"] + st["query_letters"]
-    kern = ("k_rank2g" if name == "C5" else "k_rank2") if kh["r2_launched"] else "k_rank"
+    kern = "k_rank2g" if kh["r2_launched"] else "k_rank"
     out = {"workload": wl, "value": qs.n / dt, "unit": "query-seqs/s", "ms_per_step": 1000 * dt, "hits_per_step": int(nh),
            "kernel_ms": {"ranking": st["ms_rank"], "k_align": st["ms_align"], "k_rank_setup": st["ms_rank_setup"]},
            "kernel": kern + " + k_rank over %d deferred units" % kh["deferred"], "algorithmic_bytes": int(b_rank),

@@ -84,7 +84,7 @@ def test_bitmap_kernel_with_small_partitions_and_several_windows(c2_small):
 
 @pytest.mark.parametrize("g", ["8192", "16384", None])
 def test_bitmap_kernel_with_a_nearly_full_kept_key_list(c2_small, g):
-    """families of 200-250 near-identical targets spread over the partitions: every member keeps a key (count >= 3 keys are never
+    """families of 120-200 targets that share a window with the query, spread over the partitions: every member keeps a key (count >= 3 keys are never
     pruned), so the kept-key list - the LAST region of the wave's LDS carve - fills to just under its capacity of 252.  ADVICE r04:
     the host sized the carve with the gather kernel's smaller hash filters, the top of the list lay outside the allocation
     (dropped writes, reads of 0 = a key of count 15 / row 0 / target 0) wherever the 1280-byte LDS granule did not cover it."""
@@ -93,7 +93,7 @@ def test_bitmap_kernel_with_a_nearly_full_kept_key_list(c2_small, g):
     L = 250
     seqs = base.seqs.reshape(base.n, L).copy()
     q = []
-    for f, size in enumerate((200, 224, 236, 244, 250)):
+    for f, size in enumerate((120, 140, 160, 180, 200)):      # (+ ~100 unpruned count-2 keys of unrelated targets: 220 ... 300 kept keys against a list of 252)
         # a member shares ONE 75-letter window with its family's prototype (3-4 of the query's ~11 sampled words: a count >= 3 key, which is
         # never pruned, for two or three records - a partition's record list stays far from its 128 entries), the rest of it is unrelated
         proto = seqs[1000 + f].copy()
@@ -118,8 +118,8 @@ def test_bitmap_kernel_with_a_nearly_full_kept_key_list(c2_small, g):
     a = _search(db, qs, {"UGS_RANK2": "0", "UGS_LONGROWS": "0"}, is_nucleo=True, id=0.97)[0]
     b = _search(db, qs, env, is_nucleo=True, id=0.97)[0]
     assert b[1]["r2_launched"] == 1 and b[1]["r2_units"] + b[1]["deferred"] == qs.n
-    if g:                                               # (small partitions: the families' records fit, only the 250-member family may overflow the key list)
-        assert b[1]["r2_units"] >= 500 + 36, b[1]
+    if g:                                               # (small partitions: the families' records fit; the largest families overflow the key list and defer)
+        assert b[1]["r2_units"] >= 500 + 24 and b[1]["deferred"] >= 1, b[1]
     n_fam = a[2][2][500:]
     assert n_fam.min() >= 30, n_fam                     # the family queries do see their hundreds of count >= 3 targets
     for x, y in zip(a[2], b[2]):
