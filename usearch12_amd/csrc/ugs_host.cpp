@@ -278,6 +278,7 @@ UgsTune ugs_tune_read()
   t.r2_g = env_int("UGS_R2_G", 8192, 65536, 0); if (t.r2_g % 8192) t.r2_g = 0;
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
+  t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
   t.qpk = getenv("UGS_QPK") != nullptr;
   t.align_group = env_int("UGS_ALIGN_GROUP", 0, 64, -1);
   return t;
@@ -827,7 +828,16 @@ static int plan_launch(ugs_batch *b)
     b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
     b->r2.W = std::max<uint32_t>(4u, std::min<uint32_t>(28u, (db->v.np2 + 3u) / 4u * 4u));
     if (b->cl_mode && b->rl.longrows) b->r2.clcap *= 2;                 // (room for the chunks of long sub-rows)
+    if (db->tune.r2_clcap) b->r2.clcap = (uint32_t)db->tune.r2_clcap / 4u * 4u;
     b->r2.lds = (uint32_t)ugs_rank2_lds(db->v.gsize2, kcap, b->r2.clcap, b->cl_mode ? 1 : 0);
+    if (!b->cl_mode && !db->tune.r2_kcap && !db->tune.r2_clcap) {
+      // 16 waves per CU need <= 10 240 bytes of LDS per wave: a chunk list of 128 descriptors (the scan then takes a unit's partitions in
+      // two or three windows) and a kept-key list of 188 (a few hundred of a million C2 units more are deferred) buy the two waves
+      // that a 7 KB bitmap otherwise costs (C2: 31.5 -> 29.5 ms per 1 M queries, r5)
+      const uint32_t kc = std::max<uint32_t>(188u, 4u * b->K), cc = 128u;
+      const uint32_t lds_c = (uint32_t)ugs_rank2_lds(db->v.gsize2, kc, cc, 0);
+      if (lds_c <= 10240u && b->r2.lds > 10240u && kc < kcap) { kcap = kc; b->r2.kcap = kc; b->r2.clcap = cc; b->r2.lds = lds_c; }
+    }
     int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));

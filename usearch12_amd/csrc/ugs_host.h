@@ -24,6 +24,7 @@ struct UgsTune {
   bool qpk;                     // UGS_QPK=1                  nt query letters packed once by k_rank_setup for k_align (off: k_align packs them per unit; measured slower on)
   int align_group;              // UGS_ALIGN_GROUP            -1 unset (= 1), 0 off, n: rejects of a unit after which k_align tests its candidates four at a time
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
+  int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
 };
 UgsTune ugs_tune_read();
 

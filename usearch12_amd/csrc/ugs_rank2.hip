@@ -49,13 +49,19 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define R2_HB_BITS 2048u        // bits of each of the two hash filters
 #endif
 #define R2_KEY_INF 0xffffffffu
-// 32-bit words of k_rank2's LDS carve between the bitmap and the chunk list: staging records, the two hash filters, s_c2 / s_cum / s_fpk /
+// 32-bit words of k_rank2's LDS carve between the bitmap and the chunk list: staging records, the hash filter, s_c2 / s_cum / s_fpk /
 // s_slots (16 each), s_rs (16 x u64), s_pe (32).  ONE definition for the kernel's carve and the host's size (ugs_rank2_lds).
-__host__ __device__ constexpr uint32_t r2_fixed_words(bool cl) { return (cl ? R2_SCAP_CL : R2_SCAP) + 2u * (R2_HB_BITS / 32u) + 16u * 4u + 32u + 32u; }
+__host__ __device__ constexpr uint32_t r2_fixed_words(bool cl) { return (cl ? R2_SCAP_CL : R2_SCAP) + R2_HB_BITS / 32u + 16u * 4u + 32u + 32u; }
+#ifndef R2_V2
+#define R2_V2 1                 // the ring's stage body, second version (r5); 0 = the r4 body (A/B builds)
+#endif
 #ifndef UGS_R2_DEPTH
 #define UGS_R2_DEPTH 4          // ring slots: posting chunks in flight per wave (3 behind the one being counted)
 #endif
 
+// the lanes' predicate as a 64-bit mask: ONE v_cmp into a scalar pair (HIP's __ballot(int) compares a 0 / 1 value made by v_cndmask
+// against zero again wherever the predicate is a conjunction)
+__device__ __forceinline__ uint64_t r2_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t r2_mbcnt(uint64_t m)
 {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -104,6 +110,15 @@ template <int K> __device__ __forceinline__ void r2_take(uint32_t (&t)[4])
   if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\tv_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
 }
 
+// LDS byte address of target t's bitmap word: ((t >> 5) << 2) + nsub8 as a shift and ONE v_lshl_add_u32 (the compiler's own choice
+// for the expression is shift, and, add)
+__device__ __forceinline__ uint32_t r2_word_addr(uint32_t t, uint32_t nsub8)
+{
+  uint32_t a;
+  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(t >> 5), "v"(nsub8));
+  return a;
+}
+
 // what the emission of a chunk needs after its atomics were issued
 struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 
@@ -125,9 +140,8 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
   const uint32_t bm_bytes = G / 8u;
   constexpr uint32_t SCAP = CL ? R2_SCAP_CL : R2_SCAP;                 // records of one partition the grouping handles
   uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [SCAP] records of the partition being scanned
-  uint32_t *s_hba = s_stg + SCAP;                                       // [64] hash filter A
-  uint32_t *s_hbb = s_hba + R2_HB_BITS / 32;                            // [64] hash filter B
-  uint32_t *s_c2 = s_hbb + R2_HB_BITS / 32;                             // [16] kept count-2 keys per row
+  uint32_t *s_hba = s_stg + SCAP;                                       // [R2_HB_BITS / 32] hash filter of the grouping
+  uint32_t *s_c2 = s_hba + R2_HB_BITS / 32;                             // [16] kept count-2 keys per row
   uint32_t *s_cum = s_c2 + 16;                                          // [16] ... with that row or a lower one
   uint32_t *s_fpk = s_cum + 16;                                         // [16] smallest key per (15 - count)
   uint32_t *s_slots = s_fpk + 16;                                       // [16] sampled slots of the unit
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 #define R2_CLK2(...)
 #endif
 
-  for (uint32_t k = lane; k < R2_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;      // both filters start clean and are left clean
+  for (uint32_t k = lane; k < R2_HB_BITS / 32; k += 64) s_hba[k] = 0;         // the filter starts clean and is left clean
 
   uint32_t ubase = 0, uidx = 4;
   for (;;) {
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool hit = (S.old[j] & S.bit[j]) != 0u;
-          const uint64_t m = __ballot(hit);
+          const uint64_t m = r2_ballot(hit);
           if (m) {
             uint32_t pos = n_stg + r2_mbcnt(m);
             pos = pos < SCAP - 1u ? pos : SCAP - 1u;                   // (beyond the capacity the unit is deferred: n_stg tells)
@@ -242,7 +256,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
       auto zero_bitmap = [&]() {
         uint4 z; z.x = z.y = z.z = z.w = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t o = lane * 16u; o < bm_bytes; o += 1024u) *(uint4 *)(smem + o) = z;
+        // (bm_bytes is a multiple of 1024: every store is all lanes or none - straight-line stores with immediate offsets)
+        unsigned char *zp = smem + lane * 16u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) if (k * 1024u < bm_bytes) *(uint4 *)(zp + k * 1024u) = z;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
       // ---- a partition is done: group its records by target, make keys, prune, keep (NB register batches of 64 records)
@@ -288,60 +305,42 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           cnt[b] = 2; drop[b] = false;
           cumv[b] = act[b] ? s_cum[row[b]] : 0u;
         }
-        // filter A: "a record with this hash came before me"; those set filter B, which then marks every record of a shared bucket
+        // the hash filter: "a record with this hash came before me" flags every record but the first of a bucket; a flagged record's
+        // target is then compared with ALL records (the first of the bucket included), so one pass over the filter is enough
         uint32_t olda[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int b = 0; b < NB; ++b) fl[b] = act[b] && (olda[b] & hbit[b]) != 0u;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int b = 0; b < NB; ++b) if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; }     // both filters clean again
-        if constexpr (CL) {
-          // cluster_fast: most records share their target with others (the centroids of the read's species are hit by every sampled
-          // word), so the flagged records are taken a TARGET at a time: the records were staged in scan order = descending rows, a
-          // target's LAST record carries its first-touch row; count = its records + 1, every other record of it is dropped
+        for (int b = 0; b < NB; ++b) if (act[b]) s_hba[wofs[b]] = 0;                              // the filter is clean again
+        {
+          // the flagged records are taken a TARGET at a time.  The records were staged in scan order = descending rows, so a target's
+          // LAST record carries its first-touch row; count = its records + 1, every other record of it is dropped.  (cluster_fast:
+          // most records share their target with others - the centroids of the read's species are hit by every sampled word)
           uint64_t fm[NB];
 #pragma unroll
-          for (int b = 0; b < NB; ++b) fm[b] = __ballot(fl[b]);
+          for (int b = 0; b < NB; ++b) fm[b] = r2_ballot(fl[b]);
 #pragma unroll
           for (int bb = 0; bb < NB; ++bb) {
             while (fm[bb]) {
               const int L = __ffsll((long long)fm[bb]) - 1;
               const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L);
               uint32_t nsame = 0; int lastb = 0; uint64_t lastm = 0;
+              uint64_t mbs[NB];
 #pragma unroll
               for (int b = 0; b < NB; ++b) {
-                const uint64_t mb = __ballot(act[b] && t[b] == tL);
-                nsame += (uint32_t)__popcll(mb);
-                if (mb) { lastb = b; lastm = mb; }
-                fm[b] &= ~mb;
+                mbs[b] = r2_ballot(act[b] && t[b] == tL);
+                nsame += (uint32_t)__popcll(mbs[b]);
+                if (mbs[b]) { lastb = b; lastm = mbs[b]; }
+                fm[b] &= ~mbs[b];
               }
-              const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(lastm);
+              if (nsame >= 2u) {                                        // (1: another target in the same bucket)
+                const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(lastm);
 #pragma unroll
-              for (int b = 0; b < NB; ++b) if (act[b] && t[b] == tL) { cnt[b] = nsame + 1u; drop[b] = !(b == lastb && lane == lastl); }
+                for (int b = 0; b < NB; ++b) if (act[b] && t[b] == tL) { cnt[b] = nsame + 1u; drop[b] = !(b == lastb && lane == lastl); }
+              }
             }
-          }
-        } else
-        // the flagged records (a handful) against all records: count = records of the target + 1, first row = the lowest row
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-          uint64_t m = __ballot(fl[bb]);
-          while (m) {
-            const int L = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L), rL = (uint32_t)__builtin_amdgcn_readlane((int)row[bb], L);
-            uint32_t nsame = 0, lower = 0;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              const bool sb = act[b] && t[b] == tL;
-              nsame += (uint32_t)__popcll(__ballot(sb));
-              lower += (uint32_t)__popcll(__ballot(sb && row[b] < rL));
-            }
-            if (nsame >= 2u && lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = lower != 0u; }
           }
         }
         // keys; a count-2 key stays only while fewer than K count-2 keys of EARLIER partitions with its row or a lower one are kept
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           const uint32_t key = ((15u - cnt[b]) << 28) | rec[b];
           if constexpr (CL) { if (act[b] && !drop[b]) atomicMin(&s_fpk[15u - cnt[b]], key); }      // (every target's key, kept or not)
           const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
-          const uint64_t m = __ballot(keep);
+          const uint64_t m = r2_ballot(keep);
           uint32_t pos = nk_new + r2_mbcnt(m);
           pos = pos < kcap ? pos : kcap;                                 // (slot kcap is scratch; nk > kcap defers the unit)
           if (keep) s_kl[pos] = key;
@@ -387,8 +386,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
       // (as many partitions per window as the chunk list holds for this unit's row count: a multiple of 4)
       uint32_t W = ((clcap - 16u) / ((ns + 4u) & ~3u)) & ~3u;
       W = W < 4u ? 4u : (W > prm.W ? prm.W : W);
+      R2_CLK(tpre = clock64() - tk0;)                                     // (the unit's prologue: row descriptors)
       for (uint32_t p0 = 0; p0 < np && !bad; ) {
         const uint32_t Wn = np - p0 < W ? np - p0 : W;
+        R2_CLK(const unsigned long long tw0 = clock64();)
         // (1) the window's chunk list -> LDS.  Lane = (partition of the window: lane >> 4, row: ns - 1 - (lane & 15)), so lane order is the
         // scan order (partition ascending, row DESCENDING); a sub-row's bounds are two adjacent words of the row's partition-table
         // line; a sub-row longer than 256 postings gives several chunks.  Inside the scan nothing but the posting loads touches
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
             gbase += pad;
           }
           const uint32_t base = mybase + incl - nc;
-          for (uint32_t j = 0; __ballot(j < nc) != 0ull; ++j) {
+          for (uint32_t j = 0; r2_ballot(j < nc) != 0ull; ++j) {
             if (j < nc && base + j < clcap) {
               const uint64_t a = a0 + (uint64_t)j * 256u;
               const uint32_t n = len - j * 256u < 256u ? len - j * 256u : 256u;
@@ -429,21 +430,124 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         }
         if (nch == 0) { p0 += Wn; continue; }
         any_posting = true;
-        R2_CLK(tpre = clock64() - tk0;)
+        R2_CLK(tpre += clock64() - tw0;)
         // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
 #ifdef R2_DEFER_STATS
-        if (nch + 2u * (uint32_t)D > clcap && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T4], 1ull << 32);
+        if (nch + (R2_V2 ? 3u : 2u) * (uint32_t)D > clcap && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T4], 1ull << 32);
 #endif
-        if (nch + 2u * (uint32_t)D > clcap) {                          // a window with more chunks than the list holds: very long rows
+        constexpr uint32_t PADN = (R2_V2 ? 3u : 2u) * (uint32_t)D;     // empty descriptors behind the list (v2 reads a loop body further ahead)
+        if (nch + PADN > clcap) {                                      // a window with more chunks than the list holds: very long rows
           if constexpr (CL) { if (W > 1u) { W = W > 4u ? 4u : W >> 1; continue; } }     // (cluster_fast: the window is cut down to one partition before the unit is given up)
           bad = true; break;
         }
-        for (uint32_t i = nch + lane; i < nch + 2u * (uint32_t)D; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
+        for (uint32_t i = nch + lane; i < nch + PADN; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // (2) the ring: D = 4 chunk slots, three posting loads in flight behind the chunk being counted (r2_issue / r2_take above).  A
         // slot is waited for with vmcnt(D - 1): loads complete in order and every stage issues exactly one, so D - 1 younger ones are
         // in flight when a chunk's data is needed.  Stage k (chunk c + k): the records of the previous chunk are emitted, slot k is
         // taken into registers and loaded again with the chunk D ahead, then the chunk is counted.
+#if R2_V2
+        // v2 of the ring (r5).  What changed against v1 (kept below for A/B builds, -DR2_V2=0):
+        //  * the descriptors of a whole loop body (four chunks) are fetched by TWO broadcast reads, before the body's last chunk is
+        //    counted - v1 read one descriptor per stage right behind the stage's atomics, and the read's lgkmcnt(0) made every stage
+        //    wait out its own four ds_or_rtn;
+        //  * a chunk's records are emitted one stage LATER, behind the next chunk's posting wait: the atomics' round trip lies in
+        //    the shadow of s_waitcnt vmcnt; the postings of two chunks are live for it (four more registers);
+        //  * the partition's first target (sub) is a loop-carried scalar set where a partition starts, not decoded per chunk;
+        //  * postings behind a chunk's end OR a zero wherever they point (no address clamp), returned words are never initialised
+        //    (bit == 0 masks them), a padding chunk counts and emits nothing by its length alone (no per-stage scalar test).
+        static_assert(D == 4, "the ring is written for four slots");
+        uint32_t mt[4], dlo[4], dhi[4];                                  // metas of the chunks in the ring | descriptors of the next four
+        auto fetch4 = [&](uint32_t j) {
+          const uint4 a = *(const uint4 *)(s_cl + j), b4 = *(const uint4 *)(s_cl + j + 2u);     // (uniform addresses: LDS broadcast reads)
+          dlo[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.x); dhi[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.y);
+          dlo[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.z); dhi[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);
+          dlo[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b4.x); dhi[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b4.y);
+          dlo[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b4.z); dhi[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b4.w);
+        };
+        auto src_of = [&](int k, uint32_t &voff) -> const uint32_t * {
+          // lane l reads postings [4l, 4l+4) of the chunk; lanes beyond it re-read the chunk's first 16 bytes (no traffic) and are masked
+          voff = lane4 < R2D_N(dhi[k]) ? lane4 * 4u : 0u;
+          return postings + (((uint64_t)R2D_AHI(dhi[k]) << 32) | dlo[k]);
+        };
+        uint32_t nsub8 = 0;                                              // minus (first target of the partition being scanned) / 8
+        uint32_t o0, o1, o2, o3;                                         // what the atomics of the chunk in flight returned
+        asm volatile("" : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3));       // (never read where the chunk's bit is 0)
+        uint32_t e_bit[4] = {0, 0, 0, 0}, e_t[4] = {0, 0, 0, 0}, e_meta = 0;
+        auto count2 = [&](uint32_t meta, const uint32_t (&t)[4]) {
+          const int vlen = (int)R2D_N(meta) - (int)lane4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { e_bit[j] = j < vlen ? (1u << (t[j] & 31u)) : 0u; e_t[j] = t[j]; }
+          e_meta = meta;
+          if (vlen > 0) {
+            // (lanes beyond the chunk hold copies of lane 0's postings: they stay out of the LDS instructions - same-address atomics are
+            // served one after the other; a posting behind the chunk's end inside an active lane ORs a zero, wherever it points)
+            // word address = ((t - sub) >> 5) * 4 = ((t >> 5) << 2) - sub / 8 (sub is a multiple of 8192): a shift and one v_lshl_add
+            o0 = __hip_atomic_fetch_or((lds32)(uintptr_t)r2_word_addr(t[0], nsub8), e_bit[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o1 = __hip_atomic_fetch_or((lds32)(uintptr_t)r2_word_addr(t[1], nsub8), e_bit[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o2 = __hip_atomic_fetch_or((lds32)(uintptr_t)r2_word_addr(t[2], nsub8), e_bit[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            o3 = __hip_atomic_fetch_or((lds32)(uintptr_t)r2_word_addr(t[3], nsub8), e_bit[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+        // the records of the chunk counted one stage ago: postings that found their bit set (row << 24 | target)
+        auto emit2 = [&]() {
+          const uint32_t rtag = R2D_ROW(e_meta) << 24;
+          const uint32_t old[4] = {o0, o1, o2, o3};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool hit = (old[j] & e_bit[j]) != 0u;
+            const uint64_t m = r2_ballot(hit);
+            if (m) {
+              uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_stg));   // n_stg + rank
+              pos = pos < SCAP - 1u ? pos : SCAP - 1u;                 // (beyond the capacity the unit is deferred: n_stg tells)
+              if (hit) s_stg[pos] = e_t[j] | rtag;
+              n_stg += (uint32_t)__popcll(m);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e_bit[j] = 0;                      // (emitted: a second call finds nothing)
+        };
+        fetch4(0);
+        { uint32_t vo; const uint32_t *sp;
+          sp = src_of(0, vo); r2_issue<0>(vo, sp); sp = src_of(1, vo); r2_issue<1>(vo, sp);
+          sp = src_of(2, vo); r2_issue<2>(vo, sp); sp = src_of(3, vo); r2_issue<3>(vo, sp); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mt[k] = dhi[k];
+        fetch4(4);
+        uint32_t pi = 0, pend = 0, pe_next = s_pe[0];
+#define R2_STAGE2(k, last)                                                                                       \
+          {                                                                                                      \
+            uint32_t tn[4], vo;                                                                                  \
+            const uint32_t *sp = src_of(k, vo);                                                                  \
+            r2_take<k>(tn);                                                                                      \
+            r2_issue<k>(vo, sp);                                                                                 \
+            emit2();                                                                                             \
+            const uint32_t pm = mt[k]; mt[k] = dhi[k];                                                           \
+            if (last) fetch4(c + 2u * (uint32_t)D);                                                              \
+            count2(pm, tn);                                                                                      \
+          }
+        for (uint32_t c = 0; c < nch && !bad; c += (uint32_t)D) {
+          if (c == pend) {
+            // a partition ended with the previous loop body: its last chunk's records, then its grouping
+            R2_CLK(const unsigned long long tf0 = clock64();)
+            emit2();
+            if (c != 0) { finalize(); if (bad) break; }
+            // (the next partition's end index was read where this one began: no LDS round trip at the boundary)
+            do { pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pe_next); ++pi; pe_next = s_pe[pi]; } while (pend == c);      // (partitions without a posting)
+            nsub8 = 0u - R2D_PART(mt[0]) * (G >> 3);                      // (a partition's first chunk is never padding)
+            zero_bitmap();
+            R2_CLK(tfin += clock64() - tf0;)
+          }
+          R2_STAGE2(0, false) R2_STAGE2(1, false) R2_STAGE2(2, false) R2_STAGE2(3, true)
+        }
+#undef R2_STAGE2
+        if (!bad) {
+          R2_CLK(const unsigned long long tf0 = clock64();)
+          emit2();
+          finalize();
+          R2_CLK(tfin += clock64() - tf0;)
+        }
+#else
         uint32_t mt[D];
         auto fetch = [&](uint32_t j, uint32_t &meta, uint32_t &voff) -> const uint32_t * {
           const uint2 e = s_cl[j];                                       // (uniform address: an LDS broadcast read)
@@ -493,6 +597,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           if (pv) { emit_chunk(S, pm); pv = false; }
           finalize();
         }
+#endif
         // every load of the ring has landed before the next window (or unit) issues into the same slots
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         p0 += Wn;
@@ -522,11 +627,11 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
     {
       // lane c (2..15) looks at count c
       const uint32_t f = (lane >= 2u && lane <= 15u) ? s_fpk[15u - lane] : R2_KEY_INF;
-      const uint64_t vm = __ballot(f != R2_KEY_INF);
+      const uint64_t vm = r2_ballot(f != R2_KEY_INF);
       if (vm) {
         M = 63u - (uint32_t)__builtin_clzll(vm);
         const uint32_t fM = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)M) & 0x0fffffffu;
-        const uint64_t lm = __ballot(f != R2_KEY_INF && lane < M && (f & 0x0fffffffu) < fM);
+        const uint64_t lm = r2_ballot(f != R2_KEY_INF && lane < M && (f & 0x0fffffffu) < fM);
         // (a count-1 first position below fp[M] gives NextValue 1 when no higher count qualifies: MinValue = NextValue / 2 is 0 either way)
         nv = lm ? 63u - (uint32_t)__builtin_clzll(lm) : 0u;
       } else M = any_posting ? 1u : 0u;
@@ -542,7 +647,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         const bool rowlane = lane < ns;
         const uint32_t slot = rowlane ? s_slots[lane] : 0u;
         const uint64_t ra = rowlane ? db.row_off[slot] : 0ull, rb = rowlane ? db.row_off[slot + 1] : 0ull;
-        const uint64_t ne_rows = __ballot(rowlane && rb > ra);
+        const uint64_t ne_rows = r2_ballot(rowlane && rb > ra);
         if (ne_rows) {
           const uint32_t r0 = (uint32_t)__ffsll((long long)ne_rows) - 1u;
           const uint64_t a0 = r2_readlane64(ra, r0);
@@ -575,7 +680,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         const uint32_t i = e0 + lane;
         const uint32_t key = i < nk ? s_kl[i] : R2_KEY_INF;
         const bool elig = key < limit;
-        nelig += (uint32_t)__popcll(__ballot(elig));
+        nelig += (uint32_t)__popcll(r2_ballot(elig));
         uint32_t rank = 0;
         const uint4 *k4 = (const uint4 *)s_kl;
         for (uint32_t j = 0; j < nk; j += 4u) {
@@ -608,7 +713,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           bool in_set = false;
           for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
           const bool e = on && !in_set;
-          const uint64_t m = __ballot(e);
+          const uint64_t m = r2_ballot(e);
           const uint32_t rank = r2_mbcnt(m);
           if (e && filled + rank < K) {
             bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u;
@@ -740,7 +845,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             prev = e[i].w;
           }
         }
-        if (__ballot(big)) bad = true;                                      // (a sub-row of more than 255 postings: not a sparse row)
+        if (r2_ballot(big)) bad = true;                                      // (a sub-row of more than 255 postings: not a sparse row)
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -768,7 +873,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
           // the partition's descriptor lanes: every row lane writes the quads of its sub-row (byte offset of the quad, valid postings | row << 8)
           const uint32_t base = rsb + cur_off * 4u;
           cur_off += r_len;
-          for (uint32_t q = 0; __ballot(q < r_nl) != 0ull; ++q) {
+          for (uint32_t q = 0; r2_ballot(q < r_nl) != 0ull; ++q) {
             const uint32_t rem = r_len - q * 4u;
             if (q < r_nl) s_desc[r_st + q] = make_uint2(base + q * 16u, (rem < 4u ? rem : 4u) | (myrow << 8));
           }
@@ -837,7 +942,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           if (bb == 1 && !two) continue;
-          uint64_t m = __ballot(fl[bb]);
+          uint64_t m = r2_ballot(fl[bb]);
           while (m) {
             const int L = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -849,8 +954,8 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
               if (b == 1 && !two) continue;
               const bool sb = act[b] && t[b] == tL;
               const uint32_t ib = (uint32_t)b * 64u + lane;
-              nsame += (uint32_t)__popcll(__ballot(sb));
-              better += (uint32_t)__popcll(__ballot(sb && (row[b] < rL || (row[b] == rL && ib < iL))));
+              nsame += (uint32_t)__popcll(r2_ballot(sb));
+              better += (uint32_t)__popcll(r2_ballot(sb && (row[b] < rL || (row[b] == rL && ib < iL))));
             }
             if (nsame >= 2u && lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = better != 0u; }
           }
@@ -861,7 +966,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
           if (b == 1 && !two) continue;
           const uint64_t key = ((uint64_t)(255u - cnt[b]) << 32) | rec[b];
           const bool keep = act[b] && !drop[b] && (cnt[b] >= 3u || cumv[b] < K);
-          const uint64_t m = __ballot(keep);
+          const uint64_t m = r2_ballot(keep);
           uint32_t pos = nk_new + r2_mbcnt(m);
           pos = pos < kcap ? pos : kcap;
           if (keep) s_kl[pos] = key;
@@ -890,11 +995,11 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       // its target (the last matching lane: lanes are in descending row order) - the first touch may be any of them
       auto emit_chunk = [&]() {
         const uint32_t myrow8 = S_lm >> 8;
-        if (__ballot(((S_old[0] & S_bit[0]) | (S_old[1] & S_bit[1]) | (S_old[2] & S_bit[2]) | (S_old[3] & S_bit[3])) != 0u) == 0ull) return;
+        if (r2_ballot(((S_old[0] & S_bit[0]) | (S_old[1] & S_bit[1]) | (S_old[2] & S_bit[2]) | (S_old[3] & S_bit[3])) != 0u) == 0ull) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool hit = (S_old[j] & S_bit[j]) != 0u;
-          uint64_t m = __ballot(hit);
+          uint64_t m = r2_ballot(hit);
           uint32_t rrow = myrow8;
           uint64_t rest = m;
           while (rest) {                                                   // (a handful of hits per unit)
@@ -903,7 +1008,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
             const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)S_t[j], L);
             uint64_t mm = 0;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) mm |= __ballot(S_bit[jj] != 0u && S_t[jj] == tL);
+            for (int jj = 0; jj < 4; ++jj) mm |= r2_ballot(S_bit[jj] != 0u && S_t[jj] == tL);
             const int last = 63 - __builtin_clzll(mm);                      // (mm holds lane L itself)
             const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)myrow8, last);
             if (lane == (uint32_t)L) rrow = low;
@@ -976,11 +1081,11 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
     uint32_t M = 0, nv = 0;
     {
       const uint64_t f = (lane >= 2u) ? s_fpk[lane] : R2G_KEY_INF;            // lane c looks at count c
-      const uint64_t vm = __ballot(f != R2G_KEY_INF);
+      const uint64_t vm = r2_ballot(f != R2G_KEY_INF);
       if (vm) {
         M = 63u - (uint32_t)__builtin_clzll(vm);
         const uint32_t fM = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f, (int)M);
-        const uint64_t lmk = __ballot(f != R2G_KEY_INF && lane < M && (uint32_t)f < fM);
+        const uint64_t lmk = r2_ballot(f != R2G_KEY_INF && lane < M && (uint32_t)f < fM);
         nv = lmk ? 63u - (uint32_t)__builtin_clzll(lmk) : 0u;
       } else M = any_posting ? 1u : 0u;
     }
@@ -994,7 +1099,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         const uint32_t i = e0 + lane;
         const uint64_t key = i < nk ? s_kl[i] : R2G_KEY_INF;
         const bool elig = key < limit;
-        nelig += (uint32_t)__popcll(__ballot(elig));
+        nelig += (uint32_t)__popcll(r2_ballot(elig));
         uint32_t rank = 0;
         for (uint32_t j = 0; j < nk; j += 2u) { rank += (s_kl[j] < key) + (s_kl[j + 1u] < key); }
         if (elig && rank < K) {
@@ -1019,7 +1124,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
           bool in_set = false;
           for (uint32_t j = 0; j < nsel; ++j) in_set = in_set || t == (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
           const bool e = on && !in_set;
-          const uint64_t m = __ballot(e);
+          const uint64_t m = r2_ballot(e);
           const uint32_t rank = r2_mbcnt(m);
           if (e && filled + rank < K) { bv.cand[(uint64_t)unit * K + filled + rank] = t; bv.cand_cnt[(uint64_t)unit * K + filled + rank] = 1u; }
           const uint32_t n = (uint32_t)__popcll(m);
