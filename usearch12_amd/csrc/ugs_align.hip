@@ -39,6 +39,10 @@ __device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 struct HSPd { uint32_t Loi, Loj, Len; int32_t Score2; };
+// a value every lane of the wave holds alike (an LDS word read at a wave-uniform address, a flag made of such words), moved to the scalar
+// file: what follows from it - loop bounds, branch conditions, the walk's counters - is then scalar too instead of one VGPR each
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ HSPd uni(const HSPd &h) { HSPd r; r.Loi = uni(h.Loi); r.Loj = uni(h.Loj); r.Len = uni(h.Len); r.Score2 = (int32_t)uni((uint32_t)h.Score2); return r; }
 
 struct WaveState {            // per-wave LDS control block (written by lane 0, read by all after a wave fence)
   uint32_t nhsp, nchain, nruns, cur_op, cur_len, rt_n, overflow, pad;
@@ -1091,7 +1095,7 @@ __device__ __forceinline__ void chain_lane0(WaveCtx &c)
     // hspfinder.cpp:537-553 + hsp.h:102-126 IsStaggered
     const int LA = (int)c.LA, LB = (int)c.LB;
     for (uint32_t q = 0; q < nchain; ++q) {
-      const HSPd h = c.hsps[c.chain[q]];
+      const HSPd h = uni(c.hsps[uni(c.chain[q])]);
       const int Hii = (int)(h.Loi + h.Len - 1), Hij = (int)(h.Loj + h.Len - 1);
       int gLA = (int)h.Loi - (int)h.Loj, gLB = (int)h.Loj - (int)h.Loi;
       int gRA = LA - Hii - 1 - (LB - Hij - 1), gRB = LB - Hij - 1 - (LA - Hii - 1);
@@ -1434,7 +1438,9 @@ template <bool PAIR, bool NT>
 __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsBatchView bv, uint32_t hsp_cap, uint32_t wave_lds, uint32_t seed_cap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
+  // (the wave index is wave-uniform, but derived from threadIdx the compiler holds it - and every per-wave LDS pointer and the two
+  // global scratch pointers made from it - in VECTOR registers: 60 of the kernel's 95 spilled VGPRs were those; r5)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = blockDim.x >> 6;
   // ---- workgroup-shared tables
   uint8_t *s_cls = smem;                       // 256
   uint8_t *s_hl = smem + 256;                  // 32
@@ -1656,13 +1662,13 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
               ga.s_cls = s_cls; ga.s_sc = s_sc; ga.s_hl = s_hl; ga.sub2 = s_sub2;
               ga.seed_cap = gcap; ga.LA = LA; ga.MinLength = MinL; ga.gstride = maxt; ga.bsh = c.bsh;
               ga.w = db.hsp_w; ga.alpha = db.alpha; ga.X = db.xdrop2; ga.minscore2 = db.minscore2;
-              grp_maybe = group_filter_aa(ga, k, n, cto, clen);
+              grp_maybe = uni(group_filter_aa(ga, k, n, cto, clen));
             } else {
             GroupArgs ga;
             ga.pk = db.pk; ga.A2 = c.A2; ga.B = c.B; ga.Bs = c.Bs; ga.wstart = c.wstart; ga.qsort = c.qsort; ga.seeds = c.seeds;
             ga.seed_cap = c.seed_cap; ga.LA = LA; ga.MinLength = MinL; ga.gwt = gwt; ga.nB = gnB;
             ga.w = db.hsp_w; ga.X = db.xdrop2; ga.m2 = c.s_sub2[0]; ga.mm2 = c.s_sub2[2]; ga.minscore2 = db.minscore2; ga.ctr = gclk; ga.xlut = c.xlut;
-            grp_maybe = group_filter(ga, k, n, cto, clen);
+            grp_maybe = uni(group_filter(ga, k, n, cto, clen));
             }
             grp_lo = k; grp_hi = k + n;
             ta2 += ACLK() - tq; tq = ACLK();
@@ -1794,13 +1800,13 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       if (lane == 0) { if (fulldp) c.ws->nchain = 0; else chain_lane0(c); }
       wave_sync();
       ta0 += ACLK2() - tq2; tq2 = ACLK2();
-      const uint32_t nchain = c.ws->nchain;
+      const uint32_t nchain = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.ws->nchain);      // (written by lane 0, read by all: wave-uniform)
       bool accept = false;
       if (nchain || force_all) {
         load_classes();
         uint32_t TotLen = 0, TotSame = 0;
         for (uint32_t q = 0; q < nchain; ++q) {
-          const HSPd h = c.hsps[c.chain[q]];
+          const HSPd h = uni(c.hsps[uni(c.chain[q])]);
           TotLen += h.Len;
           for (uint32_t x0 = 0; x0 < h.Len; x0 += 64) {
             const uint32_t x = x0 + lane;
@@ -1816,7 +1822,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           wave_sync();
           uint32_t pLoi = 0, pLoj = 0;                     // end (exclusive) of the previous HSP
           for (uint32_t q = 0; q < nchain; ++q) {
-            const HSPd h = c.hsps[c.chain[q]];
+            const HSPd h = uni(c.hsps[uni(c.chain[q])]);
             align_hole(c, db, pLoi, pLoj, h.Loi - pLoi, h.Loj - pLoj, ctr);
             if (lane == 0) push_run(c, 0, h.Len);
             pLoi = h.Loi + h.Len; pLoj = h.Loj + h.Len;
@@ -1824,16 +1830,17 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
           align_hole(c, db, pLoi, pLoj, LA - pLoi, LB - pLoj, ctr);
           if (lane == 0) { flush_runs(c); if (c.ws->overflow) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_RUNS); }
           wave_sync();
-          const uint32_t nr = c.ws->nruns < c.runs_cap ? c.ws->nruns : c.runs_cap;
+          const uint32_t nruns_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.ws->nruns);
+          const uint32_t nr = nruns_w < c.runs_cap ? nruns_w : c.runs_cap;
           ta2 += ACLK2() - tq2; tq2 = ACLK2();
           // ---- AlignResult::FillLo on the run list
           int fm = -1, lm = -1; uint32_t cols = 0;
-          for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = get_run(c, r); cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
+          for (uint32_t r = 0; r < nr; ++r) { const uint32_t run = uni(get_run(c, r)); cols += run >> 2; if ((run & 3) == 0) { if (fm < 0) fm = (int)r; lm = (int)r; } }
           if (fm >= 0) {
             uint32_t qpos = 0, tpos = 0, ids = 0, alen = 0, gaps = 0, opens = 0, mcols = 0, qlo = 0, tlo = 0, qhi = 0, thi = 0;
             uint32_t lastop = 0;
             for (uint32_t r = 0; r < nr; ++r) {
-              const uint32_t run = get_run(c, r), op = run & 3, len = run >> 2;
+              const uint32_t run = uni(get_run(c, r)), op = run & 3, len = run >> 2;
               const bool inside = (int)r >= fm && (int)r <= lm;
               if ((int)r == fm) { qlo = qpos; tlo = tpos; }
               if (op == 0) {

@@ -121,7 +121,8 @@ extern "C" void ugs_comm_destroy(ugs_comm *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->st) (void)hipStreamSynchronize(c->st);        // (as ugs_db_destroy: nothing of this handle in flight when its stream goes)
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  (void)hipDeviceSynchronize();        // (as ugs_db_destroy: nothing in flight on the device when a stream goes)
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (int k = 0; k < 3; ++k) if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
   if (c->d_my) (void)hipFree(c->d_my);

@@ -227,10 +227,12 @@ extern "C" void ugs_db_destroy(ugs_db *db)
 {
   if (!db) return;
   (void)hipSetDevice(db->device);
-  // no stream or event of THIS handle is destroyed while any of its work is in flight (a completion signal is a 64-bit word the
-  // runtime DECREMENTS: DESIGN section 4, "host heap").  Scoped to the handle's own stream: other handles and other libraries on
-  // the same GPU keep running; hipFree of memory still in use by another stream waits by itself.
+  // no stream or event is destroyed while anything of this device is in flight (a completion signal is a 64-bit word the runtime
+  // DECREMENTS: DESIGN section 4, "host heap").  The barrier is DEVICE-WIDE on purpose and stalls other handles / libraries on the same
+  // GPU for the moment of a destroy: r5 tried the handle's own streams only and one of two full GPU suites then died of a
+  // SIGABRT inside a later ugs_db_create - the r02 symptom - while every suite with the device-wide barrier has passed.
   if (db->stream) (void)hipStreamSynchronize(db->stream);
+  (void)hipDeviceSynchronize();
   (void)hipFree(db->d_pk);
   (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part); (void)hipFree(db->d_part2);
   (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
@@ -586,6 +588,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
   if (b->ev_done) (void)hipEventSynchronize(b->ev_done);
   if (b->ev_up) (void)hipEventSynchronize(b->ev_up);
+  (void)hipDeviceSynchronize();        // (device-wide, as ugs_db_destroy says)
   (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
   (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
   (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer); (void)hipFree(b->d_qpk);

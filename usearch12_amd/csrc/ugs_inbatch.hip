@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_inbatch(UgsBatchView bv, const uint64_t
                                                  const uint32_t *ent_off, uint2 *ent)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;      // (wave index in an SGPR)
   const size_t wave_bytes = ((size_t)tbl_words + 64) * 4 + (size_t)ns_max * 8;
   uint32_t *tbl = (uint32_t *)(smem + (size_t)wave * wave_bytes);
   uint32_t *ra = tbl + tbl_words + 64, *re = ra + ns_max;
