@@ -203,7 +203,10 @@ int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint
  * query order, each group sorted as HitMgr::Sort orders them (hitmgr.cpp:477-483).
  * nhits_per_query[nq] receives the group sizes.  Returns UGS_E_CAPACITY (cigar_used = runs needed) if hits_cap or
  * cigar_cap (uint32 units) is too small (hits_cap = nq * max_accepts * (1+strand_both)
- * always suffices).
+ * always suffices; max_accepts 0 = unlimited: a query may have as many hits as it has candidates - grow hits_cap and call again).
+ * Walk depth: max_accepts + max_rejects - 1 may exceed the 64 candidates a ranking pass keeps per strand, and either may be 0 =
+ * unlimited, as in the reference (terminator.cpp:22-31,64-100): the walks that use up their 64 candidates are continued over the
+ * query's complete sorted candidate list (usearch_global; -termid / -termidd are refused together with such settings).
  */
 int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
                      ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,
@@ -261,11 +264,11 @@ int ugs_hits_sort(ugs_hit *hits, const uint32_t *nhits_per_query, uint32_t nq, i
  * Stage-level entry point used by the parity tests: the ranked candidate list of every
  * query exactly as the reference's candidate loop would walk it
  * (udbusortedsearcherbig.cpp:113-134 / udbusortedsearcher.cpp:138-151), truncated to
- * the first k = max_accepts + max_rejects - 1 entries per strand.
+ * the first k = min(64, max_accepts + max_rejects - 1) entries per strand.
  * cand[(q*nstrand + s)*k + j] = target index, cnt[...] = word count, n[q*nstrand+s] = entries.
  */
 int ugs_batch_get_candidates(ugs_batch *b, uint32_t *cand, uint32_t *cnt, uint32_t *n, uint32_t k_cap);
-/* k of this batch: max_accepts + max_rejects - 1, plus the spare candidates kept for -selfid on the small path (<= 64) */
+/* k of this batch: max_accepts + max_rejects - 1, plus the spare candidates kept for -selfid on the small path (<= 64; deeper walks: 64) */
 int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
 /* Diagnostic: which ranking code the last synced search of this batch ran (the test-suite asserts that every compiled path is
  * reached by an oracle-compared test).  out[0] = units ranked by the bitmap kernel (ugs_rank2.hip), out[1] = units it deferred to the
@@ -282,6 +285,10 @@ int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
 /* Diagnostic: the name of the ranking kernel behind bit `bit` of those masks (a static string), or NULL if the library holds no such
  * instantiation - the library's own table, so that a test or tool keeps no list of its own. */
 const char *ugs_debug_rank_instance_name(int bit);
+/* Diagnostic: the deep-walk stage of the last synced search of this batch (walks that need more than the 64 candidates a ranking
+ * pass keeps - max_accepts + max_rejects - 1 > 64, or 0 = unlimited: terminator.cpp:22-31,64-100 has no depth limit): how many walks
+ * were parked and continued over their complete sorted candidate list, and how many keys those lists held. */
+int ugs_debug_deep_walks(const ugs_batch *b, uint64_t *parked_units, uint64_t *list_keys);
 
 /*
  * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the

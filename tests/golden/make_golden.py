@@ -69,6 +69,16 @@ CASES = {
     # no -id at all: ranking parameters of id 0.5, no identity filter, no error (accepter.cpp:35, makedbsearcher.cpp:195)
     "hard_noid":   dict(gen="hard", seed=44, n_fam=250, fam=6, q_n=900, aa=False, id=None, strand="both", big=100, lmin=20, lmax=300, maxaccepts=3, maxrejects=8),
     "hard_noid_s": dict(gen="hard", seed=45, n_fam=200, fam=6, q_n=700, aa=False, id=None, strand="plus", lmin=60, lmax=300),
+    # deep walks (r5): more candidates than the 64 a ranking pass keeps - unlimited walks over a DB of large families (every family member is a
+    # candidate, up to ~100 accepts per query: hit slots overflow into chained blocks), -maxrejects 128 / 256, -maxaccepts 100; both ranking paths,
+    # both strands, protein.  The reference's walk has no depth limit (terminator.cpp:22-31,64-100).
+    "deep_all_s":   dict(gen="hard", seed=46, n_fam=25, fam=120, q_n=100, aa=False, id=0.9, strand="both", lmin=100, lmax=300, maxaccepts=0, maxrejects=0),
+    "deep_all_big": dict(gen="hard", seed=47, n_fam=25, fam=120, q_n=100, aa=False, id=0.9, strand="plus", big=100, lmin=100, lmax=300, maxaccepts=0, maxrejects=0),
+    "deep_rej256":  dict(gen="hard", seed=48, n_fam=25, fam=120, q_n=300, aa=False, id=0.97, strand="both", big=100, lmin=100, lmax=300, maxaccepts=2, maxrejects=256),
+    "deep_rej128_s": dict(gen="hard", seed=49, n_fam=25, fam=120, q_n=300, aa=False, id=0.95, strand="plus", lmin=100, lmax=300, maxaccepts=3, maxrejects=128),
+    "deep_acc100":  dict(gen="hard", seed=50, n_fam=25, fam=120, q_n=150, aa=False, id=0.9, strand="plus", big=100, lmin=100, lmax=300, maxaccepts=100, maxrejects=32),
+    "deep_aa":      dict(gen="hard", seed=51, n_fam=20, fam=100, q_n=100, aa=True, id=0.8, lmin=80, lmax=250, maxaccepts=0, maxrejects=0),
+    "deep_aa_big":  dict(gen="hard", seed=52, n_fam=20, fam=100, q_n=120, aa=True, id=0.85, big=100, lmin=80, lmax=250, maxaccepts=1, maxrejects=200),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }

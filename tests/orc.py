@@ -162,13 +162,17 @@ class OrcDB:
         qoffs = np.ascontiguousarray(qoffs, dtype=np.uint64)
         nq = len(qoffs) - 1
         cap = nq * (self.p.max_accepts or 64) * (2 if self.p.strand_both else 1) * (64 if self.p.local else 1) + 1
-        hits = np.zeros(cap, dtype=HIT_DTYPE)
-        nh = np.zeros(nq + 1, dtype=np.uint32)
         cig_cap = (int(qoffs[-1]) * 2 + 64 * nq + 1024) * (8 if self.p.local else 1)
-        pool = np.zeros(cig_cap, dtype=np.uint32)
-        used = C.c_uint64(0)
-        rc = lib().orc_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
-                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used), nthreads)
+        for _ in range(8):                                  # (unlimited accepts: the caller's buffers grow until the hits fit)
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            nh = np.zeros(nq + 1, dtype=np.uint32)
+            pool = np.zeros(cig_cap, dtype=np.uint32)
+            used = C.c_uint64(0)
+            rc = lib().orc_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
+                                        nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used), nthreads)
+            if rc != -5:
+                break
+            cap *= 4; cig_cap *= 4
         assert rc == 0, rc
         nh = nh[:nq]
         return hits[:int(nh.sum())], nh, pool[:used.value]

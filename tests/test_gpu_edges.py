@@ -98,21 +98,39 @@ def test_fetch_capacity_error_reports_demand():
     assert len(p) == used.value
 
 
-def test_unlimited_rejects_fail_loudly_when_the_list_is_longer_than_the_device_keeps():
-    """maxrejects 0 on a database where walks run past 64 candidates: UGS_E_ENVELOPE at sync, never a shortened walk"""
-    db, qs = synth.make_hard(77, 60, 8, 200)
-    p = capi.params(is_nucleo=True, id=0.99, max_accepts=1, max_rejects=0)
+@pytest.mark.parametrize("kw", [dict(max_accepts=1, max_rejects=0), dict(max_accepts=0, max_rejects=0), dict(max_accepts=40, max_rejects=40),
+                                dict(max_accepts=3, max_rejects=256), dict(max_accepts=0, max_rejects=0, strand_both=1, big=0)])
+def test_walks_deeper_than_the_kept_candidates_equal_the_oracle(kw):
+    """-maxrejects 0 / -maxaccepts 0 (unlimited), 40 + 40, -maxrejects 256 on a database where walks run past the 64 candidates a ranking
+    pass keeps (r4: UGS_E_ENVELOPE; r5: the parked walks are continued over the unit's complete sorted list, ugs_deep.hip): every hit
+    record equals the oracle's, and the deep stage did run"""
+    db, qs = synth.make_hard(77, 12, 100, 160)
+    ident = 0.99 if kw.get("max_rejects") == 0 and kw.get("max_accepts") == 1 else 0.93
+    p = capi.params(is_nucleo=True, id=ident, **kw)
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
-    with pytest.raises(capi.UgsError) as e:
-        gdb.search(qs.seqs, qs.offs)
-    assert e.value.code == -6
+    bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
+    bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
+    g = bat.fetch()
+    parked, keys = bat.deep_walks()
+    assert parked > 0 and keys > 64 * parked
+    o = orc.OrcDB(orc.params(is_nucleo=True, id=ident, **kw), db.seqs, db.offs).search(qs.seqs, qs.offs, nthreads=8)
+    assert np.array_equal(g[1], o[1])
+    for f in g[0].dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(g[0][f], o[0][f]), f
+    for a, c in zip(g[0][::7], o[0][::7]):
+        assert np.array_equal(g[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])], o[2][int(c["cigar_off"]):int(c["cigar_off"]) + int(c["cigar_len"])])
+    # the same batch again (the pools have their final size now): the same table
+    bat.search(); bat.sync()
+    g2 = bat.fetch()
+    assert np.array_equal(g[1], g2[1]) and all(np.array_equal(g[0][f], g2[0][f]) for f in g[0].dtype.names if f != "cigar_off")
 
 
 def test_options_outside_the_envelope_are_refused_at_create():
     db = synth.make_db(5, 200, 120)
     for kw in (dict(local_evalue=1e-3, self=True),               # pair filters exist for usearch_global only
-               dict(local_evalue=1e-3, max_accepts=0),          # open walks too
-               dict(max_accepts=40, max_rejects=40),             # more than 64 candidates per strand
+               dict(local_evalue=1e-3, max_accepts=0),          # deep walks too
+               dict(max_accepts=0, max_rejects=0, termid=0.9, align_flags=4),   # -termid looks at both strands' hits in walk order: not with parked walks
                dict(band=-1)):
         with pytest.raises(capi.UgsError):
             capi.UgsDB(capi.params(is_nucleo=True, id=0.9, **kw), db.seqs, db.offs, device=0)

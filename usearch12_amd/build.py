@@ -8,8 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip"]
-DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip", "ugs_deep.hip"]
+DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_rank_keys.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 # per-source compiler options.  k_rank's partition loop lives on the edge of its register budget: of the machine

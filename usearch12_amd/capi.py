@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name",
+    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name", "ugs_debug_deep_walks",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -215,18 +215,21 @@ class UgsDB:
             bat.close()
             return out
         cap = nq * (self.p.max_accepts or 64) * (2 if self.p.strand_both else 1) * (self.p.max_hsps if self.p.local else 1) + 1
-        hits = np.zeros(cap, dtype=HIT_DTYPE)
-        nh = np.zeros(nq + 1, dtype=np.uint32)
         cig_cap = int(qoffs[-1]) * 2 + 64 * nq + 1024
-        pool = np.zeros(cig_cap, dtype=np.uint32)
-        used = C.c_uint64(0)
-        rc = lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
-                                    nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
-        if rc == -5 and used.value > cig_cap:                     # UGS_E_CAPACITY: retry with the run pool the library asked for
-            cig_cap = int(used.value) + 1024
+        for _ in range(10):
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            nh = np.zeros(nq + 1, dtype=np.uint32)
             pool = np.zeros(cig_cap, dtype=np.uint32)
+            used = C.c_uint64(0)
             rc = lib().ugs_search_batch(self.h, qseqs.ctypes.data, qoffs.ctypes.data, nq, hits.ctypes.data, cap,
                                         nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+            if rc != -5:
+                break
+            # UGS_E_CAPACITY: the run pool the library asked for, or (deep walks: any number of accepts per query) a larger hit array
+            if used.value > cig_cap:
+                cig_cap = int(used.value) + 1024
+            else:
+                cap *= 4
         _chk(rc)
         nh = nh[:nq]
         return hits[:int(nh.sum())], nh, pool[:used.value]
@@ -279,15 +282,19 @@ class UgsBatch:
         cap = self.nq * (p.max_accepts or 64) * (2 if p.strand_both else 1) * (p.max_hsps if p.local else 1) + 1
         cig_cap = self.nletters * 2 + 64 * self.nq + 1024
         if not reuse:
-            hits = np.zeros(cap, dtype=HIT_DTYPE)
-            nh = np.zeros(self.nq + 1, dtype=np.uint32)
-            pool = np.zeros(cig_cap, dtype=np.uint32)
-            used = C.c_uint64(0)
-            rc = lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
-            if rc == -5 and used.value > cig_cap:                 # UGS_E_CAPACITY: the library reports the run pool it needs
-                cig_cap = int(used.value) + 1024
+            for _ in range(10):
+                hits = np.zeros(cap, dtype=HIT_DTYPE)
+                nh = np.zeros(self.nq + 1, dtype=np.uint32)
                 pool = np.zeros(cig_cap, dtype=np.uint32)
+                used = C.c_uint64(0)
                 rc = lib().ugs_batch_fetch(self.h, hits.ctypes.data, cap, nh.ctypes.data, pool.ctypes.data, cig_cap, C.byref(used))
+                if rc != -5:
+                    break
+                # UGS_E_CAPACITY: the library reports the run pool it needs; otherwise the hit array was too small (deep walks)
+                if used.value > cig_cap:
+                    cig_cap = int(used.value) + 1024
+                else:
+                    cap *= 4
             _chk(rc)
             nh = nh[:self.nq]
             return hits[:int(nh.sum())], nh, pool[:used.value]
@@ -339,6 +346,14 @@ class UgsBatch:
         _chk(lib().ugs_batch_device_results(self.h, query_base, C.byref(ph), C.byref(bh), C.byref(pn), C.byref(bn),
                                             C.byref(pc), C.byref(bc)))
         return (ph.value, bh.value), (pn.value, bn.value), (pc.value, bc.value)
+
+    def deep_walks(self):
+        """(walks parked and continued past the 64 kept candidates, keys of their complete lists) of the last synced search"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        f = lib().ugs_debug_deep_walks
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; f.restype = C.c_int
+        _chk(f(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def kernel_hits(self):
         """which ranking code the last synced search ran: dict(r2_units, deferred, rank_kernel, r2_launched)"""

@@ -1545,6 +1545,10 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     // -termid / -termidd (terminator.cpp:66-87) look at the hits of BOTH strands (one HitMgr per query): with them a wave takes a
     // whole query and walks its strands one after the other
     const uint32_t tflags = PAIR ? (db.align_flags & (UGS_A_TERMID | UGS_A_TERMIDD)) : 0u;
+    // deep walks (ugs_deep.hip): a continuation pass takes the parked units from walk_units and walks on through their complete lists
+    const bool deep = PAIR && (db.align_flags & UGS_A_DEEP) != 0;
+    bool cont = false; uint32_t widx = 0;
+    if constexpr (PAIR) if (bv.walk_units) { if (unit >= bv.n_walk) break; widx = unit; unit = bv.walk_units[widx]; cont = true; }
     uint32_t strands_left = 1, t_hits = 0;
     float t_min = 1.0f, t_max = 0.0f;                          // HitMgr::GetMinFractId / GetMaxFractId hitmgr.cpp:508-532
     if constexpr (PAIR) if (tflags) {
@@ -1559,16 +1563,29 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t LA = (uint32_t)(bv.qoffs[qi + 1] - qo);
     c.LA = LA;
-    const uint32_t ncand = bv.cand_n[unit];
+    uint32_t ncand = bv.cand_n[unit];
     uint32_t nvis = 0;
     bool walk_ended = false;          // the terminator ended the walk (not the end of the list)
     uint32_t nacc = 0, nrej = 0;
+    // continuation of a parked walk: its counters, the page of its sorted key list that comes next, its overflow hit blocks
+    uint32_t page = 0, n_total = 0, xhead = 0xffffffffu, xcur = 0xffffffffu;
+    const uint64_t *dkeys = nullptr;
+    bool setup_done = false;
+    if constexpr (PAIR) if (cont) {
+      const UgsWalkState st = bv.walk_state[unit];
+      nacc = st.nacc; nrej = st.nrej; nvis = st.nvis; page = st.nvis;        // (a parked walk has no overflow block yet: its first pass saw at most K candidates)
+      dkeys = bv.deep_keys + bv.deep_off[widx];
+      n_total = (uint32_t)(bv.deep_off[widx + 1] - bv.deep_off[widx]);
+      ncand = page < n_total ? (n_total - page < 64u ? n_total - page : 64u) : 0u;
+    }
+  next_page:
     // (the candidates' offsets and the first target's letters are asked for BEFORE the query set-up: three dependent trips to HBM that
     // used to stand between the set-up and the first pair now travel behind it)
     // one lane per candidate: id, offset and length fetched once for the whole unit
     uint32_t ct = 0, clen = 0; uint64_t cto = 0;
     if ((uint32_t)lane < ncand) {
       ct = bv.cand[(uint64_t)unit * K + lane];
+      if constexpr (PAIR) if (cont) ct = (uint32_t)dkeys[page + (uint32_t)lane];        // (key = count | first-touch position: the low word is the target)
       cto = db.offs[ct];
       clen = (uint32_t)(db.offs[ct + 1] - cto);
     }
@@ -1600,7 +1617,8 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       }
     };
     if (ncand) prefetch(0);
-    if (ncand) {
+    if (ncand && !setup_done) {
+      setup_done = true;
       // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
       bool planes = NT && bv.qpk != nullptr;
       if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
@@ -1676,7 +1694,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         }
         if (k < grp_hi && !((grp_maybe >> (k - grp_lo)) & 1u)) {
           // a pair without an HSP: fetched, counted and rejected as the full path would (no chain -> no alignment -> reject)
-          nvis = k + 1;
+          nvis = page + k + 1;
           const uint32_t LBq = (uint32_t)rl((int)clen, (int)k);
           w_tletters += NT ? (((LBq + 15u) >> 4) + 1u) * 8u : LBq; ++w_pairs; ++w_grouped;
           ++nrej;
@@ -1685,7 +1703,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         }
         if (pre_k != k) { prefetch(k); pre_k = k; }
       }
-      nvis = k + 1;
+      nvis = page + k + 1;
       const uint32_t t = (uint32_t)rl((int)ct, (int)k);
       const uint64_t to = ((uint64_t)(uint32_t)rl((int)(cto >> 32), (int)k) << 32) | (uint32_t)rl((int)(uint32_t)cto, (int)k);
       const uint32_t LB = (uint32_t)rl((int)clen, (int)k);
@@ -1893,8 +1911,25 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
               coff = ((unsigned long long)(uint32_t)rl((int)(coff >> 32), 0) << 32) | (uint32_t)rl((int)(uint32_t)coff, 0);
               if (coff + nr <= bv.cigar_cap)
                 for (uint32_t r = lane; r < nr; r += 64) bv.cigar_pool[coff + r] = get_run(c, r);
-              if (lane == 0) {
-                ugs_hit *h = &bv.hits[(uint64_t)unit * max_acc + nacc];
+              bool hslot = true;
+              if constexpr (PAIR) if (nacc >= max_acc) {
+                // beyond the unit's slots (deep walks only): blocks of UGS_XBLOCK hits chained per unit.  A pool that has run out is an
+                // error flag and a demand (the counter keeps counting): the host grows the pool and runs the pass again
+                if ((nacc - max_acc) % UGS_XBLOCK == 0u) {
+                  uint32_t nb = 0;
+                  if (lane == 0) nb = (uint32_t)atomicAdd(bv.xblocks_used, 1ull);
+                  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                  if (nb < bv.xblocks_cap) {
+                    if (lane == 0) { bv.xnext[nb] = 0xffffffffu; if (xcur != 0xffffffffu) bv.xnext[xcur] = nb; }
+                    if (xcur == 0xffffffffu) xhead = nb;
+                    xcur = nb;
+                  } else { if (lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_XHITS); xcur = 0xfffffffeu; }
+                }
+                hslot = xcur < 0xfffffffeu;
+              }
+              if (lane == 0 && hslot) {
+                ugs_hit *h = &bv.hits[(uint64_t)unit * max_acc + (nacc < max_acc ? nacc : 0u)];
+                if constexpr (PAIR) if (nacc >= max_acc) h = &bv.xpool[(uint64_t)xcur * UGS_XBLOCK + (nacc - max_acc) % UGS_XBLOCK];
                 h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = alen;
                 h->opens = opens; h->qlo = qlo; h->qhi = qhi; h->tlo = tlo; h->thi = thi; h->ql = LA; h->tl = LB;
                 h->strand = strand; h->cigar_off = coff; h->cigar_len = nr; h->cols = cols; h->raw_score = 0.0f; h->flags = 0;
@@ -1913,14 +1948,24 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         break;
       }
       if (accept) ++nacc; else ++nrej;
-      if (nacc == max_acc) { walk_ended = true; break; }
+      if (nacc == (deep ? (uint32_t)db.acc_limit : max_acc)) { walk_ended = true; break; }
       if (nrej == max_rej) { if constexpr (PAIR) { if (!(db.align_flags & UGS_A_NOTERM)) { walk_ended = true; break; } } else break; }
       wave_sync();
     }
     // small path with pair filters: passed-over pairs do not count, so the walk may want more candidates than were kept
     if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
-    // unlimited maxaccepts / maxrejects: a walk that ran through a FULL candidate list without meeting its limit may have more to visit
-    if constexpr (PAIR) if ((db.align_flags & UGS_A_OPENWALK) && nvis == ncand && ncand == K && !walk_ended && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
+    if constexpr (PAIR) if (deep) {
+      if (cont) {
+        // the next page of the unit's list
+        if (!walk_ended && page + ncand < n_total) { page += ncand; ncand = n_total - page < 64u ? n_total - page : 64u; wave_sync(); goto next_page; }
+        if (lane == 0) bv.walk_state[unit].xhead = xhead;       // (only this: the parked counters stay, the pass can be run again - ugs_host.cpp deep_stage)
+      } else if (!walk_ended && nvis == ncand && ncand == K && lane == 0) {
+        // a walk that ran through a FULL candidate list without meeting a limit has more to visit: parked for the continuation pass
+        UgsWalkState st; st.nacc = nacc; st.nrej = nrej; st.nvis = nvis; st.xhead = 0xffffffffu; st.xcur = 0xffffffffu; st.pad0 = st.pad1 = st.pad2 = 0;
+        bv.walk_state[unit] = st;
+        bv.open_list[atomicAdd(&ctr[UGS_CTR_OPEN], 1ull)] = unit;
+      }
+    }
     if (lane == 0) { bv.hit_n[unit] = nacc; if (bv.walk_n) bv.walk_n[unit] = nvis; }
     wave_sync();
     if constexpr (PAIR) if (--strands_left) { ++unit; goto next_strand; }

@@ -222,10 +222,19 @@ class Searcher {
   }
   void Search(const SeqSet &q, std::vector<ugs_hit> &hits, std::vector<uint32_t> &nhits, std::vector<uint32_t> &pool) {
     const uint32_t nq = (uint32_t)q.size();
-    hits.resize((size_t)nq * p_.max_accepts * (p_.strand_both ? 2 : 1) * (p_.local ? p_.max_hsps : 1) + 1);
+    hits.resize((size_t)nq * (p_.max_accepts ? p_.max_accepts : 64) * (p_.strand_both ? 2 : 1) * (p_.local ? p_.max_hsps : 1) + 1);
     nhits.assign(nq + 1, 0);
     pool.resize(24 * (size_t)nq + 4096);                      // grown to the library's demand when a batch needs more (UGS_E_CAPACITY)
     uint64_t used = 0;
+    // UGS_E_CAPACITY: the run pool's demand comes back in `used`; otherwise the hit array was too small (unlimited accepts: any number per query)
+    auto fetch = [&](ugs_batch *bb) -> int {
+      int rc = UGS_E_CAPACITY;
+      for (int t = 0; t < 12 && rc == UGS_E_CAPACITY; ++t) {
+        rc = ugs_batch_fetch(bb, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
+        if (rc == UGS_E_CAPACITY) { if (used > pool.size()) pool.resize(used + 1024); else hits.resize(hits.size() * 4 + 1024); }
+      }
+      return rc;
+    };
     if (pair_keys()) {                                       // staged calls: the one-shot entry point has no room for per-query keys
       std::vector<uint32_t> k, z;
       keys_of(q, k, z);
@@ -235,8 +244,7 @@ class Searcher {
       if (rc == UGS_OK) rc = ugs_batch_set_pair_keys(b, k.data(), z.data());
       if (rc == UGS_OK) rc = ugs_batch_search(b);
       if (rc == UGS_OK) rc = ugs_batch_sync(b);
-      if (rc == UGS_OK) rc = ugs_batch_fetch(b, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
-      if (rc == UGS_E_CAPACITY && used > pool.size()) { pool.resize(used + 1024); rc = ugs_batch_fetch(b, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used); }
+      if (rc == UGS_OK) rc = fetch(b);
       ugs_batch_destroy(b);
       if (rc != UGS_OK) die("search with pair filters");
       return;
@@ -250,11 +258,7 @@ class Searcher {
     int rc = ugs_batch_upload(b_, q.letters.data(), q.offs.data(), nq);
     if (rc == UGS_OK) rc = ugs_batch_search(b_);
     if (rc == UGS_OK) rc = ugs_batch_sync(b_);
-    if (rc == UGS_OK) rc = ugs_batch_fetch(b_, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
-    if (rc == UGS_E_CAPACITY && used > pool.size()) {        // the demand comes back in `used`
-      pool.resize(used + 1024);
-      rc = ugs_batch_fetch(b_, hits.data(), hits.size(), nhits.data(), pool.data(), pool.size(), &used);
-    }
+    if (rc == UGS_OK) rc = fetch(b_);
     if (rc != UGS_OK) die("search");
   }
  private:
@@ -706,7 +710,7 @@ int main(int argc, char **argv)
         for (int g = 0; g < ngpus; ++g) base[(size_t)g + 1] = base[(size_t)g] + (qs[(size_t)g] ? (uint32_t)qs[(size_t)g]->size() : 0u);
         const uint32_t nq = base[(size_t)ngpus];
         SearchResult r;
-        r.hits.resize((size_t)nq * p.max_accepts * (p.strand_both ? 2 : 1) * (p.local ? p.max_hsps : 1) + 1);
+        r.hits.resize((size_t)nq * (p.max_accepts ? p.max_accepts : 64) * (p.strand_both ? 2 : 1) * (p.local ? p.max_hsps : 1) + 1);
         r.nhits.assign((size_t)nq + 1, 0);
         r.pool.resize(24 * (size_t)nq + 4096);
         std::vector<int> rcs((size_t)ngpus, UGS_OK);

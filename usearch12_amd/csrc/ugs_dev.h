@@ -59,7 +59,8 @@ struct UgsDbView {
   uint32_t filter_mask;
   float maxid, query_cov, max_query_cov, target_cov, max_target_cov;
   uint32_t mincols, maxgaps, maxdiffs, mindiffs;
-  int32_t max_accepts, max_rejects;
+  int32_t max_accepts, max_rejects;   // max_accepts: hit slots per unit AND (outside deep walks) the walk's accept limit; max_rejects: the reject limit
+  int32_t acc_limit;         // the walk's accept limit where it differs from the slots (deep walks: UGS_A_DEEP): 0x7fffffff = unlimited
   int32_t is_nucleo;
   uint32_t max_tlen;
   // pair filters (Accepter::RejectPair accepter.cpp:140-197) and -abskew: UGS_P_* bits, values, per-target keys
@@ -119,14 +120,27 @@ struct UgsBatchView {
   uint32_t *order_hist;      // [512] units per cost class | cursors (zeroed by the launcher)
   uint32_t *defer_list;      // [units] units the bitmap ranking kernel (ugs_rank2.hip) hands on to k_rank; counters[UGS_CTR_DEFER] of them
   uint32_t use_defer;        // k_rank (HOT instantiation): take the units from defer_list instead of 0 .. units-1
+  // deep walks (UGS_A_DEEP: max_accepts + max_rejects - 1 > UGS_KMAX, or one of them unlimited; ugs_deep.hip).  First pass: a walk that
+  // used up a FULL list of K candidates without meeting a limit is parked - its counters in walk_state, its unit in open_list
+  // (counters[UGS_CTR_OPEN] of them).  Continuation pass (walk_units != null): k_align takes unit walk_units[i], restores the counters
+  // and walks on through the unit's COMPLETE sorted candidate list deep_keys[deep_off[i] .. deep_off[i + 1]) from the first one it
+  // has not visited, a page of 64 at a time.  Accepted hits beyond a unit's slots go to blocks of UGS_XBLOCK hits chained per unit.
+  struct UgsWalkState *walk_state;  // [units]
+  uint32_t *open_list;              // [units]
+  const uint32_t *walk_units; uint32_t n_walk;
+  const uint64_t *deep_keys; const uint64_t *deep_off;
+  ugs_hit *xpool; uint32_t *xnext; uint32_t xblocks_cap; unsigned long long *xblocks_used;   // overflow hit blocks: pool, chain links, capacity, demand
 };
+struct UgsWalkState { uint32_t nacc, nrej, nvis, xhead, xcur, pad0, pad1, pad2; };   // xhead / xcur: first / current overflow block (0xffffffff none)
+#define UGS_XBLOCK 64u
 #define UGS_CL_EV 16
 #define UGS_A_NOTERM 0x100u  // internal align flag: rejects never end a walk (the in-batch pair stage of cluster_fast)
-#define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited): a walk that reaches the end of a full candidate list is an error
+#define UGS_A_OPENWALK 0x200u // internal: maxaccepts or maxrejects is 0 (unlimited)
+#define UGS_A_DEEP 0x400u     // internal: walks may need more than the UGS_KMAX candidates a ranking pass keeps (see UgsBatchView::walk_state)
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
-       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_GROUPED, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
-enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64 };
+       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_GROUPED, UGS_CTR_OPEN, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
+enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64, UGS_ERR_XHITS = 128 };   // XHITS: the overflow hit blocks of a deep walk ran out (the host grows the pool and runs the pass again)
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates
 struct UgsLocalView {
@@ -174,6 +188,21 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
 int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma,
                      uint32_t *d_qn, uint32_t *d_qoff, ugs_hit *d_out, void *d_tmp, size_t tmp_bytes, uint32_t query_base,
                      hipStream_t st);
+// the same in two steps for tables with overflow blocks (deep walks): counts + offsets first (the caller sizes d_out by their total), then the copy
+struct UgsXHits { const UgsWalkState *state; const ugs_hit *pool; const uint32_t *next; };
+int ugs_count_hits(const uint32_t *d_hit_n, uint32_t nq, uint32_t ns, uint32_t *d_qn, uint32_t *d_qoff, void *d_tmp, size_t tmp_bytes, hipStream_t st);
+int ugs_copy_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma, const uint32_t *d_qoff, ugs_hit *d_out,
+                  uint32_t query_base, const UgsXHits *x, hipStream_t st);
+// deep walks (ugs_deep.hip): the complete sorted candidate lists of the parked units
+struct UgsDeepArgs {
+  const uint32_t *units; uint32_t n_units;       // the parked units of this chunk
+  uint32_t *U, *R; uint64_t stride;                // per workgroup: touch counts (kept zero between units) and first-touch rows of all targets
+  uint32_t *key_n;                               // [n_units] kept keys per unit (mode 0 writes, mode 1 uses as cursor base 0)
+  const uint64_t *key_off; uint64_t *keys;       // mode 1: unit i's keys go to keys[key_off[i] ..)
+  uint32_t ns_max; int mode;
+};
+int ugs_launch_deep(const UgsDbView &db, const UgsBatchView &b, const UgsDeepArgs &a, int grid, hipStream_t st);
+int ugs_deep_sort(uint64_t *d_keys, uint64_t *d_sorted, uint64_t total, uint32_t segments, const uint64_t *d_off, void **d_tmp, size_t *tmp_bytes, hipStream_t st);
 size_t ugs_compact_tmp_bytes(uint32_t nq);
 struct UgsRank2Params;
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,

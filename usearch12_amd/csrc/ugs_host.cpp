@@ -384,11 +384,15 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   // or at the end of the candidate list; the device keeps UGS_KMAX candidates per strand and a walk that would need more
   // fails loudly at ugs_batch_sync (never a silently shortened walk)
   const bool open_walk = p->max_accepts == 0 || p->max_rejects == 0;
-  if (p->max_accepts < 0 || p->max_rejects < 0 || (!open_walk && p->max_accepts + p->max_rejects - 1 > UGS_KMAX) || p->max_accepts > UGS_KMAX) {
-    ugs_set_error("max_accepts/max_rejects must be >= 0 (0 = unlimited) and max_accepts+max_rejects-1 <= %d", UGS_KMAX);
-    return UGS_E_ENVELOPE;
+  if (p->max_accepts < 0 || p->max_rejects < 0) { ugs_set_error("max_accepts/max_rejects must be >= 0 (0 = unlimited)"); return UGS_E_ARG; }
+  // a walk that may visit more than the UGS_KMAX candidates a ranking pass keeps (-maxrejects 128, -maxaccepts 0 ...): the search runs
+  // as usual and the walks that used up their list are continued over the unit's complete sorted list (deep walks, ugs_deep.hip)
+  const bool deep_walk = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX;
+  if (deep_walk && p->local) { ugs_set_error("more than %d candidates per walk (max_accepts + max_rejects - 1, or 0 = unlimited) are implemented for usearch_global only", UGS_KMAX); return UGS_E_ENVELOPE; }
+  if (deep_walk && (p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD))) {
+    // (-termid / -termidd look at the hits of both strands of a query in walk order: a parked plus-strand walk would have to finish first)
+    ugs_set_error("-termid / -termidd with more than %d candidates per walk are outside the device envelope", UGS_KMAX); return UGS_E_ENVELOPE;
   }
-  if (open_walk && p->local) { ugs_set_error("unlimited maxaccepts/maxrejects are implemented for usearch_global only"); return UGS_E_ENVELOPE; }
   const int alpha = p->is_nucleo ? 4 : 20;
   uint64_t slots64 = 1;
   for (int i = 0; i < p->word_len; ++i) { slots64 *= alpha; if (slots64 > (1ull << 28)) break; }
@@ -484,11 +488,13 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   v.filter_mask = p->filter_mask; v.maxid = p->maxid; v.query_cov = p->query_cov; v.max_query_cov = p->max_query_cov;
   v.target_cov = p->target_cov; v.max_target_cov = p->max_target_cov;
   v.mincols = p->mincols; v.maxgaps = p->maxgaps; v.maxdiffs = p->maxdiffs; v.mindiffs = p->mindiffs;
-  v.max_accepts = p->max_accepts ? p->max_accepts : UGS_KMAX; v.max_rejects = p->max_rejects ? p->max_rejects : 0x7fffffff;
+  v.max_accepts = p->max_accepts ? std::min(p->max_accepts, UGS_KMAX) : UGS_KMAX;      // hit slots per unit (deep walks chain blocks behind them)
+  v.acc_limit = p->max_accepts ? p->max_accepts : 0x7fffffff;
+  v.max_rejects = p->max_rejects ? p->max_rejects : 0x7fffffff;
   v.is_nucleo = p->is_nucleo; v.max_tlen = max_tlen;
   v.pair_mask = p->pair_mask; v.min_sizeratio = p->min_sizeratio; v.minqt = p->minqt; v.maxqt = p->maxqt; v.minsl = p->minsl; v.maxsl = p->maxsl;
   v.abskew = p->abskew; v.t_key = nullptr; v.t_size = nullptr;
-  v.align_flags = p->align_flags | (open_walk ? UGS_A_OPENWALK : 0u); v.termid = p->termid; v.termidd = p->termidd;
+  v.align_flags = p->align_flags | (open_walk ? UGS_A_OPENWALK : 0u) | (deep_walk ? UGS_A_DEEP : 0u); v.termid = p->termid; v.termidd = p->termidd;
   // every diagonal = ViterbiFastMem: -fulldp (globalalignmem.cpp:148-152) and -band 0 (:105-108,118-119: every hole, and a whole pair
   // without HSPs, goes through the unbanded aligner)
   if ((p->align_flags & UGS_A_FULLDP) || p->band == 0) v.band = 1 << 20;
@@ -595,6 +601,8 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipFree(b->d_qkey); (void)hipFree(b->d_qsize);
   (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
   (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
+  (void)hipFree(b->d_walk_state); (void)hipFree(b->d_open_list); (void)hipFree(b->d_deepU); (void)hipFree(b->d_deepR); (void)hipFree(b->d_keyn); (void)hipFree(b->d_koff);
+  (void)hipFree(b->d_keys); (void)hipFree(b->d_keys_sorted); (void)hipFree(b->d_sort_tmp); (void)hipFree(b->d_xpool); (void)hipFree(b->d_xnext); (void)hipFree(b->d_xblocks_used);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
   if (b->ev0r) (void)hipEventDestroy(b->ev0r);
@@ -615,7 +623,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   memset(b, 0, sizeof(*b));
   b->db = db; b->max_queries = max_queries; b->max_letters = max_letters;
   b->nstrand = db->p.strand_both ? 2 : 1;
-  b->K = (db->p.max_accepts == 0 || db->p.max_rejects == 0) ? (uint32_t)UGS_KMAX : (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
+  b->K = (db->v.align_flags & UGS_A_DEEP) ? (uint32_t)UGS_KMAX : (uint32_t)(db->p.max_accepts + db->p.max_rejects - 1);
   // small path + pair filters: passed-over pairs are not counted (searcher.cpp:63-67), the walk can go deeper
   // (only -selfid is left to the aligner on that path: the other pair filters are applied where candidates are chosen)
   if ((db->p.pair_mask & UGS_P_SELFID) && !db->v.big) b->K = std::min<uint32_t>(UGS_KMAX, b->K + 32);
@@ -636,7 +644,14 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
   BCHK(hipMalloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
   BCHK(hipMalloc(&b->d_qoff, ((uint64_t)max_queries + 1) * 4));
-  BCHK(hipMalloc(&b->d_compact, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
+  b->compact_alloc = std::max<uint64_t>(units * b->hit_slots, 1);
+  BCHK(hipMalloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
+  if (db->v.align_flags & UGS_A_DEEP) {
+    BCHK(hipMalloc(&b->d_walk_state, std::max<uint64_t>(units, 1) * sizeof(UgsWalkState)));
+    BCHK(hipMalloc(&b->d_open_list, std::max<uint64_t>(units, 1) * 4));
+    BCHK(hipMalloc(&b->d_xblocks_used, 8));
+    BCHK(hipMemset(b->d_xblocks_used, 0, 8));
+  }
   b->scan_tmp_bytes = ugs_compact_tmp_bytes(max_queries);
   BCHK(hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes));
   BCHK(hipMalloc(&b->d_cigar_used, 8));
@@ -941,6 +956,8 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   v.qpk = b->qpk_stride ? (uint2 *)b->d_qpk : nullptr; v.qpk_stride = b->qpk_stride;
   v.hits = b->d_hits; v.hit_n = b->d_hit_n; v.cigar_pool = b->d_cigar; v.cigar_cap = b->cigar_cap;
   v.cigar_used = b->d_cigar_used; v.tb = b->d_tb; v.runs = b->d_runs; v.counters = b->d_ctr;
+  v.walk_state = b->d_walk_state; v.open_list = b->d_open_list; v.walk_units = nullptr; v.n_walk = 0; v.deep_keys = nullptr; v.deep_off = nullptr;
+  v.xpool = b->d_xpool; v.xnext = b->d_xnext; v.xblocks_cap = b->xblocks_cap; v.xblocks_used = b->d_xblocks_used;
   b->have_qkey = b->have_qsize = false; b->v.q_key = nullptr; b->v.q_size = nullptr;     // keys belong to one uploaded batch
   b->searched = false; b->synced = false;
   return UGS_OK;
@@ -952,6 +969,146 @@ static int enqueue_align(ugs_batch *b)
   HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
   if (db->p.local) return ugs_launch_local(db->v, b->v, b->lv, b->lgrid, b->lwpb, b->llds, db->stream);
   return ugs_launch_align(db->v, b->v, b->al, db->stream);
+}
+
+
+// ---------------------------------------------------------------- deep walks (UGS_A_DEEP; kernels: ugs_deep.hip, k_align's continuation pass)
+static inline bool is_deep(const ugs_batch *b) { return (b->db->v.align_flags & UGS_A_DEEP) != 0; }
+
+// the hit table grouped by query into d_compact on stream st.  Plain searches: count, scan and copy in one go (enqueued right behind the
+// alignment stage).  Deep walks: a unit may hold more hits than its slots (overflow blocks), so the total is read back first and d_compact
+// grows to it - synchronous, after the continuation passes.
+static int group_hits(ugs_batch *b, uint32_t query_base, hipStream_t st)
+{
+  if (!b->nq) return UGS_OK;
+  if (!is_deep(b))
+    return ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp, b->scan_tmp_bytes, query_base, st);
+  RCCHK(ugs_count_hits(b->d_hit_n, b->nq, b->nstrand, b->d_qn, b->d_qoff, b->d_scan_tmp, b->scan_tmp_bytes, st));
+  uint32_t last_off = 0, last_n = 0;
+  HIPCHK(hipMemcpyAsync(&last_off, b->d_qoff + (b->nq - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&last_n, b->d_qn + (b->nq - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint64_t total = (uint64_t)last_off + last_n;
+  if (total > b->compact_alloc) {
+    HIPCHK(hipFree(b->d_compact)); b->d_compact = nullptr;
+    b->compact_alloc = total + total / 4 + 1024;
+    HIPCHK(hipMalloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
+  }
+  UgsXHits x; x.state = b->d_walk_state; x.pool = b->d_xpool; x.next = b->d_xnext;
+  return ugs_copy_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qoff, b->d_compact, query_base, &x, st);
+}
+
+// The walks k_align parked (a full list of K candidates used up, no limit met): their complete sorted candidate lists, then the
+// continuation pass - in chunks whose lists fit a key budget.  Synchronous; runs inside ugs_batch_sync.
+static int deep_stage(ugs_batch *b)
+{
+  ugs_db *db = b->db;
+  hipStream_t st = db->stream;
+  const uint64_t n_open = b->ctr[UGS_CTR_OPEN];
+  b->deep_units = n_open; b->deep_keys_total = 0;
+  if (!n_open) return UGS_OK;
+  const uint64_t nseq = std::max<uint64_t>(db->v.nseq, 1);
+  // ---- scratch: two words per target and workgroup
+  const uint64_t scr_budget = 6ull << 30;
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_open, 256), scr_budget / (nseq * 8)));
+  if (!b->d_deepU || (uint64_t)grid * nseq > b->deep_scr_alloc) {
+    if (b->d_deepU) HIPCHK(hipFree(b->d_deepU));
+    if (b->d_deepR) HIPCHK(hipFree(b->d_deepR));
+    b->d_deepU = b->d_deepR = nullptr;
+    b->deep_scr_alloc = (uint64_t)grid * nseq;
+    HIPCHK(hipMalloc(&b->d_deepU, b->deep_scr_alloc * 4));
+    HIPCHK(hipMalloc(&b->d_deepR, b->deep_scr_alloc * 4));
+    HIPCHK(hipMemsetAsync(b->d_deepU, 0, b->deep_scr_alloc * 4, st));          // (the kernel leaves it zero)
+  }
+  if (n_open + 1 > b->keyn_alloc) {
+    if (b->d_keyn) HIPCHK(hipFree(b->d_keyn));
+    if (b->d_koff) HIPCHK(hipFree(b->d_koff));
+    b->d_keyn = nullptr; b->d_koff = nullptr;
+    b->keyn_alloc = n_open + n_open / 4 + 64;
+    HIPCHK(hipMalloc(&b->d_keyn, b->keyn_alloc * 4));
+    HIPCHK(hipMalloc(&b->d_koff, b->keyn_alloc * 8));
+  }
+  UgsDeepArgs a;
+  a.units = b->d_open_list; a.n_units = (uint32_t)n_open; a.U = b->d_deepU; a.R = b->d_deepR; a.stride = nseq;
+  a.key_n = b->d_keyn; a.key_off = nullptr; a.keys = nullptr; a.ns_max = b->rl.ns_max; a.mode = 0;
+  RCCHK(ugs_launch_deep(db->v, b->v, a, grid, st));
+  std::vector<uint32_t> keyn(n_open);
+  HIPCHK(hipMemcpyAsync(keyn.data(), b->d_keyn, n_open * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint64_t key_budget = 1ull << 28;                             // keys per chunk (2 GiB + as much for the sorted copy)
+  std::vector<uint64_t> koff;
+  for (uint64_t lo = 0; lo < n_open; ) {
+    uint64_t hi = lo, total = 0;
+    koff.assign(1, 0);
+    while (hi < n_open && (hi == lo || total + keyn[hi] <= key_budget)) { total += keyn[hi]; koff.push_back(total); ++hi; }
+    b->deep_keys_total += total;
+    if (total > b->keys_alloc) {
+      if (b->d_keys) HIPCHK(hipFree(b->d_keys));
+      if (b->d_keys_sorted) HIPCHK(hipFree(b->d_keys_sorted));
+      b->d_keys = b->d_keys_sorted = nullptr;
+      b->keys_alloc = total + total / 8 + 1024;
+      HIPCHK(hipMalloc(&b->d_keys, b->keys_alloc * 8));
+      HIPCHK(hipMalloc(&b->d_keys_sorted, b->keys_alloc * 8));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, st));
+    a.units = b->d_open_list + lo; a.n_units = (uint32_t)(hi - lo); a.key_n = b->d_keyn + lo; a.key_off = b->d_koff; a.keys = b->d_keys; a.mode = 1;
+    RCCHK(ugs_launch_deep(db->v, b->v, a, grid, st));
+    RCCHK(ugs_deep_sort(b->d_keys, b->d_keys_sorted, total, (uint32_t)(hi - lo), b->d_koff, &b->d_sort_tmp, &b->sort_tmp_bytes, st));
+    // ---- the continuation pass over this chunk; a path pool or an overflow hit pool that runs out is grown and the pass repeated
+    unsigned long long cig0 = 0, xb0 = 0;
+    HIPCHK(hipMemcpyAsync(&cig0, b->d_cigar_used, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&xb0, b->d_xblocks_used, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int attempt = 0; ; ++attempt) {
+      UgsBatchView v = b->v;
+      v.walk_units = b->d_open_list + lo; v.n_walk = (uint32_t)(hi - lo); v.deep_keys = b->d_keys_sorted; v.deep_off = b->d_koff;
+      v.xpool = b->d_xpool; v.xnext = b->d_xnext; v.xblocks_cap = b->xblocks_cap;
+      const unsigned long long zero = 0;
+      HIPCHK(hipMemcpyAsync(b->d_ctr + UGS_CTR_NEXT_UNIT, &zero, 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_ctr + UGS_CTR_ERR, &zero, 8, hipMemcpyHostToDevice, st));
+      RCCHK(ugs_launch_align(db->v, v, b->al, st));
+      unsigned long long cig1 = 0, xb1 = 0, err = 0;
+      HIPCHK(hipMemcpyAsync(&cig1, b->d_cigar_used, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&xb1, b->d_xblocks_used, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&err, b->d_ctr + UGS_CTR_ERR, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      const bool cig_over = cig1 > b->cigar_cap, x_over = (err & UGS_ERR_XHITS) != 0;
+      if (err & ~(unsigned long long)UGS_ERR_XHITS) {
+        ugs_set_error("device envelope exceeded in the continuation of a deep walk (flags 0x%llx)", err);
+        return UGS_E_ENVELOPE;
+      }
+      if (!cig_over && !x_over) break;
+      if (attempt >= 4) { ugs_set_error("deep walk: pools still too small after %d passes", attempt + 1); return UGS_E_CAPACITY; }
+      if (cig_over) {            // the paths written before this chunk stay: copy them into the larger pool
+        const uint64_t cap = cig1 + cig1 / 4 + 4096;
+        uint32_t *np = nullptr;
+        HIPCHK(hipMalloc(&np, cap * 4));
+        if (cig0) HIPCHK(hipMemcpyAsync(np, b->d_cigar, cig0 * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(b->d_cigar));
+        b->d_cigar = np; b->cigar_cap = cap; b->v.cigar_pool = np; b->v.cigar_cap = cap;
+      }
+      if (x_over) {
+        const uint32_t cap = (uint32_t)std::min<unsigned long long>(xb1 + xb1 / 4 + 64, 0xfffffff0ull);
+        ugs_hit *np = nullptr; uint32_t *nn = nullptr;
+        HIPCHK(hipMalloc(&np, (size_t)cap * UGS_XBLOCK * sizeof(ugs_hit)));
+        HIPCHK(hipMalloc(&nn, (size_t)cap * 4));
+        if (xb0) { HIPCHK(hipMemcpyAsync(np, b->d_xpool, (size_t)xb0 * UGS_XBLOCK * sizeof(ugs_hit), hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(nn, b->d_xnext, (size_t)xb0 * 4, hipMemcpyDeviceToDevice, st)); }
+        HIPCHK(hipStreamSynchronize(st));
+        if (b->d_xpool) HIPCHK(hipFree(b->d_xpool));
+        if (b->d_xnext) HIPCHK(hipFree(b->d_xnext));
+        b->d_xpool = np; b->d_xnext = nn; b->xblocks_cap = cap; b->v.xpool = np; b->v.xnext = nn; b->v.xblocks_cap = cap;
+      }
+      // (the pass is repeatable: it reads a unit's parked counters and writes only the head of its overflow chain and its hit count)
+      HIPCHK(hipMemcpyAsync(b->d_cigar_used, &cig0, 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_xblocks_used, &xb0, 8, hipMemcpyHostToDevice, st));
+    }
+    lo = hi;
+  }
+  HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
+  b->ctr[UGS_CTR_OPEN] = n_open;
+  return UGS_OK;
 }
 
 extern "C" int ugs_batch_search(ugs_batch *b)
@@ -970,6 +1127,7 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   b->v.K = b->K;
   HIPCHK(hipStreamWaitEvent(db->stream, b->ev_up, 0));          // the batch's letters and offsets have arrived
   HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
+  if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, db->stream));
   HIPCHK(hipEventRecord(b->ev0, db->stream));
   // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
   const bool r2 = b->r2_grid > 0 && (b->v.cand_key ? (b->cl_mode && !b->r2.gather && b->v.cl_ev && b->v.cl_info) : !b->v.cl_ev);
@@ -982,8 +1140,7 @@ extern "C" int ugs_batch_search(ugs_batch *b)
   HIPCHK(hipEventRecord(b->ev2, db->stream));
   // hits grouped by query on the device right behind the alignment stage (count, scan, gather): ugs_batch_fetch is then
   // nothing but copies, which overlap the kernels of whatever batch runs next
-  if (b->nq) RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                                    b->scan_tmp_bytes, b->query_base, db->stream));
+  if (b->nq && !is_deep(b)) RCCHK(group_hits(b, b->query_base, db->stream));       // (deep walks: grouped by ugs_batch_sync, behind the continuation passes)
   HIPCHK(hipEventRecord(b->ev_done, db->stream));
   if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
   b->searched = true; b->synced = false; b->compact_base = b->query_base;
@@ -1026,10 +1183,18 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
         ugs_set_error("more than max_hsps = %u HSPs on one accepted target; raise ugs_params.max_hsps", db->p.max_hsps);
         return UGS_E_CAPACITY;
       }
-      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots 64=a walk wanted more than the 64 candidates kept per strand: -selfid on the small path, or unlimited maxaccepts/maxrejects)", b->ctr[UGS_CTR_ERR]);
+      ugs_set_error("device envelope exceeded (flags 0x%llx: 1=sampled words 2=HSP capacity 4=path runs 8=candidate buffer 16=local scratch 32=local hit slots 64=a walk wanted more than the candidates kept per strand: -selfid on the small path)", b->ctr[UGS_CTR_ERR]);
       return UGS_E_ENVELOPE;
     }
-    if (b->cigar_used_host <= b->cigar_cap) { b->synced = true; return UGS_OK; }
+    if (b->cigar_used_host <= b->cigar_cap) {
+      if (is_deep(b)) {            // the parked walks go on; then the hit table is grouped
+        RCCHK(deep_stage(b));
+        RCCHK(group_hits(b, b->query_base, db->stream));
+        HIPCHK(hipStreamSynchronize(db->stream));
+        b->compact_base = b->query_base;
+      }
+      b->synced = true; return UGS_OK;
+    }
     // path pool too small: grow to the demanded size and re-run the alignment stage only
     HIPCHK(hipFree(b->d_cigar));
     b->cigar_cap = b->cigar_used_host + b->cigar_used_host / 4 + 4096;
@@ -1038,10 +1203,10 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     unsigned long long keep = b->ctr[UGS_CTR_POSTINGS];
     HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
     HIPCHK(hipMemcpyAsync(b->d_ctr, &keep, 8, hipMemcpyHostToDevice, db->stream));
+    if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, db->stream));
     RCCHK(enqueue_align(b));
     HIPCHK(hipEventRecord(b->ev2, db->stream));
-    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                           b->scan_tmp_bytes, b->query_base, db->stream));
+    if (!is_deep(b)) RCCHK(group_hits(b, b->query_base, db->stream));
   }
   ugs_set_error("path pool overflow persisted");
   return UGS_E_CAPACITY;
@@ -1096,7 +1261,7 @@ extern "C" int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, u
   // (grouped by query on the device by ugs_batch_search; a ugs_batch_device_results call in between regroups with its
   // own query base, so regroup then)
   if (b->compact_base != 0) {
-    RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp, b->scan_tmp_bytes, 0, cs));
+    RCCHK(group_hits(b, 0, cs));
     b->compact_base = 0;
   }
   (void)ns; (void)ma;
@@ -1155,6 +1320,15 @@ extern "C" int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled)
 }
 
 extern "C" const char *ugs_debug_rank_instance_name(int bit) { return ugs_rank_instance_name(bit); }
+
+// diagnostic: the deep-walk stage of the last synced search of this batch - walks that were parked and continued, keys of their complete lists
+extern "C" int ugs_debug_deep_walks(const ugs_batch *b, uint64_t *parked_units, uint64_t *list_keys)
+{
+  if (!b || !b->synced) return UGS_E_ARG;
+  if (parked_units) *parked_units = b->deep_units;
+  if (list_keys) *list_keys = b->deep_keys_total;
+  return UGS_OK;
+}
 
 // diagnostic (tests/test_gpu_paths.py): which ranking code the last synced search of this batch ran.
 //   out[0] units ranked by the bitmap kernel (ugs_rank2.hip)   out[1] units it deferred to k_rank
@@ -1308,8 +1482,7 @@ extern "C" int ugs_batch_device_results(ugs_batch *b, uint32_t query_base, void 
   uint64_t total = 0;
   if (nq) {
     if (b->compact_base != query_base) {        // (a search already grouped the table with the batch's own base: ugs_batch_set_query_base)
-      RCCHK(ugs_compact_hits(b->d_hit_n, b->d_hits, nq, ns, ma, b->d_qn, b->d_qoff, b->d_compact, b->d_scan_tmp,
-                             b->scan_tmp_bytes, query_base, b->copy_stream));
+      RCCHK(group_hits(b, query_base, b->copy_stream));
       b->compact_base = query_base;
     }
     uint32_t last_off = 0, last_n = 0;

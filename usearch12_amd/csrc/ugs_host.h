@@ -89,6 +89,14 @@ struct ugs_batch {
   uint32_t compact_base;            // query base of the grouped hit table in d_compact (query_base after a search)
   uint32_t query_base;              // ugs_batch_set_query_base: what the search's own grouping adds to ugs_hit.query (a shard's offset)
   bool searched, synced;
+  // deep walks (UGS_A_DEEP, ugs_deep.hip): parked walks, the scratch of their complete candidate lists, overflow hit blocks
+  UgsWalkState *d_walk_state; uint32_t *d_open_list;
+  uint32_t *d_deepU, *d_deepR; uint64_t deep_scr_alloc; int deep_grid;
+  uint32_t *d_keyn; uint64_t *d_koff; uint64_t keyn_alloc;
+  uint64_t *d_keys, *d_keys_sorted; uint64_t keys_alloc; void *d_sort_tmp; size_t sort_tmp_bytes;
+  ugs_hit *d_xpool; uint32_t *d_xnext; uint32_t xblocks_cap; unsigned long long *d_xblocks_used;
+  uint64_t compact_alloc;           // entries of d_compact
+  uint64_t deep_units, deep_keys_total;   // diagnostics of the last search: parked units / keys of their lists
   unsigned long long ctr[UGS_CTR_N];
   unsigned long long cigar_used_host;
   uint64_t q_letters;

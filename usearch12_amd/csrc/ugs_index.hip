@@ -334,6 +334,52 @@ int ugs_compact_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t n
   return UGS_OK;
 }
 
+// ---- the same for hit tables with overflow blocks (deep walks, UgsBatchView::xpool): hit k >= ma of unit u is entry (k - ma) % UGS_XBLOCK
+// of block (k - ma) / UGS_XBLOCK of the unit's chain (UgsWalkState::xhead, xnext[])
+__global__ void k_hits_copy_x(const uint32_t *hit_n, const ugs_hit *table, const uint32_t *qoff, uint32_t nq, uint32_t ns, uint32_t ma, ugs_hit *out,
+                              uint32_t query_base, UgsXHits x)
+{
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t o = qoff[q];
+  for (uint32_t s = 0; s < ns; ++s) {
+    const uint32_t u = q * ns + s, n = hit_n[u];
+    uint32_t blk = n > ma ? x.state[u].xhead : 0xffffffffu;
+    for (uint32_t k = 0; k < n; ++k) {
+      ugs_hit h;
+      if (k < ma) h = table[(uint64_t)u * ma + k];
+      else {
+        const uint32_t e = (k - ma) % UGS_XBLOCK;
+        if (e == 0 && k != ma) blk = x.next[blk];
+        h = x.pool[(uint64_t)blk * UGS_XBLOCK + e];
+      }
+      h.query += query_base; h.flags |= (o - qoff[q]) << UGS_HIT_ORDER_SHIFT; out[o++] = h;
+    }
+  }
+}
+
+int ugs_count_hits(const uint32_t *d_hit_n, uint32_t nq, uint32_t ns, uint32_t *d_qn, uint32_t *d_qoff, void *d_tmp, size_t tmp_bytes, hipStream_t st)
+{
+  if (nq == 0) return UGS_OK;
+  hipLaunchKernelGGL(k_hits_per_query, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, nq, ns, d_qn);
+  HIPCHK(hipGetLastError());
+  size_t need = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+  if (need > tmp_bytes) { ugs_set_error("scan scratch too small"); return UGS_E_NOMEM; }
+  HIPCHK(rocprim::exclusive_scan(d_tmp, need, d_qn, d_qoff, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+  return UGS_OK;
+}
+
+int ugs_copy_hits(const uint32_t *d_hit_n, const ugs_hit *d_table, uint32_t nq, uint32_t ns, uint32_t ma, const uint32_t *d_qoff, ugs_hit *d_out,
+                  uint32_t query_base, const UgsXHits *x, hipStream_t st)
+{
+  if (nq == 0) return UGS_OK;
+  if (x) hipLaunchKernelGGL(k_hits_copy_x, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, d_table, d_qoff, nq, ns, ma, d_out, query_base, *x);
+  else hipLaunchKernelGGL(k_hits_compact, dim3((nq + 255) / 256), dim3(256), 0, st, d_hit_n, d_table, d_qoff, nq, ns, ma, d_out, query_base);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
+
 size_t ugs_compact_tmp_bytes(uint32_t nq)
 {
   size_t need = 0;

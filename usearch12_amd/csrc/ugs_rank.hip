@@ -33,9 +33,7 @@
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 #define RCCHK_(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
 
-#define POS_BITS 44
-#define POS_MASK ((1ull << POS_BITS) - 1)
-#define CMAXV 4095u
+#include "ugs_rank_keys.h"
 #ifndef UGS_RANK_TU
 #define UGS_RANK_TU 0       // see the end of this file
 #endif
@@ -44,10 +42,6 @@
 #define SEL_REGS 8             // emitted entries held per thread during block-wide selection
 #define SELQ 4                 // entries per lane per wave in the register-resident selection
 #define TINV 0xffffffffu
-
-__device__ __forceinline__ uint64_t make_key(uint32_t c, uint64_t pos) { return ((uint64_t)(CMAXV - c) << POS_BITS) | pos; }
-__device__ __forceinline__ uint32_t key_count(uint64_t k) { return CMAXV - (uint32_t)(k >> POS_BITS); }
-__device__ __forceinline__ uint32_t key_target(uint64_t k) { return (uint32_t)k; }
 
 template <int BITS> struct Tbl {
   static constexpr uint32_t MASK = (1u << BITS) - 1u;
@@ -92,32 +86,6 @@ struct RankShared {
   uint32_t wn[8];            // emitted entries per wave (each wave fills its own segment of the candidate buffer)
   uint32_t hist[256];        // emitted entries per (count, first row) class: hist[c*16 + i], 4-bit fast path only
 };
-
-// Pair filters on the small ranking path (Accepter::RejectPair accepter.cpp:140-197): there a refused pair leaves no
-// trace in the candidate walk (udbusortedsearcher.cpp:145-147 ignores SetTarget's result, searcher.cpp:63-67 returns
-// before the terminator), so refused targets are simply not candidates: they are dropped where candidates are chosen.
-// (-selfid needs the letters and stays in k_align.)
-struct PairQ {
-  uint32_t mask, ql, qkey, qsize;
-  float min_sizeratio, minqt, maxqt, minsl, maxsl;
-  const uint64_t *offs; const uint32_t *t_key, *t_size;
-};
-__device__ __forceinline__ bool pair_reject(const PairQ &q, uint32_t t)
-{
-  const uint32_t m = q.mask;
-  if (m & (UGS_P_SELF | UGS_P_NOTSELF)) {
-    const bool same = q.qkey == q.t_key[t];
-    if (((m & UGS_P_SELF) && same) || ((m & UGS_P_NOTSELF) && !same)) return true;
-  }
-  if ((m & UGS_P_MIN_SIZERATIO) && (double)q.t_size[t] / (double)q.qsize < (double)q.min_sizeratio) return true;
-  if (m & (UGS_P_MINQT | UGS_P_MAXQT | UGS_P_MINSL | UGS_P_MAXSL)) {
-    const uint32_t tl = (uint32_t)(q.offs[t + 1] - q.offs[t]), ql = q.ql;
-    const double qt = (double)ql / (double)tl, sl = (double)(ql < tl ? ql : tl) / (double)(ql > tl ? ql : tl);
-    if (((m & UGS_P_MINQT) && qt < (double)q.minqt) || ((m & UGS_P_MAXQT) && qt > (double)q.maxqt) ||
-        ((m & UGS_P_MINSL) && sl < (double)q.minsl) || ((m & UGS_P_MAXSL) && sl > (double)q.maxsl)) return true;
-  }
-  return false;
-}
 
 struct ScanCtx {
   const PairQ *pq;           // non-null: small path with pair filters
