@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python tools/gpu_quick.py deep_all_s deep_all_big deep_rej256 deep_rej128_s deep_acc100 deep_aa deep_aa_big hard_acc0 hard_rej0 hard_big 2>&1 | tail -40
+RQ_SHAPE=aa python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
+python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
+python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
+python -m pytest tests/test_gpu_paths.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | grep -E "passed|failed|^E " | tail -5

@@ -780,9 +780,8 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [R2_SCAP + 64] records of the partition being scanned (+ slack)
   uint32_t *s_sel = s_stg;                                              //   after the scan: [64] selected targets (for the fill)
   uint64_t *s_fpk = (uint64_t *)(s_stg + 64);                           //   after the scan: [64] smallest key per count value
-  uint32_t *s_hba = s_stg + R2_SCAP + 64;                               // [R2G_HB_BITS / 32] hash filter A
-  uint32_t *s_hbb = s_hba + R2G_HB_BITS / 32;                           // ... B
-  uint32_t *s_c2 = s_hbb + R2G_HB_BITS / 32;                            // [64] kept count-2 keys per row
+  uint32_t *s_hba = s_stg + R2_SCAP + 64;                               // [R2G_HB_BITS / 32] hash filter of the grouping
+  uint32_t *s_c2 = s_hba + R2G_HB_BITS / 32;                            // [64] kept count-2 keys per row
   uint32_t *s_cum = s_c2 + 64;                                          // [64] ... with that row or a lower one
   uint32_t *s_slots = s_cum + 64;                                       // [64] sampled slots of the unit (by row)
   uint2 *s_desc = (uint2 *)(s_slots + 64);                              // [R2G_DCAP] descriptor lanes of the partition being scanned
@@ -795,7 +794,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   R2_CLK(unsigned long long tc_pre = 0, tc_scan = 0, tc_sel = 0;)
   R2_CLK2(unsigned long long tq[5] = {0, 0, 0, 0, 0};)
 
-  for (uint32_t k = lane; k < R2G_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+  for (uint32_t k = lane; k < R2G_HB_BITS / 32; k += 64) s_hba[k] = 0;
 
   uint32_t ubase = 0, uidx = 4;
   for (;;) {
@@ -889,7 +888,9 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       auto zero_bitmap = [&]() {
         uint4 z; z.x = z.y = z.z = z.w = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t o = lane * 16u; o < bm_bytes; o += 1024u) *(uint4 *)(smem + o) = z;
+        unsigned char *zp = smem + lane * 16u;                               // (bm_bytes is a multiple of 1024: straight-line stores)
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) if (k * 1024u < bm_bytes) *(uint4 *)(zp + k * 1024u) = z;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       };
       // ---- a partition is done: group its records by target, make keys, prune, keep (as k_rank2, 64-bit keys)
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
           return;
         }
         const bool two = n > 64u;                                          // (a second register batch of records: rare)
-        uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2];
+        uint32_t rec[2], t[2], row[2], wofs[2], hbit[2], cnt[2], cumv[2]; bool act[2], fl[2], drop[2], shared[2] = {false, false};
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           act[b] = false; rec[b] = 0; t[b] = 0; row[b] = 0; wofs[b] = 0; hbit[b] = 0; cnt[b] = 2; drop[b] = false; cumv[b] = 0; fl[b] = false;
@@ -929,20 +930,42 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
         uint32_t olda[2] = {0, 0};
 #pragma unroll
         for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; olda[b] = act[b] ? atomicOr(&s_hba[wofs[b]], hbit[b]) : 0u; }
+        // (one pass over the filter: "a record with this hash came before me" flags every record but the first of a bucket, and a flagged
+        // record's target is compared with ALL records below - the first of the bucket included)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; if (olda[b] & hbit[b]) atomicOr(&s_hbb[wofs[b]], hbit[b]); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; fl[b] = act[b] && (olda[b] & hbit[b]) != 0u; }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; fl[b] = act[b] && (s_hbb[wofs[b]] & hbit[b]) != 0u; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; if (act[b]) { s_hba[wofs[b]] = 0; s_hbb[wofs[b]] = 0; } }
+        for (int b = 0; b < 2; ++b) { if (b == 1 && !two) continue; if (act[b]) s_hba[wofs[b]] = 0; }
         // a target's records: count = records + 1, first row = the lowest row a record carries; the representative is the FIRST
         // record (lowest index) among those with that lowest row (several records of a chunk may carry the same row)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           if (bb == 1 && !two) continue;
           uint64_t m = r2_ballot(fl[bb]);
+          while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t tL = (uint32_t)__builtin_amdgcn_readlane((int)t[bb], L), rL = (uint32_t)__builtin_amdgcn_readlane((int)row[bb], L);
+            const uint32_t iL = (uint32_t)bb * 64u + (uint32_t)L;
+            uint32_t nsame = 0, better = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              if (b == 1 && !two) continue;
+              const bool sb = act[b] && t[b] == tL;
+              const uint32_t ib = (uint32_t)b * 64u + lane;
+              nsame += (uint32_t)__popcll(r2_ballot(sb));
+              better += (uint32_t)__popcll(r2_ballot(sb && (row[b] < rL || (row[b] == rL && ib < iL))));
+              if (sb) shared[b] = true;
+            }
+            if (nsame >= 2u && lane == (uint32_t)L) { cnt[bb] = nsame + 1u; drop[bb] = better != 0u; }
+          }
+        }
+        // the records that were not flagged themselves (the first of their bucket) but share a flagged record's target: same rule,
+        // seen from their side - a lane whose record has company takes count and rank from ballots over its own target
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          if (bb == 1 && !two) continue;
+          uint64_t m = r2_ballot(act[bb] && !fl[bb] && shared[bb]);
           while (m) {
             const int L = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -1063,7 +1086,7 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
       R2_CLK(tg2 = clock64();)
     }
     if (bad) {
-      for (uint32_t k = lane; k < R2G_HB_BITS / 32 * 2; k += 64) s_hba[k] = 0;
+      for (uint32_t k = lane; k < R2G_HB_BITS / 32; k += 64) s_hba[k] = 0;
       if (lane == 0) {
         const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
         bv.defer_list[idx] = unit;
@@ -1154,7 +1177,7 @@ size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl)
 
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
 {
-  return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + 2 * (R2G_HB_BITS / 32) + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
+  return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + R2G_HB_BITS / 32 + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
 }
 
 int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl)
