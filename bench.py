@@ -472,50 +472,55 @@ def main():
         t_parts["gather"] += time.time() - tg
         return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3]) if rank == 0 else None
 
-    def step():
+    def step(last):
+        """step i of a run: the search of step i + 1 is enqueued BEHIND step i's kernels before the host waits for step i (the GPU never
+        waits for the host between steps), then step i's hit table travels (to the host; for N > 1 first GPU to GPU to rank 0) while
+        step i + 1's kernels run, then the batch of step i + 2 is uploaded into the batch object that has just been drained."""
         i = state["i"]
         state["i"] = i + 1
         cur, nxt = bats[i % 2], bats[(i + 1) % 2]
         ta = time.time()
-        cur.search()                                                # enqueue: waits (on the GPU) for cur's upload
-        out = None
-        if state.get("pending") is not None:
-            # the previous step's hit table travels (to the host; for N > 1 first GPU to GPU to rank 0) while this step's kernels
-            # run; the last table is drained before the clock stops.  (The two batches alternate: the previous step's batch is
-            # the one the next upload goes into, so collect first.)
-            out = collect(state["pending"])
-        tu = time.time()
-        nxt.upload(qsets[(i + 1) % 2].seqs, qsets[(i + 1) % 2].offs)   # next step's batch travels while cur's kernels run
+        if not last:
+            nxt.search()                                            # enqueue: waits (on the GPU) for nxt's upload and for cur's kernels
         tw = time.time()
-        t_parts["upload_issue"] += tw - tu
         cur.sync()
-        t_parts["sync_wait"] += time.time() - tw                    # > 0: this step's kernels outlasted the previous table's journey
+        t_parts["sync_wait"] += time.time() - tw                    # the host waiting for step i's kernels
+        out = collect(cur)
+        st, kh = cur.stats(), cur.kernel_hits()                     # (this step's counters and event times: the upload below starts a new batch)
+        tu = time.time()
+        if not last:
+            cur.upload(qsets[i % 2].seqs, qsets[i % 2].offs)        # step i + 2's batch travels while step i + 1's kernels run
+        t_parts["upload_issue"] += time.time() - tu
         t_parts["search_sync"] += time.time() - ta
-        state["pending"] = cur
-        return out, cur
+        return out, st, kh
 
-    def timed_steps(n_steps, n_warm):
-        """prime the pipeline, n_warm untimed steps, then EXACTLY n_steps steps between barriers; returns (seconds, stats, kernel hits, last table)"""
+    def run_steps(n, timed):
+        """both batches uploaded (inputs resident in HBM), then - between barriers when timed - the first search enqueued and EXACTLY n steps"""
         state.clear(); state["i"] = 0
-        bats[0].upload(qsets[0].seqs, qsets[0].offs)            # step 0 finds its batch uploaded
-        for _ in range(n_warm):
-            step()
-        if state.get("pending") is not None:
-            collect(state["pending"])
-            state["pending"] = None
+        bats[0].upload(qsets[0].seqs, qsets[0].offs)
+        bats[1].upload(qsets[1].seqs, qsets[1].offs)
+        bats[0].sync_upload(); bats[1].sync_upload()
         for k in t_parts:
             t_parts[k] = 0.0
-        barrier()
+        if timed:
+            barrier()
         t0 = time.time()
-        stats, khits = [], []
-        for _ in range(n_steps):
-            _, cur = step()
-            stats.append(cur.stats())
-            khits.append(cur.kernel_hits())
-        out = collect(state["pending"])                         # drain: the last step's hit table
-        state["pending"] = None
-        barrier()
+        stats, khits, out = [], [], None
+        if n:
+            bats[0].search()
+        for i in range(n):
+            out, st, kh = step(i == n - 1)
+            stats.append(st)
+            khits.append(kh)
+        if timed:
+            barrier()
         return time.time() - t0, stats, khits, out
+
+    def timed_steps(n_steps, n_warm):
+        """n_warm untimed steps, then EXACTLY n_steps steps between barriers; returns (seconds, stats, kernel hits, last table)"""
+        if n_warm:
+            run_steps(n_warm, False)
+        return run_steps(n_steps, True)
 
     elapsed, stats, khits, out = timed_steps(args.steps, args.warmup)
     n_hits_main = int(len(out[0])) if out is not None else 0    # (the table lives in buffers the batch objects own)
@@ -612,11 +617,13 @@ def main():
                      "predicted_speedup_%d" % N: ms_full / ms_small,
                      "ms_kernels_rank0": kern_small, "ms_fixed_cost_rank0": ms_small - kern_small,
                      "ms_gather_call": 1000.0 * t_s["gather"] / psteps, "ms_gather_exchange": 1000.0 * t_s["gather_exchange"] / psteps,
-                     "ms_gather_d2h": 1000.0 * t_s["gather_d2h"] / psteps, "ms_sync_wait_after_gather": 1000.0 * t_s["sync_wait"] / psteps,
+                     "ms_gather_d2h": 1000.0 * t_s["gather_d2h"] / psteps, "ms_host_waiting_for_kernels": 1000.0 * t_s["sync_wait"] / psteps,
+                     "ms_rank_rank0": float(np.mean([x["ms_rank"] for x in st_s])), "ms_align_rank0": float(np.mean([x["ms_align"] for x in st_s])),
+                     "ms_rank_setup_rank0": float(np.mean([x["ms_rank_setup"] for x in st_s])),
                      "gathered_hits_per_step": int(len(got[0])) if got else 0, "peer_errors": [str(e) for e in perr],
                      "note": "one GPU: rank 0's kernels run alone (peers only gather), the %d-rank exchange is device-to-device copies instead of "
                              "xGMI transfers (7 x ~%d KB in parallel over separate links at ~153 GB/s each: < 0.2 ms); the gather of step i runs beside "
-                             "the kernels of step i+1, so only ms_sync_wait_after_gather == 0 would expose it" % (N, int(len(got[0]) * 80 / N / 1000) if got else 0)}
+                             "the kernels of step i+1 (enqueued before the host waits for step i)" % (N, int(len(got[0]) * 80 / N / 1000) if got else 0)}
             for pb in peers + small:
                 pb.close()
             for a in gbuf:

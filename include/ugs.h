@@ -231,6 +231,9 @@ void ugs_batch_destroy(ugs_batch *b);
  *     search on the device (its inputs are not overwritten under it), but its RESULTS are then lost - fetch first.
  * ugs_search_batch (the one-call form above) keeps the synchronous contract: it returns with everything consumed. */
 int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t *qoffs, uint32_t nq);
+/* Blocks until the letters and offsets of the last ugs_batch_upload have arrived in HBM (a caller that wants to time the search alone,
+ * or to reuse a non-pinned source buffer early; ugs_batch_search itself waits on the device, not on the host). */
+int ugs_batch_wait_upload(ugs_batch *b);
 int ugs_batch_search(ugs_batch *b);
 int ugs_batch_sync(ugs_batch *b);
 int ugs_batch_fetch(ugs_batch *b, ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,

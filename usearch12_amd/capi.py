@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
-    "ugs_batch_sync", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name", "ugs_debug_deep_walks",
+    "ugs_batch_sync", "ugs_batch_wait_upload", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name", "ugs_debug_deep_walks",
     "ugs_batch_device_results",
     "ugs_format_blast6", "ugs_format_uc_hit", "ugs_format_uc_nohit", "ugs_last_error",
     "ugs_xdrop_params_init", "ugs_xdrop_batch", "ugs_xdrop_last_stats",
@@ -262,6 +262,10 @@ class UgsBatch:
         self.nletters = int(qoffs[-1] - qoffs[0])
         self._up = qseqs            # the copy is asynchronous: the letters must stay alive until the next sync
         _chk(lib().ugs_batch_upload(self.h, qseqs.ctypes.data, qoffs.ctypes.data, self.nq))
+
+    def sync_upload(self):
+        """block until the last upload has arrived in HBM"""
+        _chk(lib().ugs_batch_wait_upload(self.h))
 
     def set_pair_keys(self, label_key=None, size=None):
         """per-query label keys / sizes of the uploaded batch (ugs_batch_set_pair_keys)"""

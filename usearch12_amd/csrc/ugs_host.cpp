@@ -963,6 +963,15 @@ extern "C" int ugs_batch_upload(ugs_batch *b, const char *qseqs, const uint64_t 
   return UGS_OK;
 }
 
+// blocks until the last ugs_batch_upload of this batch has arrived in HBM (the upload itself is asynchronous)
+extern "C" int ugs_batch_wait_upload(ugs_batch *b)
+{
+  if (!b) return UGS_E_ARG;
+  HIPCHK(hipSetDevice(b->db->device));
+  HIPCHK(hipEventSynchronize(b->ev_up));
+  return UGS_OK;
+}
+
 static int enqueue_align(ugs_batch *b)
 {
   ugs_db *db = b->db;
@@ -1154,9 +1163,13 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
   HIPCHK(hipSetDevice(db->device));
   int emit_tries = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
-    HIPCHK(hipStreamSynchronize(db->stream));
-    HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
+    // (THIS batch's search, not the handle's whole stream: another batch's search may be queued behind it - a pipeline that enqueues
+    // step i + 1 before it waits for step i must not wait for both; r5)
+    HIPCHK(hipEventSynchronize(b->ev_done));
+    // (through the batch's own non-blocking copy stream: a copy on the null stream would wait for everything queued on the handle's stream)
+    HIPCHK(hipMemcpyAsync(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost, b->copy_stream));
+    HIPCHK(hipMemcpyAsync(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost, b->copy_stream));
+    HIPCHK(hipStreamSynchronize(b->copy_stream));
     if ((b->ctr[UGS_CTR_ERR] & UGS_ERR_EMIT) && emit_tries < 6) {     // (other flags of such a run may be consequences of the truncated lists)
       // the candidate buffer was sized by earlier demand: grow it to this search's and run the search again
       ++emit_tries; ++g_emit_regrows;
@@ -1207,6 +1220,7 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     RCCHK(enqueue_align(b));
     HIPCHK(hipEventRecord(b->ev2, db->stream));
     if (!is_deep(b)) RCCHK(group_hits(b, b->query_base, db->stream));
+    HIPCHK(hipEventRecord(b->ev_done, db->stream));
   }
   ugs_set_error("path pool overflow persisted");
   return UGS_E_CAPACITY;

@@ -170,14 +170,18 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 
   for (uint32_t k = lane; k < R2_HB_BITS / 32; k += 64) s_hba[k] = 0;         // the filter starts clean and is left clean
 
-  uint32_t ubase = 0, uidx = 4;
+  // units are handed out four at a time (one same-address atomic per unit would be a tenth of this kernel) - except the last eight per
+  // wave of the grid, which go one at a time: a launch of 125 k units gives a wave 30 of them, and whole fours at the end left some waves
+  // a unit's work (a tenth of a small launch) behind the others
+  const uint32_t coarse_end = units > 8u * gridDim.x ? units - 8u * gridDim.x : 0u;
+  uint32_t ubase = 0, uidx = 4, ugot = 4;
   for (;;) {
-    // ---- next unit (handed out four at a time: one same-address atomic per unit would be a tenth of this kernel)
-    if (uidx == 4) {
+    if (uidx == ugot) {
+      const uint32_t want = (ubase + ugot < coarse_end) ? 4u : 1u;        // (ubase + ugot: the counter was at least there)
       uint32_t v = 0;
-      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK2], 4ull);
+      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK2], (unsigned long long)want);
       ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-      uidx = 0;
+      uidx = 0; ugot = want;
     }
     uint32_t unit = ubase + uidx;
     ++uidx;
