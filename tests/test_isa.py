@@ -116,11 +116,21 @@ def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
         _check_rank2_ring(isa, inst)
 
 
+def _kernel_meta(isa, mangled_prefix):
+    """the kernel's entry of the code object's metadata (one YAML list item per kernel, starting at its .agpr_count line)"""
+    blocks = isa.split("\n  - .agpr_count:")
+    hit = [b for b in blocks[1:] if re.search(r"\.name:\s+" + re.escape(mangled_prefix), b)]
+    assert len(hit) == 1, mangled_prefix
+    return ".agpr_count:" + hit[0]
+
+
 def _check_rank2_ring(isa, inst):
     body = _kernel_body(isa, inst)
-    meta = isa[isa.index(".name:           _Z7" + inst):]
-    assert re.search(r"\.vgpr_spill_count:\s*0\b", meta[:2000]), "k_rank2 spills vector registers"
-    assert re.search(r"\.agpr_count:\s*16\b", meta[:2000]) or re.search(r"\.agpr_count:\s*16\b[^\n]*(\n[^\n]*){0,25}_Z7k_rank2", isa), "the ring's 16 accumulator registers"
+    meta = _kernel_meta(isa, "_Z7" + inst)
+    assert re.search(r"\.vgpr_spill_count:\s*0\b", meta), "k_rank2 spills vector registers"
+    assert re.search(r"\.agpr_count:\s*(\d+)", meta) and int(re.search(r"\.agpr_count:\s*(\d+)", meta).group(1)) >= 16, "the ring's 16 accumulator registers"
+    if inst.endswith("Lb0EE"):
+        assert re.search(r"\.agpr_count:\s*16\b", meta), "the search kernel holds nothing but the ring in accumulator registers"
     assert "scratch_" not in body
     loads = re.findall(r"global_load_dwordx4 (a\[\d+:\d+\])", body)
     assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) == 8, loads      # prologue + ring, one slot each
@@ -140,3 +150,17 @@ def _check_rank2_ring(isa, inst):
     assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == 4
     # the atomics of the bitmap are LDS instructions (not flat), with return
     assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "flat_atomic" not in body
+
+
+def test_k_align_keeps_its_per_wave_pointers_in_scalar_registers():
+    """k_align's per-wave LDS pointers and scratch pointers derive from the wave index; read from threadIdx without readfirstlane the
+    compiler held all of them in VECTOR registers and the search kernels spilled 95 (nt) / 72 (aa) VGPRs to scratch - 3.5 GB of scratch
+    writes per C2 launch (r4).  With the index in an SGPR and the wave-uniform LDS values moved to the scalar file the two search
+    instantiations spill 19 / 1 (r5: C2 18.0 -> 15.8 ms).  Pinned with a little slack so that a change which makes the pointers
+    divergent again (or doubles the pressure of the pair loop) fails here, not in a profile."""
+    isa = _isa_of("ugs_align.hip")
+    for inst, limit in (("k_alignILb0ELb1EE", 28), ("k_alignILb0ELb0EE", 8)):            # <PAIR = false, NT = true / false>: the kernels of a plain search
+        meta = _kernel_meta(isa, "_Z7" + inst)
+        n = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
+        assert n <= limit, (inst, n)
+        assert re.search(r"v_readfirstlane_b32 s\d+, v\d+", _kernel_body(isa, inst)[:4000]), "the wave index is not moved to an SGPR at the kernel's start"

@@ -23,7 +23,7 @@ EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"],
 ALIAS = {"ugs_rank_hot.hip": "ugs_rank.hip"}
 
 
-KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_xdrop.hip", "ugs_local.hip")      # sources whose emitted code tests/test_isa.py pins
+KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_align.hip")      # sources whose emitted code tests/test_isa.py pins
 
 
 def asm_path(src):
