@@ -394,6 +394,10 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
     ugs_set_error("cluster_fast: use ugs_params_set_cluster (one accept per strand, letters as read); pair filters / -fulldp / -termid are not supported here");
     return UGS_E_ENVELOPE;
   }
+  if (pp->max_rejects < 1 || pp->max_rejects > UGS_KMAX) {
+    // (the greedy loop's walk records hold the UGS_KMAX candidates of a ranking pass: deeper walks exist for usearch_global only, ugs_deep.hip)
+    ugs_set_error("cluster_fast: max_rejects must be 1 .. %d", UGS_KMAX); return UGS_E_ENVELOPE;
+  }
   if (nseq == 0) { ugs_set_error("No sequences in input file"); return UGS_E_ARG; }                // clusterfast.cpp:91-92
   const ugs_params p = *pp;
   ugs_cluster *C = new ugs_cluster();
