@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
-UGS_LIB=usearch12_amd/variants/libugs_tb0.so python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
-RQ_SHAPE=aa python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
-RQ_SHAPE=aa UGS_LIB=usearch12_amd/variants/libugs_tb0.so python tools/rank_quick.py 1000000 2>&1 | grep -v "^\[ugs\]"
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_edges.py -q -m gpu -x 2>&1 | grep -E "passed|failed|^E " | tail -5
+for e in 0 1; do
+  if [ $e = 1 ]; then export UGS_BATCH_STREAMS=1; fi
+  python bench.py --steps 20 --warmup 5 --cpu-baseline none --other-configs none --emulate-world 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams=$e', round(d['value']/1e6,2), round(d['ms_per_step'],2), round(d['detail']['ms_rank'],2), round(d['detail']['ms_align'],2), d['detail']['hits_per_step'])"
+done

@@ -281,6 +281,7 @@ UgsTune ugs_tune_read()
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
   t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
+  t.batch_streams = getenv("UGS_BATCH_STREAMS") != nullptr;
   t.qpk = getenv("UGS_QPK") != nullptr;
   t.align_group = env_int("UGS_ALIGN_GROUP", 0, 64, -1);
   return t;
@@ -592,6 +593,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   // (as ugs_db_destroy: the handle's own streams and events only)
   if (b->db->stream) (void)hipStreamSynchronize(b->db->stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+  if (b->work_stream) (void)hipStreamSynchronize(b->work_stream);
   if (b->ev_done) (void)hipEventSynchronize(b->ev_done);
   if (b->ev_up) (void)hipEventSynchronize(b->ev_up);
   (void)hipDeviceSynchronize();        // (device-wide, as ugs_db_destroy says)
@@ -611,6 +613,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   if (b->ev_done) (void)hipEventDestroy(b->ev_done);
   if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+  if (b->work_stream) (void)hipStreamDestroy(b->work_stream);
   if (b->h_rel) (void)hipHostFree(b->h_rel);
   delete b;
 }
@@ -661,6 +664,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
   BCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   BCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  if (db->tune.batch_streams) BCHK(hipStreamCreateWithFlags(&b->work_stream, hipStreamNonBlocking));
   BCHK(hipHostMalloc((void **)&b->h_rel, ((size_t)max_queries + 1) * 8, hipHostMallocDefault));
 #undef BCHK
   (void)rc;
@@ -972,12 +976,15 @@ extern "C" int ugs_batch_wait_upload(ugs_batch *b)
   return UGS_OK;
 }
 
+// the stream a batch's kernels run on: the handle's (searches of all batches in enqueue order), or - UGS_BATCH_STREAMS=1, an experiment -
+// the batch's own, so that the ranking of one batch may run beside the alignment of another
+static inline hipStream_t bstream(const ugs_batch *b) { return (b->db->tune.batch_streams && b->work_stream) ? b->work_stream : bstream(b); }
 static int enqueue_align(ugs_batch *b)
 {
   ugs_db *db = b->db;
-  HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
-  if (db->p.local) return ugs_launch_local(db->v, b->v, b->lv, b->lgrid, b->lwpb, b->llds, db->stream);
-  return ugs_launch_align(db->v, b->v, b->al, db->stream);
+  HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, bstream(b)));
+  if (db->p.local) return ugs_launch_local(db->v, b->v, b->lv, b->lgrid, b->lwpb, b->llds, bstream(b));
+  return ugs_launch_align(db->v, b->v, b->al, bstream(b));
 }
 
 
@@ -1012,7 +1019,7 @@ static int group_hits(ugs_batch *b, uint32_t query_base, hipStream_t st)
 static int deep_stage(ugs_batch *b)
 {
   ugs_db *db = b->db;
-  hipStream_t st = db->stream;
+  hipStream_t st = bstream(b);
   const uint64_t n_open = b->ctr[UGS_CTR_OPEN];
   b->deep_units = n_open; b->deep_keys_total = 0;
   if (!n_open) return UGS_OK;
@@ -1134,24 +1141,24 @@ extern "C" int ugs_batch_search(ugs_batch *b)
     }
   }
   b->v.K = b->K;
-  HIPCHK(hipStreamWaitEvent(db->stream, b->ev_up, 0));          // the batch's letters and offsets have arrived
-  HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
-  if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, db->stream));
-  HIPCHK(hipEventRecord(b->ev0, db->stream));
+  HIPCHK(hipStreamWaitEvent(bstream(b), b->ev_up, 0));          // the batch's letters and offsets have arrived
+  HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, bstream(b)));
+  if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, bstream(b)));
+  HIPCHK(hipEventRecord(b->ev0, bstream(b)));
   // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
   const bool r2 = b->r2_grid > 0 && (b->v.cand_key ? (b->cl_mode && !b->r2.gather && b->v.cl_ev && b->v.cl_info) : !b->v.cl_ev);
-  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, db->stream, b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r)); else HIPCHK(hipEventRecord(b->ev0s, db->stream));
+  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, bstream(b), b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r)); else HIPCHK(hipEventRecord(b->ev0s, bstream(b)));
   b->r2_ran = r2 && b->nq;
-  HIPCHK(hipEventRecord(b->ev1, db->stream));
+  HIPCHK(hipEventRecord(b->ev1, bstream(b)));
   const bool dbg = db->tune.debug_sync != 0;             // fault isolation: finish each stage before the next
-  if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] ranking stage done\n"); }
-  if (b->nq) RCCHK(enqueue_align(b)); else HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, db->stream));
-  HIPCHK(hipEventRecord(b->ev2, db->stream));
+  if (dbg) { HIPCHK(hipStreamSynchronize(bstream(b))); fprintf(stderr, "[ugs] ranking stage done\n"); }
+  if (b->nq) RCCHK(enqueue_align(b)); else HIPCHK(hipMemsetAsync(b->d_cigar_used, 0, 8, bstream(b)));
+  HIPCHK(hipEventRecord(b->ev2, bstream(b)));
   // hits grouped by query on the device right behind the alignment stage (count, scan, gather): ugs_batch_fetch is then
   // nothing but copies, which overlap the kernels of whatever batch runs next
-  if (b->nq && !is_deep(b)) RCCHK(group_hits(b, b->query_base, db->stream));       // (deep walks: grouped by ugs_batch_sync, behind the continuation passes)
-  HIPCHK(hipEventRecord(b->ev_done, db->stream));
-  if (dbg) { HIPCHK(hipStreamSynchronize(db->stream)); fprintf(stderr, "[ugs] alignment stage done\n"); }
+  if (b->nq && !is_deep(b)) RCCHK(group_hits(b, b->query_base, bstream(b)));       // (deep walks: grouped by ugs_batch_sync, behind the continuation passes)
+  HIPCHK(hipEventRecord(b->ev_done, bstream(b)));
+  if (dbg) { HIPCHK(hipStreamSynchronize(bstream(b))); fprintf(stderr, "[ugs] alignment stage done\n"); }
   b->searched = true; b->synced = false; b->compact_base = b->query_base;
   return UGS_OK;
 }
@@ -1202,8 +1209,8 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     if (b->cigar_used_host <= b->cigar_cap) {
       if (is_deep(b)) {            // the parked walks go on; then the hit table is grouped
         RCCHK(deep_stage(b));
-        RCCHK(group_hits(b, b->query_base, db->stream));
-        HIPCHK(hipStreamSynchronize(db->stream));
+        RCCHK(group_hits(b, b->query_base, bstream(b)));
+        HIPCHK(hipStreamSynchronize(bstream(b)));
         b->compact_base = b->query_base;
       }
       b->synced = true; return UGS_OK;
@@ -1214,13 +1221,13 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
     HIPCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
     b->v.cigar_pool = b->d_cigar; b->v.cigar_cap = b->cigar_cap;
     unsigned long long keep = b->ctr[UGS_CTR_POSTINGS];
-    HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, db->stream));
-    HIPCHK(hipMemcpyAsync(b->d_ctr, &keep, 8, hipMemcpyHostToDevice, db->stream));
-    if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, db->stream));
+    HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, bstream(b)));
+    HIPCHK(hipMemcpyAsync(b->d_ctr, &keep, 8, hipMemcpyHostToDevice, bstream(b)));
+    if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, bstream(b)));
     RCCHK(enqueue_align(b));
-    HIPCHK(hipEventRecord(b->ev2, db->stream));
-    if (!is_deep(b)) RCCHK(group_hits(b, b->query_base, db->stream));
-    HIPCHK(hipEventRecord(b->ev_done, db->stream));
+    HIPCHK(hipEventRecord(b->ev2, bstream(b)));
+    if (!is_deep(b)) RCCHK(group_hits(b, b->query_base, bstream(b)));
+    HIPCHK(hipEventRecord(b->ev_done, bstream(b)));
   }
   ugs_set_error("path pool overflow persisted");
   return UGS_E_CAPACITY;

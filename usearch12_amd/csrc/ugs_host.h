@@ -25,6 +25,7 @@ struct UgsTune {
   int align_group;              // UGS_ALIGN_GROUP            -1 unset (= 1), 0 off, n: rejects of a unit after which k_align tests its candidates four at a time
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
+  bool batch_streams;           // UGS_BATCH_STREAMS=1        every batch object runs its kernels on a stream of its own (experiment: ranking of one batch beside the alignment of another)
 };
 UgsTune ugs_tune_read();
 
@@ -85,6 +86,7 @@ struct ugs_batch {
   bool cl_mode;                     // the batch of a cluster_fast loop (ugs_cluster.cpp): its searches leave walk records, the bitmap kernel runs its CL instantiation
   // upload path: H2D copies go through the batch's own copy stream; the search waits for ev_up on the handle's stream,
   // so the upload of one batch overlaps the kernels of another (h_rel: page-locked staging of the relative offsets)
+  hipStream_t work_stream;          // UGS_BATCH_STREAMS: the batch's own kernel stream (null: the handle's)
   hipStream_t copy_stream; hipEvent_t ev_up, ev_done; uint64_t *h_rel;   // ev_done: end of the last enqueued search
   uint32_t compact_base;            // query base of the grouped hit table in d_compact (query_base after a search)
   uint32_t query_base;              // ugs_batch_set_query_base: what the search's own grouping adds to ugs_hit.query (a shard's offset)
