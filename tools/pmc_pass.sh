@@ -7,7 +7,7 @@ REPO=$(pwd)
 export TMPDIR=/tmp
 mkdir -p "$REPO/gpurun_out/pmc_$tag"
 cd /tmp
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$REPO/gpurun_out/pmc_$tag" -- python "$REPO/bench.py" --steps 1 --warmup 0 --cpu-baseline none > "$REPO/gpurun_out/pmc_$tag/bench.log" 2>&1 || { tail -5 "$REPO/gpurun_out/pmc_$tag/bench.log"; exit 1; }
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$REPO/gpurun_out/pmc_$tag" -- python "$REPO/bench.py" --steps 1 --warmup 0 --cpu-baseline none --other-configs none --emulate-world 0 > "$REPO/gpurun_out/pmc_$tag/bench.log" 2>&1 || { tail -5 "$REPO/gpurun_out/pmc_$tag/bench.log"; exit 1; }
 cd "$REPO"
 python - "$tag" <<'PY'
 import csv, glob, sys, collections

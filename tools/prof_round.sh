@@ -6,8 +6,8 @@ tag=${1:-r02d}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 if [ "$2" != "pmc-only" ]; then
-python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_c2.json
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats -- python $GRAFT_REPO_ROOT/bench.py --cpu-baseline none 2>/dev/null | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_c2_under_rocprof.json )
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_c2.json
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats -- python $GRAFT_REPO_ROOT/bench.py --cpu-baseline none --other-configs none --emulate-world 0 2>/dev/null | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_c2_under_rocprof.json )
 f=$(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_kernel_stats.csv; python tools/prof_summary.py gpurun_out/${tag}_kernel_stats.csv 14 > gpurun_out/${tag}_kernel_stats.txt
 rm -rf gpurun_out/${tag}_stats
 fi
