@@ -130,7 +130,7 @@ def test_cli_text_identical_to_reference(tmp_path):
     import subprocess
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
     for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask", "hard_termid", "hard_termidd",
-                 "hard_noid", "hard_noid_s"):
+                 "hard_noid", "hard_noid_s", "deep_all_s", "deep_acc100", "deep_rej256", "deep_aa"):        # (deep_*: walks past 64 candidates, > 64 hits per query)
         c, db, qs, b6, uc = G.load(name)
         dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
