@@ -206,7 +206,7 @@ int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_slots, uint
  * always suffices; max_accepts 0 = unlimited: a query may have as many hits as it has candidates - grow hits_cap and call again).
  * Walk depth: max_accepts + max_rejects - 1 may exceed the 64 candidates a ranking pass keeps per strand, and either may be 0 =
  * unlimited, as in the reference (terminator.cpp:22-31,64-100): the walks that use up their 64 candidates are continued over the
- * query's complete sorted candidate list (usearch_global; -termid / -termidd are refused together with such settings).
+ * query's complete sorted candidate list (usearch_global and usearch_local; -termid / -termidd are refused together with such settings).
  */
 int ugs_search_batch(ugs_db *db, const char *qseqs, const uint64_t *qoffs, uint32_t nq,
                      ugs_hit *hits, uint64_t hits_cap, uint32_t *nhits_per_query,

@@ -25,6 +25,10 @@ CASES = {
     "loc_aa":       dict(seed=45, n_fam=250, fam=6, q_n=900, aa=True, evalue=1e-6),
     "loc_aa_acc":   dict(seed=46, n_fam=250, fam=6, q_n=900, aa=True, evalue=10.0, maxaccepts=4, maxrejects=4, target_cov=0.2, maxdiffs=60),
     "loc_nt_long":  dict(seed=47, n_fam=40, fam=4, q_n=120, aa=False, evalue=1e-6, strand="both", lmin=800, lmax=3000),
+    # deep walks (r5): more candidates than the 64 a ranking pass keeps - families of 100, unlimited walks / -maxrejects 128 / -maxaccepts 80
+    "loc_deep_nt":  dict(seed=48, n_fam=20, fam=100, q_n=80, aa=False, evalue=1e-6, strand="both", maxaccepts=0, maxrejects=0),
+    "loc_deep_aa":  dict(seed=49, n_fam=20, fam=100, q_n=120, aa=True, evalue=1e-3, maxaccepts=80, maxrejects=128),
+    "loc_deep_big": dict(seed=50, n_fam=20, fam=100, q_n=100, aa=False, evalue=1e-6, strand="plus", id=0.8, big=100, maxaccepts=2, maxrejects=200),
 }
 
 
@@ -55,8 +59,11 @@ USER_CASES = ("loc_nt_both", "loc_aa_acc")      # -userout with every supported 
 def main():
     assert os.path.exists(REF), "build the reference first: oracle/build_ref.sh"
     manifest = {}
+    only = set(sys.argv[1:])
     with tempfile.TemporaryDirectory() as tmp:
         for name, c in CASES.items():
+            if only and name not in only:
+                continue
             db, qs = make_inputs(c)
             dbfa, qfa = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa")
             db.write_fasta(dbfa)
@@ -94,7 +101,10 @@ def main():
                                   cmd=" ".join(["usearch12"] + [os.path.basename(x) if x.startswith(tmp) else x
                                                                  for x in cmd[1:]]).replace(HERE + "/", ""))
             print(name, "hits", len(lines), "pairs with >1 HSP", manifest[name]["n_multi_hsp_pairs"])
-    json.dump(manifest, open(os.path.join(HERE, "local_manifest.json"), "w"), indent=1, sort_keys=True)
+    path = os.path.join(HERE, "local_manifest.json")
+    if only and os.path.exists(path):
+        old = json.load(open(path)); old.update(manifest); manifest = old
+    json.dump(manifest, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -129,7 +129,6 @@ def test_walks_deeper_than_the_kept_candidates_equal_the_oracle(kw):
 def test_options_outside_the_envelope_are_refused_at_create():
     db = synth.make_db(5, 200, 120)
     for kw in (dict(local_evalue=1e-3, self=True),               # pair filters exist for usearch_global only
-               dict(local_evalue=1e-3, max_accepts=0),          # deep walks too
                dict(max_accepts=0, max_rejects=0, termid=0.9, align_flags=4),   # -termid looks at both strands' hits in walk order: not with parked walks
                dict(band=-1)):
         with pytest.raises(capi.UgsError):

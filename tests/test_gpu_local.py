@@ -40,7 +40,7 @@ def test_gpu_local_matches_reference_text(name):
     assert np.all(hits["flags"] & 1 == 1)
 
 
-@pytest.mark.parametrize("name", ["loc_nt_both", "loc_aa_acc", "loc_nt_long", "loc_nt_id"])
+@pytest.mark.parametrize("name", ["loc_nt_both", "loc_aa_acc", "loc_nt_long", "loc_nt_id", "loc_deep_nt", "loc_deep_aa"])
 def test_gpu_local_hits_equal_oracle_records(name):
     c, db, qs, b6 = G.load_local(name)
     p, hits, nh, pool = _run_gpu(c, db, qs)

@@ -389,7 +389,6 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   // a walk that may visit more than the UGS_KMAX candidates a ranking pass keeps (-maxrejects 128, -maxaccepts 0 ...): the search runs
   // as usual and the walks that used up their list are continued over the unit's complete sorted list (deep walks, ugs_deep.hip)
   const bool deep_walk = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX;
-  if (deep_walk && p->local) { ugs_set_error("more than %d candidates per walk (max_accepts + max_rejects - 1, or 0 = unlimited) are implemented for usearch_global only", UGS_KMAX); return UGS_E_ENVELOPE; }
   if (deep_walk && (p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD))) {
     // (-termid / -termidd look at the hits of both strands of a query in walk order: a parked plus-strand walk would have to finish first)
     ugs_set_error("-termid / -termidd with more than %d candidates per walk are outside the device envelope", UGS_KMAX); return UGS_E_ENVELOPE;
@@ -1082,7 +1081,8 @@ static int deep_stage(ugs_batch *b)
       const unsigned long long zero = 0;
       HIPCHK(hipMemcpyAsync(b->d_ctr + UGS_CTR_NEXT_UNIT, &zero, 8, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(b->d_ctr + UGS_CTR_ERR, &zero, 8, hipMemcpyHostToDevice, st));
-      RCCHK(ugs_launch_align(db->v, v, b->al, st));
+      if (db->p.local) RCCHK(ugs_launch_local(db->v, v, b->lv, b->lgrid, b->lwpb, b->llds, st));
+      else RCCHK(ugs_launch_align(db->v, v, b->al, st));
       unsigned long long cig1 = 0, xb1 = 0, err = 0;
       HIPCHK(hipMemcpyAsync(&cig1, b->d_cigar_used, 8, hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpyAsync(&xb1, b->d_xblocks_used, 8, hipMemcpyDeviceToHost, st));

@@ -101,13 +101,27 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
     uint32_t unit = 0;
     if (lane == 0) unit = (uint32_t)atomicAdd(&ctr[UGS_CTR_NEXT_UNIT], 1ull);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    // deep walks (ugs_deep.hip, as k_align): a continuation pass takes the parked units from walk_units and walks on through their complete lists
+    const bool deep = (db.align_flags & UGS_A_DEEP) != 0;
+    bool cont = false; uint32_t widx = 0;
+    if (bv.walk_units) { if (unit >= bv.n_walk) break; widx = unit; unit = bv.walk_units[widx]; cont = true; }
     if (unit >= units) break;
     const uint32_t qi = unit / bv.nstrand, strand = unit % bv.nstrand;
     const uint64_t qo = bv.qoffs[qi];
     const uint32_t QL = (uint32_t)(bv.qoffs[qi + 1] - qo);
-    const uint32_t ncand = bv.cand_n[unit];
+    uint32_t ncand = bv.cand_n[unit];
     const int2 thr = lv.qthr[qi];                      // (ungapped, gapped) minimum scores in half-units
     uint32_t nhit = 0, nacc = 0, nrej = 0;
+    uint32_t page = 0, n_total = 0, xhead = 0xffffffffu, xcur = 0xffffffffu;
+    const uint64_t *dkeys = nullptr;
+    bool walk_ended = false;
+    if (cont) {
+      const UgsWalkState st = bv.walk_state[unit];
+      nacc = st.nacc; nrej = st.nrej; page = st.nvis; nhit = st.pad0;
+      dkeys = bv.deep_keys + bv.deep_off[widx];
+      n_total = (uint32_t)(bv.deep_off[widx + 1] - bv.deep_off[widx]);
+      ncand = page < n_total ? (n_total - page < 64u ? n_total - page : 64u) : 0u;
+    }
     const uint32_t nqw = QL > SW ? QL - SW + 1 : 0;    // localaligner2.cpp:72-73: QL <= W leaves the query without words
     if (ncand) {
       for (uint32_t p = lane; p < QL; p += 64) {
@@ -140,9 +154,10 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
             wave_sync();
           }
     }
+  next_page:
     uint32_t ct = 0, clen = 0; uint64_t cto = 0;
     if ((uint32_t)lane < ncand) {
-      ct = bv.cand[(uint64_t)unit * K + lane];
+      ct = cont ? (uint32_t)dkeys[page + (uint32_t)lane] : bv.cand[(uint64_t)unit * K + lane];
       cto = db.offs[ct];
       clen = (uint32_t)(db.offs[ct + 1] - cto);
     }
@@ -340,7 +355,25 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
               }
               if (accept) {
                 any_accept = true;
-                if (nhit >= lv.hit_slots) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL_HITS);
+                bool hslot = true;
+                if (nhit >= lv.hit_slots) {
+                  if (!deep) { atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_LOCAL_HITS); hslot = false; }
+                  else {
+                    // beyond the unit's slots (deep walks): blocks of UGS_XBLOCK hits chained per unit, as k_align's
+                    if ((nhit - lv.hit_slots) % UGS_XBLOCK == 0u) {
+                      uint32_t nb = 0;
+                      if (lane == 0) nb = (uint32_t)atomicAdd(bv.xblocks_used, 1ull);
+                      nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                      if (nb < bv.xblocks_cap) {
+                        if (lane == 0) { bv.xnext[nb] = 0xffffffffu; if (xcur != 0xffffffffu) bv.xnext[xcur] = nb; }
+                        if (xcur == 0xffffffffu) xhead = nb;
+                        xcur = nb;
+                      } else { if (lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_XHITS); xcur = 0xfffffffeu; }
+                    }
+                    hslot = xcur < 0xfffffffeu;
+                  }
+                }
+                if (!hslot) { if (deep) { ++nhit; ++w_hits; } }
                 else {
                   unsigned long long coff = 0;
                   if (lane == 0) coff = atomicAdd(bv.cigar_used, (unsigned long long)nm);
@@ -348,7 +381,8 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
                   if (coff + nm <= bv.cigar_cap)
                     for (uint32_t r = lane; r < nm; r += 64) bv.cigar_pool[coff + r] = xl32(&mruns[r]);
                   if (lane == 0) {
-                    ugs_hit *h = &bv.hits[(uint64_t)unit * lv.hit_slots + nhit];
+                    ugs_hit *h = nhit < lv.hit_slots ? &bv.hits[(uint64_t)unit * lv.hit_slots + nhit]
+                                                     : &bv.xpool[(uint64_t)xcur * UGS_XBLOCK + (nhit - lv.hit_slots) % UGS_XBLOCK];
                     h->query = qi; h->target = t; h->ids = ids; h->mism = mcols - ids; h->gaps_int = gaps; h->aln_len = cols;
                     h->opens = opens; h->qlo = Loi; h->qhi = Loi + Leni - 1; h->tlo = Loj; h->thi = Loj + Lenj - 1; h->ql = QL; h->tl = TL;
                     h->strand = strand; h->cigar_off = coff; h->cigar_len = nm; h->cols = cols;
@@ -369,8 +403,19 @@ __global__ __launch_bounds__(256) void k_local(UgsDbView db, UgsBatchView bv, Ug
       }
       // Terminator::Terminate (terminator.cpp:64-100): one accept or reject per target
       if (any_accept) ++nacc; else ++nrej;
-      if (nacc == max_acc || nrej == max_rej) break;
+      if (nacc == (deep ? (uint32_t)db.acc_limit : max_acc) || nrej == max_rej) { walk_ended = true; break; }
       wave_sync();
+    }
+    if (deep) {
+      if (cont) {
+        if (!walk_ended && page + ncand < n_total) { page += ncand; ncand = n_total - page < 64u ? n_total - page : 64u; wave_sync(); goto next_page; }
+        if (lane == 0) bv.walk_state[unit].xhead = xhead;         // (only this: the parked counters stay, the pass can be run again)
+      } else if (!walk_ended && ncand == K && lane == 0) {
+        // the walk used up a FULL list of K candidates without meeting a limit: parked for the continuation pass
+        UgsWalkState st; st.nacc = nacc; st.nrej = nrej; st.nvis = ncand; st.xhead = 0xffffffffu; st.xcur = 0xffffffffu; st.pad0 = nhit; st.pad1 = st.pad2 = 0;
+        bv.walk_state[unit] = st;
+        bv.open_list[atomicAdd(&ctr[UGS_CTR_OPEN], 1ull)] = unit;
+      }
     }
     if (lane == 0) bv.hit_n[unit] = nhit;
     wave_sync();
