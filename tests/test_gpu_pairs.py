@@ -77,13 +77,43 @@ def test_small_path_walk_deeper_than_kept_candidates_is_loud():
     try:
         hits, nh, pool = gdb.search(qs.seqs, qs.offs, pair_keys=(qk, qz))
     except capi.UgsError as e:
-        assert e.code == -6 and "64 candidates" in str(e)
+        assert e.code == -6 and "candidates" in str(e)
         return
     # no walk needed more than 64 candidates: then the result must be the oracle's
     odb = orc.OrcDB(orc.params(is_nucleo=True, id=c["id"], **kw), db.seqs, db.offs)
     odb.set_pair_keys(tk, tz); odb.set_query_pair_keys(qk, qz)
     oh, onh, _ = odb.search(qs.seqs, qs.offs, nthreads=4)
     assert np.array_equal(nh, onh) and np.array_equal(hits["target"], oh["target"])
+
+
+def test_small_path_selfid_among_many_identical_sequences_walks_on():
+    """-selfid on the small path passes over a target that equals the query without counting it (searcher.cpp:63-67): among 150 copies
+    of the query the walk needs candidate 151 and beyond.  r4 kept 32 spare candidates and failed loudly (UGS_ERR_PAIRCAP) past them; r5
+    parks such a walk and continues it over the complete list (deep walks): the oracle's records."""
+    rng = np.random.default_rng(91)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    base = rnd(300)
+    near = [base[:k] + ("A" if base[k] != "A" else "C") + base[k + 1:] for k in (40, 120, 200, 260)]
+    seqs = [base] * 150 + near + [rnd(300) for _ in range(200)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    offs = np.zeros(len(seqs) + 1, np.uint64); offs[1:] = np.cumsum([len(x) for x in seqs])
+    dseq = np.frombuffer("".join(seqs).encode(), np.uint8).copy()
+    q = [base, near[0], rnd(300)]
+    qoff = np.zeros(len(q) + 1, np.uint64); qoff[1:] = np.cumsum([len(x) for x in q])
+    qseq = np.frombuffer("".join(q).encode(), np.uint8).copy()
+    kw = dict(selfid=True, max_accepts=2, max_rejects=8)
+    p = capi.params(is_nucleo=True, id=0.9, **kw)
+    gdb = capi.UgsDB(p, dseq, offs, device=0)
+    bat = capi.UgsBatch(gdb, len(q), int(qoff[-1]))
+    bat.upload(qseq, qoff); bat.search(); bat.sync()
+    hits, nh, pool = bat.fetch()
+    assert bat.deep_walks()[0] >= 1
+    oh, onh, _ = orc.OrcDB(orc.params(is_nucleo=True, id=0.9, **kw), dseq, offs).search(qseq, qoff)
+    assert np.array_equal(nh, onh) and nh[0] == 2
+    for f in hits.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(hits[f], oh[f]), f
 
 
 def test_cli_pair_filters_identical_to_reference(tmp_path):

@@ -1953,7 +1953,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       wave_sync();
     }
     // small path with pair filters: passed-over pairs do not count, so the walk may want more candidates than were kept
-    if constexpr (PAIR) if ((db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);
+    if constexpr (PAIR) if (!deep && (db.pair_mask & UGS_P_SELFID) && !db.big && nacc < max_acc && nrej < max_rej && ncand == K && lane == 0) atomicOr(&ctr[UGS_CTR_ERR], (unsigned long long)UGS_ERR_PAIRCAP);      // (with deep walks such a walk is parked below)
     if constexpr (PAIR) if (deep) {
       if (cont) {
         // the next page of the unit's list

@@ -388,7 +388,10 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   if (p->max_accepts < 0 || p->max_rejects < 0) { ugs_set_error("max_accepts/max_rejects must be >= 0 (0 = unlimited)"); return UGS_E_ARG; }
   // a walk that may visit more than the UGS_KMAX candidates a ranking pass keeps (-maxrejects 128, -maxaccepts 0 ...): the search runs
   // as usual and the walks that used up their list are continued over the unit's complete sorted list (deep walks, ugs_deep.hip)
-  const bool deep_walk = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX;
+  // ... and the small path with -selfid: pairs that filter passes over are not counted (searcher.cpp:63-67), so a walk among many identical
+  // sequences may want any number of candidates (r4: UGS_ERR_PAIRCAP beyond 32 spare ones)
+  const bool deep_walk = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX ||
+                         ((p->pair_mask & UGS_P_SELFID) && !p->local && (uint64_t)nseq <= (uint64_t)p->big);
   if (deep_walk && (p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD))) {
     // (-termid / -termidd look at the hits of both strands of a query in walk order: a parked plus-strand walk would have to finish first)
     ugs_set_error("-termid / -termidd with more than %d candidates per walk are outside the device envelope", UGS_KMAX); return UGS_E_ENVELOPE;
