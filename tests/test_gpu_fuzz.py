@@ -36,10 +36,22 @@ def config(seed):
                     target_cov=0.7, max_target_cov=0.98, maxdiffs=int(rng.integers(1, 30)), mindiffs=int(rng.integers(1, 4)))
         for k in rng.choice(sorted(opts), size=int(rng.integers(1, 4)), replace=False):
             kw[str(k)] = opts[str(k)]
+    if seed >= 48:
+        # r5, deep walks: walk depths beyond the 64 candidates of a ranking pass (0 = unlimited) over databases of LARGE families, so that
+        # lists are hundreds of candidates long and queries collect more hits than a unit's slots
+        r2 = np.random.default_rng([seed, 0xDEE9])
+        kw["max_accepts"] = int(r2.choice([0, 1, 3, 70, 100]))
+        kw["max_rejects"] = int(r2.choice([0, 40, 100, 200]))
+        if kw["max_accepts"] and kw["max_rejects"] and kw["max_accepts"] + kw["max_rejects"] - 1 <= 64:
+            kw["max_rejects"] = 100
+        n_fam, fam = int(r2.integers(3, 15)), int(r2.integers(40, 130))
+        nq = int(r2.integers(30, 150))
+        lmin = max(lmin, 30)
+        lmax = max(lmax, lmin)
     return aa, lmin, lmax, n_fam, fam, nq, ident, kw
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("UGS_FUZZ_FROM", 0)), int(os.environ.get("UGS_FUZZ_TO", 48))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("UGS_FUZZ_FROM", 0)), int(os.environ.get("UGS_FUZZ_TO", 64))))
 def test_random_configuration_matches_oracle(seed):
     aa, lmin, lmax, n_fam, fam, nq, ident, kw = config(seed)
     db, qs = synth.make_hard(1000 + seed, n_fam, fam, nq, lmin=lmin, lmax=lmax, aa=aa)
