@@ -37,6 +37,10 @@
 #endif
 __device__ __forceinline__ int sat_add(int x, int c) { return x <= NEGT ? NEG : x + c; }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// the lane index made on the spot (two instructions).  A phase that takes its lane from here instead of the kernel's `lane` does not
+// keep the loop-invariant values the compiler derives from it (lane masks, lane * stride addresses) alive across the whole unit loop:
+// those were the VGPRs k_align spilled - stored once per kernel, loaded back once per unit (r5)
+__device__ __forceinline__ int fresh_lane() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
 
 struct HSPd { uint32_t Loi, Loj, Len; int32_t Score2; };
 // a value every lane of the wave holds alike (an LDS word read at a wave-uniform address, a flag made of such words), moved to the scalar
@@ -98,7 +102,7 @@ __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
   const uint32_t t0 = __builtin_amdgcn_readlane((int)v, 15), t1 = __builtin_amdgcn_readlane((int)v, 31), t2 = __builtin_amdgcn_readlane((int)v, 47);
-  const uint32_t row = (uint32_t)(threadIdx.x & 63) >> 4;
+  const uint32_t row = (uint32_t)fresh_lane() >> 4;
   return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
 }
 // LDS-only hand-off inside one wave: the LDS unit executes a wave's operations in program order,
@@ -136,7 +140,7 @@ __device__ __forceinline__ uint32_t nt_word(const uint32_t *w2, uint32_t pos, in
 // (word, pos) so a word's first MaxReps positions are contiguous and ascending.
 __device__ __forceinline__ void build_query_words(WaveCtx &c, int w, int alpha)
 {
-  const int lane = c.lane;
+  const int lane = fresh_lane();
   const uint32_t LA = c.LA;
   c.nwA = LA >= (uint32_t)w ? LA - w + 1 : 0;
   uint32_t n2 = 64; while (n2 < c.nwA) n2 <<= 1;
@@ -289,8 +293,9 @@ __device__ __forceinline__ uint64_t nzbytes(uint64_t x)
 }
 
 // nt score codes (bytes, 0..3 = A,C,G,T/U, 4 = other) -> 2 bits per letter + "other" bits in the same layout
-__device__ __forceinline__ void pack_codes(const uint8_t *codes, uint32_t L, uint32_t *w2, uint32_t *wi, int lane)
+__device__ __forceinline__ void pack_codes(const uint8_t *codes, uint32_t L, uint32_t *w2, uint32_t *wi)
 {
+  const int lane = fresh_lane();
   const uint32_t nw = (L + 15) >> 4;
   for (uint32_t k = lane; k < nw + 3; k += 64) {
     uint32_t v = 0, iv = 0;
@@ -1619,6 +1624,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
     if (ncand) prefetch(0);
     if (ncand && !setup_done) {
       setup_done = true;
+      const int lane = fresh_lane();            // (a lane index of the set-up's own: see fresh_lane)
       // nt: the unit's letters arrive packed (2 bits + the "other letter" plane, k_rank_setup) - only the class bytes are made here
       bool planes = NT && bv.qpk != nullptr;
       if constexpr (PAIR) planes = planes && bv.unit_map == nullptr;
@@ -1638,7 +1644,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
       }
       wave_sync();
       if (NT && !planes) {
-        pack_codes(c.As, LA, c.A2, c.Ai, lane);
+        pack_codes(c.As, LA, c.A2, c.Ai);
         bool any = false;
         for (uint32_t p = lane; p < LA; p += 64) any = any || c.As[p] > 3;
         c.a_inv = __ballot(any) != 0;
@@ -1769,7 +1775,7 @@ __global__ __launch_bounds__(256, UGS_ALIGN_WGS) void k_align(UgsDbView db, UgsB
         if (want) { prefetch(k + 1); pre_k = k + 1; }
       }
       wave_sync();
-      if (NT && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi, lane); wave_sync(); }
+      if (NT && !pack_direct) { pack_codes(c.Bs, LB, c.B2, c.Bi); wave_sync(); }
       if constexpr (PAIR) if (db.pair_mask) {
         // Accepter::RejectPair accepter.cpp:140-197.  Big path: the pair is a reject for the terminator
         // (udbusortedsearcherbig.cpp:118-127); small path: it is passed over without a trace (searcher.cpp:63-67)
