@@ -32,6 +32,9 @@
 #define LTB 1024               // per-wave LDS traceback bytes (holes up to ~25x36 cells)
 #define LRUNS 32               // runs kept in LDS per wave before spilling to HBM scratch
 
+#ifndef UGS_TB_RUNS
+#define UGS_TB_RUNS 1        // viterbi_hole's traceback takes a run of match columns in one trip
+#endif
 #ifndef UGS_ALIGN_CLOCKS
 #define UGS_ALIGN_CLOCKS 0
 #endif
@@ -1394,6 +1397,33 @@ __device__ __forceinline__ void viterbi_hole(WaveCtx &c, uint32_t a0, uint32_t L
       return (uint8_t)__builtin_amdgcn_readfirstlane((int)tb_ld((uint64_t)ti * stride + idx));
     };
     while (i != 0 || j != 0) {
+#if UGS_TB_RUNS
+      // A run of match columns in ONE trip (r5): in state M the chain goes down the diagonal for as long as the bytes on it say "M came
+      // from M" - at 0.97 identity for dozens of cells - and lane k can look at the k-th cell of the diagonal by itself: one LDS read,
+      // one ballot, and the walk moves to the first cell that says otherwise (or 64 cells on, or to the edge of the matrix).
+      if (State == 0 && i != 0 && j != 0) {
+        const uint32_t n0 = i < j ? i : j, n = n0 < 64u ? n0 : 64u;
+        const uint32_t k = (uint32_t)lane;
+        const bool in = k < n;
+        const uint32_t ti = in ? i - 1u - k : 0u, tj = in ? j - 1u - k : 0u;          // (ti < LA, tj < LB: the common case of tbget)
+        uint32_t sj, ej;
+        get_range_j(LA, LB, dlo, dhi, ti, sj, ej);
+        const int idx = (int)tj - (int)sj + 1;
+        uint8_t tv = 0;
+        if (in && idx >= 0 && idx < (int)stride - 1) tv = tb_ld((uint64_t)ti * stride + (uint32_t)idx);
+        const uint64_t mleave = __ballot(in && (tv & (TB_DM | TB_IM)) != 0);
+        uint32_t steps = n, nstate = 0;
+        if (mleave) {
+          const int k0 = __ffsll((long long)mleave) - 1;
+          const uint32_t t0 = (uint32_t)rl((int)tv, k0);
+          steps = (uint32_t)k0 + 1u; nstate = (t0 & TB_DM) ? 1u : 2u;
+        }
+        if (curop == 0) curlen += steps;
+        else { if (curlen) { if (lane == 0) put_rt(c, nrt, (curlen << 2) | curop); ++nrt; } curop = 0; curlen = steps; }
+        i -= steps; j -= steps; State = nstate;
+        continue;
+      }
+#endif
       if (State == curop) ++curlen;
       else { if (curlen) { if (lane == 0) put_rt(c, nrt, (curlen << 2) | curop); ++nrt; } curop = State; curlen = 1; }
       uint8_t t;
