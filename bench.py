@@ -242,7 +242,7 @@ def other_config(capi, synth, name, device):
     dt = (time.time() - t1) / nsteps
     capi.lib().ugs_host_unregister(qs.seqs.ctypes.data)
     b_rank = 4 * st["postings"] + st["query_letters"]
-    kern = "k_rank2g" if kh["r2_launched"] else "k_rank"
+    kern = kh.get("r2_kernel") or "k_rank"
     out = {"workload": wl, "value": qs.n / dt, "unit": "query-seqs/s", "ms_per_step": 1000 * dt, "hits_per_step": int(nh),
            "kernel_ms": {"ranking": st["ms_rank"], "k_align": st["ms_align"], "k_rank_setup": st["ms_rank_setup"]},
            "kernel": kern + " + k_rank over %d deferred units" % kh["deferred"], "algorithmic_bytes": int(b_rank),

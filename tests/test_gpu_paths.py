@@ -174,13 +174,19 @@ def aa_small():
     return db, qs
 
 
+# the two kernels of the sparse Big path: k_rank3g (two filter passes per super-partition, the default) and k_rank2g (UGS_R3=0)
+SPARSE_KERNELS = ["1", "0"]
+
+
+@pytest.mark.parametrize("r3", SPARSE_KERNELS)
 @pytest.mark.parametrize("g", ["", "8192", "24576"])
-def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g):
-    """protein index (rows of tens of postings): k_rank2g ranks every unit, same candidates as the counter kernel; also with small
-    partitions (37 of them for 300 k sequences: sub-rows of 0-3 postings, many chunks per unit)"""
+def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g, r3):
+    """protein index (rows of tens of postings): k_rank3g / k_rank2g rank every unit, same candidates as the counter kernel; also with
+    small partitions (37 of them for 300 k sequences: sub-rows of 0-3 postings, many chunks per unit)"""
     db, qs = aa_small
     a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=False, id=0.8)[0]
-    b = _search(db, qs, {"UGS_R2_G": g} if g else None, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, dict({"UGS_R2_G": g} if g else {}, UGS_R3=r3), is_nucleo=False, id=0.8)[0]
+    assert b[1]["r2_kernel"] == ("k_rank3g" if r3 == "1" else "k_rank2g")
     assert a[1]["r2_launched"] == 0 and a[1]["r2_units"] == 0
     assert b[1]["r2_launched"] == 1 and b[1]["r2_units"] > 0.95 * qs.n and b[1]["r2_units"] + b[1]["deferred"] == qs.n
     for x, y in zip(a[2], b[2]):
@@ -188,8 +194,9 @@ def test_gather_kernel_takes_the_sparse_big_path_and_equals_k_rank(aa_small, g):
     assert a[0] == b[0]
 
 
-def test_gather_kernel_short_protein_queries(aa_small):
-    """queries of 12-19 residues have <= 15 words (a 4-bit launch of k_rank): the gather kernel takes them all the same"""
+@pytest.mark.parametrize("r3", SPARSE_KERNELS)
+def test_gather_kernel_short_protein_queries(aa_small, r3):
+    """queries of 12-19 residues have <= 15 words (a 4-bit launch of k_rank): the sparse-index kernels take them all the same"""
     db, _ = aa_small
     rng = np.random.default_rng(24)
     rows = db.seqs.reshape(db.n, 300)
@@ -199,18 +206,19 @@ def test_gather_kernel_short_protein_queries(aa_small):
         parts.append(rows[t, p0:p0 + L]); offs.append(offs[-1] + L)
     qs = synth.SeqSet(np.concatenate(parts), np.array(offs, dtype=np.uint64), lambda i: "q%d" % i)
     a = _search(db, qs, {"UGS_RANK2": "0"}, is_nucleo=False, id=0.8)[0]
-    b = _search(db, qs, None, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, {"UGS_R3": r3}, is_nucleo=False, id=0.8)[0]
     assert (a[1]["rank_kernel"] >> 1) & 0x7f == 4 and b[1]["r2_launched"] == 1 and b[1]["r2_units"] > 0.95 * qs.n
     for x, y in zip(a[2], b[2]):
         assert np.array_equal(x, y)
     assert a[0] == b[0]
 
 
-def test_gather_kernel_deferred_units_and_oracle(aa_small):
-    """a kept-key list of 8 entries defers the units with hits to the 8-bit counter kernel behind k_rank2g; both against the oracle"""
+@pytest.mark.parametrize("r3", SPARSE_KERNELS)
+def test_gather_kernel_deferred_units_and_oracle(aa_small, r3):
+    """a kept-key list of 8 entries defers the units with hits to the 8-bit counter kernel behind k_rank3g / k_rank2g; both against the oracle"""
     db, _ = aa_small
     qs = synth.make_queries(22, db, 900, 300, aa=True)
-    outs = [_search(db, qs, env, is_nucleo=False, id=0.8)[0] for env in (None, {"UGS_R2_KCAP": "8"})]
+    outs = [_search(db, qs, dict(env, UGS_R3=r3), is_nucleo=False, id=0.8)[0] for env in ({}, {"UGS_R2_KCAP": "8"})]
     assert outs[0][1]["r2_launched"] == 1 and outs[0][1]["deferred"] == 0
     assert outs[1][1]["r2_launched"] == 1 and outs[1][1]["deferred"] > 0 and outs[1][1]["r2_units"] + outs[1][1]["deferred"] == qs.n
     assert outs[0][0] == outs[1][0]
@@ -224,7 +232,28 @@ def test_gather_kernel_deferred_units_and_oracle(aa_small):
             assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
 
 
-def test_gather_kernel_defers_units_of_abundant_families():
+@pytest.mark.parametrize("sp", ["1", "2", "63"])
+def test_filter_kernel_super_partition_sizes_and_oracle(aa_small, sp):
+    """k_rank3g with super-partitions of one and two partitions of the index (65 536 / 131 072 targets: few false suspects, many
+    group-step lists) and starting from ONE super-partition over all 300 k targets (its group-step list overflows: scanned again as
+    halves): the same candidates and counts as the oracle's ranking, unit by unit"""
+    db, _ = aa_small
+    qs = synth.make_queries(25, db, 1500, 300, aa=True)
+    out = _search(db, qs, {"UGS_R3": "1", "UGS_R3_SP": sp}, is_nucleo=False, id=0.8)[0]
+    kh = out[1]
+    assert kh["r2_launched"] == 1 and kh["r2_kernel"] == "k_rank3g" and kh["r2_units"] + kh["deferred"] == qs.n
+    assert kh["deferred"] <= qs.n // 100            # (a super-partition that overflows is scanned again as two halves, not deferred)
+    odb = orc.OrcDB(orc.params(is_nucleo=False, id=0.8), db.seqs, db.offs)
+    cand, cnt, n = out[2]
+    for qi in range(0, qs.n, 5):
+        q = qs.seqs[int(qs.offs[qi]):int(qs.offs[qi + 1])]
+        on, oc, occ = odb.rank(q, cap=cand.shape[1])
+        m = min(on, cand.shape[1])
+        assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
+
+
+@pytest.mark.parametrize("r3", SPARSE_KERNELS)
+def test_gather_kernel_defers_units_of_abundant_families(r3):
     """families of near-identical sequences give sub-rows far longer than a quad (300 copies: > 255 postings of a row in one partition;
     60 copies: more descriptor lanes than a partition's table holds): those units go to k_rank, the others stay"""
     base = synth.make_db(23, 200000, 300, aa=True)
@@ -255,7 +284,7 @@ def test_gather_kernel_defers_units_of_abundant_families():
     qoffs = np.concatenate([qs0.offs, qs0.offs[-1] + np.arange(1, len(extra) + 1, dtype=np.uint64) * np.uint64(L)])
     qs = synth.SeqSet(qseqs, qoffs, lambda i: "q%d" % i)
     a = _search(db, qs, {"UGS_RANK2": "0", "UGS_LONGROWS": "0"}, is_nucleo=False, id=0.8)[0]
-    b = _search(db, qs, {"UGS_LONGROWS": "0"}, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, {"UGS_LONGROWS": "0", "UGS_R3": r3}, is_nucleo=False, id=0.8)[0]
     assert b[1]["r2_launched"] == 1 and b[1]["deferred"] >= len(extra) // 2 and b[1]["r2_units"] > 2000
     assert b[1]["r2_units"] + b[1]["deferred"] == qs.n
     for x, y in zip(a[2], b[2]):

@@ -90,6 +90,42 @@ def test_rank2g_ring_is_counted_by_hand_and_the_table_lines_load_together():
     assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "flat_atomic" not in body
 
 
+def test_rank3g_ring_is_counted_by_hand_in_both_passes():
+    """k_rank3g (ugs_rank3.hip: the sparse-index kernel with two filter passes) streams through the same ring in BOTH passes: posting
+    loads only into a[0:3] .. a[12:15], each slot waited for with vmcnt(3) right in front of its four v_accvgpr_read, no compiler wait
+    for ALL loads between a pass's first load and its drain (that would stall the ring on every stage), no scratch, no spill, no
+    flat atomic; pass 1 counts with one ds_or_rtn_b32 per posting, the grouping inserts with ds_cmpst_rtn_b32."""
+    isa = _isa_of("ugs_rank3.hip")
+    body = _kernel_body(isa, "k_rank3g")
+    i = isa.index(".name:           _Z8k_rank3g")
+    meta = isa[isa.rindex("- .agpr_count", 0, i):i + 600]
+    assert re.search(r"\.vgpr_spill_count:\s*0\b", meta) and re.search(r"\.private_segment_fixed_size:\s*0\b", meta), meta
+    assert int(re.search(r"\.agpr_count:\s*(\d+)", meta).group(1)) <= 20 and int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1)) <= 128
+    assert "scratch_" not in body and "flat_" not in body
+    loads = re.findall(r"global_load_dwordx4 (a\[\d+:\d+\])", body)
+    assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) % 8 == 0 and len(loads) >= 16, loads
+    assert "global_load_dwordx4 v" not in body
+    assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == len(loads) - 8      # (the four priming loads of each pass are not waited for one by one)
+    for m in re.finditer(r"v_accvgpr_(?:write_b32|mov_b32) a(\d+)", body):
+        assert int(m.group(1)) >= 16, m.group(0)                   # the compiler's own accumulator registers lie behind the ring's
+    # inside a pass - from its first ring load to the drain the source places behind it - the only vmcnt waits are the ring's own
+    lines = body.split("\n")
+    in_ring = False
+    n_pass = 0
+    for k, ln in enumerate(lines):
+        t = ln.strip()
+        if t.startswith("global_load_dwordx4 a[0:3]") and not in_ring:
+            in_ring = True
+            n_pass += 1
+        elif in_ring and t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+            assert "lgkmcnt" not in t and "expcnt" not in t, "a compiler wait for all loads inside the ring: " + t      # (the drain is a bare asm vmcnt(0))
+            in_ring = False
+        elif in_ring and t.startswith("s_waitcnt") and "vmcnt" in t:
+            assert "vmcnt(3)" in t, t
+    assert n_pass >= 2 and not in_ring
+    assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "ds_cmpst_rtn_b32" in body
+
+
 def test_xdrop_cross_lane_traffic_is_explicit():
     """k_xdrop / k_local hand traceback bytes, row windows and run lists from one lane to another through HBM scratch.
     Pinned on the emitted code (ugs_xdrop_dev.h, UGS_XD_SYNC): the readers are agent-scope loads (sc1: never served by a

@@ -54,7 +54,7 @@ def check(name, db, qs, aa, ident, n_oracle, **kw):
                roofline_k_rank=dict(bound="hbm", algorithmic_bytes=int(4 * best["postings"] + best["query_letters"]), kernel_ms=round(best["ms_rank"], 3),
                                     achieved_GBps=round((4.0 * best["postings"] + best["query_letters"]) / (best["ms_rank"] * 1e-3) / 1e9, 1), peak_GBps=8000.0,
                                     frac=round((4.0 * best["postings"] + best["query_letters"]) / (best["ms_rank"] * 1e-3) / 8e12, 4),
-                                    kernels=("k_rank2g" if kh["r2_launched"] and aa else "k_rank2" if kh["r2_launched"] else "k_rank") + (" + k_rank over %d deferred units" % kh["deferred"] if kh["r2_launched"] else ""),
+                                    kernels=(kh.get("r2_kernel") or "k_rank") + (" + k_rank over %d deferred units" % kh["deferred"] if kh["r2_launched"] else ""),
                                     ms_bitmap_kernel=round(kh["ms_rank2"], 3), ms_k_rank_behind_it=round(kh["ms_rank_deferred"], 3), units_bitmap_kernel=kh["r2_units"]),
                pairs_aligned=int(best["pairs_aligned"]), index_build_s=round(t_build, 2),
                oracle_checked_queries=n_oracle, oracle_index_build_s=round(t_obuild, 1), oracle_search_s=round(t2 - t1 - t_obuild, 1))

@@ -8,8 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip", "ugs_deep.hip"]
-DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_rank_keys.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
+SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_rank3.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip", "ugs_deep.hip"]
+DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_ring_dev.h", "ugs_rank_keys.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 # per-source compiler options.  k_rank's partition loop lives on the edge of its register budget: of the machine
@@ -17,13 +17,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # iterative-minreg 128) but costs the mid-identity instantiations 10 %, so the HOT kernel is a translation unit of its own
 # (ugs_rank.hip, UGS_RANK_TU); with -amdgpu-schedule-relaxed-occupancy on top 52.9 ms (that option without the scheduler: 56.2).
 # ugs_align.hip gains nothing from any of them and does not compile with iterative-maxocc (tools/build_hot_variant.sh, tools/ab_variants.sh)
-EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"],
+EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"], 
          "ugs_rank_hot.hip": ["-DUGS_RANK_TU=1", "-mllvm", "-amdgpu-sched-strategy=iterative-maxocc", "-mllvm", "-amdgpu-schedule-relaxed-occupancy"]}
 # objects compiled from another source file's text under other options: ugs_rank_hot.o = the HOT instantiation of k_rank alone
 ALIAS = {"ugs_rank_hot.hip": "ugs_rank.hip"}
 
 
-KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_align.hip")      # sources whose emitted code tests/test_isa.py pins
+KEEP_ASM = ("ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_rank3.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_align.hip")      # sources whose emitted code tests/test_isa.py pins
 
 
 def asm_path(src):

@@ -361,12 +361,13 @@ class UgsBatch:
 
     def kernel_hits(self):
         """which ranking code the last synced search ran: dict(r2_units, deferred, rank_kernel, r2_launched)"""
-        out = (C.c_uint64 * 7)()
+        out = (C.c_uint64 * 8)()
         f = lib().ugs_debug_kernel_hits
         f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]; f.restype = C.c_int
-        _chk(f(self.h, out, 7))
+        _chk(f(self.h, out, 8))
         return {"r2_units": int(out[0]), "deferred": int(out[1]), "rank_kernel": int(out[2]), "r2_launched": int(out[3]),
-                "ms_rank2": out[4] / 1000.0, "ms_rank_deferred": out[5] / 1000.0, "group_rejects": int(out[6])}
+                "ms_rank2": out[4] / 1000.0, "ms_rank_deferred": out[5] / 1000.0, "group_rejects": int(out[6]),
+                "r2_kernel": ("", "k_rank2", "k_rank2g", "k_rank3g", "k_rank2<CL>")[int(out[7])]}
 
     def candidates(self):
         p = self.db.p

@@ -177,7 +177,8 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8
   X(5, SMALL4, "small 4-bit") X(6, SMALL4_LONG, "small 4-bit long rows") X(7, SMALL_FLAT, "small 8/16-bit flattened") \
   X(8, SMALL_DENSE, "small 8/16-bit dense") X(9, SMALL_DENSE_LONG, "small 8/16-bit dense, long rows") \
   X(12, BIG4_WIDE, "HOT, 64-bit offsets") X(13, BIG4_LONG_WIDE, "long rows, 64-bit offsets") \
-  X(14, R2, "k_rank2 (bitmap)") X(15, R2G, "k_rank2g (bitmap, sparse index)") X(16, R2_CL, "k_rank2, cluster_fast instantiation")
+  X(14, R2, "k_rank2 (bitmap)") X(15, R2G, "k_rank2g (bitmap, sparse index)") X(16, R2_CL, "k_rank2, cluster_fast instantiation") \
+  X(17, R3G, "k_rank3g (two filter passes, sparse index)")
 #define UGS_RANK_INST_ENUM(i, n, s) UGS_RI_##n = i,
 enum { UGS_RANK_INST_TABLE(UGS_RANK_INST_ENUM) UGS_RI_END };
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);

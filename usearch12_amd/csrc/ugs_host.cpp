@@ -281,6 +281,9 @@ UgsTune ugs_tune_read()
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
   t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
+  t.r3 = env_int("UGS_R3", 0, 1, -1);
+  t.r3_sp = env_int("UGS_R3_SP", 1, 63, 0);
+  t.r3_pps = env_int("UGS_R3_PPS", 64, 1 << 20, 0);
   t.batch_streams = getenv("UGS_BATCH_STREAMS") != nullptr;
   t.qpk = getenv("UGS_QPK") != nullptr;
   t.align_group = env_int("UGS_ALIGN_GROUP", 0, 64, -1);
@@ -836,7 +839,16 @@ static int plan_launch(ugs_batch *b)
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
     b->r2.clcap = 0; b->r2.W = 0; b->r2.gather = 1;
     b->r2.lds = (uint32_t)ugs_rank2g_lds(db->v.gsize2, kcap, db->v.np2);
-    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 1), 32));
+    int wcu;
+    if (db->tune.r3 != 0) {
+      // k_rank3g (ugs_rank3.hip): two filter passes per super-partition of ~ 262 144 targets instead of an exact bitmap per partition
+      b->r2.gather = 2;
+      b->r2.W = db->tune.r3_sp ? (uint32_t)db->tune.r3_sp : 0u;           // 0: per unit, from its postings (UgsRank2Params::clcap per super-partition)
+      b->r2.clcap = db->tune.r3_pps ? (uint32_t)db->tune.r3_pps : 4096u;
+      b->r2.lds = (uint32_t)ugs_rank3g_lds(kcap);
+      wcu = std::max(1, std::min(ugs_rank3g_blocks_per_cu(b->r2.lds), 32));
+    } else
+    wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 1), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   } else
@@ -1369,6 +1381,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
   if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];
+  if (n >= 8) out[7] = !b->r2_ran ? 0u : b->r2.gather == 2u ? 3u : b->r2.gather ? 2u : b->v.cand_key ? 4u : 1u;
   return UGS_OK;
 }
 

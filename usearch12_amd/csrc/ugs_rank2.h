@@ -7,13 +7,18 @@ struct UgsRank2Params {
   uint32_t G;          // targets per partition: a multiple of 8192, <= 65536 (one bit per target in LDS)
   uint32_t np;         // partitions = ceil(nseq / G) = UgsDbView::np2
   uint32_t kcap;       // kept keys per unit the LDS list holds (more defers the unit to k_rank)
-  uint32_t W;          // partitions per window of the scan (a multiple of 4)
-  uint32_t clcap;      // chunk descriptors the LDS list of a window holds
+  uint32_t W;          // partitions per window of the scan (a multiple of 4); k_rank3g: partitions per super-partition (0: per unit)
+  uint32_t clcap;      // chunk descriptors the LDS list of a window holds; k_rank3g: postings per super-partition aimed at (W == 0)
   uint32_t lds;        // dynamic LDS bytes per wave
-  uint32_t gather;     // 1: k_rank2g (sparse index: one chunk = the sub-rows of all sampled rows of a partition)
+  uint32_t gather;     // 1: k_rank2g (sparse index: one chunk = the sub-rows of all sampled rows of a partition); 2: k_rank3g (sparse index,
+                       //    two filter passes per super-partition, ugs_rank3.hip)
 };
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl = 0);
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np);
 int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl = 0);      // cl: the cluster_fast instantiation (walk records)
+// k_rank3g (ugs_rank3.hip)
+size_t ugs_rank3g_lds(uint32_t kcap);
+int ugs_rank3g_blocks_per_cu(size_t lds);
+int ugs_launch_rank3g(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st);
 int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2Params &prm, int grid, hipStream_t st);
