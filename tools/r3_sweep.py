@@ -8,7 +8,10 @@ from usearch12_amd import capi, synth
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 ndb = int(sys.argv[2]) if len(sys.argv) > 2 else 2000000
-pps = sys.argv[3:] or ["1024", "1536", "2048", "3072", "4096"]
+pps = [a for a in sys.argv[3:] if "=" not in a] or ["1024", "1536", "2048", "3072", "4096"]
+for a in sys.argv[3:]:
+    if "=" in a:
+        k, v = a.split("=", 1); os.environ[k] = v
 db = synth.make_db(5, ndb, 300, aa=True)
 qs = synth.make_queries(5, db, nq, 300, aa=True)
 ref = None

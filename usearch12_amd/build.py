@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # iterative-minreg 128) but costs the mid-identity instantiations 10 %, so the HOT kernel is a translation unit of its own
 # (ugs_rank.hip, UGS_RANK_TU); with -amdgpu-schedule-relaxed-occupancy on top 52.9 ms (that option without the scheduler: 56.2).
 # ugs_align.hip gains nothing from any of them and does not compile with iterative-maxocc (tools/build_hot_variant.sh, tools/ab_variants.sh)
-EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"], 
+EXTRA = {"ugs_rank.hip": ["-DUGS_RANK_TU=2"],
          "ugs_rank_hot.hip": ["-DUGS_RANK_TU=1", "-mllvm", "-amdgpu-sched-strategy=iterative-maxocc", "-mllvm", "-amdgpu-schedule-relaxed-occupancy"]}
 # objects compiled from another source file's text under other options: ugs_rank_hot.o = the HOT instantiation of k_rank alone
 ALIAS = {"ugs_rank_hot.hip": "ugs_rank.hip"}

@@ -12,10 +12,10 @@
 // k_rank3g asks the cheaper question first.  The target space is cut into a few SUPER-partitions (whole partitions of the index's
 // partition table, as many per unit as keep ~ 1 500 postings in each: C5 ~ 262 144 targets); per super-partition the rows' segments
 // are streamed TWICE, in any order:
-//   pass 1  every posting goes through a blocked three-bit filter in LDS (4 KB: word = target bits 5..14, one bit from the target's low
-//           five bits, two from a multiplicative hash; ONE ds_or_rtn per posting).  A posting that finds all its bits set is a
+//   pass 1  every posting goes through a blocked two-bit filter in LDS (4 KB: word = target bits 5..14, one bit from the target's low
+//           five bits, one from a multiplicative hash; ONE ds_or_rtn per posting).  A posting that finds both its bits set is a
 //           SUSPECT: a target with count >= 2 is always one (its second posting finds the bits its first one set), a false suspect
-//           costs time only (~ 8 per super-partition).
+//           costs time only (a few dozen per super-partition).
 //   pass 2  the filter is zeroed, the suspects' exact bits (target mod 32 768) are set, and the same segments are streamed again
 //           (they come from the L2 now): every posting whose bit is set leaves a RECORD (row, target) - ALL occurrences of every
 //           target with count >= 2, plus the single occurrences of false suspects and of their aliases.
@@ -41,7 +41,15 @@
 #define R3_GSCAP 256u           // group-steps (8 quads = up to 32 postings of one row) of one super-partition; more: the unit is deferred
 #define R3_RCAP 256u            // records (pass 1: suspects, pass 2: occurrences) of one super-partition; more: deferred
 #define R3_TAB 512u             // entries of the grouping table: 32-bit keys (2 KB) | 64-bit row masks (4 KB) over the filter AND the group-step list
-#define R3_HMUL 0x9E3779u       // 24-bit multiplier of the filter's second bit
+#define R3_HMUL 0x9E3779u       // 24-bit multiplier of the filter's second (and third) bit
+#ifndef R3_FBITS
+#define R3_FBITS 2              // bits a posting sets in its filter word (3: fewer false suspects, two more instructions per posting - C5 shape 4.51 vs 4.39 ms per 200 k queries)
+#endif
+#if R3_FBITS == 3
+#define R3_THIRD_BIT(h) | (1u << (((h) >> 5) & 31u))
+#else
+#define R3_THIRD_BIT(h)
+#endif
 #ifdef R3_DEFER_STATS          // why units are deferred, in the profiling counters T5 (group-step list), T6 (records), T7 (kept keys)
 #define R3_WHY(c) do { if (lane == 0) atomicAdd(&bv.counters[c], 1ull); } while (0)
 #define R3_STAT(c, v) do { if (lane == 0) atomicAdd(&bv.counters[c], (unsigned long long)(v)); } while (0)
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
         uint32_t n_rec = 0;
         uint32_t lm[4];
         uint32_t S_t[4] = {0, 0, 0, 0}, S_old[4] = {0, 0, 0, 0}, S_m[4] = {0, 0, 0, 0}, S_row = 0;
+        uint64_t S_vm[4] = {0, 0, 0, 0};
         bool pv = false;
         // a chunk's descriptor: byte offset of the lane's quad, first place | end place << 2 | row << 8 (0: nothing valid)
         auto fetch = [&](uint32_t step, uint32_t &voff, uint32_t &m) {
@@ -174,21 +183,21 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
         // the postings of the counted chunk that passed: pass 1 the suspects' targets, pass 2 (row, target) records
 #define R3_EMIT(P2)                                                                                               \
         {                                                                                                         \
-          bool hit[4];                                                                                            \
+          uint64_t hm[4];                                                                                         \
           _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
-            hit[j] = (P2) ? (S_old[j] & S_m[j]) != 0u : (S_m[j] != 0u && (S_old[j] & S_m[j]) == S_m[j]);          \
-          if (r2_ballot(hit[0] || hit[1] || hit[2] || hit[3]) != 0ull) {                                          \
+            hm[j] = S_vm[j] & r2_ballot((P2) ? (S_old[j] & S_m[j]) != 0u : (S_old[j] & S_m[j]) == S_m[j]);        \
+          if ((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull) {                                                          \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-              const uint64_t hm = r2_ballot(hit[j]);                                                              \
-              const uint32_t pos = n_rec + r2_mbcnt(hm);                                                          \
-              if (hit[j] && pos < R3_RCAP + 64u) s_rec[pos] = (P2) ? (S_t[j] | (S_row << 24)) : S_t[j];           \
-              n_rec += (uint32_t)__popcll(hm);                                                                    \
+              const uint32_t pos = n_rec + r2_mbcnt(hm[j]);                                                       \
+              if (((hm[j] >> lane) & 1ull) && pos < R3_RCAP + 64u) s_rec[pos] = (P2) ? (S_t[j] | (S_row << 24)) : S_t[j]; \
+              n_rec += (uint32_t)__popcll(hm[j]);                                                                 \
             }                                                                                                     \
           }                                                                                                       \
           pv = false;                                                                                             \
         }
         // one stage: wait for slot k, issue the chunk four ahead into it, emit the previous chunk's hits (their LDS round trip lies
-        // behind the posting wait), count this one
+        // behind the posting wait), count this one.  Places outside a segment take no part: their lanes are masked out of the LDS
+        // instruction (fewer bank conflicts) and out of the hits (S_vm: the valid lanes as scalar masks)
 #define R3_STAGE(k, P2)                                                                                           \
         {                                                                                                         \
           uint32_t Tq[4];                                                                                         \
@@ -205,13 +214,14 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
             const bool valid = rel + (uint32_t)j < span;                  /* (unsigned: places below `first` wrap) */ \
             const uint32_t ad = (t >> 3) & ((R3_BW - 1u) << 2);                                                   \
             S_t[j] = t;                                                                                           \
+            S_vm[j] = r2_ballot(valid);                                                                           \
             if (P2) {                                                                                             \
-              S_m[j] = valid ? 1u << (t & 31u) : 0u;                                                              \
-              S_old[j] = *(const uint32_t *)((const unsigned char *)s_bm + ad);                                   \
+              S_m[j] = 1u << (t & 31u);                                                                           \
+              if (valid) S_old[j] = *(lds32)(uintptr_t)ad;               /* (the filter lies at LDS address 0: no static LDS in this kernel) */                        \
             } else {                                                                                              \
-              const uint32_t h2 = __umulhi(t & 0xffffffu, R3_HMUL)   /* (v_mul_hi_u32_u24) */;                              \
-              S_m[j] = valid ? (1u << (t & 31u)) | (1u << (h2 & 31u)) | (1u << ((h2 >> 5) & 31u)) : 0u;                                       \
-              S_old[j] = __hip_atomic_fetch_or((uint32_t *)((unsigned char *)s_bm + ad), S_m[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+              const uint32_t h2 = __umulhi(t & 0xffffffu, R3_HMUL);       /* (v_mul_hi_u32_u24) */                \
+              S_m[j] = (1u << (t & 31u)) | (1u << (h2 & 31u)) R3_THIRD_BIT(h2);                                   \
+              if (valid) S_old[j] = __hip_atomic_fetch_or((lds32)(uintptr_t)ad, S_m[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
             }                                                                                                     \
           }                                                                                                       \
           pv = true;                                                                                              \
