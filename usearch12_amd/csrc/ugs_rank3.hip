@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
           _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
             hm[j] = S_vm[j] & r2_ballot((P2) ? (S_old[j] & S_m[j]) != 0u : (S_old[j] & S_m[j]) == S_m[j]);        \
           if ((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull) {                                                          \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (hm[j] != 0ull) {      /* (a chunk has a few hits: one or two of its four posting places) */ \
               const uint32_t pos = n_rec + r2_mbcnt(hm[j]);                                                       \
               if (((hm[j] >> lane) & 1ull) && pos < R3_RCAP + 64u) s_rec[pos] = (P2) ? (S_t[j] | (S_row << 24)) : S_t[j]; \
               n_rec += (uint32_t)__popcll(hm[j]);                                                                 \
