@@ -39,6 +39,7 @@
 
 #define R3_BW 1024u             // 32-bit words of the filter (pass 1) = the suspects' bitmap (pass 2) = the grouping table
 #define R3_GSCAP 256u           // group-steps (8 quads = up to 32 postings of one row) of one super-partition; more: the unit is deferred
+#define R3_GSPAD 40u            // empty group-steps behind the list (the ring's look-ahead reads them instead of testing the index)
 #define R3_RCAP 256u            // records (pass 1: suspects, pass 2: occurrences) of one super-partition; more: deferred
 #define R3_TAB 512u             // entries of the grouping table: 32-bit keys (2 KB) | 64-bit row masks (4 KB) over the filter AND the group-step list
 #define R3_HMUL 0x9E3779u       // 24-bit multiplier of the filter's second (and third) bit
@@ -70,7 +71,7 @@
 #define R3_CLK(...)
 #endif
 
-__host__ __device__ constexpr uint32_t r3_fixed_bytes() { return R3_BW * 4u + R3_GSCAP * 8u + (R3_RCAP + 64u) * 4u + 64u * 3u * 4u; }
+__host__ __device__ constexpr uint32_t r3_fixed_bytes() { return R3_BW * 4u + (R3_GSCAP + R3_GSPAD) * 8u + (R3_RCAP + 64u) * 4u + 64u * 3u * 4u; }
 
 __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
   const uint32_t np = prm.np, K = bv.K, kcap = prm.kcap;
   // ---- LDS carve (r3_fixed_bytes + the kept keys)
   uint32_t *s_bm = (uint32_t *)smem;                                    // [R3_BW] filter | suspects' bitmap | grouping table
-  uint2 *s_gs = (uint2 *)(smem + R3_BW * 4u);                           // [R3_GSCAP] group-steps of the super-partition
-  uint32_t *s_rec = (uint32_t *)(s_gs + R3_GSCAP);                      // [R3_RCAP + 64] records (+ slack)
+  uint2 *s_gs = (uint2 *)(smem + R3_BW * 4u);                           // [R3_GSCAP + R3_GSPAD] group-steps of the super-partition
+  uint32_t *s_rec = (uint32_t *)(s_gs + R3_GSCAP + R3_GSPAD);           // [R3_RCAP + 64] records (+ slack)
   uint32_t *s_sel = s_rec;                                              //   after the scan: [64] selected targets (for the fill)
   uint64_t *s_fpk = (uint64_t *)(s_rec + 64);                           //   after the scan: [64] smallest key per count value
   uint32_t *s_c2 = s_rec + R3_RCAP + 64;                                // [64] kept count-2 keys per row
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
               s_gs[st + k] = make_uint2(a0 + k * 128u, (k == 0u ? lead : 0u) | ((rem < 32u ? rem : 32u) << 2) | (lane << 8));
             }
           }
+          if (lane < R3_GSPAD) s_gs[T + lane] = make_uint2(0u, 0u);           // what the ring reads ahead of the last chunk (<= 4 chunks + the last one's rest)
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         R3_CLK(const unsigned long long q1 = clock64();)
@@ -175,9 +177,7 @@ __global__ __launch_bounds__(64, 4) void k_rank3g(UgsDbView db, UgsBatchView bv,
         bool pv = false;
         // a chunk's descriptor: byte offset of the lane's quad, first place | end place << 2 | row << 8 (0: nothing valid)
         auto fetch = [&](uint32_t step, uint32_t &voff, uint32_t &m) {
-          const uint32_t idx = step * 8u + grp;
-          uint2 d = make_uint2(0u, 0u);
-          if (idx < T) d = s_gs[idx];
+          const uint2 d = s_gs[step * 8u + grp];                          // (behind the list: 40 entries of nothing, see the layout)
           voff = d.x + lo16; m = d.y;
         };
         // the postings of the counted chunk that passed: pass 1 the suspects' targets, pass 2 (row, target) records
