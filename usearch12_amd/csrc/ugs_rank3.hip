@@ -10,14 +10,14 @@
 // quarter-full chunks, a grouping and a bitmap reset: its time is per-partition overhead (DESIGN.md section 3 "K-rank2g": 0.18 of HBM peak).
 //
 // k_rank3g asks the cheaper question first.  The target space is cut into a few SUPER-partitions (whole partitions of the index's
-// partition table, as many per unit as keep ~ 1 500 postings in each: C5 ~ 262 144 targets); per super-partition the rows' segments
+// partition table, as many per unit as keep ~ 4 096 postings in each: C5 three of ~ 700 k targets); per super-partition the rows' segments
 // are streamed TWICE, in any order:
 //   pass 1  every posting goes through a blocked two-bit filter in LDS (4 KB: word = target bits 5..14, one bit from the target's low
 //           five bits, one from a multiplicative hash; ONE ds_or_rtn per posting).  A posting that finds both its bits set is a
 //           SUSPECT: a target with count >= 2 is always one (its second posting finds the bits its first one set), a false suspect
 //           costs time only (a few dozen per super-partition).
 //   pass 2  the filter is zeroed, the suspects' exact bits (target mod 32 768) are set, and the same segments are streamed again
-//           (they come from the L2 now): every posting whose bit is set leaves a RECORD (row, target) - ALL occurrences of every
+//           (from the L2 / MALL now): every posting whose bit is set leaves a RECORD (row, target) - ALL occurrences of every
 //           target with count >= 2, plus the single occurrences of false suspects and of their aliases.
 //   then    the few dozen records are grouped by target through a 512-entry hash table in the same LDS (compare-and-swap insertion,
 //           the rows of a target's records as a 64-bit mask): count = its bits, first-touch row = the lowest - no scan order is needed -,
@@ -25,8 +25,9 @@
 // A chunk of the stream = 8 groups of 8 lanes, a group = 8 consecutive 16-byte quads of ONE row's segment (a "group-step"; the list
 // of a super-partition's group-steps is laid out once - a prefix sum over the row lanes - and serves both passes).  The loads run
 // through the accumulator-register ring of k_rank2 (four chunks in flight, waits counted by hand).
-// Outside the envelope (more than 63 sampled rows, more than R3_GSCAP group-steps or R3_RCAP records in a super-partition, a full
-// kept-key list) the unit is DEFERRED to k_rank like k_rank2g's.  Never a different result, never a CPU path.
+// A super-partition that overflows the group-step list (R3_GSCAP) or the records (R3_RCAP) is scanned again as two halves.  Outside the
+// envelope (more than 63 sampled rows, a SINGLE partition that overflows - an abundant family -, a full kept-key list) the unit is
+// DEFERRED to k_rank like k_rank2g's.  Never a different result, never a CPU path.
 #include "ugs_dev.h"
 #include "ugs_rank2.h"
 #include <cstdlib>
@@ -38,9 +39,9 @@
 #include "ugs_ring_dev.h"
 
 #define R3_BW 1024u             // 32-bit words of the filter (pass 1) = the suspects' bitmap (pass 2) = the grouping table
-#define R3_GSCAP 256u           // group-steps (8 quads = up to 32 postings of one row) of one super-partition; more: the unit is deferred
+#define R3_GSCAP 256u           // group-steps (8 quads = up to 32 postings of one row) of one super-partition; more: it is halved
 #define R3_GSPAD 40u            // empty group-steps behind the list (the ring's look-ahead reads them instead of testing the index)
-#define R3_RCAP 256u            // records (pass 1: suspects, pass 2: occurrences) of one super-partition; more: deferred
+#define R3_RCAP 256u            // records (pass 1: suspects, pass 2: occurrences) of one super-partition; more: it is halved
 #define R3_TAB 512u             // entries of the grouping table: 32-bit keys (2 KB) | 64-bit row masks (4 KB) over the filter AND the group-step list
 #define R3_HMUL 0x9E3779u       // 24-bit multiplier of the filter's second (and third) bit
 #ifndef R3_FBITS
@@ -51,7 +52,8 @@
 #else
 #define R3_THIRD_BIT(h)
 #endif
-#ifdef R3_DEFER_STATS          // why units are deferred, in the profiling counters T5 (group-step list), T6 (records), T7 (kept keys)
+#ifdef R3_DEFER_STATS          // profiling counters: T0 / T1 suspects / records, T2 group-steps, T3 super-partitions scanned, T4 most suspects of one; why
+                               // units are deferred: T5 (suspects), T6 (records), T7 (group-step list or kept keys)
 #define R3_WHY(c) do { if (lane == 0) atomicAdd(&bv.counters[c], 1ull); } while (0)
 #define R3_STAT(c, v) do { if (lane == 0) atomicAdd(&bv.counters[c], (unsigned long long)(v)); } while (0)
 #define R3_STATMAX(c, v) do { if (lane == 0) atomicMax(&bv.counters[c], (unsigned long long)(v)); } while (0)
