@@ -40,6 +40,11 @@ CASES = {
     "cl_sizein": dict(gen="reads", seed=50, n=5000, species=40, dup=0.05, id=0.97, strand="plus", big=250, sort="size", sizes=1.0, sizein=1,
                       sizeout=1, minsize=3),
     "cl_sizein_nosort": dict(gen="reads", seed=51, n=3000, species=30, dup=0.05, id=0.97, strand="both", sizes=1.0, sizein=1),
+    # protein (UCLUST's other everyday use): families of 20-400 residue sequences, small path only / across the small -> Big latch
+    # (sparse index: on the device the Big-phase searches are ranked by k_rank), a lower identity with deeper walks
+    "cl_aa_small": dict(gen="hard", seed=52, n=3000, id=0.9, strand="plus", aa=1),
+    "cl_aa_latch": dict(gen="hard", seed=53, n=4000, id=0.9, strand="plus", aa=1, big=300),
+    "cl_aa_id70":  dict(gen="hard", seed=54, n=3000, id=0.7, strand="plus", aa=1, big=250),
 }
 
 
@@ -69,7 +74,7 @@ def make_reads(c):
         r = synth.make_reads(c["seed"], c["n"], n_species=c["species"], dup_frac=c["dup"],
                              p_sub=c.get("sub", 0.01), p_del=c.get("indel", 0.001), p_ins=c.get("indel", 0.001))
     else:
-        _, r = synth.make_hard(c["seed"], 200, 6, c["n"], lmin=120, lmax=400)
+        _, r = synth.make_hard(c["seed"], 200, 6, c["n"], lmin=120, lmax=400, aa=bool(c.get("aa")))
     if c["strand"] == "both":
         r = synth.revcomp_some(c["seed"], r)
     if c.get("sizes"):

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _cluster(c, r, batch=None):
     kw = {"big": c["big"]} if "big" in c else {}
-    p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", **kw)
+    p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", is_nucleo=not c.get("aa"), **kw)
     old = os.environ.pop("UGS_CLUSTER_BATCH", None)
     if batch:
         os.environ["UGS_CLUSTER_BATCH"] = str(batch)
@@ -129,7 +129,7 @@ def test_c3_full_size_properties_and_prefix_parity():
     _same(g, o)
 
 
-@pytest.mark.parametrize("name", ["cl_both", "cl_sizein", "cl_sortlen2"])
+@pytest.mark.parametrize("name", ["cl_both", "cl_sizein", "cl_sortlen2", "cl_aa_latch"])
 def test_cli_cluster_fast_writes_the_reference_files(name, tmp_path):
     """the C++ driver end to end: FASTA in, -uc and -centroids out, byte-identical to the reference's files"""
     import subprocess

@@ -449,8 +449,8 @@ def udb_write(path, db, labels):
 
 
 # ---- cluster_fast (include/ugs.h ugs_cluster_*)
-def cluster_params(id=0.97, strand_both=False, **kw):
-    p = params(is_nucleo=True, id=id, strand_both=1 if strand_both else 0, **kw)
+def cluster_params(id=0.97, strand_both=False, is_nucleo=True, **kw):
+    p = params(is_nucleo=is_nucleo, id=id, strand_both=1 if strand_both else 0, **kw)
     _chk(lib().ugs_params_set_cluster(C.byref(p)))
     return p
 

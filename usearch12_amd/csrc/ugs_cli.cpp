@@ -491,9 +491,9 @@ int main(int argc, char **argv)
     SeqSet in;
     { FastaReader r(clusterfast.c_str()); while (r.read(in, 1u << 20)) {} }
     if (in.size() == 0) { fprintf(stderr, "No sequences in input file\n"); return 1; }      // clusterfast.cpp:91-92
-    if (!guess_nucleo(in)) { fprintf(stderr, "cluster_fast: amino acid input is not supported by this build\n"); return 1; }
+    const bool cl_nucleo = dbtype >= 0 ? dbtype != 0 : guess_nucleo(in);                     // (protein input: UCLUST's other everyday use)
     ugs_params p;
-    ugs_params_init(&p, 1, id);
+    ugs_params_init(&p, cl_nucleo ? 1 : 0, id);
     ugs_params_set_cluster(&p);
     if (!strand.empty()) {                                                                   // StrandOptToRevComp(false, false) clusterfast.cpp:18-36
       if (strand == "both") p.strand_both = 1; else if (strand != "plus") { fprintf(stderr, "Invalid -strand\n"); return 1; }
