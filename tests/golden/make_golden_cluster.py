@@ -45,6 +45,11 @@ CASES = {
     "cl_aa_small": dict(gen="hard", seed=52, n=3000, id=0.9, strand="plus", aa=1),
     "cl_aa_latch": dict(gen="hard", seed=53, n=4000, id=0.9, strand="plus", aa=1, big=300),
     "cl_aa_id70":  dict(gen="hard", seed=54, n=3000, id=0.7, strand="plus", aa=1, big=250),
+    # -maxrejects other than the command's 8 (terminator.cpp:22-31): deeper walks before a read founds a cluster, up to the 64 candidates
+    # of a ranking pass; and a walk that gives up after two rejects
+    "cl_rej32":    dict(gen="reads", seed=55, n=5000, species=40, dup=0.02, id=0.90, strand="both", big=200, sub=0.04, indel=0.005, maxrejects=32),
+    "cl_rej64_aa": dict(gen="hard", seed=56, n=3000, id=0.8, strand="plus", aa=1, big=250, maxrejects=64),
+    "cl_rej2":     dict(gen="reads", seed=57, n=4000, species=30, dup=0.02, id=0.95, strand="plus", big=200, sub=0.03, maxrejects=2),
 }
 
 
@@ -119,6 +124,8 @@ def main():
                     cmd += ["-" + flag]
             if c.get("minsize"):
                 cmd += ["-minsize", str(c["minsize"])]
+            if c.get("maxrejects"):
+                cmd += ["-maxrejects", str(c["maxrejects"])]
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             uct = open(uc, "rb").read()
             gz_write(os.path.join(HERE, name + ".uc.gz"), uct)

@@ -278,9 +278,10 @@ def _vp(a):
     return a.ctypes.data
 
 
-def cluster_params(id=0.97, strand_both=False, is_nucleo=True, **kw):
+def cluster_params(id=0.97, strand_both=False, is_nucleo=True, max_rejects=None, **kw):
     """cmd_cluster_fast's searcher: terminator 1 accept / 8 rejects (terminator.cpp:10-14), letters used as read"""
-    return params(is_nucleo=is_nucleo, id=id, max_accepts=1, max_rejects=8, dbmask=2, strand_both=1 if strand_both else 0, **kw)
+    return params(is_nucleo=is_nucleo, id=id, max_accepts=1, max_rejects=8 if max_rejects is None else int(max_rejects), dbmask=2,
+                  strand_both=1 if strand_both else 0, **kw)
 
 
 class ClusterResult:

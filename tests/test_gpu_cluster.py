@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _cluster(c, r, batch=None):
     kw = {"big": c["big"]} if "big" in c else {}
-    p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", is_nucleo=not c.get("aa"), **kw)
+    p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", is_nucleo=not c.get("aa"), max_rejects=c.get("maxrejects"), **kw)
     old = os.environ.pop("UGS_CLUSTER_BATCH", None)
     if batch:
         os.environ["UGS_CLUSTER_BATCH"] = str(batch)
@@ -129,7 +129,7 @@ def test_c3_full_size_properties_and_prefix_parity():
     _same(g, o)
 
 
-@pytest.mark.parametrize("name", ["cl_both", "cl_sizein", "cl_sortlen2", "cl_aa_latch"])
+@pytest.mark.parametrize("name", ["cl_both", "cl_sizein", "cl_sortlen2", "cl_aa_latch", "cl_rej32"])
 def test_cli_cluster_fast_writes_the_reference_files(name, tmp_path):
     """the C++ driver end to end: FASTA in, -uc and -centroids out, byte-identical to the reference's files"""
     import subprocess
@@ -139,7 +139,7 @@ def test_cli_cluster_fast_writes_the_reference_files(name, tmp_path):
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
     ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
     extra = (["-sort", c["sort"]] if c.get("sort") else []) + [f for f in ("-sizein", "-sizeout") if c.get(f[1:])] + \
-        (["-minsize", str(c["minsize"])] if c.get("minsize") else [])
+        (["-minsize", str(c["minsize"])] if c.get("minsize") else []) + (["-maxrejects", str(c["maxrejects"])] if c.get("maxrejects") else [])
     subprocess.check_call([cli, "-cluster_fast", fa, "-id", str(c["id"]), "-strand", c["strand"], "-big", str(c.get("big", 100000)), "-uc", ucp,
                            "-centroids", cp] + extra, stderr=subprocess.DEVNULL)
     assert open(ucp).read() == uc

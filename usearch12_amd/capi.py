@@ -449,9 +449,11 @@ def udb_write(path, db, labels):
 
 
 # ---- cluster_fast (include/ugs.h ugs_cluster_*)
-def cluster_params(id=0.97, strand_both=False, is_nucleo=True, **kw):
+def cluster_params(id=0.97, strand_both=False, is_nucleo=True, max_rejects=None, **kw):
     p = params(is_nucleo=is_nucleo, id=id, strand_both=1 if strand_both else 0, **kw)
     _chk(lib().ugs_params_set_cluster(C.byref(p)))
+    if max_rejects is not None:              # -maxrejects on top of the command's defaults (1 .. 64)
+        p.max_rejects = int(max_rejects)
     return p
 
 
