@@ -79,9 +79,23 @@ CASES = {
     "deep_acc100":  dict(gen="hard", seed=50, n_fam=25, fam=120, q_n=150, aa=False, id=0.9, strand="plus", big=100, lmin=100, lmax=300, maxaccepts=100, maxrejects=32),
     "deep_aa":      dict(gen="hard", seed=51, n_fam=20, fam=100, q_n=100, aa=True, id=0.8, lmin=80, lmax=250, maxaccepts=0, maxrejects=0),
     "deep_aa_big":  dict(gen="hard", seed=52, n_fam=20, fam=100, q_n=120, aa=True, id=0.85, big=100, lmin=80, lmax=250, maxaccepts=1, maxrejects=200),
+    # options of the index and of the aligner that the other cases leave at their defaults (r5): -wordlength (udbparams.cpp), -stepwords / -bump
+    # (small-path sampling, udbusortedsearcher.cpp), -minhsp / -xdrop_nw / -hspw (hspfinder.cpp), -match / -mismatch (alnparams.cpp)
+    "opt_word6":    dict(gen="hard", seed=60, n_fam=250, fam=6, q_n=800, aa=False, id=0.9, strand="both", big=100, lmin=40, lmax=300, wordlength=6),
+    "opt_word7_s":  dict(gen="hard", seed=61, n_fam=250, fam=6, q_n=800, aa=False, id=0.95, strand="plus", lmin=40, lmax=300, wordlength=7),
+    "opt_word4_aa": dict(gen="hard", seed=62, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, big=100, lmin=30, lmax=250, wordlength=4),
+    "opt_step0_s":  dict(gen="hard", seed=63, n_fam=250, fam=6, q_n=800, aa=False, id=0.9, strand="plus", lmin=60, lmax=300, stepwords=0),
+    "opt_step3_s":  dict(gen="hard", seed=64, n_fam=250, fam=6, q_n=800, aa=False, id=0.9, strand="both", lmin=60, lmax=300, stepwords=3, bump=10),
+    "opt_bump90_s": dict(gen="hard", seed=65, n_fam=250, fam=6, q_n=800, aa=False, id=0.95, strand="plus", lmin=60, lmax=300, bump=90),
+    "opt_minhsp":   dict(gen="hard", seed=66, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="both", big=100, lmin=20, lmax=300, minhsp=24, xdrop_nw=4),
+    "opt_minhsp8":  dict(gen="hard", seed=67, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="plus", lmin=20, lmax=300, minhsp=8, xdrop_nw=16),
+    "opt_match":    dict(gen="hard", seed=68, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="plus", big=100, lmin=20, lmax=300, match=2.0, mismatch=-3.0),
+    "opt_hspw4":    dict(gen="hard", seed=69, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="both", big=100, lmin=20, lmax=300, hspw=4),
+    "opt_hspw2_aa": dict(gen="hard", seed=70, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, lmin=30, lmax=250, hspw=2, minhsp=10),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
+EXTRA_OPTS = ("wordlength", "stepwords", "bump", "minhsp", "xdrop_nw", "match", "mismatch", "hspw")      # reference option -> ugs_params field: golden_util.params_kw
 FILTER_OPTS = ("maxid", "mincols", "maxgaps", "query_cov", "max_query_cov", "target_cov", "max_target_cov", "maxdiffs", "mindiffs")
 
 
@@ -115,7 +129,7 @@ def ref_cmd(c, qfa, dbfa, prefix):
     for opt in ("big", "maxaccepts", "maxrejects", "band") + FILTER_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
-    for opt in ("termid", "termidd"):
+    for opt in ("termid", "termidd") + EXTRA_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
     for flag in ("fulldp", "gaforce", "hardmask"):

@@ -54,6 +54,10 @@ def params_kw(c):
         if opt in c:
             kw["align_flags"] = kw.get("align_flags", 0) | bit
             kw[opt] = c[opt]
+    for opt, field in (("wordlength", "word_len"), ("stepwords", "stepwords"), ("bump", "bump_pct"), ("minhsp", "minhsp"), ("xdrop_nw", "xdrop_nw"),
+                       ("match", "match"), ("mismatch", "mismatch"), ("hspw", "hsp_word_len")):
+        if opt in c:
+            kw[field] = c[opt]
     for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
         if opt in c:
             kw[opt] = c[opt]

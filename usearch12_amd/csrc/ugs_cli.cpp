@@ -3,6 +3,7 @@
 //
 //   ugs_cli -usearch_global q.fa -db db.fa|db.udb -id 0.97 -strand plus|both [-blast6out f] [-uc f]
 //           [-maxaccepts n] [-maxrejects n] [-big n] [-device n] [-batch n]
+//           [-wordlength n] [-stepwords n] [-bump n] [-hspw n] [-minhsp n] [-xdrop_nw x] [-band n] [-match x] [-mismatch x]
 //   ugs_cli -makeudb_usearch db.fa -output db.udb [-dbtype nt|aa]       (makeudb.cpp:27-66; index built on the GPU)
 //   ugs_cli -cluster_fast reads.fa -id 0.97 [-strand both] [-sort length|size] [-sizein] [-sizeout] [-minsize n] -uc c.uc -centroids c.fa   (clusterfast.cpp:37-138)
 //   ugs_cli -usearch_local q.fa -db db.fa|db.udb -evalue 1e-6 [-id ..] -strand plus|both -blast6out f
@@ -434,6 +435,7 @@ int main(int argc, char **argv)
   bool local_cmd = false; double evalue = -1; double xdrop_u = -1, xdrop_g = -1, ka_dbsize = -1; long maxhsps = -1, hspw = -1;
   int ngpus = 1;                                                     // -gpus N: devices device .. device+N-1, one host thread each
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 18; int dbtype = -1;
+  long wordlength = -1, bump = -1, minhsp = -1, band = -1; double xdrop_nw = -1, match = 0, mismatch = 0; bool match_set = false, mismatch_set = false;   // index / aligner options
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
@@ -448,6 +450,9 @@ int main(int argc, char **argv)
     else if (a == "-usearch_local") { qpath = val(); local_cmd = true; } else if (a == "-evalue") evalue = atof(val());
     else if (a == "-xdrop_u") xdrop_u = atof(val()); else if (a == "-xdrop_g") xdrop_g = atof(val()); else if (a == "-ka_dbsize") ka_dbsize = atof(val());
     else if (a == "-maxhsps") maxhsps = atol(val()); else if (a == "-hspw") hspw = atol(val());
+    else if (a == "-wordlength") wordlength = atol(val()); else if (a == "-bump") bump = atol(val()); else if (a == "-minhsp") minhsp = atol(val());
+    else if (a == "-band") band = atol(val()); else if (a == "-xdrop_nw") xdrop_nw = atof(val());
+    else if (a == "-match") { match = atof(val()); match_set = true; } else if (a == "-mismatch") { mismatch = atof(val()); mismatch_set = true; }
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
     else if (a == "-maxaccepts") maxacc = atoi(val()); else if (a == "-maxrejects") maxrej = atoi(val());
@@ -528,6 +533,7 @@ int main(int argc, char **argv)
     const bool nucleo = dbtype >= 0 ? dbtype != 0 : guess_nucleo(db);
     ugs_params p;
     ugs_params_init(&p, nucleo, 0.5);
+    if (wordlength > 0) p.word_len = (int32_t)wordlength;
     Searcher s(p, db, device);
     std::string labels;
     for (const std::string &l : db.labels) { labels += l; labels.push_back('\0'); }
@@ -587,6 +593,13 @@ int main(int argc, char **argv)
     }
   }
   if (hspw > 0) p.hsp_word_len = (int32_t)hspw;
+  if (wordlength > 0) p.word_len = (int32_t)wordlength;
+  if (bump >= 0) p.bump_pct = (uint32_t)bump;
+  if (minhsp >= 0) p.minhsp = (int32_t)minhsp;
+  if (band >= 0) p.band = (int32_t)band;
+  if (xdrop_nw >= 0) p.xdrop_nw = (float)xdrop_nw;
+  if (match_set) p.match = (float)match;
+  if (mismatch_set) p.mismatch = (float)mismatch;
   p.strand_both = nucleo && strand == "both";
   if (maxacc >= 0) p.max_accepts = maxacc;
   if (maxrej >= 0) p.max_rejects = maxrej;
