@@ -28,6 +28,13 @@ CASES = {
     # deep walks (r5): more candidates than the 64 a ranking pass keeps - families of 100, unlimited walks / -maxrejects 128 / -maxaccepts 80
     "loc_deep_nt":  dict(seed=48, n_fam=20, fam=100, q_n=80, aa=False, evalue=1e-6, strand="both", maxaccepts=0, maxrejects=0),
     "loc_deep_aa":  dict(seed=49, n_fam=20, fam=100, q_n=120, aa=True, evalue=1e-3, maxaccepts=80, maxrejects=128),
+    # options every other case leaves at their defaults (r5): -xdrop_u / -xdrop_g / -maxhsps / -hspw (localaligner2.cpp), -ka_dbsize (estats.cpp),
+    # -lopen / -lext (alnparams.cpp), -match / -mismatch
+    "loc_opt_nt":   dict(seed=51, n_fam=250, fam=6, q_n=700, aa=False, evalue=1e-6, strand="both", xdrop_u=8, xdrop_g=16, hspw=4),
+    "loc_opt_aa":   dict(seed=52, n_fam=250, fam=6, q_n=700, aa=True, evalue=1e-3, xdrop_u=24, xdrop_g=48, ka_dbsize=1e6, hspw=2),
+    "loc_opt_gap":  dict(seed=53, n_fam=250, fam=6, q_n=700, aa=False, evalue=1e-6, strand="plus", lopen=6.0, lext=2.0, maxaccepts=2, maxrejects=8),
+    "loc_opt_gap_aa": dict(seed=54, n_fam=250, fam=6, q_n=700, aa=True, evalue=1e-6, lopen=14.0, lext=0.5),
+    "loc_opt_match": dict(seed=55, n_fam=250, fam=6, q_n=700, aa=False, evalue=1e-6, strand="both", match=2.0, mismatch=-3.0, id=0.8, big=100),
     "loc_deep_big": dict(seed=50, n_fam=20, fam=100, q_n=100, aa=False, evalue=1e-6, strand="plus", id=0.8, big=100, maxaccepts=2, maxrejects=200),
 }
 
@@ -44,10 +51,13 @@ def ref_cmd(c, qfa, dbfa, prefix):
     cmd = [REF, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-blast6out", prefix + ".b6", "-threads", "1"]
     if not c["aa"]:
         cmd += ["-strand", c["strand"]]
-    for opt in ("id", "big", "maxaccepts", "maxrejects") + FILTER_OPTS:
+    for opt in ("id", "big", "maxaccepts", "maxrejects") + FILTER_OPTS + LOCAL_OPTS:
         if opt in c:
             cmd += ["-" + opt, str(c[opt])]
     return cmd
+
+
+LOCAL_OPTS = ("xdrop_u", "xdrop_g", "maxhsps", "ka_dbsize", "hspw", "lopen", "lext", "match", "mismatch")      # -> ugs_params: golden_util.local_params_kw
 
 
 USER_FIELDS = ("query+target+clusternr+evalue+id+fractid+dist+mid+pctpv+pctgaps+pairs+gaps+allgaps+qlo+qhi+tlo+thi+qlor+qhir+tlor+thir+"

@@ -107,6 +107,10 @@ def local_params_kw(c):
     kw = params_kw(c)
     kw["local_evalue"] = c["evalue"]
     kw["id"] = c.get("id")
+    for opt, field, sign in (("xdrop_u", "xdrop_u", 1), ("xdrop_g", "xdrop_g", 1), ("maxhsps", "max_hsps", 1), ("ka_dbsize", "ka_dbsize", 1), ("hspw", "hsp_word_len", 1),
+                             ("lopen", "local_open", -1), ("lext", "local_ext", -1), ("match", "match", 1), ("mismatch", "mismatch", 1)):
+        if opt in c:
+            kw[field] = sign * c[opt] if sign < 0 else c[opt]
     return kw
 
 

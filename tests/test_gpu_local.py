@@ -86,7 +86,7 @@ def test_cli_usearch_local_text_identical_to_reference(tmp_path):
     import os
     import subprocess
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
-    for name in ("loc_nt_both", "loc_aa_acc", "loc_nt_id"):
+    for name in ("loc_nt_both", "loc_aa_acc", "loc_nt_id", "loc_opt_nt", "loc_opt_aa", "loc_opt_gap", "loc_opt_gap_aa", "loc_opt_match"):
         c, db, qs, b6 = G.load_local(name)
         dbfa, qfa, out = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "o.b6")
         db.write_fasta(dbfa); qs.write_fasta(qfa)
@@ -96,7 +96,7 @@ def test_cli_usearch_local_text_identical_to_reference(tmp_path):
         cmd = [cli, "-usearch_local", qfa, "-db", dbfa, "-evalue", repr(c["evalue"]), "-blast6out", out, "-batch", "400"]
         if not c["aa"]:
             cmd += ["-strand", c["strand"]]
-        for opt in ("id", "big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS:
+        for opt in ("id", "big", "maxaccepts", "maxrejects") + G._mg.FILTER_OPTS + G._mgl.LOCAL_OPTS:
             if opt in c:
                 cmd += ["-" + opt, str(c[opt])]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)

@@ -436,6 +436,7 @@ int main(int argc, char **argv)
   int ngpus = 1;                                                     // -gpus N: devices device .. device+N-1, one host thread each
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 18; int dbtype = -1;
   long wordlength = -1, bump = -1, minhsp = -1, band = -1; double xdrop_nw = -1, match = 0, mismatch = 0; bool match_set = false, mismatch_set = false;   // index / aligner options
+  double lopen = -1, lext = -1;                                      // usearch_local gap penalties (positive, as the reference takes them)
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
@@ -452,6 +453,7 @@ int main(int argc, char **argv)
     else if (a == "-maxhsps") maxhsps = atol(val()); else if (a == "-hspw") hspw = atol(val());
     else if (a == "-wordlength") wordlength = atol(val()); else if (a == "-bump") bump = atol(val()); else if (a == "-minhsp") minhsp = atol(val());
     else if (a == "-band") band = atol(val()); else if (a == "-xdrop_nw") xdrop_nw = atof(val());
+    else if (a == "-lopen") lopen = atof(val()); else if (a == "-lext") lext = atof(val());
     else if (a == "-match") { match = atof(val()); match_set = true; } else if (a == "-mismatch") { mismatch = atof(val()); mismatch_set = true; }
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
@@ -588,6 +590,8 @@ int main(int argc, char **argv)
     if (xdrop_g >= 0) p.xdrop_g = (float)xdrop_g;
     if (ka_dbsize > 0) p.ka_dbsize = (float)ka_dbsize;
     if (maxhsps > 0) p.max_hsps = (uint32_t)maxhsps;
+    if (lopen >= 0) p.local_open = (float)-lopen;
+    if (lext >= 0) p.local_ext = (float)-lext;
     if (!pairspath.empty() || !qsegpath.empty() || !tsegpath.empty() || !trimpath.empty() || otutab_cmd || closedref_cmd) {
       fprintf(stderr, "-usearch_local writes -blast6out, -uc, -userout, -alnout, -matched/-notmatched and -dbmatched/-dbnotmatched only\n"); return 1;
     }
