@@ -92,10 +92,16 @@ CASES = {
     "opt_match":    dict(gen="hard", seed=68, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="plus", big=100, lmin=20, lmax=300, match=2.0, mismatch=-3.0),
     "opt_hspw4":    dict(gen="hard", seed=69, n_fam=250, fam=6, q_n=800, aa=False, id=0.85, strand="both", big=100, lmin=20, lmax=300, hspw=4),
     "opt_hspw2_aa": dict(gen="hard", seed=70, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, lmin=30, lmax=250, hspw=2, minhsp=10),
+    # -dbmask none (everything upper case: the lower-case stretches of the hard set become ordinary letters) / user (letters as given: lower case
+    # voids words and never counts as identical), makeudb.cpp:11-25, seqdb.cpp:415-449
+    "opt_mask_none": dict(gen="hard", seed=71, n_fam=250, fam=6, q_n=800, aa=False, id=0.9, strand="both", big=100, lmin=40, lmax=300, dbmask="none"),
+    "opt_mask_user": dict(gen="hard", seed=72, n_fam=250, fam=6, q_n=800, aa=False, id=0.9, strand="plus", lmin=40, lmax=300, dbmask="user"),
+    "opt_mask_none_aa": dict(gen="hard", seed=73, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, big=100, lmin=30, lmax=250, dbmask="none"),
+    "opt_mask_user_aa": dict(gen="hard", seed=74, n_fam=200, fam=6, q_n=600, aa=True, id=0.7, lmin=30, lmax=250, dbmask="user"),
     "hard_filt_aa": dict(gen="hard", seed=32, n_fam=300, fam=8, q_n=1000, aa=True, id=0.8, big=100, maxaccepts=2, maxrejects=16,
                          query_cov=0.95, maxgaps=4, mindiffs=3),
 }
-EXTRA_OPTS = ("wordlength", "stepwords", "bump", "minhsp", "xdrop_nw", "match", "mismatch", "hspw")      # reference option -> ugs_params field: golden_util.params_kw
+EXTRA_OPTS = ("wordlength", "stepwords", "bump", "minhsp", "xdrop_nw", "match", "mismatch", "hspw", "dbmask")      # reference option -> ugs_params field: golden_util.params_kw
 FILTER_OPTS = ("maxid", "mincols", "maxgaps", "query_cov", "max_query_cov", "target_cov", "max_target_cov", "maxdiffs", "mindiffs")
 
 

@@ -58,6 +58,8 @@ def params_kw(c):
                        ("match", "match"), ("mismatch", "mismatch"), ("hspw", "hsp_word_len")):
         if opt in c:
             kw[field] = c[opt]
+    if "dbmask" in c:                   # -dbmask none = everything upper case (0), user = letters as given (2)
+        kw["dbmask"] = {"none": 0, "user": 2}[c["dbmask"]]
     for opt in _mg.FILTER_OPTS:         # optional accept filters (params() sets the filter_mask bit)
         if opt in c:
             kw[opt] = c[opt]

@@ -131,7 +131,7 @@ def test_cli_text_identical_to_reference(tmp_path):
     cli = os.path.join(os.path.dirname(capi.LIB_PATH), "ugs_cli")
     for name in ("hard_both", "hard_aa", "hard_filt", "hard_filt_s", "hard_fulldp", "hard_gaforce", "hard_hardmask", "hard_termid", "hard_termidd",
                  "hard_noid", "hard_noid_s", "deep_all_s", "deep_acc100", "deep_rej256", "deep_aa",          # (deep_*: walks past 64 candidates, > 64 hits per query)
-                 "hard_band0", "opt_word6", "opt_word7_s", "opt_word4_aa", "opt_step3_s", "opt_bump90_s", "opt_minhsp", "opt_match", "opt_hspw4", "opt_hspw2_aa"):
+                 "hard_band0", "opt_word6", "opt_word7_s", "opt_word4_aa", "opt_step3_s", "opt_bump90_s", "opt_minhsp", "opt_match", "opt_hspw4", "opt_hspw2_aa", "opt_mask_none", "opt_mask_user_aa"):
         c, db, qs, b6, uc = G.load(name)
         dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
         db.write_fasta(dbfa); qs.write_fasta(qfa)

@@ -436,6 +436,7 @@ int main(int argc, char **argv)
   int ngpus = 1;                                                     // -gpus N: devices device .. device+N-1, one host thread each
   double id = -1; int maxacc = -1, maxrej = -1, device = 0; long big = -1; size_t batch = 1u << 18; int dbtype = -1;
   long wordlength = -1, bump = -1, minhsp = -1, band = -1; double xdrop_nw = -1, match = 0, mismatch = 0; bool match_set = false, mismatch_set = false;   // index / aligner options
+  std::string dbmask;                                               // -dbmask none | user | fastnucleo | fastamino | default (makeudb.cpp:11-25)
   double lopen = -1, lext = -1;                                      // usearch_local gap penalties (positive, as the reference takes them)
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -454,6 +455,7 @@ int main(int argc, char **argv)
     else if (a == "-wordlength") wordlength = atol(val()); else if (a == "-bump") bump = atol(val()); else if (a == "-minhsp") minhsp = atol(val());
     else if (a == "-band") band = atol(val()); else if (a == "-xdrop_nw") xdrop_nw = atof(val());
     else if (a == "-lopen") lopen = atof(val()); else if (a == "-lext") lext = atof(val());
+    else if (a == "-dbmask") dbmask = val();
     else if (a == "-match") { match = atof(val()); match_set = true; } else if (a == "-mismatch") { mismatch = atof(val()); mismatch_set = true; }
     else if (a == "-usearch_global") qpath = val(); else if (a == "-db") dbpath = val(); else if (a == "-id") id = atof(val());
     else if (a == "-strand") strand = val(); else if (a == "-blast6out") b6path = val(); else if (a == "-uc") ucpath = val();
@@ -614,6 +616,12 @@ int main(int argc, char **argv)
   p.max_target_cov = filt.max_target_cov; p.maxdiffs = filt.maxdiffs; p.mindiffs = filt.mindiffs;
   p.pair_mask = filt.pair_mask; p.min_sizeratio = filt.min_sizeratio; p.minqt = filt.minqt; p.maxqt = filt.maxqt; p.minsl = filt.minsl;
   p.maxsl = filt.maxsl; p.abskew = filt.abskew; p.align_flags = filt.align_flags; p.termid = filt.termid; p.termidd = filt.termidd;
+  if (!dbmask.empty()) {
+    std::string m = dbmask; for (char &ch : m) ch = (char)tolower((unsigned char)ch);
+    if (m == "none") p.dbmask = 0; else if (m == "user") p.dbmask = 2;
+    else if (m == "default" || m == (nucleo ? "fastnucleo" : "fastamino")) p.dbmask = 1;
+    else { fprintf(stderr, "-dbmask %s is not supported (none, user, default, %s)\n", dbmask.c_str(), nucleo ? "fastnucleo" : "fastamino"); return 1; }
+  }
   if (hardmask) p.dbmask = 3;
   if (from_udb) { p.dbmask = 2; p.word_len = (int32_t)udb_word; }   // stored letters are the masked ones (makeudb.cpp:54)
   auto open_out = [](const std::string &path) -> FILE * {
