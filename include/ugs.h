@@ -308,7 +308,7 @@ int ugs_debug_deep_walks(const ugs_batch *b, uint64_t *parked_units, uint64_t *l
  *   UGS_RANK2=0|1           bitmap ranking kernel off / on wherever the index allows it (default: on for dense Big-path indexes)
  *   UGS_R2_G=n UGS_R2_KCAP=n UGS_R2_WAVES=n   its partition size (multiple of 8192), kept-key capacity, waves per CU
  *   UGS_R3=0|1 UGS_R3_SP=n UGS_R3_PPS=n       sparse (protein) Big-path index: 0 = k_rank2g instead of k_rank3g; k_rank3g's partitions per
- *                           super-partition (default: per unit, so that a super-partition holds ~ UGS_R3_PPS = 1536 of its postings)
+ *                           super-partition (default: per unit, so that a super-partition holds ~ UGS_R3_PPS = 4096 of its postings)
  *   UGS_DEBUG_SYNC=1 UGS_PHASE_CLOCKS=1       finish and log every stage / print the kernels' phase clocks with the stats
  * (ugs_cluster_fast reads UGS_CLUSTER_BATCH / UGS_CLUSTER_PROFILE at its start; ugs_cli reads UGS_CLI_PROFILE / UGS_CLI_FORCE_GATHER.)
  */

@@ -69,6 +69,21 @@ def test_protein_queries_with_repeats_and_full_word_buckets():
     both(db, qs, aa=True, ident=0.8)
 
 
+def test_long_protein_queries_on_the_small_path():
+    """1 500-residue proteins against a small database: the small path samples EVERY word (1 496 rows per query, counts beyond 255), and a
+    16-bit counter table of one partition no longer fits the LDS beside the row lists - the plan sizes the tables for 8 bits and the
+    kernel walks each partition in sub-ranges (an ad-hoc sweep of the fuzzer's long-sequence mode found the refusal, seed 463); same
+    hits as the oracle, both strands of the nt twin as well"""
+    for aa, kw in ((True, dict(max_accepts=4, max_rejects=16, bump_pct=10)), (False, dict(strand_both=1, max_accepts=2, max_rejects=8))):
+        db, qs = synth.make_hard(77 + int(aa), 8, 10, 30, lmin=1500, lmax=1520, aa=aa)
+        g = capi.UgsDB(capi.params(is_nucleo=not aa, id=0.9, **kw), db.seqs, db.offs, device=0).search(qs.seqs, qs.offs)
+        o = orc.OrcDB(orc.params(is_nucleo=not aa, id=0.9, **kw), db.seqs, db.offs).search(qs.seqs, qs.offs, nthreads=4)
+        assert len(g[0]) > 20 and np.array_equal(g[1], o[1])
+        for f in g[0].dtype.names:
+            if f != "cigar_off":
+                assert np.array_equal(g[0][f], o[0][f]), (aa, f)
+
+
 def test_query_beyond_envelope_is_an_error_not_a_crash():
     rng = np.random.default_rng(3)
     dseq, doff = pack(["".join("ACGT"[i] for i in rng.integers(0, 4, 300))])

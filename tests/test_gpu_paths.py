@@ -252,6 +252,20 @@ def test_filter_kernel_super_partition_sizes_and_oracle(aa_small, sp):
         assert n[qi] == m and np.array_equal(cand[qi, :m], oc[:m]) and np.array_equal(cnt[qi, :m], occ[:m]), qi
 
 
+def test_filter_kernel_keeps_an_index_with_long_rows(aa_small):
+    """an index whose longest rows pass the long-row latch (forced here; a skewed protein dictionary in the field) used to fall back to
+    k_rank as a whole: k_rank3g has no sub-row limit and keeps it - same candidates as k_rank's long-row instantiation, nothing deferred"""
+    db, qs = aa_small
+    a = _search(db, qs, {"UGS_RANK2": "0", "UGS_LONGROWS": "1"}, is_nucleo=False, id=0.8)[0]
+    b = _search(db, qs, {"UGS_LONGROWS": "1"}, is_nucleo=False, id=0.8)[0]
+    c = _search(db, qs, {"UGS_LONGROWS": "1", "UGS_R3": "0"}, is_nucleo=False, id=0.8)[0]
+    assert a[1]["r2_launched"] == 0 and c[1]["r2_launched"] == 0                 # (k_rank2g stays out of long-row indexes)
+    assert b[1]["r2_kernel"] == "k_rank3g" and b[1]["r2_units"] + b[1]["deferred"] == qs.n and b[1]["deferred"] <= qs.n // 100
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    assert a[0] == b[0] == c[0]
+
+
 @pytest.mark.parametrize("r3", SPARSE_KERNELS)
 def test_gather_kernel_defers_units_of_abundant_families(r3):
     """families of near-identical sequences give sub-rows far longer than a quad (300 copies: > 255 postings of a row in one partition;

@@ -752,8 +752,8 @@ static int plan_launch(ugs_batch *b)
     const uint32_t nu = maxNu - k;
     ns_typ = std::max(ns_typ, db->v.big ? (nu + db->step[nu] - 1) / db->step[nu] : nu);
   }
-  const int bits = ns_typ <= 15 ? 4 : (ns_typ <= 255 ? 8 : 16);
-  const size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;      // + 64 dummy words per wave
+  int bits = ns_typ <= 15 ? 4 : (ns_typ <= 255 ? 8 : 16);
+  size_t tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;            // + 64 dummy words per wave
   // LDS cache of the sampled rows' partition-table rows (hot configuration: <= 15 rows, 4-bit counters)
   uint32_t part_words = 0;
   // which instantiation will run (ugs_rank.hip rank_kernel): the LDS carve and the residency differ between them
@@ -773,6 +773,15 @@ static int plan_launch(ugs_batch *b)
   const size_t fixed = ugs_rank_fixed_lds(ns_max, b->max_qlen, part_words, hot);
   int wpb = 4;
   while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
+  if (fixed + wpb * tbl_bytes > LDS_MAX && bits == 16) {
+    // queries of more than 255 sampled words (the small path samples every word: a 1 500-residue protein) whose 16-bit counter table of one
+    // partition does not fit beside their row lists: a table of half the size - the kernel (the same 8 / 16-bit instantiation) walks a
+    // partition in sub-ranges then, as it does for any unit that needs wider counters than the batch's typical query (scan_generic)
+    bits = 8;
+    tbl_bytes = ((size_t)db->v.gsize * bits) / 8 + 256;
+    wpb = 4;
+    while (wpb > 1 && fixed + wpb * tbl_bytes > LDS_MAX) wpb >>= 1;
+  }
   if (fixed + wpb * tbl_bytes > LDS_MAX) { ugs_set_error("ranking LDS footprint %zu exceeds 160 KiB", fixed + wpb * tbl_bytes); return UGS_E_ENVELOPE; }
   // (the HOT kernel keeps its selection scratch, (4 * UGS_KMAX + 8) keys, inside the counter tables at the end of the carve: with a partition
   // size forced far below the planner's the tables alone would not hold it - the allocation then covers the scratch)
@@ -833,22 +842,25 @@ static int plan_launch(ugs_batch *b)
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
   b->r2.gather = 0;
-  if (db->v.part2 && db->r2_gather && bits <= 8 && ns_typ <= 63 && !b->rl.longrows && b->K <= 64) {
+  // (k_rank2g reads a sub-row as at most 255 postings and 256 quads per partition: an index with long rows keeps k_rank there.  k_rank3g has
+  // no such limit - a heavy super-partition is halved, a unit it cannot take is deferred - so a skewed protein dictionary stays with it)
+  if (db->v.part2 && db->r2_gather && bits <= 8 && ns_typ <= 63 && (!b->rl.longrows || db->tune.r3 != 0) && b->K <= 64) {
     // (a sparse index gives a unit tens of count-2 targets, not hundreds: a kept-key list of 4 K, and the eleventh wave per CU that buys)
     const uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(116u, 4u * b->K - 12u);
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
     b->r2.clcap = 0; b->r2.W = 0; b->r2.gather = 1;
-    b->r2.lds = (uint32_t)ugs_rank2g_lds(db->v.gsize2, kcap, db->v.np2);
     int wcu;
     if (db->tune.r3 != 0) {
-      // k_rank3g (ugs_rank3.hip): two filter passes per super-partition of ~ 262 144 targets instead of an exact bitmap per partition
+      // k_rank3g (ugs_rank3.hip, the default): two filter passes per super-partition instead of an exact bitmap per partition
       b->r2.gather = 2;
       b->r2.W = db->tune.r3_sp ? (uint32_t)db->tune.r3_sp : 0u;           // 0: per unit, from its postings (UgsRank2Params::clcap per super-partition)
       b->r2.clcap = db->tune.r3_pps ? (uint32_t)db->tune.r3_pps : 4096u;
       b->r2.lds = (uint32_t)ugs_rank3g_lds(kcap);
       wcu = std::max(1, std::min(ugs_rank3g_blocks_per_cu(b->r2.lds), 32));
-    } else
-    wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 1), 32));
+    } else {
+      b->r2.lds = (uint32_t)ugs_rank2g_lds(db->v.gsize2, kcap, db->v.np2);
+      wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 1), 32));
+    }
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   } else

@@ -26,7 +26,7 @@ struct UgsTune {
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
   int r3, r3_sp, r3_pps;        // UGS_R3 / UGS_R3_SP / UGS_R3_PPS  sparse index: -1 unset (= k_rank3g), 0 = k_rank2g; k_rank3g: partitions per super-partition
-                                //                            (0 unset = per unit, from its postings), postings per super-partition aimed at (0 unset = 1536)
+                                //                            (0 unset = per unit, from its postings), postings per super-partition aimed at (0 unset = 4096)
   bool batch_streams;           // UGS_BATCH_STREAMS=1        every batch object runs its kernels on a stream of its own (experiment: ranking of one batch beside the alignment of another)
 };
 UgsTune ugs_tune_read();
