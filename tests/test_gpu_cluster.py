@@ -73,6 +73,41 @@ def test_gpu_cluster_fast_equals_oracle(seed, n, species, both, big, idv, batch)
     assert res.stats.batches >= 1
 
 
+def _cluster_fuzz_config(seed):
+    rng = np.random.default_rng([seed, 0xC1F5])
+    aa = bool(rng.random() < 0.3)
+    c = dict(id=float(rng.choice([0.6, 0.8, 0.9] if aa else [0.8, 0.9, 0.95, 0.97, 0.99])), strand="both" if (not aa and rng.random() < 0.4) else "plus",
+             big=int(rng.choice([30, 120, 400, 100000])))
+    if aa:
+        c["aa"] = 1
+    if rng.random() < 0.4:
+        c["maxrejects"] = int(rng.choice([1, 2, 4, 16, 32, 64]))
+    n = int(rng.integers(300, 2500))
+    batch = None if rng.random() < 0.3 else int(rng.choice([1, 7, 37, 128, 700]))
+    if aa or rng.random() < 0.3:
+        lmin = int(rng.choice([12, 40, 120])); lmax = lmin + int(rng.choice([0, 60, 300]))
+        _, r = synth.make_hard(9000 + seed, int(rng.integers(3, 120)), int(rng.integers(1, 10)), n, lmin=lmin, lmax=lmax, aa=aa)
+    else:
+        r = synth.make_reads(9000 + seed, n, n_species=int(rng.integers(1, 60)), dup_frac=float(rng.choice([0.0, 0.03, 0.3])),
+                             p_sub=float(rng.choice([0.005, 0.01, 0.04])))
+    if c["strand"] == "both":
+        r = synth.revcomp_some(seed, r)
+    sort = [None, None, "length", "size"][int(rng.integers(0, 4))]
+    return c, r, batch, sort, aa
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("UGS_CFUZZ_FROM", 0)), int(os.environ.get("UGS_CFUZZ_TO", 12))))
+def test_gpu_cluster_fast_random_configuration_equals_oracle(seed):
+    """cluster_fast fuzz (r5): nt reads / variable-length families / protein, both strands, -maxrejects 1 .. 64, -sort, latch sizes and device
+    batch sizes at random - every array and hit record of the device loop against the oracle's serial loop"""
+    c, r, batch, sort, aa = _cluster_fuzz_config(seed)
+    c = dict(c, sort=sort)
+    res = _cluster(c, r, batch)
+    o = orc.cluster_fast(orc.cluster_params(c["id"], strand_both=c["strand"] == "both", is_nucleo=not aa, max_rejects=c.get("maxrejects"), big=c["big"]),
+                         r.seqs, r.offs, sort=sort, size_in=orc.label_sizes(r.labels()))
+    _same(res, o)
+
+
 def test_db_append_equals_building_at_once():
     """ugs_db_append: a database grown in three steps searches exactly like one built from all sequences"""
     db = synth.make_db(9, 3000, 200)
