@@ -16,8 +16,12 @@ before it; both are inside the timed region.
   --workload C4  BASELINE.json configs[3]: 10M x 250 nt queries split into N contiguous shards vs a 5M-sequence DB
          (STRONG scaling; a 5M-sequence index makes every query read 5x the postings of C2, so its lines compare with
          `--gpus 1 --workload C4`, not with the C2 lines).
-`python bench.py --gpus N` starts its N ranks itself (torch.distributed.run on 127.0.0.1) when it is not already
-running under a launcher, and refuses to run when the launcher's world size differs from --gpus.
+`python bench.py --gpus N` starts its N ranks itself (one process per GPU, 127.0.0.1) when it is not already running under a launcher
+(the driver's `python -m torch.distributed.run ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), and
+refuses to run when the launcher's world size differs from --gpus.  The RANK PROCESSES never import torch: torch's wheel bundles a HIP
+runtime and an RCCL of its own under the system libraries' SONAMEs (usearch12_amd/hostgroup.py), so a rank rendezvouses over plain
+sockets, runs ONE HIP runtime and ONE RCCL - the system ones libugs.so / libugs_rccl.so link - and reports the libraries it has mapped
+(detail.runtime_libs); the barriers of the timed region are the socket barrier + ugs_device_synchronize (= hipDeviceSynchronize).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -38,11 +42,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-class DevArray:
-    """Expose a raw HIP device pointer to torch through __cuda_array_interface__ (no copy)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+def runtime_libs():
+    """the HIP / HSA / RCCL libraries this process has mapped (from /proc/self/maps) and whether torch was imported: a rank must hold
+    exactly one of each - two copies of a runtime in one process corrupt each other's heap (usearch12_amd/hostgroup.py)"""
+    import re
+    found = {}
+    try:
+        for ln in open("/proc/self/maps"):
+            m = re.search(r"(/\S*/(libamdhip64|libhsa-runtime64|librccl)[^/\s]*)$", ln.strip())
+            if m:
+                found.setdefault(m.group(2), set()).add(os.path.realpath(m.group(1)))
+    except OSError:
+        pass
+    out = {k: sorted(v) for k, v in found.items()}
+    out["torch_imported"] = "torch" in sys.modules
+    return out
 
 
 def blast6_lines(capi, hits, qlabel, tlabel):
@@ -312,9 +326,9 @@ def main():
                     "auto = all three on a default one-GPU C2 run, none otherwise")
     ap.add_argument("--emulate-world", type=int, default=8, help="one-GPU C2 runs: strong-scaling proxy - rank 0's step at 1/N of the batch with the "
                     "N-rank gather (loopback transport), detail.strong_scaling_proxy; 0 = off")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo: functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, "
-                         "tables travel through the host) - not a measurement")
+    ap.add_argument("--backend", choices=["nccl", "host", "gloo"], default="nccl",
+                    help="nccl: the product's gather over RCCL (libugs_rccl.so), the measurement.  host (old name: gloo): functional dry run of "
+                         "the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, tables travel through the host) - not a measurement")
     args = ap.parse_args()
 
     # ONE line on stdout: whatever the libraries below print there (RCCL's version banner at communicator creation, for one) goes to
@@ -324,12 +338,27 @@ def main():
     os.dup2(2, 1)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.call(cmd, env=env, stdout=real_stdout))
+        # not under a launcher: start the N ranks ourselves (one process per GPU; RCCL over xGMI between them)
+        port = free_port()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=real_stdout))
+        rc = 0
+        while procs:                                                # a rank that fails takes the others with it (they would wait in a barrier)
+            time.sleep(0.05)
+            for p_ in list(procs):
+                r_ = p_.poll()
+                if r_ is None:
+                    continue
+                procs.remove(p_)
+                if r_ != 0 and rc == 0:
+                    rc = abs(r_) or 1
+                    for q_ in procs:
+                        q_.terminate()
+        sys.exit(rc)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL between processes needs it on this driver)
     rank = int(os.environ.get("RANK", "0"))
@@ -337,24 +366,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to report a mislabelled line" % (args.gpus, world))
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    cdev = "cpu" if args.backend == "gloo" else "cuda"
+    if args.backend == "gloo":
+        args.backend = "host"                                       # (the old name of the dry-run transport)
 
     from usearch12_amd import capi, synth, multigpu
     from usearch12_amd.build import csrc_hash
+    from usearch12_amd.hostgroup import SocketGroup
     csrc_sha = csrc_hash()
+    capi.lib()
+    group = None
+    if world > 1:
+        ndev = capi.device_count()
+        if args.backend == "host":
+            local_rank = local_rank % max(ndev, 1)                  # dry run: the ranks share the GPUs there are
+        elif local_rank >= ndev:
+            sys.exit("bench.py rank %d: LOCAL_RANK %d but %d GPU(s) visible (use --backend host for a functional dry run on fewer GPUs)" % (rank, local_rank, ndev))
+        group = SocketGroup(rank, world)
 
     workload = args.workload if args.workload != "auto" else "C2"
     seed = 2 if workload == "C2" else 4
@@ -383,7 +410,7 @@ def main():
             db0 = synth.make_db(seed, db_n, args.length)
             np.save(tag + "_seqs.npy", db0.seqs); np.save(tag + "_offs.npy", db0.offs)
             del db0
-        dist.barrier()
+        group.barrier()
         db = synth.SeqSet(np.load(tag + "_seqs.npy", mmap_mode="r"), np.load(tag + "_offs.npy", mmap_mode="r"), lambda i: "t%d" % i)
     else:
         db = synth.make_db(seed, db_n, args.length)
@@ -399,33 +426,32 @@ def main():
     for q in qsets:                                                 # page-locked once: uploads are then true async DMA
         capi._chk(capi.lib().ugs_host_register(q.seqs.ctypes.data, q.seqs.nbytes))
     if world > 1:
-        dist.barrier()                                              # every rank has built its index and its queries from the mapped file
+        group.barrier()                                             # every rank has built its index and its queries from the mapped file
         if rank == 0:
             os.remove(tag + "_seqs.npy"); os.remove(tag + "_offs.npy")
-    # ---- the exchange.  nccl backend (the measurement): the product's C++ gather over its own RCCL communicator; the id
-    # travels through torch.distributed, which is otherwise only the launcher's rendezvous, barrier and max-reduction.
-    # gloo backend (dry run on a box with fewer GPUs than ranks): torch.distributed gathers through the host.
+    # ---- the exchange.  nccl backend (the measurement): the product's C++ gather over its own RCCL communicator; the unique id
+    # travels through the rank group, which is otherwise only rendezvous, barrier and max-reduction.  A rank without a communicator
+    # FAILS the run (r5 fell back to another gather silently: the line would then not have measured the product's).
+    # host backend (dry run on a box with fewer GPUs than ranks): every rank fetches its table, the tables travel through the host.
     comm = None
-    gather_note = None
     use_cpp_gather = (world > 1 and args.backend == "nccl") or (world == 1 and args.force_gather)
     if use_cpp_gather:
-        ids = [capi.UgsComm.unique_id() if rank == 0 else None]
+        uid = capi.UgsComm.unique_id() if rank == 0 else None
         if world > 1:
-            dist.broadcast_object_list(ids, src=0)
+            uid = group.broadcast(uid, 0)
         comm_err = None
         try:
-            comm = capi.UgsComm.init_rank(ids[0], rank, world, local_rank)
-        except Exception as e:                                      # (reported in the line; the ranks agree on the path below)
+            comm = capi.UgsComm.init_rank(uid, rank, world, local_rank)
+        except Exception as e:
             comm_err = "%s: %s" % (type(e).__name__, e)
-        if world > 1:
-            okt = torch.tensor([0 if comm is None else 1], device=cdev, dtype=torch.int32)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if int(okt.item()) == 0:                                # some rank has no communicator: every rank gathers through torch.distributed
-                sys.stderr.write("bench.py rank %d: C++ communicator unavailable (%s); gathering through torch.distributed\n" % (rank, comm_err))
-                comm = None
-                gather_note = "torch.distributed (%s) - the product's communicator could not be created on every rank" % args.backend
-        elif comm is None:
-            raise RuntimeError(comm_err)
+        errs = group.allgather(comm_err) if world > 1 else [comm_err]
+        if any(errs):
+            sys.exit("bench.py rank %d: the product's communicator (ugs_comm_init_rank, libugs_rccl.so) could not be created on every rank: %r" % (rank, errs))
+    libs = runtime_libs()
+    all_libs = group.allgather(libs) if world > 1 else [libs]
+    for r_, l_ in enumerate(all_libs):
+        if l_["torch_imported"] or any(len(l_.get(k, [])) > 1 for k in ("libamdhip64", "libhsa-runtime64", "librccl")):
+            sys.exit("bench.py: rank %d maps more than one copy of a GPU runtime library (or imported torch): %r" % (r_, l_))
     if comm is not None:
         for b in bats:
             b.set_query_base(lo)                                    # the search's own grouping stamps global query ids
@@ -442,16 +468,18 @@ def main():
     t_upload = time.time() - t0
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        """both sides of the timed region: every rank's device idle, then all ranks together"""
+        capi._chk(capi.lib().ugs_device_synchronize(local_rank))
+        if group is not None:
+            group.barrier()
+            capi._chk(capi.lib().ugs_device_synchronize(local_rank))
 
     t_parts = {"search_sync": 0.0, "fetch": 0.0, "gather": 0.0, "upload_issue": 0.0, "sync_wait": 0.0, "gather_exchange": 0.0, "gather_d2h": 0.0}
     state = {"i": 0}
 
     def collect(b):
         """the hit table of a synced batch to the host: plain fetch (one GPU), the C++ gather to rank 0 (N ranks over RCCL),
-        or torch.distributed through the host (gloo dry run)"""
+        or the rank group through the host (dry run)"""
         if comm is not None:
             tg = time.time()
             try:
@@ -467,21 +495,18 @@ def main():
             ex, d2h = comm.last_times()
             t_parts["gather_exchange"] += ex; t_parts["gather_d2h"] += d2h
             return got
-        if dist is None:
+        if group is None:
             tf = time.time()
             out = b.fetch(reuse=True)
             t_parts["fetch"] += time.time() - tf
             return out
-        tg = time.time()
-        (ph, bh), (pn, bn), (pc, bc) = b.device_results(query_base=lo)   # compacted + global query ids on device
-        t_h = torch.as_tensor(DevArray(ph, bh), device="cuda") if bh else torch.zeros(0, dtype=torch.uint8, device="cuda")
-        t_n = torch.as_tensor(DevArray(pn, bn), device="cuda")
-        t_c = torch.as_tensor(DevArray(pc, bc), device="cuda") if bc else torch.zeros(0, dtype=torch.uint8, device="cuda")
-        if cdev == "cpu":
-            t_h, t_n, t_c = t_h.cpu(), t_n.cpu(), t_c.cpu()
-        got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, rank, world, dst=0)
+        tg = time.time()                                             # host transport (dry run): fetch, global query ids, gather through the rank group
+        h, nh, pool = b.fetch(reuse=True)
+        h = h.copy()
+        h["query"] += np.uint32(lo)
+        got = multigpu.gather_tables(group, h, nh, pool, dst=0)
         t_parts["gather"] += time.time() - tg
-        return multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3]) if rank == 0 else None
+        return multigpu.merge_tables(*got) if rank == 0 else None
 
     def step(last):
         """step i of a run: the search of step i + 1 is enqueued BEHIND step i's kernels before the host waits for step i (the GPU never
@@ -536,21 +561,18 @@ def main():
     elapsed, stats, khits, out = timed_steps(args.steps, args.warmup)
     n_hits_main = int(len(out[0])) if out is not None else 0    # (the table lives in buffers the batch objects own)
     per_rank = None
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if group is not None:
+        elapsed = group.max(elapsed)                                 # the slowest rank's clock between the two barriers
         ns = max(args.steps, 1)
-        mine = torch.tensor([float(np.mean([s["ms_rank"] for s in stats])), float(np.mean([s["ms_align"] for s in stats])),
-                             float(np.mean([s["ms_rank_setup"] for s in stats])), 1000.0 * t_parts["gather"] / (ns + 1),
-                             1000.0 * t_parts["gather_exchange"] / (ns + 1), 1000.0 * t_parts["gather_d2h"] / (ns + 1),
-                             1000.0 * t_parts["sync_wait"] / ns, 1000.0 * t_parts["search_sync"] / ns, float(shard_n)], device=cdev, dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        mine = [float(np.mean([s["ms_rank"] for s in stats])), float(np.mean([s["ms_align"] for s in stats])),
+                float(np.mean([s["ms_rank_setup"] for s in stats])), 1000.0 * t_parts["gather"] / (ns + 1),
+                1000.0 * t_parts["gather_exchange"] / (ns + 1), 1000.0 * t_parts["gather_d2h"] / (ns + 1),
+                1000.0 * t_parts["sync_wait"] / ns, 1000.0 * t_parts["search_sync"] / ns, float(shard_n)]
+        allr = group.allgather(mine)
         # ms_gather: host time inside one gather call (exchange over xGMI + rank 0's device-to-host copies); it runs beside the next
         # step's kernels, ms_sync_wait_after = how long that step's kernels still ran when the gather had returned (0 = exposed)
         per_rank = [dict(zip(("ms_rank", "ms_align", "ms_rank_setup", "ms_gather", "ms_gather_exchange", "ms_gather_d2h",
-                              "ms_sync_wait_after", "ms_step_host", "queries"), [float(x) for x in t.tolist()])) for t in allr]
+                              "ms_sync_wait_after", "ms_step_host", "queries"), [float(x) for x in t])) for t in allr]
 
     steps = max(args.steps, 1)
     value = total_q * steps / elapsed
@@ -717,7 +739,7 @@ def main():
         n_hits = n_hits_main
         # (the CPU baseline is a single-GPU-run item - rank 0 at N=1, measured above: the other ranks of a multi-GPU run would only wait for it)
         how = ("ugs_gather_results (libugs_rccl.so: ncclAllGather of sizes + grouped ncclSend/ncclRecv), issued beside the next step's kernels"
-               if comm is not None else (gather_note or ("torch.distributed gloo through the host (dry run)" if dist is not None else "none (one GPU: plain fetch)")))
+               if comm is not None else ("host transport: every rank fetches, the tables travel through the rank group's sockets (dry run, not a measurement)" if group is not None else "none (one GPU: plain fetch)"))
         if workload == "C2":
             wl = ("C2: usearch_global %d x %d nt queries per GPU and step vs %d-seq DB, -id %.2f -strand plus, reference defaults (maxaccepts 1, "
                   "maxrejects 32, Big ranking path); every step uploads and searches a batch different from the previous one%s" %
@@ -760,7 +782,7 @@ def main():
                             "issue_roofline": issue_roofline("k_align", ms_align)}},
             "cpu_baseline": cb,
             "parity_sample": parity,
-            "detail": {"csrc_sha16": csrc_sha, "other_configs": others, "strong_scaling_proxy": proxy,
+            "detail": {"csrc_sha16": csrc_sha, "runtime_libs": all_libs, "other_configs": others, "strong_scaling_proxy": proxy,
                        "ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),
                        "pairs_aligned_per_query": st["pairs_aligned"] / max(qs.n, 1),
@@ -779,9 +801,9 @@ def main():
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define UGS_ABI_VERSION 5   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
+#define UGS_ABI_VERSION 6   /* 2: accept filters in ugs_params, setup-kernel time in ugs_batch_stats; 3: usearch_local mode
                              * (ugs_params.local..., ugs_hit.raw_score/flags); 4: ugs_db_append, cluster_fast (ugs_cluster_*);
                              * 5: ugs_batch_upload is asynchronous (lifetime rule at its declaration), max_accepts / max_rejects 0 =
-                             * unlimited, band 0 = unbanded, ugs_comm.h (RCCL gather) */
+                             * unlimited, band 0 = unbanded, ugs_comm.h (RCCL gather); 6: ugs_device_synchronize, ugs_debug_alloc_stats
+                             * (additive) */
 
 /* error codes */
 #define UGS_OK            0
@@ -177,6 +178,9 @@ int ugs_local_evalue(const ugs_params *p, double raw_score, uint32_t ql, double 
 
 int ugs_abi_version(void);
 int ugs_device_count(void);
+/* Blocks until everything enqueued on `device` by this process has finished (hipDeviceSynchronize): what a multi-rank driver puts
+ * beside its inter-process barrier on both sides of a timed region (the reference has no counterpart: search.cpp:121-128 joins threads). */
+int ugs_device_synchronize(int device);
 
 /*
  * Replaces LoadUDB + UDBData::FromSeqDB (loaddb.cpp:100-125, udbbuild.cpp:303-398):
@@ -293,6 +297,10 @@ const char *ugs_debug_rank_instance_name(int bit);
  * pass keeps - max_accepts + max_rejects - 1 > 64, or 0 = unlimited: terminator.cpp:22-31,64-100 has no depth limit): how many walks
  * were parked and continued over their complete sorted candidate list, and how many keys those lists held. */
 int ugs_debug_deep_walks(const ugs_batch *b, uint64_t *parked_units, uint64_t *list_keys);
+/* Diagnostic: the library's device allocator.  out[0] = UGS_GUARD_ALLOC mode (0 = hipMalloc / hipFree; 1 / 2 = every buffer a mapping of
+ * its own, right-aligned against an unmapped page: an out-of-bounds access of any kernel faults deterministically), out[1] / out[2] =
+ * guarded allocations made / released, out[3] / out[4] = bytes mapped now / at the peak. */
+int ugs_debug_alloc_stats(unsigned long long out[5]);
 
 /*
  * Debug / tuning switches.  NOT part of the contract: they exist for A/B measurements and fault isolation, are read from the
@@ -310,6 +318,11 @@ int ugs_debug_deep_walks(const ugs_batch *b, uint64_t *parked_units, uint64_t *l
  *   UGS_R3=0|1 UGS_R3_SP=n UGS_R3_PPS=n       sparse (protein) Big-path index: 0 = k_rank2g instead of k_rank3g; k_rank3g's partitions per
  *                           super-partition (default: per unit, so that a super-partition holds ~ UGS_R3_PPS = 4096 of its postings)
  *   UGS_DEBUG_SYNC=1 UGS_PHASE_CLOCKS=1       finish and log every stage / print the kernels' phase clocks with the stats
+ * Read once per PROCESS (ugs_alloc.cpp):
+ *   UGS_GUARD_ALLOC=1|2 UGS_GUARD_ALIGN=n     the guard allocator (ugs_debug_alloc_stats; 2: freed address ranges stay reserved; n: alignment of the
+ *                           pointers handed out, default 16 bytes)
+ *   UGS_ABORT_BT=file|1     a SIGABRT handler that writes the backtrace of the aborting THREAD (a runtime thread reporting a GPU fault, glibc
+ *                           reporting a corrupted heap) to `file` (1: stderr) and chains to the previous handler
  * (ugs_cluster_fast reads UGS_CLUSTER_BATCH / UGS_CLUSTER_PROFILE at its start; ugs_cli reads UGS_CLI_PROFILE / UGS_CLI_FORCE_GATHER.)
  */
 

@@ -10,12 +10,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# torch (used only for device-pointer plumbing in the multi-GPU tests) ships its own HIP runtime; load it before
-# libugs.so pulls in the system one, whatever subset of the tests runs, or torch later reports "No HIP GPUs".
-try:
-    import torch  # noqa: F401,E402
-except Exception:  # torch is optional for the CPU-only tests
-    pass
+# NO torch in a test process that loads libugs.so: torch's wheel bundles a HIP runtime, an HSA runtime and an RCCL under the system
+# libraries' SONAMEs (usearch12_amd/hostgroup.py).  Rounds 1-5 imported torch here first, so the whole GPU suite ran the product on
+# torch's ROCm 7.0 runtime instead of the system one the product ships with; the tests that want torch.distributed
+# (world-2 gloo) run it in child processes that never load libugs.so.
+
+
+def d2h(ptr, nbytes):
+    """`nbytes` of device memory at `ptr` as a numpy byte array (hipMemcpy through the runtime libugs.so is linked with)"""
+    import ctypes
+    import numpy as np
+    from usearch12_amd import capi
+    capi.lib()
+    hip = ctypes.CDLL("libamdhip64.so.7")                         # (already mapped: the loader hands back the same library)
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    out = np.zeros(int(nbytes), np.uint8)
+    if nbytes:
+        rc = hip.hipMemcpy(out.ctypes.data, ctypes.c_void_p(int(ptr)), int(nbytes), 2)      # hipMemcpyDeviceToHost
+        assert rc == 0, "hipMemcpy: %d" % rc
+    return out
 
 
 import pytest  # noqa: E402

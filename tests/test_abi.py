@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(capi.EXPORTS) == names
-    assert L.ugs_abi_version() == 5
+    assert L.ugs_abi_version() == 6
 
 
 def test_rccl_library_exports_every_symbol_of_ugs_comm_h():

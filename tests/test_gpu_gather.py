@@ -151,3 +151,25 @@ def test_rccl_gather_over_every_device_of_the_box():
     assert want[0].nbytes > 6_000_000
     _same(res[0], want)
     [c.close() for c in comms]
+
+
+def test_bench_ranks_over_every_device_of_the_box():
+    """`bench.py --gpus ndev` with the product's gather over RCCL between PROCESSES (one rank per device) on a box with more than one GPU -
+    the command the driver's scaling run issues; on a one-GPU box: the same pipeline with a communicator of one rank (--force-gather)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ndev = capi.device_count()
+    args = ["--gpus", str(ndev), "--steps", "2", "--warmup", "1", "--db", "20000", "--queries", "6000", "--cpu-baseline", "none"]
+    if ndev == 1:
+        args.append("--force-gather")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == ndev and "ugs_gather_results" in j["config"]["gather"]
+    assert j["detail"]["hits_per_step"] > 0.6 * 6000 * ndev
+    for l_ in j["detail"]["runtime_libs"]:
+        assert not l_["torch_imported"] and len(l_["libamdhip64"]) == 1 and len(l_["librccl"]) == 1

@@ -106,7 +106,7 @@ def test_cli_usearch_local_text_identical_to_reference(tmp_path):
 def test_device_results_plus_sort_equal_fetch():
     """the multi-GPU result path: ugs_batch_device_results hands out candidate-order tables; ugs_hits_sort on the host
     gives exactly what ugs_batch_fetch returns"""
-    import torch
+    from conftest import d2h
     from usearch12_amd import multigpu
     c, db, qs, b6 = G.load_local("loc_aa_acc")
     p = capi.params(is_nucleo=False, **G.local_params_kw(c))
@@ -114,9 +114,8 @@ def test_device_results_plus_sort_equal_fetch():
     bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
     bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
     hits, nh, pool = bat.fetch()
-    import bench
     (ph, bh), (pn, bn), (pc, bc) = bat.device_results(0)
-    dh, dn, dp = (torch.as_tensor(bench.DevArray(ptr, n), device="cuda").cpu().numpy() for ptr, n in ((ph, bh), (pn, bn), (pc, bc)))
+    dh, dn, dp = (d2h(ptr, n) for ptr, n in ((ph, bh), (pn, bn), (pc, bc)))
     ghits, gcnt, gpool = multigpu.merge_tables([dh], [dn], [dp])
     assert np.array_equal(gcnt, nh)
     capi.sort_hits(ghits, gcnt, local=True)

@@ -101,11 +101,9 @@ def test_gpu_small_partitions(monkeypatch):
 
 def test_gpu_device_results_view_matches_fetch():
     """The device-resident hit table exposed for the RCCL gather (ugs_batch_device_results) holds the
-    same records ugs_batch_fetch returns; it is wrapped zero-copy through __cuda_array_interface__."""
-    import torch
+    same records ugs_batch_fetch returns."""
+    from conftest import d2h
     from usearch12_amd import multigpu
-    from usearch12_amd.abi import HIT_DTYPE
-    import bench
     c, db, qs, b6, uc = G.load("hard_acc")
     p = capi.params(is_nucleo=True, id=c["id"], **G.params_kw(c))
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
@@ -113,9 +111,7 @@ def test_gpu_device_results_view_matches_fetch():
     bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
     hits, nh, pool = bat.fetch()
     (ph, bh), (pn, bn), (pc, bc) = bat.device_results(query_base=1000)
-    t_h = torch.as_tensor(bench.DevArray(ph, bh), device="cuda").cpu().numpy()
-    t_n = torch.as_tensor(bench.DevArray(pn, bn), device="cuda").cpu().numpy()
-    t_c = torch.as_tensor(bench.DevArray(pc, bc), device="cuda").cpu().numpy()
+    t_h, t_n, t_c = d2h(ph, bh), d2h(pn, bn), d2h(pc, bc)
     ghits, gcnt, gpool = multigpu.merge_tables([t_h], [t_n], [t_c])
     assert len(ghits) == len(hits) and np.array_equal(gcnt, nh)
     ghits["query"] -= 1000
@@ -262,38 +258,3 @@ def test_gpu_fetch_into_reused_pinned_buffers():
                                   p1[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])])
         bat.search(); bat.sync()
     bat.close()
-
-
-def test_gpu_nccl_gather_world1():
-    """The multi-GPU step of bench.py on one rank: device-resident results -> RCCL collectives (world size 1) -> device-side
-    concatenation / path-offset rebase -> one page-locked copy per table -> zero-copy merge, equal to ugs_batch_fetch."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from usearch12_amd import multigpu
-    import bench
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        c, db, qs, b6, uc = G.load("hard_acc")
-        p = capi.params(is_nucleo=True, id=c["id"], **G.params_kw(c))
-        gdb = capi.UgsDB(p, db.seqs, db.offs, device=0)
-        bat = capi.UgsBatch(gdb, qs.n, int(qs.offs[-1]))
-        bat.upload(qs.seqs, qs.offs); bat.search(); bat.sync()
-        hits, nh, pool = bat.fetch()
-        for _ in range(2):                      # second trip reuses the page-locked host buffers
-            (ph, bh), (pn, bn), (pc, bc) = bat.device_results(query_base=0)
-            t_h = torch.as_tensor(bench.DevArray(ph, bh), device="cuda")
-            t_n = torch.as_tensor(bench.DevArray(pn, bn), device="cuda")
-            t_c = torch.as_tensor(bench.DevArray(pc, bc), device="cuda")
-            got = multigpu.gather_tables(dist, torch, t_h, t_n, t_c, 0, 1, dst=0)
-            ghits, gcnt, gpool = multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3])
-            assert len(ghits) == len(hits) and np.array_equal(gcnt, nh)
-            key = lambda a: sorted(zip(a["query"].tolist(), a["target"].tolist(), a["ids"].tolist(), a["aln_len"].tolist()))
-            assert key(ghits) == key(hits)
-            for a in ghits[::7]:
-                assert int(a["cigar_off"]) + int(a["cigar_len"]) <= len(gpool)
-    finally:
-        dist.destroy_process_group()

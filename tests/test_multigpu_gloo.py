@@ -1,58 +1,44 @@
-"""world_size-2 gloo test of the N>1 path on CPU: query shards, gather of fixed-size hit tables to
-rank 0, merge into global hits.  The per-rank "device tables" are produced by the oracle here
-(there is no GPU on this box); on GPUs bench.py feeds the same functions from ugs_batch_device_results."""
+"""world_size-2 tests of the N > 1 path on CPU: query shards, gather of the per-rank hit tables to rank 0, merge into global hits.
+The per-rank "device tables" are produced by the oracle here (there is no GPU on this box).  Two transports carry them:
+  * torch.distributed with the gloo backend (usearch12_amd/hostgroup.py GlooGroup) - in CHILD processes (tests/gloo_worker.py) that
+    never load libugs.so: torch's bundled HIP runtime and the system one must not meet in one process;
+  * the socket group bench.py's ranks use (SocketGroup), in multiprocessing children.
+On GPUs the tables travel through the product's C++ gather (ugs_gather.cpp; tests/test_gpu_gather.py)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 import golden_util as G
 import orc
 from usearch12_amd import multigpu
-from usearch12_amd.abi import HIT_DTYPE, cigar_text
+from usearch12_amd.abi import cigar_text
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, case, out_path):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    if case.startswith("loc_"):                     # usearch_local: several HSPs per target, 80-byte records with raw scores
-        c, db, qs, b6 = G.load_local(case)
-        p = orc.params(is_nucleo=not c["aa"], **G.local_params_kw(c))
-    else:
-        c, db, qs, b6, uc = G.load(case)
-        p = orc.params(is_nucleo=not c["aa"], id=c["id"], **G.params_kw(c))
-    lo, hi = multigpu.shard_range(qs.n, world, rank)
-    shard = qs.slice(lo, hi)
-    odb = orc.OrcDB(p, db.seqs, db.offs)            # replica of the index on every rank
-    hits, nh, pool = odb.search(shard.seqs, shard.offs)
-    hits = hits.copy()
-    hits["query"] += np.uint32(lo)                  # what the device compaction does with query_base
-    t_h = torch.from_numpy(hits.view(np.uint8).reshape(-1).copy())
-    t_n = torch.from_numpy(nh.astype(np.uint32).view(np.uint8).copy())
-    t_p = torch.from_numpy(pool.astype(np.uint32).view(np.uint8).copy())
-    got = multigpu.gather_tables(dist, torch, t_h, t_n, t_p, rank, world, dst=0)
-    if rank == 0:
-        ghits, gcnt, gpool = multigpu.merge_tables(got[0], got[1], got[2], rebased=got[3])
-        assert int(gcnt.sum()) == len(ghits) and len(gcnt) == qs.n
-        np.save(out_path + ".hits.npy", ghits)
-        np.save(out_path + ".pool.npy", gpool)
-    dist.barrier()
-    dist.destroy_process_group()
+def _spawn(world, case, out, transport="gloo"):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "gloo_worker.py"), transport, case, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        log = p.communicate(timeout=600)[0]
+        assert p.returncode == 0, log[-3000:]
 
 
 def test_two_rank_gather_equals_single_run(tmp_path):
     case = "hard_acc"          # maxaccepts 4: several hits per query
     out = str(tmp_path / "g")
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, case, out), nprocs=2, join=True)
+    _spawn(2, case, out)
     ghits = np.load(out + ".hits.npy")
     gpool = np.load(out + ".pool.npy")
     c, db, qs, b6, uc = G.load(case)
@@ -71,7 +57,7 @@ def test_two_rank_gather_equals_single_run(tmp_path):
 def test_two_rank_gather_local_hits(tmp_path):
     case = "loc_nt_both"
     out = str(tmp_path / "g")
-    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    _spawn(2, case, out)
     ghits = np.load(out + ".hits.npy")
     gpool = np.load(out + ".pool.npy")
     c, db, qs, b6 = G.load_local(case)
@@ -85,6 +71,15 @@ def test_two_rank_gather_local_hits(tmp_path):
     assert got == b6
     for a, b in zip(ghits[::29], hits[::29]):
         assert cigar_text(gpool, a["cigar_off"], a["cigar_len"]) == cigar_text(pool, b["cigar_off"], b["cigar_len"])
+
+
+def test_socket_group_three_ranks_equal_gloo(tmp_path):
+    """bench.py's own rank group (sockets, no torch) carries the same tables to the same merged result, with an odd world"""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    _spawn(3, "hard_acc", a, transport="socket")
+    _spawn(3, "hard_acc", b, transport="gloo")
+    for suffix in (".hits.npy", ".pool.npy"):
+        assert np.array_equal(np.load(a + suffix), np.load(b + suffix))
 
 
 def test_hits_sort_orders_a_candidate_order_table():

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libugs.so")
 LIB_RCCL = os.path.join(HERE, "libugs_rccl.so")       # include/ugs_comm.h: the RCCL gather (libugs.so itself has no RCCL dependency)
 CLI = os.path.join(HERE, "ugs_cli")
-SOURCES = ["ugs_host.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_rank3.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip", "ugs_deep.hip"]
+SOURCES = ["ugs_host.cpp", "ugs_alloc.cpp", "ugs_writers.cpp", "ugs_cluster.cpp", "ugs_index.hip", "ugs_rank.hip", "ugs_rank_hot.hip", "ugs_rank2.hip", "ugs_rank3.hip", "ugs_align.hip", "ugs_xdrop.hip", "ugs_local.hip", "ugs_inbatch.hip", "ugs_deep.hip"]
 DEPS = [x for x in SOURCES if x != "ugs_rank_hot.hip"] + ["ugs_dev.h", "ugs_host.h", "ugs_rank2.h", "ugs_ring_dev.h", "ugs_rank_keys.h", "ugs_xdrop_dev.h", os.path.join("..", "..", "include", "ugs.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
@@ -81,36 +81,45 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def _compile(src, obj, path, verbose):
+    if src in KEEP_ASM:
+        # the same compilation also leaves the device assembly behind (-save-temps): tests/test_isa.py reads it
+        import shutil
+        import tempfile
+        tmpd = tempfile.mkdtemp(prefix="ugs_build_")
+        try:
+            base = os.path.splitext(os.path.basename(path))[0]              # (the temporaries are named after the input file)
+            cmd = ["hipcc"] + flags_for(src) + ["-save-temps=obj", "-c", path, "-o", os.path.join(tmpd, base + ".o")]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)      # (-save-temps repeats every warning of the unused-result kind: shown only on failure)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr)
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            shutil.move(os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s"), asm_path(src))
+            shutil.move(os.path.join(tmpd, base + ".o"), obj)
+        finally:
+            shutil.rmtree(tmpd, ignore_errors=True)
+        return
+    cmd = ["hipcc"] + flags_for(src) + ["-c", path, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def build(force=False, verbose=False):
-    objs = []
+    from concurrent.futures import ThreadPoolExecutor
+    objs, todo = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         path = real_src(src)
         if force or _mtime(obj) < _newest(path):
-            if src in KEEP_ASM:
-                # the same compilation also leaves the device assembly behind (-save-temps): tests/test_isa.py reads it
-                import shutil
-                import tempfile
-                tmpd = tempfile.mkdtemp(prefix="ugs_build_")
-                try:
-                    base = os.path.splitext(os.path.basename(path))[0]              # (the temporaries are named after the input file)
-                    cmd = ["hipcc"] + flags_for(src) + ["-save-temps=obj", "-c", path, "-o", os.path.join(tmpd, base + ".o")]
-                    if verbose:
-                        print(" ".join(cmd))
-                    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)      # (-save-temps repeats every warning of the unused-result kind: shown only on failure)
-                    if r.returncode != 0:
-                        sys.stderr.write(r.stderr)
-                        raise subprocess.CalledProcessError(r.returncode, cmd)
-                    shutil.move(os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s"), asm_path(src))
-                    shutil.move(os.path.join(tmpd, base + ".o"), obj)
-                finally:
-                    shutil.rmtree(tmpd, ignore_errors=True)
-                continue
-            cmd = ["hipcc"] + flags_for(src) + ["-c", path, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            todo.append((src, obj, path))
+    if todo:                                   # the translation units are independent: compile them side by side (hipcc is single-threaded)
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)) as ex:
+            for f in [ex.submit(_compile, s_, o_, p_, verbose) for s_, o_, p_ in todo]:
+                f.result()
     if force or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

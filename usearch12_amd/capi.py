@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("UGS_LIB") or os.path.join(HERE, "libugs.so")     # UG
 _lib = None
 
 EXPORTS = [
-    "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
+    "ugs_params_init", "ugs_abi_version", "ugs_device_count", "ugs_device_synchronize", "ugs_debug_alloc_stats", "ugs_db_create", "ugs_db_destroy", "ugs_db_stats",
     "ugs_search_batch", "ugs_batch_create", "ugs_batch_destroy", "ugs_batch_upload", "ugs_batch_search",
     "ugs_batch_sync", "ugs_batch_wait_upload", "ugs_batch_fetch", "ugs_batch_set_query_base", "ugs_batch_get_stats", "ugs_batch_get_candidates", "ugs_batch_candidate_k", "ugs_debug_kernel_hits", "ugs_debug_rank_instances", "ugs_debug_rank_instance_name", "ugs_debug_deep_walks",
     "ugs_batch_device_results",
@@ -47,6 +47,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
         L.ugs_params_init.argtypes = [C.POINTER(Params), i32, C.c_double]
+        L.ugs_device_synchronize.argtypes = [i32]
+        L.ugs_debug_alloc_stats.argtypes = [C.POINTER(C.c_ulonglong)]
         L.ugs_db_create.argtypes = [C.POINTER(Params), vp, vp, u32, i32, C.POINTER(vp)]
         L.ugs_db_destroy.argtypes = [vp]
         L.ugs_db_destroy.restype = None

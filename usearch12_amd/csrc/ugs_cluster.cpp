@@ -71,18 +71,18 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
   if (db->nletters + add + 64 > db->seq_cap) {
     const uint64_t cap = (db->nletters + add) * 2 + 4096;
     uint8_t *p = nullptr;
-    HIPCHK(hipMalloc(&p, cap));
+    HIPCHK(ugs_malloc(&p, cap));
     if (db->nletters) HIPCHK(hipMemcpyAsync(p, db->d_seqs, db->nletters, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(db->d_seqs)); db->d_seqs = p; db->seq_cap = cap;
+    HIPCHK(ugs_free(db->d_seqs)); db->d_seqs = p; db->seq_cap = cap;
   }
   if ((uint64_t)old_n + n + 1 > db->off_cap) {
     const uint64_t cap = ((uint64_t)old_n + n) * 2 + 1024;
     uint64_t *p = nullptr;
-    HIPCHK(hipMalloc(&p, cap * 8));
+    HIPCHK(ugs_malloc(&p, cap * 8));
     HIPCHK(hipMemcpyAsync(p, db->d_offs, ((size_t)old_n + 1) * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(db->d_offs)); db->d_offs = p; db->off_cap = cap;
+    HIPCHK(ugs_free(db->d_offs)); db->d_offs = p; db->off_cap = cap;
   }
   if (add) HIPCHK(hipMemcpyAsync(db->d_seqs + db->nletters, seqs + offs[0], add, hipMemcpyHostToDevice, st));
   if (db->p.is_nucleo) {                          // the packed letters follow: every word the new letters touch is packed again from the bytes
@@ -90,11 +90,11 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
     if (need > db->pack_cap) {
       const uint64_t cap = need * 2;
       uint2 *a = nullptr;
-      HIPCHK(hipMalloc(&a, cap * 8));
+      HIPCHK(ugs_malloc(&a, cap * 8));
       HIPCHK(hipMemsetAsync(a, 0, cap * 8, st));
       if (db->d_pk) HIPCHK(hipMemcpyAsync(a, db->d_pk, db->pack_cap * 8, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
-      (void)hipFree(db->d_pk);
+      (void)ugs_free(db->d_pk);
       db->d_pk = a; db->pack_cap = cap;
     }
     RCCHK(ugs_launch_pack(db->d_tab, db->d_seqs, db->nletters / 16, (db->nletters + add + 15) / 16, db->d_pk, st));
@@ -102,9 +102,9 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
   HIPCHK(hipMemcpyAsync(db->d_offs + old_n, abs_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
   struct Tmp {                                    // released on every way out, error returns included
     uint64_t *rel = nullptr, *drow = nullptr; uint32_t *dpost = nullptr, *dmax = nullptr;
-    ~Tmp() { (void)hipFree(rel); (void)hipFree(drow); (void)hipFree(dpost); (void)hipFree(dmax); }
+    ~Tmp() { (void)ugs_free(rel); (void)ugs_free(drow); (void)ugs_free(dpost); (void)ugs_free(dmax); }
   } t;
-  HIPCHK(hipMalloc(&t.rel, ((size_t)n + 1) * 8));
+  HIPCHK(ugs_malloc(&t.rel, ((size_t)n + 1) * 8));
   HIPCHK(hipMemcpyAsync(t.rel, rel_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
   // index of the new sequences on their own (targets 0..n-1), then row-wise append
   uint64_t n_dpost = 0; uint32_t dmax = 0;
@@ -114,14 +114,14 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
   const uint64_t total = db->n_postings + n_dpost;
   // the merged index goes into the handle's spare arrays, which then change places with the live ones (a multi-GB
   // hipMalloc / hipFree per append would cost more than the merge)
-  if (!db->d_row_off2) HIPCHK(hipMalloc(&db->d_row_off2, ((size_t)db->v.slots + 1) * 8));
+  if (!db->d_row_off2) HIPCHK(ugs_malloc(&db->d_row_off2, ((size_t)db->v.slots + 1) * 8));
   if (!db->d_postings2 || total + 256 > db->post_cap2) {
-    if (db->d_postings2) HIPCHK(hipFree(db->d_postings2));
+    if (db->d_postings2) HIPCHK(ugs_free(db->d_postings2));
     db->d_postings2 = nullptr;
     db->post_cap2 = total + total / 2 + 4096 + 256;
-    HIPCHK(hipMalloc(&db->d_postings2, db->post_cap2 * 4));
+    HIPCHK(ugs_malloc(&db->d_postings2, db->post_cap2 * 4));
   }
-  HIPCHK(hipMalloc(&t.dmax, 4));
+  HIPCHK(ugs_malloc(&t.dmax, 4));
   rc = ugs_index_merge(db->d_row_off, db->d_postings, t.drow, t.dpost, db->v.slots, old_n, db->d_row_off2, db->d_postings2, total, t.dmax, st);
   if (rc == UGS_OK && hipMemcpyAsync(&db->max_row, t.dmax, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = UGS_E_HIP;
   if (hipStreamSynchronize(st) != hipSuccess) rc = UGS_E_HIP;
@@ -251,12 +251,12 @@ struct DevBuf {            // a device array that only ever grows
   void *p = nullptr; size_t cap = 0;
   int need(size_t bytes) {
     if (bytes <= cap) return UGS_OK;
-    if (p) (void)hipFree(p);
+    if (p) (void)ugs_free(p);
     p = nullptr; cap = bytes + bytes / 2 + 4096;
-    if (hipMalloc(&p, cap) != hipSuccess) { cap = 0; ugs_set_error("hipMalloc(%zu) failed", bytes); return UGS_E_HIP; }
+    if (ugs_malloc(&p, cap) != hipSuccess) { cap = 0; ugs_set_error("ugs_malloc(%zu) failed", bytes); return UGS_E_HIP; }
     return UGS_OK;
   }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) (void)ugs_free(p); }
 };
 
 enum { ST_UNKNOWN = 0, ST_MEMBER = 1, ST_CENTROID = 2, ST_MAYBE = 3 };
@@ -497,7 +497,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
     // ---- the batch's own index and the in-batch word counts (count, scan, write)
     uint64_t *d_brow = nullptr; uint32_t *d_bpost = nullptr; uint64_t n_bpost = 0; uint32_t bmax = 0;
     RCCHK(ugs_build_index(db->d_tab, b->d_qseqs, b->d_qoffs, B, stage.size(), p.word_len, db->v.alpha, db->v.slots, &d_brow, &d_bpost, &n_bpost, &bmax, st));
-    struct FreeIdx { uint64_t *a; uint32_t *b; ~FreeIdx() { (void)hipFree(a); (void)hipFree(b); } } free_idx{d_brow, d_bpost};
+    struct FreeIdx { uint64_t *a; uint32_t *b; ~FreeIdx() { (void)ugs_free(a); (void)ugs_free(b); } } free_idx{d_brow, d_bpost};
     RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, nullptr, nullptr, st));
     H.nq = B; H.ns = ns; H.K = K;
     H.ent_n.resize(units); H.ent_off.resize(units);
@@ -586,10 +586,10 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
         if (attempt == 0 && want > b->cigar_cap) {
           uint32_t *np_ = nullptr;
           const uint64_t cap = want + want / 4;
-          HIPCHK(hipMalloc(&np_, cap * 4));
+          HIPCHK(ugs_malloc(&np_, cap * 4));
           if (frozen_runs) HIPCHK(hipMemcpyAsync(np_, b->d_cigar, frozen_runs * 4, hipMemcpyDeviceToDevice, st));
           HIPCHK(hipStreamSynchronize(st));
-          HIPCHK(hipFree(b->d_cigar)); b->d_cigar = np_; b->cigar_cap = cap; b->v.cigar_pool = np_; b->v.cigar_cap = cap;
+          HIPCHK(ugs_free(b->d_cigar)); b->d_cigar = np_; b->cigar_cap = cap; b->v.cigar_pool = np_; b->v.cigar_cap = cap;
         }
         UgsBatchView bv2 = b->v;
         bv2.nq = npu; bv2.nstrand = 1; bv2.K = Kp;
@@ -611,10 +611,10 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
         if (attempt == 2) { ugs_set_error("path pool overflow persisted"); return UGS_E_CAPACITY; }
         uint32_t *np_ = nullptr;
         const uint64_t cap = used + used / 4 + 4096;
-        HIPCHK(hipMalloc(&np_, cap * 4));
+        HIPCHK(ugs_malloc(&np_, cap * 4));
         if (frozen_runs) HIPCHK(hipMemcpyAsync(np_, b->d_cigar, frozen_runs * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipFree(b->d_cigar)); b->d_cigar = np_; b->cigar_cap = cap; b->v.cigar_pool = np_; b->v.cigar_cap = cap;
+        HIPCHK(ugs_free(b->d_cigar)); b->d_cigar = np_; b->cigar_cap = cap; b->v.cigar_pool = np_; b->v.cigar_cap = cap;
       }
       RCCHK(ugs_compact_hits((const uint32_t *)d_phitn.p, (const ugs_hit *)d_phits.p, npu, 1, Kp, (uint32_t *)d_pqn.p, (uint32_t *)d_pqoff.p,
                              (ugs_hit *)d_pcompact.p, d_scan.p, d_scan.cap, 0, st));

@@ -150,9 +150,9 @@ int ugs_deep_sort(uint64_t *d_keys, uint64_t *d_sorted, uint64_t total, uint32_t
   size_t need = 0;
   HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, need, d_keys, d_sorted, (unsigned int)total, segments, d_off, d_off + 1, 0, 64, st));
   if (need > *tmp_bytes) {
-    if (*d_tmp) HIPCHK(hipFree(*d_tmp));
+    if (*d_tmp) HIPCHK(ugs_free(*d_tmp));
     *d_tmp = nullptr; *tmp_bytes = 0;
-    HIPCHK(hipMalloc(d_tmp, need + 256));
+    HIPCHK(ugs_malloc(d_tmp, need + 256));
     *tmp_bytes = need + 256;
   }
   HIPCHK(rocprim::segmented_radix_sort_keys(*d_tmp, need, d_keys, d_sorted, (unsigned int)total, segments, d_off, d_off + 1, 0, 64, st));

@@ -213,6 +213,10 @@ size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t max_tlen, uint
 int ugs_local_blocks_per_cu(int threads, size_t lds);
 int ugs_launch_local(const UgsDbView &db, const UgsBatchView &b, const UgsLocalView &lv, int grid, int wpb, size_t lds, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);
+// device memory (ugs_alloc.cpp): hipMalloc / hipFree, or - UGS_GUARD_ALLOC=1 - a mapping per buffer, right-aligned against an unmapped page
+hipError_t ugs_malloc_bytes(void **p, size_t bytes);
+hipError_t ugs_free(void *p);
+template <class T> static inline hipError_t ugs_malloc(T **p, size_t bytes) { return ugs_malloc_bytes((void **)p, bytes); }
 void ugs_xdrop_tables(int is_nucleo, float m2, float mm2, int8_t sub2[1024], uint8_t cls[256]);   // ugs_xdrop.hip
 extern const char UGS_B62_ORDER[];          // the 23 alphabetic BLOSUM62 symbols
 extern const signed char UGS_B62[23][23];

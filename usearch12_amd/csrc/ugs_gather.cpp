@@ -57,8 +57,8 @@ static int comm_common_init(ugs_comm *c)
 {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&c->d_my, 4 * 8));
-  HIPCHK(hipMalloc(&c->d_all, (size_t)c->world * 4 * 8));
+  HIPCHK(ugs_malloc(&c->d_my, 4 * 8));
+  HIPCHK(ugs_malloc(&c->d_all, (size_t)c->world * 4 * 8));
   c->all.assign((size_t)c->world * 3, 0);
   c->all4.assign((size_t)c->world * 4, 0);
   return UGS_OK;
@@ -124,9 +124,9 @@ extern "C" void ugs_comm_destroy(ugs_comm *c)
   if (c->st) (void)hipStreamSynchronize(c->st);
   (void)hipDeviceSynchronize();        // (as ugs_db_destroy: nothing in flight on the device when a stream goes)
   if (c->nccl) ncclCommDestroy(c->nccl);
-  for (int k = 0; k < 3; ++k) if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
-  if (c->d_my) (void)hipFree(c->d_my);
-  if (c->d_all) (void)hipFree(c->d_all);
+  for (int k = 0; k < 3; ++k) if (c->d_stage[k]) (void)ugs_free(c->d_stage[k]);
+  if (c->d_my) (void)ugs_free(c->d_my);
+  if (c->d_all) (void)ugs_free(c->d_all);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -210,10 +210,10 @@ extern "C" int ugs_gather_results(ugs_comm *c, ugs_batch *b, uint32_t query_base
   if (R == dst)
     for (int k = 0; k < 3 && !my[3]; ++k)
       if (tot[k] > c->stage_cap[k]) {
-        if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
+        if (c->d_stage[k]) (void)ugs_free(c->d_stage[k]);
         c->d_stage[k] = nullptr; c->stage_cap[k] = 0;
         const uint64_t want = tot[k] + tot[k] / 4 + 4096;
-        const hipError_t e = hipMalloc(&c->d_stage[k], want);
+        const hipError_t e = ugs_malloc(&c->d_stage[k], want);
         if (e != hipSuccess) { (void)hipGetLastError(); ugs_set_error("gather: %llu bytes of staging on rank %d: %s", (unsigned long long)want, R, hipGetErrorString(e)); my[3] = (uint64_t)(uint32_t)(-UGS_E_NOMEM); }
         else c->stage_cap[k] = want;
       }

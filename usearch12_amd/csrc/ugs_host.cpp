@@ -29,6 +29,13 @@ extern "C" int ugs_device_count(void)
   return n;
 }
 
+extern "C" int ugs_device_synchronize(int device)
+{
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
+  return UGS_OK;
+}
+
 // o_defaults.inc, terminator.cpp:26-31, udbparams.cpp:235-261, alnheuristics.cpp:36,44;
 // option values are stored as float in the reference (opts.cpp:265)
 extern "C" int ugs_params_init(ugs_params *p, int is_nucleo, double id)
@@ -233,10 +240,10 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   // SIGABRT inside a later ugs_db_create - the r02 symptom - while every suite with the device-wide barrier has passed.
   if (db->stream) (void)hipStreamSynchronize(db->stream);
   (void)hipDeviceSynchronize();
-  (void)hipFree(db->d_pk);
-  (void)hipFree(db->d_seqs); (void)hipFree(db->d_offs); (void)hipFree(db->d_row_off); (void)hipFree(db->d_postings); (void)hipFree(db->d_part); (void)hipFree(db->d_part2);
-  (void)hipFree(db->d_row_off2); (void)hipFree(db->d_postings2);
-  (void)hipFree(db->d_step); (void)hipFree(db->d_tab); (void)hipFree(db->d_xsub2); (void)hipFree(db->d_xcls); (void)hipFree(db->d_tkey); (void)hipFree(db->d_tsize);
+  (void)ugs_free(db->d_pk);
+  (void)ugs_free(db->d_seqs); (void)ugs_free(db->d_offs); (void)ugs_free(db->d_row_off); (void)ugs_free(db->d_postings); (void)ugs_free(db->d_part); (void)ugs_free(db->d_part2);
+  (void)ugs_free(db->d_row_off2); (void)ugs_free(db->d_postings2);
+  (void)ugs_free(db->d_step); (void)ugs_free(db->d_tab); (void)ugs_free(db->d_xsub2); (void)ugs_free(db->d_xcls); (void)ugs_free(db->d_tkey); (void)ugs_free(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
   delete db;
 }
@@ -247,8 +254,8 @@ static int db_step_table(ugs_db *db, uint32_t n)
   size_t old = db->step.size();
   db->step.resize(n);
   for (size_t i = old; i < n; ++i) db->step[i] = query_step(db->p, (uint32_t)i);
-  if (db->d_step) HIPCHK(hipFree(db->d_step));
-  HIPCHK(hipMalloc(&db->d_step, n * sizeof(uint32_t)));
+  if (db->d_step) HIPCHK(ugs_free(db->d_step));
+  HIPCHK(ugs_malloc(&db->d_step, n * sizeof(uint32_t)));
   HIPCHK(hipMemcpy(db->d_step, db->step.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
   db->v.step_tab = db->d_step; db->v.step_n = (uint32_t)n;
   return UGS_OK;
@@ -284,7 +291,6 @@ UgsTune ugs_tune_read()
   t.r3 = env_int("UGS_R3", 0, 1, -1);
   t.r3_sp = env_int("UGS_R3_SP", 1, 63, 0);
   t.r3_pps = env_int("UGS_R3_PPS", 64, 1 << 20, 0);
-  t.batch_streams = getenv("UGS_BATCH_STREAMS") != nullptr;
   t.qpk = getenv("UGS_QPK") != nullptr;
   t.align_group = env_int("UGS_ALIGN_GROUP", 0, 64, -1);
   return t;
@@ -325,10 +331,10 @@ int ugs_db_replan(ugs_db *db)
   const uint32_t np = nseq ? (uint32_t)(((uint64_t)nseq - 1) / gsize + 1) : 1;
   const uint64_t need = (uint64_t)slots * (np + 1);
   if (!db->d_part || need > db->part_cap) {
-    if (db->d_part) HIPCHK(hipFree(db->d_part));
+    if (db->d_part) HIPCHK(ugs_free(db->d_part));
     db->d_part = nullptr;
     db->part_cap = need + need / 4;
-    HIPCHK(hipMalloc(&db->d_part, (size_t)db->part_cap * sizeof(uint32_t)));
+    HIPCHK(ugs_malloc(&db->d_part, (size_t)db->part_cap * sizeof(uint32_t)));
   }
   RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np, gsize, db->d_part, db->stream));
   HIPCHK(hipStreamSynchronize(db->stream));
@@ -356,10 +362,10 @@ int ugs_db_replan(ugs_db *db)
   if (gsize2) {
     const uint64_t need2 = (uint64_t)slots * (np2 + 1);
     if (!db->d_part2 || need2 > db->part2_cap) {
-      if (db->d_part2) HIPCHK(hipFree(db->d_part2));
+      if (db->d_part2) HIPCHK(ugs_free(db->d_part2));
       db->d_part2 = nullptr;
       db->part2_cap = need2 + need2 / 4;
-      HIPCHK(hipMalloc(&db->d_part2, (size_t)db->part2_cap * sizeof(uint32_t)));
+      HIPCHK(ugs_malloc(&db->d_part2, (size_t)db->part2_cap * sizeof(uint32_t)));
     }
     RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np2, gsize2, db->d_part2, db->stream));
     HIPCHK(hipStreamSynchronize(db->stream));
@@ -393,11 +399,14 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   // as usual and the walks that used up their list are continued over the unit's complete sorted list (deep walks, ugs_deep.hip)
   // ... and the small path with -selfid: pairs that filter passes over are not counted (searcher.cpp:63-67), so a walk among many identical
   // sequences may want any number of candidates (r4: UGS_ERR_PAIRCAP beyond 32 spare ones)
-  const bool deep_walk = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX ||
-                         ((p->pair_mask & UGS_P_SELFID) && !p->local && (uint64_t)nseq <= (uint64_t)p->big);
-  if (deep_walk && (p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD))) {
+  const bool termid_on = (p->align_flags & (UGS_A_TERMID | UGS_A_TERMIDD)) != 0;
+  const bool deep_by_depth = open_walk || (int64_t)p->max_accepts + p->max_rejects - 1 > UGS_KMAX;
+  // (-selfid together with -termid / -termidd keeps round 4's scheme - K + 32 spare candidates, UGS_ERR_PAIRCAP if a walk wants more -
+  //  instead of being refused as "deeper than 64": its configured depth is not)
+  const bool deep_walk = deep_by_depth || (!termid_on && (p->pair_mask & UGS_P_SELFID) && !p->local && (uint64_t)nseq <= (uint64_t)p->big);
+  if (deep_by_depth && termid_on) {
     // (-termid / -termidd look at the hits of both strands of a query in walk order: a parked plus-strand walk would have to finish first)
-    ugs_set_error("-termid / -termidd with more than %d candidates per walk are outside the device envelope", UGS_KMAX); return UGS_E_ENVELOPE;
+    ugs_set_error("-termid / -termidd with more than %d candidates per walk (max_accepts + max_rejects - 1, or an unlimited walk) are outside the device envelope", UGS_KMAX); return UGS_E_ENVELOPE;
   }
   const int alpha = p->is_nucleo ? 4 : 20;
   uint64_t slots64 = 1;
@@ -450,17 +459,17 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   UgsTables T;
   if ((rc = build_tables(*p, T)) != UGS_OK) return fail(rc);
 #define DBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return fail(UGS_E_HIP); } } while (0)
-  DBCHK(hipMalloc(&db->d_tab, sizeof(UgsTables)));
+  DBCHK(ugs_malloc(&db->d_tab, sizeof(UgsTables)));
   DBCHK(hipMemcpy(db->d_tab, &T, sizeof(T), hipMemcpyHostToDevice));
-  DBCHK(hipMalloc(&db->d_seqs, nletters + 64));          // padded: the aligner prefetches letters as unaligned dwords
-  DBCHK(hipMalloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
+  DBCHK(ugs_malloc(&db->d_seqs, nletters + 64));          // padded: the aligner prefetches letters as unaligned dwords
+  DBCHK(ugs_malloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
   if (nletters) DBCHK(hipMemcpy(db->d_seqs, seqs, nletters, hipMemcpyHostToDevice));
   DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (p->dbmask < 0 || p->dbmask > 3) { ugs_set_error("dbmask must be 0..3"); return fail(UGS_E_ARG); }
   if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask == 3 ? (1 | ((p->is_nucleo ? 'N' : 'X') << 8)) : p->dbmask, db->stream)) != UGS_OK) return fail(rc);
   if (p->is_nucleo) {                                       // the masked letters packed 2 bits each (UgsDbView::pk)
     db->pack_cap = (nletters + 64) / 16 + 8;
-    DBCHK(hipMalloc(&db->d_pk, db->pack_cap * 8));
+    DBCHK(ugs_malloc(&db->d_pk, db->pack_cap * 8));
     DBCHK(hipMemsetAsync(db->d_pk, 0, db->pack_cap * 8, db->stream));
     if ((rc = ugs_launch_pack(db->d_tab, db->d_seqs, 0, (nletters + 15) / 16, db->d_pk, db->stream)) != UGS_OK) return fail(rc);
   }
@@ -508,7 +517,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   if (p->local) {   // x-drop tables (the ones ugs_xdrop_batch uses) and the constants of LocalAligner / XDropAlignMem
     int8_t xsub2[1024]; uint8_t xcls[256];
     ugs_xdrop_tables(p->is_nucleo, p->match * 2.0f, p->mismatch * 2.0f, xsub2, xcls);
-    if (hipMalloc(&db->d_xsub2, 1024) != hipSuccess || hipMalloc(&db->d_xcls, 256) != hipSuccess ||
+    if (ugs_malloc(&db->d_xsub2, 1024) != hipSuccess || ugs_malloc(&db->d_xcls, 256) != hipSuccess ||
         hipMemcpy(db->d_xsub2, xsub2, 1024, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(db->d_xcls, xcls, 256, hipMemcpyHostToDevice) != hipSuccess) { ugs_set_error("x-drop tables: HIP error"); return fail(UGS_E_HIP); }
     UgsLocalView &lv = db->lv;
@@ -527,7 +536,7 @@ static int upload_keys(uint32_t **d, const uint32_t *h, size_t n, bool *have, hi
 {
   *have = false;
   if (!h) return UGS_OK;
-  if (!*d) HIPCHK(hipMalloc(d, std::max<size_t>(n, 1) * 4));
+  if (!*d) HIPCHK(ugs_malloc(d, std::max<size_t>(n, 1) * 4));
   if (n) HIPCHK(hipMemcpyAsync(*d, h, n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   *have = true;
@@ -554,8 +563,8 @@ extern "C" int ugs_batch_set_pair_keys(ugs_batch *b, const uint32_t *label_key, 
   HIPCHK(hipSetDevice(db->device));
   const bool need_size = (db->p.pair_mask & UGS_P_MIN_SIZERATIO) || (db->p.filter_mask & UGS_F_ABSKEW);
   if (need_size && size && sizes_missing(size, b->nq)) { ugs_set_error("Missing size= in a query label (-min_sizeratio / -abskew need it, label.cpp:152-161)"); return UGS_E_ARG; }
-  if (b->d_qkey && label_key) { HIPCHK(hipFree(b->d_qkey)); b->d_qkey = nullptr; }     // sized for the uploaded batch
-  if (b->d_qsize && size) { HIPCHK(hipFree(b->d_qsize)); b->d_qsize = nullptr; }
+  if (b->d_qkey && label_key) { HIPCHK(ugs_free(b->d_qkey)); b->d_qkey = nullptr; }     // sized for the uploaded batch
+  if (b->d_qsize && size) { HIPCHK(ugs_free(b->d_qsize)); b->d_qsize = nullptr; }
   RCCHK(upload_keys(&b->d_qkey, label_key, b->nq, &b->have_qkey, db->stream));
   RCCHK(upload_keys(&b->d_qsize, size, b->nq, &b->have_qsize, db->stream));
   b->v.q_key = b->d_qkey; b->v.q_size = b->d_qsize;
@@ -598,18 +607,17 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   // (as ugs_db_destroy: the handle's own streams and events only)
   if (b->db->stream) (void)hipStreamSynchronize(b->db->stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
-  if (b->work_stream) (void)hipStreamSynchronize(b->work_stream);
   if (b->ev_done) (void)hipEventSynchronize(b->ev_done);
   if (b->ev_up) (void)hipEventSynchronize(b->ev_up);
   (void)hipDeviceSynchronize();        // (device-wide, as ugs_db_destroy says)
-  (void)hipFree(b->d_qseqs); (void)hipFree(b->d_qoffs); (void)hipFree(b->d_cand); (void)hipFree(b->d_cand_cnt); (void)hipFree(b->d_cand_n);
-  (void)hipFree(b->d_hit_n); (void)hipFree(b->d_cigar); (void)hipFree(b->d_runs); (void)hipFree(b->d_hits); (void)hipFree(b->d_emit); (void)hipFree(b->d_tb);
-  (void)hipFree(b->d_unit_ns); (void)hipFree(b->d_unit_slots); (void)hipFree(b->d_defer); (void)hipFree(b->d_qpk);
-  (void)hipFree(b->d_qkey); (void)hipFree(b->d_qsize);
-  (void)hipFree(b->d_qthr); (void)hipFree(b->d_ltb); (void)hipFree(b->d_lrow); (void)hipFree(b->d_lruns);
-  (void)hipFree(b->d_cigar_used); (void)hipFree(b->d_ctr);
-  (void)hipFree(b->d_walk_state); (void)hipFree(b->d_open_list); (void)hipFree(b->d_deepU); (void)hipFree(b->d_deepR); (void)hipFree(b->d_keyn); (void)hipFree(b->d_koff);
-  (void)hipFree(b->d_keys); (void)hipFree(b->d_keys_sorted); (void)hipFree(b->d_sort_tmp); (void)hipFree(b->d_xpool); (void)hipFree(b->d_xnext); (void)hipFree(b->d_xblocks_used);
+  (void)ugs_free(b->d_qseqs); (void)ugs_free(b->d_qoffs); (void)ugs_free(b->d_cand); (void)ugs_free(b->d_cand_cnt); (void)ugs_free(b->d_cand_n);
+  (void)ugs_free(b->d_hit_n); (void)ugs_free(b->d_cigar); (void)ugs_free(b->d_runs); (void)ugs_free(b->d_hits); (void)ugs_free(b->d_emit); (void)ugs_free(b->d_tb);
+  (void)ugs_free(b->d_unit_ns); (void)ugs_free(b->d_unit_slots); (void)ugs_free(b->d_defer); (void)ugs_free(b->d_qpk);
+  (void)ugs_free(b->d_qkey); (void)ugs_free(b->d_qsize);
+  (void)ugs_free(b->d_qthr); (void)ugs_free(b->d_ltb); (void)ugs_free(b->d_lrow); (void)ugs_free(b->d_lruns);
+  (void)ugs_free(b->d_cigar_used); (void)ugs_free(b->d_ctr);
+  (void)ugs_free(b->d_walk_state); (void)ugs_free(b->d_open_list); (void)ugs_free(b->d_deepU); (void)ugs_free(b->d_deepR); (void)ugs_free(b->d_keyn); (void)ugs_free(b->d_koff);
+  (void)ugs_free(b->d_keys); (void)ugs_free(b->d_keys_sorted); (void)ugs_free(b->d_sort_tmp); (void)ugs_free(b->d_xpool); (void)ugs_free(b->d_xnext); (void)ugs_free(b->d_xblocks_used);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
   if (b->ev0r) (void)hipEventDestroy(b->ev0r);
@@ -618,7 +626,6 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   if (b->ev_done) (void)hipEventDestroy(b->ev_done);
   if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
-  if (b->work_stream) (void)hipStreamDestroy(b->work_stream);
   if (b->h_rel) (void)hipHostFree(b->h_rel);
   delete b;
 }
@@ -639,37 +646,36 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   b->hit_slots = (uint32_t)db->v.max_accepts * (db->p.local ? db->p.max_hsps : 1u);
   int rc = UGS_OK;
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); ugs_batch_destroy(b); return UGS_E_HIP; } } while (0)
-  BCHK(hipMalloc(&b->d_qseqs, max_letters ? max_letters : 16));
-  BCHK(hipMalloc(&b->d_qoffs, ((size_t)max_queries + 1) * 8));
-  BCHK(hipMalloc(&b->d_cand, std::max<uint64_t>(units * b->K, 1) * 4));
-  BCHK(hipMalloc(&b->d_cand_cnt, std::max<uint64_t>(units * b->K, 1) * 4));
-  BCHK(hipMalloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
-  BCHK(hipMalloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
-  BCHK(hipMalloc(&b->d_defer, std::max<uint64_t>(units, 1) * 4));
-  BCHK(hipMalloc(&b->d_hits, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
+  BCHK(ugs_malloc(&b->d_qseqs, max_letters ? max_letters : 16));
+  BCHK(ugs_malloc(&b->d_qoffs, ((size_t)max_queries + 1) * 8));
+  BCHK(ugs_malloc(&b->d_cand, std::max<uint64_t>(units * b->K, 1) * 4));
+  BCHK(ugs_malloc(&b->d_cand_cnt, std::max<uint64_t>(units * b->K, 1) * 4));
+  BCHK(ugs_malloc(&b->d_cand_n, std::max<uint64_t>(units, 1) * 4));
+  BCHK(ugs_malloc(&b->d_hit_n, std::max<uint64_t>(units, 1) * 4));
+  BCHK(ugs_malloc(&b->d_defer, std::max<uint64_t>(units, 1) * 4));
+  BCHK(ugs_malloc(&b->d_hits, std::max<uint64_t>(units * b->hit_slots, 1) * sizeof(ugs_hit)));
   b->cigar_cap = units * std::max(db->p.max_accepts, 1) * 12 + 4096;
-  if (db->p.local) BCHK(hipMalloc(&b->d_qthr, std::max<uint64_t>(max_queries, 1) * sizeof(int2)));
-  BCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
-  BCHK(hipMalloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
-  BCHK(hipMalloc(&b->d_qoff, ((uint64_t)max_queries + 1) * 4));
+  if (db->p.local) BCHK(ugs_malloc(&b->d_qthr, std::max<uint64_t>(max_queries, 1) * sizeof(int2)));
+  BCHK(ugs_malloc(&b->d_cigar, b->cigar_cap * 4));
+  BCHK(ugs_malloc(&b->d_qn, std::max<uint64_t>(max_queries, 1) * 4));
+  BCHK(ugs_malloc(&b->d_qoff, ((uint64_t)max_queries + 1) * 4));
   b->compact_alloc = std::max<uint64_t>(units * b->hit_slots, 1);
-  BCHK(hipMalloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
+  BCHK(ugs_malloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
   if (db->v.align_flags & UGS_A_DEEP) {
-    BCHK(hipMalloc(&b->d_walk_state, std::max<uint64_t>(units, 1) * sizeof(UgsWalkState)));
-    BCHK(hipMalloc(&b->d_open_list, std::max<uint64_t>(units, 1) * 4));
-    BCHK(hipMalloc(&b->d_xblocks_used, 8));
+    BCHK(ugs_malloc(&b->d_walk_state, std::max<uint64_t>(units, 1) * sizeof(UgsWalkState)));
+    BCHK(ugs_malloc(&b->d_open_list, std::max<uint64_t>(units, 1) * 4));
+    BCHK(ugs_malloc(&b->d_xblocks_used, 8));
     BCHK(hipMemset(b->d_xblocks_used, 0, 8));
   }
   b->scan_tmp_bytes = ugs_compact_tmp_bytes(max_queries);
-  BCHK(hipMalloc(&b->d_scan_tmp, b->scan_tmp_bytes));
-  BCHK(hipMalloc(&b->d_cigar_used, 8));
+  BCHK(ugs_malloc(&b->d_scan_tmp, b->scan_tmp_bytes));
+  BCHK(ugs_malloc(&b->d_cigar_used, 8));
   BCHK(hipMemset(b->d_cigar_used, 0, 8));
-  BCHK(hipMalloc(&b->d_ctr, UGS_CTR_N * 8));
+  BCHK(ugs_malloc(&b->d_ctr, UGS_CTR_N * 8));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev0r)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
   BCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   BCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-  if (db->tune.batch_streams) BCHK(hipStreamCreateWithFlags(&b->work_stream, hipStreamNonBlocking));
   BCHK(hipHostMalloc((void **)&b->h_rel, ((size_t)max_queries + 1) * 8, hipHostMallocDefault));
 #undef BCHK
   (void)rc;
@@ -702,16 +708,16 @@ static int plan_local(ugs_batch *b)
   b->lgrid = (int)((waves + wpb - 1) / wpb); b->lwpb = wpb; b->llds = lds;
   const uint64_t nw = (uint64_t)b->lgrid * wpb;
   if (!b->d_ltb || nw * lv.tb_cap > b->ltb_alloc) {
-    if (b->d_ltb) HIPCHK(hipFree(b->d_ltb));
-    HIPCHK(hipMalloc(&b->d_ltb, nw * lv.tb_cap)); b->ltb_alloc = nw * lv.tb_cap;
+    if (b->d_ltb) HIPCHK(ugs_free(b->d_ltb));
+    HIPCHK(ugs_malloc(&b->d_ltb, nw * lv.tb_cap)); b->ltb_alloc = nw * lv.tb_cap;
   }
   if (!b->d_lrow || nw * lv.rows_cap > b->lrow_alloc) {
-    if (b->d_lrow) HIPCHK(hipFree(b->d_lrow));
-    HIPCHK(hipMalloc(&b->d_lrow, nw * lv.rows_cap * sizeof(uint2))); b->lrow_alloc = nw * lv.rows_cap;
+    if (b->d_lrow) HIPCHK(ugs_free(b->d_lrow));
+    HIPCHK(ugs_malloc(&b->d_lrow, nw * lv.rows_cap * sizeof(uint2))); b->lrow_alloc = nw * lv.rows_cap;
   }
   if (!b->d_lruns || nw * 3 * lv.runbuf_cap > b->lruns_alloc) {
-    if (b->d_lruns) HIPCHK(hipFree(b->d_lruns));
-    HIPCHK(hipMalloc(&b->d_lruns, nw * 3 * lv.runbuf_cap * 4)); b->lruns_alloc = nw * 3 * lv.runbuf_cap;
+    if (b->d_lruns) HIPCHK(ugs_free(b->d_lruns));
+    HIPCHK(ugs_malloc(&b->d_lruns, nw * 3 * lv.runbuf_cap * 4)); b->lruns_alloc = nw * 3 * lv.runbuf_cap;
   }
   lv.tb = b->d_ltb; lv.rowinfo = b->d_lrow; lv.runbuf = b->d_lruns; lv.qthr = b->d_qthr;
   return UGS_OK;
@@ -807,18 +813,18 @@ static int plan_launch(ugs_batch *b)
     // (a database that grows - cluster_fast - asks for a little more with every batch: over-allocate then, a multi-GB
     // hipMalloc per batch costs more than the batch's kernels)
     const uint64_t want = ecap * (uint64_t)b->rl.grid, cap = b->d_emit ? want + want / 2 : want;
-    if (b->d_emit) HIPCHK(hipFree(b->d_emit));
+    if (b->d_emit) HIPCHK(ugs_free(b->d_emit));
     b->d_emit = nullptr;
-    HIPCHK(hipMalloc(&b->d_emit, cap * 8));
+    HIPCHK(ugs_malloc(&b->d_emit, cap * 8));
     b->emit_cap_alloc = cap;
   }
   b->v.emit_cap = ecap;
   {   // sampled rows per unit (k_rank_setup -> k_rank)
     const uint64_t need = (uint64_t)units * b->rl.ns_max;
-    if (!b->d_unit_ns) HIPCHK(hipMalloc(&b->d_unit_ns, (size_t)b->max_queries * 2 * 4));
+    if (!b->d_unit_ns) HIPCHK(ugs_malloc(&b->d_unit_ns, (size_t)b->max_queries * 2 * 4));
     if (!b->d_unit_slots || need > b->unit_slots_alloc) {
-      if (b->d_unit_slots) HIPCHK(hipFree(b->d_unit_slots));
-      HIPCHK(hipMalloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
+      if (b->d_unit_slots) HIPCHK(ugs_free(b->d_unit_slots));
+      HIPCHK(ugs_malloc(&b->d_unit_slots, (size_t)std::max<uint64_t>(need, 1) * 4));
       b->unit_slots_alloc = need;
     }
   }
@@ -829,9 +835,9 @@ static int plan_launch(ugs_batch *b)
     const uint64_t need = units * (uint64_t)stride * 8u;
     if (p.is_nucleo && !p.local && db->tune.qpk && need <= (1ull << 30)) {
       if (!b->d_qpk || need > b->qpk_alloc) {
-        if (b->d_qpk) HIPCHK(hipFree(b->d_qpk));
+        if (b->d_qpk) HIPCHK(ugs_free(b->d_qpk));
         b->d_qpk = nullptr;
-        HIPCHK(hipMalloc(&b->d_qpk, (size_t)std::max<uint64_t>(need, 8)));
+        HIPCHK(ugs_malloc(&b->d_qpk, (size_t)std::max<uint64_t>(need, 8)));
         b->qpk_alloc = need;
       }
       b->qpk_stride = stride;
@@ -919,13 +925,13 @@ static int plan_launch(ugs_batch *b)
   const uint64_t tb_stride = ((uint64_t)(b->max_qlen + 1) * ((uint64_t)std::max(b->max_qlen, db->max_tlen) + 2 * band_eff + 4) + 63) & ~63ull;
   const uint32_t runs_stride = 2 * (b->max_qlen + db->max_tlen + 4);
   if (!b->d_tb || tb_stride * waves > b->tb_alloc) {
-    if (b->d_tb) HIPCHK(hipFree(b->d_tb));
-    HIPCHK(hipMalloc(&b->d_tb, tb_stride * waves));
+    if (b->d_tb) HIPCHK(ugs_free(b->d_tb));
+    HIPCHK(ugs_malloc(&b->d_tb, tb_stride * waves));
     b->tb_alloc = tb_stride * waves;
   }
   if (!b->d_runs || (uint64_t)runs_stride * waves > b->runs_alloc) {
-    if (b->d_runs) HIPCHK(hipFree(b->d_runs));
-    HIPCHK(hipMalloc(&b->d_runs, (uint64_t)runs_stride * waves * 4));
+    if (b->d_runs) HIPCHK(ugs_free(b->d_runs));
+    HIPCHK(ugs_malloc(&b->d_runs, (uint64_t)runs_stride * waves * 4));
     b->runs_alloc = (uint64_t)runs_stride * waves;
   }
   b->v.tb_stride = tb_stride; b->v.runs_stride = runs_stride;
@@ -1002,9 +1008,9 @@ extern "C" int ugs_batch_wait_upload(ugs_batch *b)
   return UGS_OK;
 }
 
-// the stream a batch's kernels run on: the handle's (searches of all batches in enqueue order), or - UGS_BATCH_STREAMS=1, an experiment -
-// the batch's own, so that the ranking of one batch may run beside the alignment of another
-static inline hipStream_t bstream(const ugs_batch *b) { return (b->db->tune.batch_streams && b->work_stream) ? b->work_stream : bstream(b); }
+// every kernel, memset and event of a batch is enqueued on the HANDLE's stream (r5 had an experiment with a stream per batch whose fall-back
+// branch called itself - ADVICE r05: the optimiser folded it to the batch's null work_stream field, i.e. the legacy NULL stream)
+static inline hipStream_t bstream(const ugs_batch *b) { return b->db->stream; }
 static int enqueue_align(ugs_batch *b)
 {
   ugs_db *db = b->db;
@@ -1032,9 +1038,9 @@ static int group_hits(ugs_batch *b, uint32_t query_base, hipStream_t st)
   HIPCHK(hipStreamSynchronize(st));
   const uint64_t total = (uint64_t)last_off + last_n;
   if (total > b->compact_alloc) {
-    HIPCHK(hipFree(b->d_compact)); b->d_compact = nullptr;
+    HIPCHK(ugs_free(b->d_compact)); b->d_compact = nullptr;
     b->compact_alloc = total + total / 4 + 1024;
-    HIPCHK(hipMalloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
+    HIPCHK(ugs_malloc(&b->d_compact, b->compact_alloc * sizeof(ugs_hit)));
   }
   UgsXHits x; x.state = b->d_walk_state; x.pool = b->d_xpool; x.next = b->d_xnext;
   return ugs_copy_hits(b->d_hit_n, b->d_hits, b->nq, b->nstrand, b->hit_slots, b->d_qoff, b->d_compact, query_base, &x, st);
@@ -1053,22 +1059,33 @@ static int deep_stage(ugs_batch *b)
   // ---- scratch: two words per target and workgroup
   const uint64_t scr_budget = 6ull << 30;
   const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_open, 256), scr_budget / (nseq * 8)));
+  // (pointers and capacities are committed only when every allocation of a group succeeded - a failed multi-GB request
+  //  leaves the batch without the buffers AND without a capacity that claims them, and the call returns UGS_E_NOMEM)
   if (!b->d_deepU || (uint64_t)grid * nseq > b->deep_scr_alloc) {
-    if (b->d_deepU) HIPCHK(hipFree(b->d_deepU));
-    if (b->d_deepR) HIPCHK(hipFree(b->d_deepR));
-    b->d_deepU = b->d_deepR = nullptr;
-    b->deep_scr_alloc = (uint64_t)grid * nseq;
-    HIPCHK(hipMalloc(&b->d_deepU, b->deep_scr_alloc * 4));
-    HIPCHK(hipMalloc(&b->d_deepR, b->deep_scr_alloc * 4));
-    HIPCHK(hipMemsetAsync(b->d_deepU, 0, b->deep_scr_alloc * 4, st));          // (the kernel leaves it zero)
+    const uint64_t want = (uint64_t)grid * nseq;
+    (void)ugs_free(b->d_deepU); (void)ugs_free(b->d_deepR);
+    b->d_deepU = b->d_deepR = nullptr; b->deep_scr_alloc = 0;
+    uint32_t *u = nullptr, *r = nullptr;
+    if (ugs_malloc(&u, want * 4) != hipSuccess || ugs_malloc(&r, want * 4) != hipSuccess) {
+      (void)ugs_free(u); (void)ugs_free(r);
+      ugs_set_error("deep walk: 2 x %llu bytes of device scratch not available", (unsigned long long)(want * 4)); return UGS_E_NOMEM;
+    }
+    b->d_deepU = u; b->d_deepR = r; b->deep_scr_alloc = want; b->deep_dirty = true;
   }
+  if (b->deep_dirty) {           // fresh scratch, or a pass that did not reach its end: k_deep expects (and leaves) U all zero
+    HIPCHK(hipMemsetAsync(b->d_deepU, 0, b->deep_scr_alloc * 4, st));
+  }
+  b->deep_dirty = true;          // until this stage has run to its end
   if (n_open + 1 > b->keyn_alloc) {
-    if (b->d_keyn) HIPCHK(hipFree(b->d_keyn));
-    if (b->d_koff) HIPCHK(hipFree(b->d_koff));
-    b->d_keyn = nullptr; b->d_koff = nullptr;
-    b->keyn_alloc = n_open + n_open / 4 + 64;
-    HIPCHK(hipMalloc(&b->d_keyn, b->keyn_alloc * 4));
-    HIPCHK(hipMalloc(&b->d_koff, b->keyn_alloc * 8));
+    const uint64_t want = n_open + n_open / 4 + 64;
+    (void)ugs_free(b->d_keyn); (void)ugs_free(b->d_koff);
+    b->d_keyn = nullptr; b->d_koff = nullptr; b->keyn_alloc = 0;
+    uint32_t *kn = nullptr; uint64_t *ko = nullptr;
+    if (ugs_malloc(&kn, want * 4) != hipSuccess || ugs_malloc(&ko, want * 8) != hipSuccess) {
+      (void)ugs_free(kn); (void)ugs_free(ko);
+      ugs_set_error("deep walk: %llu bytes of device memory for the list sizes not available", (unsigned long long)(want * 12)); return UGS_E_NOMEM;
+    }
+    b->d_keyn = kn; b->d_koff = ko; b->keyn_alloc = want;
   }
   UgsDeepArgs a;
   a.units = b->d_open_list; a.n_units = (uint32_t)n_open; a.U = b->d_deepU; a.R = b->d_deepR; a.stride = nseq;
@@ -1085,19 +1102,23 @@ static int deep_stage(ugs_batch *b)
     while (hi < n_open && (hi == lo || total + keyn[hi] <= key_budget)) { total += keyn[hi]; koff.push_back(total); ++hi; }
     b->deep_keys_total += total;
     if (total > b->keys_alloc) {
-      if (b->d_keys) HIPCHK(hipFree(b->d_keys));
-      if (b->d_keys_sorted) HIPCHK(hipFree(b->d_keys_sorted));
-      b->d_keys = b->d_keys_sorted = nullptr;
-      b->keys_alloc = total + total / 8 + 1024;
-      HIPCHK(hipMalloc(&b->d_keys, b->keys_alloc * 8));
-      HIPCHK(hipMalloc(&b->d_keys_sorted, b->keys_alloc * 8));
+      const uint64_t want = total + total / 8 + 1024;
+      (void)ugs_free(b->d_keys); (void)ugs_free(b->d_keys_sorted);
+      b->d_keys = b->d_keys_sorted = nullptr; b->keys_alloc = 0;
+      uint64_t *k1 = nullptr, *k2 = nullptr;
+      if (ugs_malloc(&k1, want * 8) != hipSuccess || ugs_malloc(&k2, want * 8) != hipSuccess) {
+        (void)ugs_free(k1); (void)ugs_free(k2);
+        ugs_set_error("deep walk: 2 x %llu bytes of device memory for the candidate lists not available", (unsigned long long)(want * 8)); return UGS_E_NOMEM;
+      }
+      b->d_keys = k1; b->d_keys_sorted = k2; b->keys_alloc = want;
     }
     HIPCHK(hipMemcpyAsync(b->d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, st));
     a.units = b->d_open_list + lo; a.n_units = (uint32_t)(hi - lo); a.key_n = b->d_keyn + lo; a.key_off = b->d_koff; a.keys = b->d_keys; a.mode = 1;
     RCCHK(ugs_launch_deep(db->v, b->v, a, grid, st));
     RCCHK(ugs_deep_sort(b->d_keys, b->d_keys_sorted, total, (uint32_t)(hi - lo), b->d_koff, &b->d_sort_tmp, &b->sort_tmp_bytes, st));
     // ---- the continuation pass over this chunk; a path pool or an overflow hit pool that runs out is grown and the pass repeated
-    unsigned long long cig0 = 0, xb0 = 0;
+    unsigned long long cig0 = 0, xb0 = 0, ctr0[UGS_CTR_N];   // (ctr0: a repeated pass must not count its pairs and hits twice)
+    HIPCHK(hipMemcpyAsync(ctr0, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&cig0, b->d_cigar_used, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&xb0, b->d_xblocks_used, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1125,29 +1146,32 @@ static int deep_stage(ugs_batch *b)
       if (cig_over) {            // the paths written before this chunk stay: copy them into the larger pool
         const uint64_t cap = cig1 + cig1 / 4 + 4096;
         uint32_t *np = nullptr;
-        HIPCHK(hipMalloc(&np, cap * 4));
+        HIPCHK(ugs_malloc(&np, cap * 4));
         if (cig0) HIPCHK(hipMemcpyAsync(np, b->d_cigar, cig0 * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipFree(b->d_cigar));
+        HIPCHK(ugs_free(b->d_cigar));
         b->d_cigar = np; b->cigar_cap = cap; b->v.cigar_pool = np; b->v.cigar_cap = cap;
       }
       if (x_over) {
         const uint32_t cap = (uint32_t)std::min<unsigned long long>(xb1 + xb1 / 4 + 64, 0xfffffff0ull);
         ugs_hit *np = nullptr; uint32_t *nn = nullptr;
-        HIPCHK(hipMalloc(&np, (size_t)cap * UGS_XBLOCK * sizeof(ugs_hit)));
-        HIPCHK(hipMalloc(&nn, (size_t)cap * 4));
+        HIPCHK(ugs_malloc(&np, (size_t)cap * UGS_XBLOCK * sizeof(ugs_hit)));
+        HIPCHK(ugs_malloc(&nn, (size_t)cap * 4));
         if (xb0) { HIPCHK(hipMemcpyAsync(np, b->d_xpool, (size_t)xb0 * UGS_XBLOCK * sizeof(ugs_hit), hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(nn, b->d_xnext, (size_t)xb0 * 4, hipMemcpyDeviceToDevice, st)); }
         HIPCHK(hipStreamSynchronize(st));
-        if (b->d_xpool) HIPCHK(hipFree(b->d_xpool));
-        if (b->d_xnext) HIPCHK(hipFree(b->d_xnext));
+        if (b->d_xpool) HIPCHK(ugs_free(b->d_xpool));
+        if (b->d_xnext) HIPCHK(ugs_free(b->d_xnext));
         b->d_xpool = np; b->d_xnext = nn; b->xblocks_cap = cap; b->v.xpool = np; b->v.xnext = nn; b->v.xblocks_cap = cap;
       }
       // (the pass is repeatable: it reads a unit's parked counters and writes only the head of its overflow chain and its hit count)
       HIPCHK(hipMemcpyAsync(b->d_cigar_used, &cig0, 8, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(b->d_xblocks_used, &xb0, 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_ctr, ctr0, UGS_CTR_N * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
     }
     lo = hi;
   }
+  b->deep_dirty = false;
   HIPCHK(hipMemcpy(b->ctr, b->d_ctr, UGS_CTR_N * 8, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&b->cigar_used_host, b->d_cigar_used, 8, hipMemcpyDeviceToHost));
   b->ctr[UGS_CTR_OPEN] = n_open;
@@ -1216,8 +1240,8 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
         return UGS_E_ENVELOPE;
       }
       if (want > b->emit_cap_alloc) {
-        HIPCHK(hipFree(b->d_emit)); b->d_emit = nullptr;
-        HIPCHK(hipMalloc(&b->d_emit, want * 8));
+        HIPCHK(ugs_free(b->d_emit)); b->d_emit = nullptr;
+        HIPCHK(ugs_malloc(&b->d_emit, want * 8));
         b->emit_cap_alloc = want;
       }
       b->v.emit_buf = b->d_emit; b->v.emit_cap = ecap;
@@ -1243,9 +1267,9 @@ extern "C" int ugs_batch_sync(ugs_batch *b)
       b->synced = true; return UGS_OK;
     }
     // path pool too small: grow to the demanded size and re-run the alignment stage only
-    HIPCHK(hipFree(b->d_cigar));
+    HIPCHK(ugs_free(b->d_cigar));
     b->cigar_cap = b->cigar_used_host + b->cigar_used_host / 4 + 4096;
-    HIPCHK(hipMalloc(&b->d_cigar, b->cigar_cap * 4));
+    HIPCHK(ugs_malloc(&b->d_cigar, b->cigar_cap * 4));
     b->v.cigar_pool = b->d_cigar; b->v.cigar_cap = b->cigar_cap;
     unsigned long long keep = b->ctr[UGS_CTR_POSTINGS];
     HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, bstream(b)));

@@ -27,7 +27,6 @@ struct UgsTune {
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
   int r3, r3_sp, r3_pps;        // UGS_R3 / UGS_R3_SP / UGS_R3_PPS  sparse index: -1 unset (= k_rank3g), 0 = k_rank2g; k_rank3g: partitions per super-partition
                                 //                            (0 unset = per unit, from its postings), postings per super-partition aimed at (0 unset = 4096)
-  bool batch_streams;           // UGS_BATCH_STREAMS=1        every batch object runs its kernels on a stream of its own (experiment: ranking of one batch beside the alignment of another)
 };
 UgsTune ugs_tune_read();
 
@@ -88,7 +87,6 @@ struct ugs_batch {
   bool cl_mode;                     // the batch of a cluster_fast loop (ugs_cluster.cpp): its searches leave walk records, the bitmap kernel runs its CL instantiation
   // upload path: H2D copies go through the batch's own copy stream; the search waits for ev_up on the handle's stream,
   // so the upload of one batch overlaps the kernels of another (h_rel: page-locked staging of the relative offsets)
-  hipStream_t work_stream;          // UGS_BATCH_STREAMS: the batch's own kernel stream (null: the handle's)
   hipStream_t copy_stream; hipEvent_t ev_up, ev_done; uint64_t *h_rel;   // ev_done: end of the last enqueued search
   uint32_t compact_base;            // query base of the grouped hit table in d_compact (query_base after a search)
   uint32_t query_base;              // ugs_batch_set_query_base: what the search's own grouping adds to ugs_hit.query (a shard's offset)
@@ -96,6 +94,7 @@ struct ugs_batch {
   // deep walks (UGS_A_DEEP, ugs_deep.hip): parked walks, the scratch of their complete candidate lists, overflow hit blocks
   UgsWalkState *d_walk_state; uint32_t *d_open_list;
   uint32_t *d_deepU, *d_deepR; uint64_t deep_scr_alloc; int deep_grid;
+  bool deep_dirty;                  // d_deepU may hold counts of a pass that did not reach its end (zeroed before the next one)
   uint32_t *d_keyn; uint64_t *d_koff; uint64_t keyn_alloc;
   uint64_t *d_keys, *d_keys_sorted; uint64_t keys_alloc; void *d_sort_tmp; size_t sort_tmp_bytes;
   ugs_hit *d_xpool; uint32_t *d_xnext; uint32_t xblocks_cap; unsigned long long *d_xblocks_used;

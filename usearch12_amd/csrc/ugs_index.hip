@@ -182,18 +182,18 @@ int scratch_get(int i, size_t bytes, void **out, bool *cached)
 {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
-  if (bytes > SCRATCH_KEEP) { *cached = false; HIPCHK(hipMalloc(out, bytes)); return UGS_OK; }
+  if (bytes > SCRATCH_KEEP) { *cached = false; HIPCHK(ugs_malloc(out, bytes)); return UGS_OK; }
   Scratch &sc = g_scratch[i];
   if (sc.dev != dev || sc.cap < bytes) {
     if (sc.p) {                                               // the old buffer may belong to the device this thread used before
       if (sc.dev != dev) HIPCHK(hipSetDevice(sc.dev));
-      const hipError_t e = hipFree(sc.p);
+      const hipError_t e = ugs_free(sc.p);
       if (sc.dev != dev) HIPCHK(hipSetDevice(dev));
       HIPCHK(e);
     }
     sc.p = nullptr; sc.cap = 0; sc.dev = dev;
     const size_t want = bytes + bytes / 4 + 4096;
-    HIPCHK(hipMalloc(&sc.p, want));
+    HIPCHK(ugs_malloc(&sc.p, want));
     sc.cap = want;
   }
   *cached = true; *out = sc.p;
@@ -206,11 +206,11 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
                     uint32_t **d_postings_out, uint64_t *n_postings, uint32_t *max_row, hipStream_t st)
 {
   uint64_t *row_off = nullptr; uint32_t *postings = nullptr;
-  HIPCHK(hipMalloc(&row_off, ((size_t)slots + 1) * sizeof(uint64_t)));
+  HIPCHK(ugs_malloc(&row_off, ((size_t)slots + 1) * sizeof(uint64_t)));
   *d_row_off_out = row_off; *d_postings_out = nullptr; *n_postings = 0; *max_row = 0;
   if (nseq == 0 || nletters == 0) {
     HIPCHK(hipMemsetAsync(row_off, 0, ((size_t)slots + 1) * sizeof(uint64_t), st));
-    HIPCHK(hipMalloc(&postings, 256 * sizeof(uint32_t)));
+    HIPCHK(ugs_malloc(&postings, 256 * sizeof(uint32_t)));
     *d_postings_out = postings;
     return UGS_OK;
   }
@@ -243,7 +243,7 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   uint64_t np_host = 0;
   HIPCHK(hipMemcpyAsync(&np_host, row_off + slots, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipMalloc(&postings, (np_host + 256) * sizeof(uint32_t)));        // padded: rows are read in whole-wave units
+  HIPCHK(ugs_malloc(&postings, (np_host + 256) * sizeof(uint32_t)));        // padded: rows are read in whole-wave units
   HIPCHK(hipMemsetAsync(postings + np_host, 0, 256 * sizeof(uint32_t), st));
   if (np_host) {
     hipLaunchKernelGGL(k_postings, dim3((unsigned)((np_host + 255) / 256)), dim3(256), 0, st, keys, np_host, postings);
@@ -253,10 +253,10 @@ int ugs_build_index(const UgsTables *d_tab, const uint8_t *d_seqs, const uint64_
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(max_row, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (!c_tmp) HIPCHK(hipFree(tmp));
-  if (!c_keys) HIPCHK(hipFree(keys));
-  if (!c_keys2) HIPCHK(hipFree(keys2));
-  if (!c_cnt) HIPCHK(hipFree(d_count));
+  if (!c_tmp) HIPCHK(ugs_free(tmp));
+  if (!c_keys) HIPCHK(ugs_free(keys));
+  if (!c_keys2) HIPCHK(ugs_free(keys2));
+  if (!c_cnt) HIPCHK(ugs_free(d_count));
   *d_postings_out = postings;
   *n_postings = np_host;
   return UGS_OK;

@@ -191,7 +191,7 @@ struct DevBufs {
   bool own_st = false, own_ev = false;
   ~DevBufs()
   {
-    for (void *p : ptrs) (void)hipFree(p);
+    for (void *p : ptrs) (void)ugs_free(p);
     if (own_ev && e0) (void)hipEventDestroy(e0);
     if (own_ev && e1) (void)hipEventDestroy(e1);
     if (own_st && st) (void)hipStreamDestroy(st);
@@ -221,7 +221,7 @@ struct DevBufs {
   template <class T> hipError_t alloc(T **p, size_t n)
   {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+    hipError_t e = ugs_malloc(&q, (n ? n : 1) * sizeof(T));
     if (e == hipSuccess) { ptrs.push_back(q); *p = (T *)q; }
     return e;
   }
