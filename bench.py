@@ -142,6 +142,66 @@ def cpu_baseline(kind, db, qs, ident, sweep_q, parity_q, nproc):
              "sample": "%d of the same C2 queries vs the full %d-seq DB, oracle/ugs_oracle.c with %d threads" % (sample.n, db.n, nproc)}, None, 0)
 
 
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "usearch12")
+
+
+def ref_parity_global(capi, db, qs, ident, gpu_hits, par_n, threads=16, what=""):
+    """checker leg (never inside a timed region): the unmodified reference binary's own -blast6out for the first `par_n` queries of `qs`
+    against ugs_format_blast6 of the GPU hit table `gpu_hits` for the same queries, as sorted multisets of lines (blast6out.cpp:27-80)"""
+    if not os.path.exists(REF_BIN):
+        return {"skipped": "oracle/_ref/usearch12 is not on this box"}
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        dbfa, qfa, udb, out = (os.path.join(tmp, x) for x in ("db.fa", "q.fa", "db.udb", "o.b6"))
+        db.write_fasta(dbfa)
+        qs.slice(0, par_n).write_fasta(qfa)
+        rc = subprocess.call([REF_BIN, "-makeudb_usearch", dbfa, "-output", udb], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dbarg = udb if rc == 0 and os.path.exists(udb) else dbfa
+        t1 = time.time()
+        subprocess.check_call([REF_BIN, "-usearch_global", qfa, "-db", dbarg, "-id", str(ident), "-blast6out", out, "-threads", str(threads)],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t2 = time.time()
+        theirs = sorted(open(out, "rb").read().splitlines(keepends=True))
+    mine = sorted(blast6_lines(capi, gpu_hits, qs.label, db.label))
+    same = mine == theirs
+    res = {"queries": par_n, "hits_gpu": len(mine), "hits_reference": len(theirs), "identical": bool(same), "reference_threads": threads,
+           "reference_search_s": round(t2 - t1, 2), "leg_s": round(time.time() - t0, 1),
+           "what": what + "every -blast6out line of the unmodified reference binary for the first %d queries vs ugs_format_blast6 of the GPU hit table "
+                          "for the same queries, as sorted multisets of lines" % par_n}
+    if not same:
+        res["first_differences"] = [x.decode(errors="replace") for x in sorted(set(mine) ^ set(theirs))[:4]]
+    return res
+
+
+def ref_parity_cluster(capi, reads, ident, par_n, device):
+    """checker leg: `usearch12 -cluster_fast -id .. -uc -threads 1` (the reference's deterministic setting) on the first `par_n` reads against
+    ugs_cluster_write_uc of the GPU run on the same prefix, byte for byte (outputuc.cpp:45-93, clusterfast.cpp:81-133)"""
+    if not os.path.exists(REF_BIN):
+        return {"skipped": "oracle/_ref/usearch12 is not on this box"}
+    t0 = time.time()
+    sub = reads.slice(0, par_n)
+    with tempfile.TemporaryDirectory() as tmp:
+        fa, ruc, guc = (os.path.join(tmp, x) for x in ("r.fa", "ref.uc", "gpu.uc"))
+        sub.write_fasta(fa)
+        t1 = time.time()
+        subprocess.check_call([REF_BIN, "-cluster_fast", fa, "-id", str(ident), "-uc", ruc, "-threads", "1", "-strand", "plus"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t2 = time.time()
+        res = capi.UgsCluster(capi.cluster_params(ident), sub.seqs, sub.offs, device=device)
+        res.write_uc(sub.labels(), guc)
+        ncl = int(res.n_clusters)
+        res.close()
+        a, b = open(ruc, "rb").read(), open(guc, "rb").read()
+    out = {"reads": par_n, "identical": bool(a == b), "uc_bytes": len(a), "clusters": ncl, "reference_s_1_thread": round(t2 - t1, 2), "leg_s": round(time.time() - t0, 1),
+           "what": "C3: the -uc file of the unmodified reference binary (-cluster_fast -id %s -threads 1) for the first %d reads vs ugs_cluster_write_uc of the "
+                   "GPU run on the same reads, byte for byte" % (ident, par_n)}
+    if a != b:
+        la, lb = a.splitlines(), b.splitlines()
+        k = next((i for i, (x, y) in enumerate(zip(la, lb)) if x != y), min(len(la), len(lb)))
+        out["first_difference"] = {"line": k, "reference": la[k].decode(errors="replace") if k < len(la) else None, "gpu": lb[k].decode(errors="replace") if k < len(lb) else None}
+    return out
+
+
 def c4_on_one_device(capi, synth, device, world=8, total_q=10_000_000, db_n=5_000_000, length=250):
     """BASELINE.json configs[3] on the ONE GPU the driver's bench box has: the 10 M-query stream in `world` contiguous shards, one rank
     (batch object + communicator rank + host thread for the collective) per shard, the shards searched one after the other against the
@@ -205,7 +265,7 @@ def c4_on_one_device(capi, synth, device, world=8, total_q=10_000_000, db_n=5_00
     return out
 
 
-def other_config(capi, synth, name, device):
+def other_config(capi, synth, name, device, parity=True):
     """One of BASELINE.json's other configurations, once, on this GPU (driver-visible numbers for what DESIGN.md section 4 quotes; VERDICT
     r04 item 2).  Same step as the bench line: upload + kernels + fetch; 1 warm-up + 3 timed steps of one batch."""
     t0 = time.time()
@@ -226,6 +286,8 @@ def other_config(capi, synth, name, device):
                "kernel": "k_rank2<cluster_fast> + k_rank over its deferred units", "algorithmic_bytes": 4 * int(st.postings),
                "frac": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
         res.close()
+        if parity:
+            out["parity_sample"] = ref_parity_cluster(capi, r, 0.97, 150_000, device)
         return out
     if name != "C5":
         raise ValueError("unknown configuration %r" % name)
@@ -261,6 +323,12 @@ def other_config(capi, synth, name, device):
            "kernel_ms": {"ranking": st["ms_rank"], "k_align": st["ms_align"], "k_rank_setup": st["ms_rank_setup"]},
            "kernel": kern + " + k_rank over %d deferred units" % kh["deferred"], "algorithmic_bytes": int(b_rank),
            "frac": b_rank / (st["ms_rank"] * 1e-3) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
+    if parity:
+        par_n = 100_000
+        sub = qs.slice(0, par_n)
+        bats[0].upload(sub.seqs, sub.offs); bats[0].search(); bats[0].sync()
+        h, _nh, _pool = bats[0].fetch()
+        out["parity_sample"] = ref_parity_global(capi, db, qs, 0.8, h, par_n, what="C5: ")
     for b in bats:
         b.close()
     gdb.close()
@@ -673,7 +741,7 @@ def main():
             others = []
             for name in which:
                 try:
-                    others.append(other_config(capi, synth, name, local_rank))
+                    others.append(other_config(capi, synth, name, local_rank, parity=args.parity_sample > 0))
                 except Exception as e:                              # (reported, never hidden: the C2 line above is already measured)
                     others.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
 
@@ -781,7 +849,10 @@ def main():
                             "valu_per_pair": (mix["k_align"]["SQ_INSTS_VALU"] / max(st["pairs_aligned"], 1)) if "k_align" in mix else None,
                             "issue_roofline": issue_roofline("k_align", ms_align)}},
             "cpu_baseline": cb,
-            "parity_sample": parity,
+            # one entry per configuration that was compared with the reference BINARY's own output on this box (C2: 384 k queries, C5: 100 k
+            # protein queries, C3: the -uc of a 150 k-read prefix at -threads 1)
+            "parity_sample": ([dict(parity, config="C2")] if parity else []) +
+                             [dict(o["parity_sample"], config=o["workload"][:2]) for o in (others or []) if isinstance(o, dict) and o.get("parity_sample")],
             "detail": {"csrc_sha16": csrc_sha, "runtime_libs": all_libs, "other_configs": others, "strong_scaling_proxy": proxy,
                        "ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),

@@ -61,6 +61,27 @@ def test_bitmap_kernel_takes_the_dense_big_path_and_equals_k_rank(c2_small):
     assert a[0] == b[0]
 
 
+@pytest.mark.parametrize("g", [None, "8192", "24576", "65536"])
+def test_bitmap_kernel_over_16_bit_postings_equals_the_32_bit_stream(c2_small, g):
+    """r6: a plain search streams the postings as 16-bit offsets inside their partition (the default); UGS_R2_P16=0 keeps the 32-bit
+    stream.  Same candidates, counts and hit tables as each other and as k_rank, for the default partition size and for 8 192-target
+    (37 partitions, sub-rows of ~30 postings: most chunks start 1-3 elements early), 24 576- and 65 536-target partitions; both strands."""
+    db, qs = c2_small
+    sub = qs.slice(0, 6000)
+    env = {"UGS_RANK2": "1"}
+    if g:
+        env["UGS_R2_G"] = g
+    for kw in (dict(is_nucleo=True, id=0.97), dict(is_nucleo=True, id=0.97, strand_both=1)):
+        a = _search(db, sub, {"UGS_RANK2": "0"}, **kw)[0]
+        b = _search(db, sub, dict(env, UGS_R2_P16="0"), **kw)[0]
+        c = _search(db, sub, env, **kw)[0]
+        assert b[1]["r2_kernel"] == "k_rank2" and c[1]["r2_kernel"] == "k_rank2<P16>"
+        assert b[1]["r2_units"] == c[1]["r2_units"] and b[1]["deferred"] == c[1]["deferred"] and c[1]["r2_units"] > 0.9 * sub.n * (2 if "strand_both" in kw else 1)
+        for x, y, z in zip(a[2], b[2], c[2]):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        assert a[0] == b[0] == c[0]
+
+
 def test_units_deferred_to_k_rank_give_the_same_candidates(c2_small):
     """a kept-key list of 8 entries defers nearly every unit: the general kernel behind the bitmap kernel then ranks them"""
     db, qs = c2_small

@@ -148,8 +148,11 @@ def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
     scratch access (a scratch store or load would sit in the same in-order VMEM queue), and (4) the ring is drained (vmcnt(0))
     before the slots are used again."""
     isa = _isa_of("ugs_rank2.hip")
-    for inst in ("k_rank2ILi4ELb0EE", "k_rank2ILi4ELb1EE"):          # the search kernel and its cluster_fast instantiation
+    for inst in ("k_rank2ILi4ELb0ELb0EE", "k_rank2ILi4ELb1ELb0EE"):  # the search kernel over 32-bit postings and its cluster_fast instantiation
         _check_rank2_ring(isa, inst)
+    # <D = 4, CL = false, P16 = true>: the search kernel over 16-bit partition-relative postings (r6) - the same ring at half width:
+    # 8-byte loads into a[2k : 2k+1], eight accumulator registers
+    _check_rank2_ring(isa, "k_rank2ILi4ELb0ELb1EE", half=True)
 
 
 def _kernel_meta(isa, mangled_prefix):
@@ -160,29 +163,41 @@ def _kernel_meta(isa, mangled_prefix):
     return ".agpr_count:" + hit[0]
 
 
-def _check_rank2_ring(isa, inst):
+def _check_rank2_ring(isa, inst, half=False):
     body = _kernel_body(isa, inst)
     meta = _kernel_meta(isa, "_Z7" + inst)
+    nreg = 8 if half else 16                                          # accumulator registers of the ring
+    plain = "ILi4ELb0E" in inst                                       # (not the cluster_fast instantiation)
     assert re.search(r"\.vgpr_spill_count:\s*0\b", meta), "k_rank2 spills vector registers"
-    assert re.search(r"\.agpr_count:\s*(\d+)", meta) and int(re.search(r"\.agpr_count:\s*(\d+)", meta).group(1)) >= 16, "the ring's 16 accumulator registers"
-    if inst.endswith("Lb0EE"):
-        assert re.search(r"\.agpr_count:\s*16\b", meta), "the search kernel holds nothing but the ring in accumulator registers"
+    assert re.search(r"\.agpr_count:\s*(\d+)", meta) and int(re.search(r"\.agpr_count:\s*(\d+)", meta).group(1)) >= nreg, "the ring's accumulator registers"
+    if plain:
+        assert re.search(r"\.agpr_count:\s*%d\b" % nreg, meta), "the search kernel holds nothing but the ring in accumulator registers"
     assert "scratch_" not in body
-    loads = re.findall(r"global_load_dwordx4 (a\[\d+:\d+\])", body)
-    assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) == 8, loads      # prologue + ring, one slot each
-    assert not re.search(r"global_load_dwordx4 v\[", body), "a posting load with a VGPR destination"
+    if half:
+        loads = re.findall(r"global_load_dwordx2 (a\[\d+:\d+\])", body)
+        assert sorted(set(loads)) == ["a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]"] and len(loads) == 8, loads
+        assert not re.search(r"global_load_dwordx4 a\[", body)
+    else:
+        loads = re.findall(r"global_load_dwordx4 (a\[\d+:\d+\])", body)
+        assert sorted(set(loads)) == ["a[0:3]", "a[12:15]", "a[4:7]", "a[8:11]"] and len(loads) == 8, loads      # prologue + ring, one slot each
+    if half:
+        # (the compiler's own 8-byte loads - partition-table pairs, row offsets - have VGPR destinations; none of them may sit inside the ring)
+        first, last = body.index("global_load_dwordx2 a["), body.rindex("global_load_dwordx2 a[")
+        assert not re.search(r"global_load_dword(x\d)? v", body[first:last]), "a compiler load inside the ring: the hand-counted vmcnt(3) would be off"
+    else:
+        assert not re.search(r"global_load_dwordx4 v\[", body), "a posting load with a VGPR destination"
     reads = re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", body)
-    ring = [a for a in reads if int(a[1:]) < 16]
-    assert len(ring) == 16 and sorted(set(ring), key=lambda a: int(a[1:])) == ["a%d" % i for i in range(16)], reads
-    if inst.endswith("Lb0EE"):
-        assert len(reads) == 16 and "v_accvgpr_write" not in body and "v_accvgpr_mov" not in body
+    ring = [a for a in reads if int(a[1:]) < nreg]
+    assert len(ring) == nreg and sorted(set(ring), key=lambda a: int(a[1:])) == ["a%d" % i for i in range(nreg)], reads
+    if plain:
+        assert len(reads) == nreg and "v_accvgpr_write" not in body and "v_accvgpr_mov" not in body
     else:
         # the cluster_fast instantiation: the compiler parks a few spilled values in accumulator registers of its own - never in
         # the ring's a0 .. a15 (a load may still be in flight to those after the statement that names them as clobbered)
         for m in re.finditer(r"v_accvgpr_(?:write_b32 (a\d+)|mov_b32 (a\d+), (a\d+))", body):
             for a in m.groups():
                 assert a is None or int(a[1:]) >= 16, m.group(0)
-    # every block of four reads follows its own counted wait inside one asm statement
+    # every block of reads follows its own counted wait inside one asm statement
     assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == 4
     # the atomics of the bitmap are LDS instructions (not flat), with return
     assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "flat_atomic" not in body

@@ -369,7 +369,7 @@ class UgsBatch:
         _chk(f(self.h, out, 8))
         return {"r2_units": int(out[0]), "deferred": int(out[1]), "rank_kernel": int(out[2]), "r2_launched": int(out[3]),
                 "ms_rank2": out[4] / 1000.0, "ms_rank_deferred": out[5] / 1000.0, "group_rejects": int(out[6]),
-                "r2_kernel": ("", "k_rank2", "k_rank2g", "k_rank3g", "k_rank2<CL>")[int(out[7])]}
+                "r2_kernel": ("", "k_rank2", "k_rank2g", "k_rank3g", "k_rank2<CL>", "k_rank2<P16>")[int(out[7])]}
 
     def candidates(self):
         p = self.db.p

@@ -27,9 +27,11 @@
 #include <unordered_map>
 
 namespace {
-struct GuardRec { void *va; size_t va_bytes; void *map_at; size_t map_bytes; hipMemGenericAllocationHandle_t h; int dev; size_t asked; };
+struct GuardRec { void *va; size_t va_bytes; void *map_at; size_t map_bytes; hipMemGenericAllocationHandle_t h; int dev; size_t asked; const char *file; int line; void *user; };
 std::mutex g_mu;
 std::unordered_map<void *, GuardRec> g_live;
+GuardRec g_freed[64];                 // the last released buffers (a fault on one of their pages is a use after free)
+unsigned g_freed_n = 0;
 int g_mode = -1;            // -1 unread, 0 off, 1 guard, 2 guard + keep the address range
 size_t g_align = 16;
 unsigned long long g_n_alloc = 0, g_n_free = 0, g_bytes_live = 0, g_bytes_peak = 0;
@@ -47,7 +49,7 @@ int guard_mode()
   return g_mode;
 }
 
-hipError_t guard_malloc(void **out, size_t bytes)
+hipError_t guard_malloc(void **out, size_t bytes, const char *file, int line)
 {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -65,7 +67,7 @@ hipError_t guard_malloc(void **out, size_t bytes)
   const size_t user = (want + g_align - 1) / g_align * g_align;
   const size_t map_bytes = (user + gran - 1) / gran * gran;
   GuardRec r;
-  r.dev = dev; r.asked = bytes; r.map_bytes = map_bytes; r.va_bytes = map_bytes + 2 * gran;
+  r.dev = dev; r.asked = bytes; r.file = file; r.line = line; r.map_bytes = map_bytes; r.va_bytes = map_bytes + 2 * gran;
   e = hipMemAddressReserve(&r.va, r.va_bytes, gran, nullptr, 0);
   if (e != hipSuccess) return e;
   e = hipMemCreate(&r.h, map_bytes, &prop, 0);
@@ -79,6 +81,7 @@ hipError_t guard_malloc(void **out, size_t bytes)
   e = hipMemSetAccess(r.map_at, map_bytes, &acc, 1);
   if (e != hipSuccess) { (void)hipMemUnmap(r.map_at, map_bytes); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.va_bytes); return e; }
   void *p = (char *)r.map_at + (map_bytes - user);
+  r.user = p;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     g_live[p] = r;
@@ -97,6 +100,7 @@ hipError_t guard_free(void *p)
     if (it == g_live.end()) return hipErrorInvalidValue;
     r = it->second;
     g_live.erase(it);
+    g_freed[g_freed_n++ % 64] = r;
     ++g_n_free; g_bytes_live -= r.map_bytes;
   }
   int cur = 0;
@@ -111,10 +115,10 @@ hipError_t guard_free(void *p)
 }
 }  // namespace
 
-hipError_t ugs_malloc_bytes(void **p, size_t bytes)
+hipError_t ugs_malloc_at(void **p, size_t bytes, const char *file, int line)
 {
   if (guard_mode() == 0) return hipMalloc(p, bytes);
-  return guard_malloc(p, bytes);
+  return guard_malloc(p, bytes, file, line);
 }
 
 hipError_t ugs_free(void *p)
@@ -145,12 +149,28 @@ void on_abort(int sig, siginfo_t *si, void *uc)
   if (!g_in_bt) {
     g_in_bt = 1;
     const int fd = g_bt_fd >= 0 ? g_bt_fd : 2;
-    char line[128];
+    char line[256];
     snprintf(line, sizeof(line), "\n[ugs] SIGABRT on thread %ld of pid %d - backtrace of the aborting thread:\n", (long)gettid(), (int)getpid());
     wr(fd, line);
     void *frames[96];
     const int n = backtrace(frames, 96);
     backtrace_symbols_fd(frames, n, fd);
+    if (g_mode > 0) {
+      // the guard allocator's table: the runtime's message above names the faulting PAGE - the buffer whose [user, end) lies right in front
+      // of it was overrun, one that begins right behind it was underrun, a released one was used after its free
+      wr(fd, "[ugs] guard allocator, live buffers (user pointer, end = first unmapped byte, bytes asked for, allocated at):\n");
+      for (const auto &kv : g_live) {                      // (no lock: the process is dying; a torn read costs a garbled line)
+        const GuardRec &r = kv.second;
+        snprintf(line, sizeof(line), "  %p .. %p  %zu  %s:%d\n", r.user, (void *)((char *)r.map_at + r.map_bytes), r.asked, r.file ? r.file : "?", r.line);
+        wr(fd, line);
+      }
+      wr(fd, "[ugs] guard allocator, the last released buffers:\n");
+      for (unsigned k = 0; k < 64 && k < g_freed_n; ++k) {
+        const GuardRec &r = g_freed[(g_freed_n - 1 - k) % 64];
+        snprintf(line, sizeof(line), "  %p .. %p  %zu  %s:%d (released)\n", r.user, (void *)((char *)r.map_at + r.map_bytes), r.asked, r.file ? r.file : "?", r.line);
+        wr(fd, line);
+      }
+    }
     wr(fd, "[ugs] /proc/self/maps lines of libamdhip64 / libhsa-runtime64 / librccl / libugs:\n");
     const int mfd = open("/proc/self/maps", O_RDONLY);
     if (mfd >= 0) {                                        // (no stdio, no malloc: the heap may be what is broken)

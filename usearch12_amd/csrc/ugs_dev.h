@@ -178,7 +178,7 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8
   X(8, SMALL_DENSE, "small 8/16-bit dense") X(9, SMALL_DENSE_LONG, "small 8/16-bit dense, long rows") \
   X(12, BIG4_WIDE, "HOT, 64-bit offsets") X(13, BIG4_LONG_WIDE, "long rows, 64-bit offsets") \
   X(14, R2, "k_rank2 (bitmap)") X(15, R2G, "k_rank2g (bitmap, sparse index)") X(16, R2_CL, "k_rank2, cluster_fast instantiation") \
-  X(17, R3G, "k_rank3g (two filter passes, sparse index)")
+  X(17, R3G, "k_rank3g (two filter passes, sparse index)") X(18, R2_P16, "k_rank2 over 16-bit postings")
 #define UGS_RANK_INST_ENUM(i, n, s) UGS_RI_##n = i,
 enum { UGS_RANK_INST_TABLE(UGS_RANK_INST_ENUM) UGS_RI_END };
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);
@@ -214,9 +214,10 @@ int ugs_local_blocks_per_cu(int threads, size_t lds);
 int ugs_launch_local(const UgsDbView &db, const UgsBatchView &b, const UgsLocalView &lv, int grid, int wpb, size_t lds, hipStream_t st);
 void ugs_set_error(const char *fmt, ...);
 // device memory (ugs_alloc.cpp): hipMalloc / hipFree, or - UGS_GUARD_ALLOC=1 - a mapping per buffer, right-aligned against an unmapped page
-hipError_t ugs_malloc_bytes(void **p, size_t bytes);
+hipError_t ugs_malloc_at(void **p, size_t bytes, const char *file, int line);
 hipError_t ugs_free(void *p);
-template <class T> static inline hipError_t ugs_malloc(T **p, size_t bytes) { return ugs_malloc_bytes((void **)p, bytes); }
+template <class T> static inline hipError_t ugs_malloc_t(T **p, size_t bytes, const char *file, int line) { return ugs_malloc_at((void **)p, bytes, file, line); }
+#define ugs_malloc(p, n) ugs_malloc_t((p), (n), __FILE__, __LINE__)      // (the call site goes into the guard allocator's table)
 void ugs_xdrop_tables(int is_nucleo, float m2, float mm2, int8_t sub2[1024], uint8_t cls[256]);   // ugs_xdrop.hip
 extern const char UGS_B62_ORDER[];          // the 23 alphabetic BLOSUM62 symbols
 extern const signed char UGS_B62[23][23];

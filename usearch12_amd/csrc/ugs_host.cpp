@@ -242,6 +242,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   (void)hipDeviceSynchronize();
   (void)ugs_free(db->d_pk);
   (void)ugs_free(db->d_seqs); (void)ugs_free(db->d_offs); (void)ugs_free(db->d_row_off); (void)ugs_free(db->d_postings); (void)ugs_free(db->d_part); (void)ugs_free(db->d_part2);
+  (void)ugs_free(db->d_post16);
   (void)ugs_free(db->d_row_off2); (void)ugs_free(db->d_postings2);
   (void)ugs_free(db->d_step); (void)ugs_free(db->d_tab); (void)ugs_free(db->d_xsub2); (void)ugs_free(db->d_xcls); (void)ugs_free(db->d_tkey); (void)ugs_free(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
@@ -288,6 +289,7 @@ UgsTune ugs_tune_read()
   t.r2_kcap = env_int("UGS_R2_KCAP", 8, 4096, 0);
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
   t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
+  t.r2_p16 = env_int("UGS_R2_P16", 0, 1, -1);
   t.r3 = env_int("UGS_R3", 0, 1, -1);
   t.r3_sp = env_int("UGS_R3_SP", 1, 63, 0);
   t.r3_pps = env_int("UGS_R3_PPS", 64, 1 << 20, 0);
@@ -370,6 +372,7 @@ int ugs_db_replan(ugs_db *db)
     RCCHK(ugs_build_part(db->d_row_off, db->d_postings, slots, np2, gsize2, db->d_part2, db->stream));
     HIPCHK(hipStreamSynchronize(db->stream));
   }
+  ++db->index_gen;                      // (d_post16, if any, belongs to the index before this call)
   UgsDbView &v = db->v;
   v.seqs = db->d_seqs; v.offs = db->d_offs; v.row_off = db->d_row_off; v.postings = db->d_postings; v.part = db->d_part;
   v.part2 = gsize2 ? db->d_part2 : nullptr; v.np2 = np2; v.gsize2 = gsize2;
@@ -440,6 +443,7 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   db->p = *p; db->device = device; db->num_cu = prop.multiProcessorCount;
   db->tune = ugs_tune_read();
   db->d_part2 = nullptr; db->part2_cap = 0;
+  db->d_post16 = nullptr; db->post16_cap = 0; db->index_gen = 0; db->post16_gen = 0;
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
   db->d_pk = nullptr; db->pack_cap = 0;
   db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0; db->gsize_limit = 0;
@@ -576,7 +580,7 @@ extern "C" int ugs_db_stats(const ugs_db *db, uint64_t *n_postings, uint64_t *n_
   if (!db) return UGS_E_ARG;
   if (n_postings) *n_postings = db->n_postings;
   if (n_slots) *n_slots = db->v.slots;
-  if (hbm_bytes) *hbm_bytes = db->hbm_bytes;
+  if (hbm_bytes) *hbm_bytes = db->hbm_bytes + (db->d_post16 ? db->post16_cap * 2 : 0);
   return UGS_OK;
 }
 
@@ -847,7 +851,7 @@ static int plan_launch(ugs_batch *b)
   // sampled rows for the typical query (4-bit count field; a longer query is deferred per unit), uniform rows.  Units outside its
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
-  b->r2.gather = 0;
+  b->r2.gather = 0; b->r2.post16 = nullptr;
   // (k_rank2g reads a sub-row as at most 255 postings and 256 quads per partition: an index with long rows keeps k_rank there.  k_rank3g has
   // no such limit - a heavy super-partition is halved, a unit it cannot take is deferred - so a skewed protein dictionary stays with it)
   if (db->v.part2 && db->r2_gather && bits <= 8 && ns_typ <= 63 && (!b->rl.longrows || db->tune.r3 != 0) && b->K <= 64) {
@@ -877,6 +881,26 @@ static int plan_launch(ugs_batch *b)
     uint32_t kcap = db->tune.r2_kcap ? (uint32_t)db->tune.r2_kcap : std::max<uint32_t>(252u, 6u * b->K);
     if (b->cl_mode) kcap = std::min<uint32_t>(std::max<uint32_t>(kcap, db->tune.r2_kcap ? 0u : b->K + 260u), 508u);   // (the CL instantiation compacts a full list - to K keys, in eight register batches - before a partition's <= 256 keys are added)
     b->r2.ns_max = ns_max; b->r2.G = db->v.gsize2; b->r2.np = db->v.np2; b->r2.kcap = kcap;
+    // 16-bit postings (r6): a plain search streams the index as offsets inside the partitions - half the bytes of the dominant stream.  A
+    // second copy of the postings at half their size (C2 + 0.46 GB, C4 + 2.3 GB), made on the first search plan that wants it and again
+    // after the index changed; cluster_fast's index grows batch by batch and keeps the 32-bit stream.
+    b->r2.post16 = nullptr;
+    if (!b->cl_mode && db->tune.r2_p16 != 0 && db->v.np2 <= 512u && db->v.gsize2 <= 65536u && db->n_postings) {
+      if (!db->d_post16 || db->post16_gen != db->index_gen) {
+        const uint64_t want = db->n_postings + 512;                 // (a chunk reads up to 256 + 3 elements past a sub-row's start)
+        if (!db->d_post16 || want > db->post16_cap) {
+          (void)ugs_free(db->d_post16); db->d_post16 = nullptr; db->post16_cap = 0;
+          uint16_t *np16 = nullptr;
+          if (ugs_malloc(&np16, want * 2) != hipSuccess) { ugs_set_error("16-bit postings: %llu bytes of device memory not available", (unsigned long long)(want * 2)); return UGS_E_NOMEM; }
+          db->d_post16 = np16; db->post16_cap = want;
+        }
+        HIPCHK(hipMemsetAsync(db->d_post16 + db->n_postings, 0, (db->post16_cap - db->n_postings) * 2, db->stream));
+        RCCHK(ugs_build_post16(db->d_postings, db->n_postings, db->v.gsize2, db->d_post16, db->stream));
+        HIPCHK(hipStreamSynchronize(db->stream));
+        db->post16_gen = db->index_gen;
+      }
+      b->r2.post16 = db->d_post16;
+    }
     // the chunk list of a window: every partition takes its rows' chunks rounded up to a multiple of 4; sized for 16 partitions of
     // the typical query with room for sub-rows of two chunks (the kernel fits each unit's window to the list)
     b->r2.clcap = std::max<uint32_t>(96u, 16u * ((nsm + 4u) / 4u * 4u) + 16u);
@@ -892,7 +916,7 @@ static int plan_launch(ugs_batch *b)
       const uint32_t lds_c = (uint32_t)ugs_rank2_lds(db->v.gsize2, kc, cc, 0);
       if (lds_c <= 10240u && b->r2.lds > 10240u && kc < kcap) { kcap = kc; b->r2.kcap = kc; b->r2.clcap = cc; b->r2.lds = lds_c; }
     }
-    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0), 32));
+    int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0, b->r2.post16 ? 1 : 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   }
@@ -1417,7 +1441,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
   if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];
-  if (n >= 8) out[7] = !b->r2_ran ? 0u : b->r2.gather == 2u ? 3u : b->r2.gather ? 2u : b->v.cand_key ? 4u : 1u;
+  if (n >= 8) out[7] = !b->r2_ran ? 0u : b->r2.gather == 2u ? 3u : b->r2.gather ? 2u : b->v.cand_key ? 4u : (b->r2.post16 ? 5u : 1u);
   return UGS_OK;
 }
 

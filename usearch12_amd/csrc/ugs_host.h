@@ -25,6 +25,7 @@ struct UgsTune {
   int align_group;              // UGS_ALIGN_GROUP            -1 unset (= 1), 0 off, n: rejects of a unit after which k_align tests its candidates four at a time
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
+  int r2_p16;                   // UGS_R2_P16                 -1 unset (= on), 0: the bitmap kernel streams the 32-bit postings (A/B)
   int r3, r3_sp, r3_pps;        // UGS_R3 / UGS_R3_SP / UGS_R3_PPS  sparse index: -1 unset (= k_rank3g), 0 = k_rank2g; k_rank3g: partitions per super-partition
                                 //                            (0 unset = per unit, from its postings), postings per super-partition aimed at (0 unset = 4096)
 };
@@ -40,6 +41,8 @@ struct ugs_db {
   // owned device memory
   uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
   uint32_t *d_part2; uint64_t part2_cap;   // dense Big-path indexes: the partition table of the bitmap ranking kernel (ugs_rank2.hip)
+  uint16_t *d_post16; uint64_t post16_cap; // ... and the postings as 16-bit offsets inside their partition (built on first use by a plain search: plan_launch)
+  uint64_t index_gen, post16_gen;          // the index as it stands (counts ugs_db_replan calls) / the one d_post16 was made from
   uint2 *d_pk; uint64_t pack_cap;   // nt: 2-bit letters + "other" bits, one uint2 per 16 letters (ugs_dev.h UgsDbView::pk)
   uint32_t *d_step; UgsTables *d_tab;
   std::vector<uint32_t> step;       // host copy: step[Nu]

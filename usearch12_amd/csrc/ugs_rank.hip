@@ -1944,7 +1944,7 @@ unsigned long long ugs_rank_instances_seen(unsigned long long *compiled)
 {
 #define UGS_RI_BIT(i, n, s) | (1ull << (i))
 #ifdef UGS_ONLY_HOT
-  if (compiled) *compiled = (1ull << UGS_RI_BIG4) | (1ull << UGS_RI_R2) | (1ull << UGS_RI_R2G) | (1ull << UGS_RI_R2_CL) | (1ull << UGS_RI_R3G);
+  if (compiled) *compiled = (1ull << UGS_RI_BIG4) | (1ull << UGS_RI_R2) | (1ull << UGS_RI_R2G) | (1ull << UGS_RI_R2_CL) | (1ull << UGS_RI_R3G) | (1ull << UGS_RI_R2_P16);
 #else
   if (compiled) *compiled = 0ull UGS_RANK_INST_TABLE(UGS_RI_BIT);
 #endif
@@ -2021,7 +2021,7 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   }
   int ordinal = 0;
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide, &ordinal);
-  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather == 2u ? UGS_RI_R3G : r2->gather ? UGS_RI_R2G : (b.cand_key ? UGS_RI_R2_CL : UGS_RI_R2))) : 0ull));
+  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather == 2u ? UGS_RI_R3G : r2->gather ? UGS_RI_R2G : (b.cand_key ? UGS_RI_R2_CL : (r2->post16 ? UGS_RI_R2_P16 : UGS_RI_R2)))) : 0ull));
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;

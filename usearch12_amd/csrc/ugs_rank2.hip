@@ -65,6 +65,13 @@ __host__ __device__ constexpr uint32_t r2_fixed_words(bool cl) { return (cl ? R2
 #define R2D_ROW(m) (((m) >> 9) & 15u)
 #define R2D_PART(m) (((m) >> 13) & 2047u)
 #define R2D_AHI(m) ((m) >> 24)
+// P16 (16-bit partition-relative postings, r6): a chunk = <= 256 consecutive u16 ELEMENTS starting at a multiple of four elements (8-byte
+// loads per lane); the first `lead` (0..3) of them belong to the sub-row in front and are masked:
+//   lo = low 32 bits of the chunk's first element index (a multiple of 4)
+//   hi = span (lead + valid postings, 1..256; 0 = padding) | row << 9 | partition << 13 (9 bits) | lead << 22 | high 8 bits of the index << 24
+#define R2D_PART16(m) (((m) >> 13) & 511u)
+#define R2D_LEAD16(m) (((m) >> 22) & 3u)
+#define R2_P16_MAXNP 512u
 
 // LDS byte address of target t's bitmap word: ((t >> 5) << 2) + nsub8 as a shift and ONE v_lshl_add_u32 (the compiler's own choice
 // for the expression is shift, and, add)
@@ -85,9 +92,14 @@ struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 // the list is COMPACTED to its K smallest keys (the smallest key of every count value is tracked apart, s_fpk, as the keys are made).
 #define R2_CMAXV 4095u          // ugs_rank.hip make_key: (CMAXV - count) << POS_BITS | first row << 32 | target
 #define R2_POS_BITS 44
-template <int D, bool CL>
+// P16: the scan streams UgsRank2Params::post16 - the index's postings as 16-bit offsets inside their partition (target mod G), same
+// element positions as UgsDbView::postings - instead of the 32-bit targets: half the bytes of the dominant stream, four postings per
+// 8-byte load and lane (the same lane occupancy and instruction count per posting as the 16-byte loads of four 32-bit targets).
+template <int D, bool CL, bool P16>
 __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
+  static_assert(!(P16 && CL), "the cluster_fast instantiation reads the 32-bit postings (its index grows batch by batch)");
+  static_assert(!P16 || R2_V2, "16-bit postings exist for the v2 ring only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x;
   const uint32_t lane4 = lane * 4u;
@@ -365,7 +377,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           if (valid) __builtin_memcpy(&lh, db.part2 + (uint64_t)s_slots[r] * (np + 1u) + p, 8);
           const uint32_t len = lh.y - lh.x;
           const uint64_t a0 = s_rs[r] + lh.x;
-          const uint32_t nc = (len + 255u) >> 8;
+          // (P16: chunks start at multiples of four elements; the sub-row's first chunk begins up to three elements early)
+          const uint32_t lead = P16 ? ((uint32_t)a0 & 3u) : 0u;
+          const uint32_t spanall = len ? lead + len : 0u;
+          const uint32_t nc = (spanall + 255u) >> 8;
           const uint32_t incl = r2_row16_incl_sum(nc);                    // inside the partition's 16 lanes
           uint32_t gbase = nch, mybase = 0, mytot = 0, mypad = 0;
 #pragma unroll
@@ -378,9 +393,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           const uint32_t base = mybase + incl - nc;
           for (uint32_t j = 0; r2_ballot(j < nc) != 0ull; ++j) {
             if (j < nc && base + j < clcap) {
-              const uint64_t a = a0 + (uint64_t)j * 256u;
-              const uint32_t n = len - j * 256u < 256u ? len - j * 256u : 256u;
+              const uint64_t a = a0 - lead + (uint64_t)j * 256u;
+              const uint32_t n = spanall - j * 256u < 256u ? spanall - j * 256u : 256u;
               uint2 e; e.x = (uint32_t)a; e.y = n | (r << 9) | (p << 13) | ((uint32_t)(a >> 32) << 24);
+              if constexpr (P16) { if (j == 0u) e.y |= lead << 22; }
               s_cl[base + j] = e;
             }
           }
@@ -427,6 +443,10 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         };
         auto src_of = [&](int k, uint32_t &voff) -> const uint32_t * {
           // lane l reads postings [4l, 4l+4) of the chunk; lanes beyond it re-read the chunk's first 16 bytes (no traffic) and are masked
+          if constexpr (P16) {
+            voff = lane4 < R2D_N(dhi[k]) ? lane4 * 2u : 0u;               // (four 16-bit postings = 8 bytes per lane)
+            return (const uint32_t *)(prm.post16 + (((uint64_t)R2D_AHI(dhi[k]) << 32) | dlo[k]));
+          }
           voff = lane4 < R2D_N(dhi[k]) ? lane4 * 4u : 0u;
           return postings + (((uint64_t)R2D_AHI(dhi[k]) << 32) | dlo[k]);
         };
@@ -436,6 +456,28 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         uint32_t e_bit[4] = {0, 0, 0, 0}, e_t[4] = {0, 0, 0, 0}, e_meta = 0;
         auto count2 = [&](uint32_t meta, const uint32_t (&t)[4]) {
           const int vlen = (int)R2D_N(meta) - (int)lane4;
+          if constexpr (P16) {
+            // t[0], t[1] = four 16-bit postings (offsets inside the partition).  Validity: element 4 lane + j of the chunk counts when
+            // lead <= 4 lane + j < span - the lead only ever concerns lane 0
+            const uint32_t x0 = t[0], x1 = t[1];
+            const uint32_t hi_n = (uint32_t)(vlen < 0 ? 0 : (vlen > 4 ? 4 : vlen));
+            uint32_t m4 = (1u << hi_n) - 1u;
+            m4 &= 0xfu << (lane == 0u ? R2D_LEAD16(meta) : 0u);
+            e_t[0] = x0; e_t[1] = x1;
+            e_bit[0] = (m4 & 1u) << (x0 & 31u);
+            e_bit[1] = ((m4 >> 1) & 1u) << ((x0 >> 16) & 31u);
+            e_bit[2] = ((m4 >> 2) & 1u) << (x1 & 31u);
+            e_bit[3] = ((m4 >> 3) & 1u) << ((x1 >> 16) & 31u);
+            e_meta = meta;
+            if (vlen > 0) {
+              // bitmap word of offset o: byte (o >> 5) * 4 - the bitmap sits at LDS offset 0 and o < G <= 65536
+              o0 = __hip_atomic_fetch_or((lds32)(uintptr_t)((x0 >> 3) & 0x1ffcu), e_bit[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              o1 = __hip_atomic_fetch_or((lds32)(uintptr_t)((x0 >> 19) & 0x1ffcu), e_bit[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              o2 = __hip_atomic_fetch_or((lds32)(uintptr_t)((x1 >> 3) & 0x1ffcu), e_bit[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              o3 = __hip_atomic_fetch_or((lds32)(uintptr_t)((x1 >> 19) & 0x1ffcu), e_bit[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return;
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) { e_bit[j] = j < vlen ? (1u << (t[j] & 31u)) : 0u; e_t[j] = t[j]; }
           e_meta = meta;
@@ -453,6 +495,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         auto emit2 = [&]() {
           const uint32_t rtag = R2D_ROW(e_meta) << 24;
           const uint32_t old[4] = {o0, o1, o2, o3};
+          const uint32_t psub = P16 ? R2D_PART16(e_meta) * G : 0u;        // (P16: the partition's first target, added back to the offsets)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const bool hit = (old[j] & e_bit[j]) != 0u;
@@ -460,7 +503,13 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
             if (m) {
               uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_stg));   // n_stg + rank
               pos = pos < SCAP - 1u ? pos : SCAP - 1u;                 // (beyond the capacity the unit is deferred: n_stg tells)
-              if (hit) s_stg[pos] = e_t[j] | rtag;
+              if constexpr (P16) {
+                const uint32_t x = e_t[j >> 1];
+                const uint32_t o16 = (j & 1) ? (x >> 16) : (x & 0xffffu);
+                if (hit) s_stg[pos] = (psub + o16) | rtag;
+              } else {
+                if (hit) s_stg[pos] = e_t[j] | rtag;
+              }
               n_stg += (uint32_t)__popcll(m);
             }
           }
@@ -469,8 +518,8 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         };
         fetch4(0);
         { uint32_t vo; const uint32_t *sp;
-          sp = src_of(0, vo); r2_issue<0>(vo, sp); sp = src_of(1, vo); r2_issue<1>(vo, sp);
-          sp = src_of(2, vo); r2_issue<2>(vo, sp); sp = src_of(3, vo); r2_issue<3>(vo, sp); }
+          sp = src_of(0, vo); r2_issue<0, P16>(vo, sp); sp = src_of(1, vo); r2_issue<1, P16>(vo, sp);
+          sp = src_of(2, vo); r2_issue<2, P16>(vo, sp); sp = src_of(3, vo); r2_issue<3, P16>(vo, sp); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) mt[k] = dhi[k];
         fetch4(4);
@@ -479,8 +528,8 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           {                                                                                                      \
             uint32_t tn[4], vo;                                                                                  \
             const uint32_t *sp = src_of(k, vo);                                                                  \
-            r2_take<k>(tn);                                                                                      \
-            r2_issue<k>(vo, sp);                                                                                 \
+            r2_take<k, P16>(tn);                                                                                 \
+            r2_issue<k, P16>(vo, sp);                                                                            \
             emit2();                                                                                             \
             const uint32_t pm = mt[k]; mt[k] = dhi[k];                                                           \
             if (last) fetch4(c + 2u * (uint32_t)D);                                                              \
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
             if (c != 0) { finalize(); if (bad) break; }
             // (the next partition's end index was read where this one began: no LDS round trip at the boundary)
             do { pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pe_next); ++pi; pe_next = s_pe[pi]; } while (pend == c);      // (partitions without a posting)
-            nsub8 = 0u - R2D_PART(mt[0]) * (G >> 3);                      // (a partition's first chunk is never padding)
+            if constexpr (!P16) nsub8 = 0u - R2D_PART(mt[0]) * (G >> 3);  // (a partition's first chunk is never padding)
             zero_bitmap();
             R2_CLK(tfin += clock64() - tf0;)
           }
@@ -1043,7 +1092,27 @@ __global__ __launch_bounds__(64, 2) void k_rank2g(UgsDbView db, UgsBatchView bv,
   if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
 }
 
-static const void *rank2_kernel(int gather = 0, int cl = 0) { return gather ? (const void *)k_rank2g : cl ? (const void *)k_rank2<UGS_R2_DEPTH, true> : (const void *)k_rank2<UGS_R2_DEPTH, false>; }
+// post16[i] = postings[i] mod G: a posting's offset inside its partition (what k_rank2<.., P16> streams); same element positions
+__global__ void k_post16(const uint32_t *postings, uint64_t n, uint32_t G, uint16_t *out)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint16_t)(postings[i] % G);
+}
+
+int ugs_build_post16(const uint32_t *d_postings, uint64_t n, uint32_t G, uint16_t *d_out, hipStream_t st)
+{
+  if (!n) return UGS_OK;
+  if (G == 0 || G > 65536u) { ugs_set_error("16-bit postings need a partition size <= 65536"); return UGS_E_ENVELOPE; }
+  hipLaunchKernelGGL(k_post16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_postings, n, G, d_out);
+  HIPCHK(hipGetLastError());
+  return UGS_OK;
+}
+
+static const void *rank2_kernel(int gather = 0, int cl = 0, int p16 = 0)
+{
+  return gather ? (const void *)k_rank2g : cl ? (const void *)k_rank2<UGS_R2_DEPTH, true, false>
+                : p16 ? (const void *)k_rank2<UGS_R2_DEPTH, false, true> : (const void *)k_rank2<UGS_R2_DEPTH, false, false>;
+}
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl)
 {
@@ -1055,10 +1124,10 @@ size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
   return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + R2G_HB_BITS / 32 + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
 }
 
-int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl)
+int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl, int p16)
 {
   int n = 0;
-  const void *fn = rank2_kernel(gather, cl);
+  const void *fn = rank2_kernel(gather, cl, p16);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess || n < 1) n = 1;
   return n;
@@ -1068,7 +1137,9 @@ int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2P
 {
   const bool cl = b.cand_key != nullptr;                               // cluster_fast's walk records (ugs_cluster.cpp)
   if (cl && (prm.gather || !b.cl_ev || !b.cl_info || prm.kcap > 508u)) { ugs_set_error("bitmap ranking kernel: cluster mode outside its envelope"); return UGS_E_ENVELOPE; }
-  const void *fn = rank2_kernel((int)prm.gather, cl ? 1 : 0);
+  const bool p16 = prm.post16 != nullptr;
+  if (p16 && (cl || prm.gather || prm.np > R2_P16_MAXNP || prm.G > 65536u)) { ugs_set_error("bitmap ranking kernel: 16-bit postings outside their envelope"); return UGS_E_ENVELOPE; }
+  const void *fn = rank2_kernel((int)prm.gather, cl ? 1 : 0, p16 ? 1 : 0);
   const size_t need = prm.gather ? ugs_rank2g_lds(prm.G, prm.kcap, prm.np) : ugs_rank2_lds(prm.G, prm.kcap, prm.clcap, cl ? 1 : 0);
   if (prm.lds < need) { ugs_set_error("bitmap ranking kernel: %u bytes of LDS per wave, its carve needs %zu", prm.lds, need); return UGS_E_ENVELOPE; }
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));

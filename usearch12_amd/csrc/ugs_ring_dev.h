@@ -37,16 +37,31 @@ __device__ __forceinline__ uint32_t r2_row16_incl_sum(uint32_t v)
 // the compiler never touches those registers (this kernel has no MFMA and spills nothing: tests/test_isa.py pins both), whereas a
 // VGPR destination may be copied or re-used by the register allocator between the load and its wait (seen at a loop
 // back-edge).  r2_take<K> waits for slot K and DEFINES four fresh VGPR values from it.
-template <int K> __device__ __forceinline__ void r2_issue(uint32_t voff, const uint32_t *src)
+// H (half-width ring, k_rank2's 16-bit postings): slot k = a[2k : 2k+1], an 8-byte load per lane; r2_take defines t[0], t[1] only.
+template <int K, bool H = false> __device__ __forceinline__ void r2_issue(uint32_t voff, const uint32_t *src)
 {
   static_assert(K >= 0 && K < 4, "four ring slots");
+  if constexpr (H) {
+    if constexpr (K == 0) asm volatile("global_load_dwordx2 a[0:1], %0, %1" : : "v"(voff), "s"(src) : "memory", "a0", "a1");
+    if constexpr (K == 1) asm volatile("global_load_dwordx2 a[2:3], %0, %1" : : "v"(voff), "s"(src) : "memory", "a2", "a3");
+    if constexpr (K == 2) asm volatile("global_load_dwordx2 a[4:5], %0, %1" : : "v"(voff), "s"(src) : "memory", "a4", "a5");
+    if constexpr (K == 3) asm volatile("global_load_dwordx2 a[6:7], %0, %1" : : "v"(voff), "s"(src) : "memory", "a6", "a7");
+    return;
+  }
   if constexpr (K == 0) asm volatile("global_load_dwordx4 a[0:3], %0, %1" : : "v"(voff), "s"(src) : "memory", "a0", "a1", "a2", "a3");
   if constexpr (K == 1) asm volatile("global_load_dwordx4 a[4:7], %0, %1" : : "v"(voff), "s"(src) : "memory", "a4", "a5", "a6", "a7");
   if constexpr (K == 2) asm volatile("global_load_dwordx4 a[8:11], %0, %1" : : "v"(voff), "s"(src) : "memory", "a8", "a9", "a10", "a11");
   if constexpr (K == 3) asm volatile("global_load_dwordx4 a[12:15], %0, %1" : : "v"(voff), "s"(src) : "memory", "a12", "a13", "a14", "a15");
 }
-template <int K> __device__ __forceinline__ void r2_take(uint32_t (&t)[4])
+template <int K, bool H = false> __device__ __forceinline__ void r2_take(uint32_t (&t)[4])
 {
+  if constexpr (H) {
+    if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1" : "=v"(t[0]), "=v"(t[1]) : : "memory");
+    if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a3" : "=v"(t[0]), "=v"(t[1]) : : "memory");
+    if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5" : "=v"(t[0]), "=v"(t[1]) : : "memory");
+    if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a6\n\tv_accvgpr_read_b32 %1, a7" : "=v"(t[0]), "=v"(t[1]) : : "memory");
+    return;
+  }
   if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
   if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\tv_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
   if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(3)\n\tv_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]) : : "memory");
