@@ -2037,7 +2037,9 @@ int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignL
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.hsp_cap, a4 = L.seed_cap;
   void *args[] = {&a0, &a1, &a2, &wave_lds, &a4};
+  if (ugs_kernel_log) ugs_before_launch("k_align");
   HIPCHK(hipLaunchKernel(fn, dim3(L.grid), dim3(64 * L.wpb), args, L.lds, st));
+  if (ugs_kernel_log) ugs_after_launch("k_align", st);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

@@ -136,6 +136,16 @@ extern "C" int ugs_debug_alloc_stats(unsigned long long out[5])
   return UGS_OK;
 }
 
+// ---------------------------------------------------------------- UGS_KERNEL_LOG
+int ugs_kernel_log = 0;
+void ugs_before_launch(const char *kernel) { fprintf(stderr, "[ugs] kernel %.160s launched\n", kernel); fflush(stderr); }
+void ugs_after_launch(const char *kernel, hipStream_t st)
+{
+  const hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "[ugs] kernel %.160s %s\n", kernel, e == hipSuccess ? "done" : hipGetErrorString(e));
+  fflush(stderr);
+}
+
 // ---------------------------------------------------------------- UGS_ABORT_BT
 namespace {
 struct sigaction g_old_abrt;
@@ -205,6 +215,7 @@ void on_abort(int sig, siginfo_t *si, void *uc)
 
 __attribute__((constructor)) void ugs_install_abort_bt()
 {
+  { const char *k = getenv("UGS_KERNEL_LOG"); ugs_kernel_log = (k && *k && *k != '0') ? 1 : 0; }
   const char *e = getenv("UGS_ABORT_BT");
   if (!e || !*e) return;
   if (strcmp(e, "1") != 0 && strcmp(e, "stderr") != 0) g_bt_fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);

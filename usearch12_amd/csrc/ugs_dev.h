@@ -5,6 +5,20 @@
 #include <stdint.h>
 #include "../../include/ugs.h"
 
+// UGS_KERNEL_LOG=1 (debug, read when the library is loaded): every kernel launch of the library - rocPRIM's included - is named on stderr,
+// waited for, and named again when it has finished: the last "launched" line without its "done" is the kernel a GPU fault belongs to
+// (with UGS_GUARD_ALLOC=1 and UGS_ABORT_BT: which buffer, allocated where, overrun by which kernel).  ugs_alloc.cpp.
+extern int ugs_kernel_log;
+void ugs_after_launch(const char *kernel, hipStream_t st);
+void ugs_before_launch(const char *kernel);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                          \
+  do {                                                                                                                              \
+    if (ugs_kernel_log) ugs_before_launch(#kernelName);                                                                             \
+    hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__);                    \
+    if (ugs_kernel_log) ugs_after_launch(#kernelName, (streamId));                                                                  \
+  } while (0)
+
 #define UGS_WAVE 64
 #define UGS_MAXREPS 8          // hspfinder.h:10
 #define UGS_XLUT_D 17          // k_align: x-drop deficits (in units of 2 half-units) the extension table covers: X <= 32 half-units

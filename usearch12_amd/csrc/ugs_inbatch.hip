@@ -160,7 +160,9 @@ int ugs_launch_inbatch(const UgsBatchView &bv, const uint64_t *brow_off, const u
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + wpb - 1) / wpb, (uint64_t)num_cu * per_cu));
   UgsBatchView a0 = bv; uint32_t a3 = ns_max, a4 = (uint32_t)small_path, a5 = max_rej, a6 = tbl_words;
   void *args[] = {&a0, &brow_off, &bpost, &a3, &a4, &a5, &a6, &ent_n, &ent_off, &ent};
+  if (ugs_kernel_log) ugs_before_launch("k_inbatch");
   HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, lds, st));
+  if (ugs_kernel_log) ugs_after_launch("k_inbatch", st);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }

@@ -2027,7 +2027,9 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
     a1.use_defer = r2 ? 1u : 0u;
     void *args[] = {&a0, &a1, &a2, &a3, &a4};
+    if (ugs_kernel_log) ugs_before_launch("k_rank");
     HIPCHK(hipLaunchKernel(fn, grid, block, args, L.lds, st));
+    if (ugs_kernel_log) ugs_after_launch("k_rank", st);
   }
   HIPCHK(hipGetLastError());
   return UGS_OK;

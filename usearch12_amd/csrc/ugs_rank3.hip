@@ -376,7 +376,9 @@ int ugs_launch_rank3g(const UgsDbView &db, const UgsBatchView &b, const UgsRank2
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.lds));
   UgsDbView a0 = db; UgsBatchView a1 = b; UgsRank2Params a2 = prm;
   void *args[] = {&a0, &a1, &a2};
+  if (ugs_kernel_log) ugs_before_launch("k_rank3g");
   HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(64), args, prm.lds, st));
+  if (ugs_kernel_log) ugs_after_launch("k_rank3g", st);
   HIPCHK(hipGetLastError());
   return UGS_OK;
 }
