@@ -283,13 +283,14 @@ int ugs_batch_candidate_k(const ugs_batch *b, uint32_t *k);
  * the bitmap kernel was launched; with n >= 6 also out[4] / out[5] = microseconds of the bitmap kernel / of the general kernel behind it
  * (HIP events on the handle's stream); with n >= 7 also out[6] = candidate pairs k_align rejected through its group filter (pairs without
  * an HSP, tested four at a time); with n >= 8 also out[7] = WHICH kernel of the bitmap family ran: 0 none, 1 k_rank2, 2 k_rank2g, 3 k_rank3g
- * (sparse index, two filter passes), 4 k_rank2's cluster_fast instantiation, 5 k_rank2 over 16-bit postings.  n >= 4. */
+ * (sparse index, two filter passes), 4 k_rank2's cluster_fast instantiation, 5 k_rank2 over 16-bit postings; with n >= 9 also out[8] = units of
+ * the deferred list that the heavy-unit instantiation ranked (cluster_fast; the rest of the list went on to the general kernel).  n >= 4. */
 int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n);
 /* Diagnostic: *seen = the ranking kernels this process has launched so far, *compiled = the ones the library holds, one bit each
  * (bits 0-4: Big path - 4-bit counters, its long-row twin, 8/16-bit flattened (sparse index), 8/16-bit dense, 8/16-bit dense + long
  * rows; bits 5-9: the same five on the small path; 12 / 13: the two Big-path 4-bit kernels with 64-bit offsets; 14: the bitmap kernel,
  * 15: its gather variant for sparse indexes, 16: its cluster_fast instantiation, 17: k_rank3g, the two-pass filter kernel for sparse indexes,
- * 18: the bitmap kernel over 16-bit partition-relative postings).  The test-suite ends with seen == compiled. */
+ * 18: the bitmap kernel over 16-bit partition-relative postings, 19: its heavy-unit instantiation for cluster_fast).  The test-suite ends with seen == compiled. */
 int ugs_debug_rank_instances(uint64_t *seen, uint64_t *compiled);
 /* Diagnostic: the name of the ranking kernel behind bit `bit` of those masks (a static string), or NULL if the library holds no such
  * instantiation - the library's own table, so that a test or tool keeps no list of its own. */
@@ -316,6 +317,7 @@ int ugs_debug_alloc_stats(unsigned long long out[5]);
  *   UGS_WIDE_OFFSETS=1      k_rank's Big-path 4-bit kernels with 64-bit table / row offsets (chosen by themselves for an index that needs them)
  *   UGS_RANK2=0|1           bitmap ranking kernel off / on wherever the index allows it (default: on for dense Big-path indexes)
  *   UGS_R2_G=n UGS_R2_KCAP=n UGS_R2_WAVES=n   its partition size (multiple of 8192), kept-key capacity, waves per CU
+ *   UGS_R2_HV=0             cluster_fast: the units the bitmap kernel defers go straight to the general kernel (no heavy-unit stage; A/B); 2: EVERY unit is deferred to the heavy-unit stage (tests)
  *   UGS_R2_P16=0            the bitmap kernel streams the 32-bit postings instead of the 16-bit partition-relative copy (A/B)
  *   UGS_R3=0|1 UGS_R3_SP=n UGS_R3_PPS=n       sparse (protein) Big-path index: 0 = k_rank2g instead of k_rank3g; k_rank3g's partitions per
  *                           super-partition (default: per unit, so that a super-partition holds ~ UGS_R3_PPS = 4096 of its postings)
@@ -541,7 +543,7 @@ typedef struct ugs_cluster_stats {
   uint32_t batches;          /* device batches run                                                      */
   uint32_t batches_cut;      /* batches ended early because a query could not be replayed from the device's data */
   uint32_t max_batch;
-  uint32_t reserved_;
+  uint32_t units_heavy;      /* units ranked by the heavy-unit kernel (k_rank2<HV>: reads of abundant species, ugs_rank2.hip) - r6, was reserved_ */
   uint64_t queries_redone;   /* queries searched again in a later batch (cut batches, the small -> Big latch) */
   uint64_t inbatch_entries;  /* (query strand, earlier query of the batch) pairs with shared words that could matter */
   uint64_t pairs_in_batch;   /* of those, aligned on the device                                          */

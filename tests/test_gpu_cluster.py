@@ -14,18 +14,24 @@ from usearch12_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _cluster(c, r, batch=None):
+def _cluster(c, r, batch=None, hv=None):
     kw = {"big": c["big"]} if "big" in c else {}
     p = capi.cluster_params(c["id"], strand_both=c["strand"] == "both", is_nucleo=not c.get("aa"), max_rejects=c.get("maxrejects"), **kw)
     old = os.environ.pop("UGS_CLUSTER_BATCH", None)
+    old_hv = os.environ.pop("UGS_R2_HV", None)
     if batch:
         os.environ["UGS_CLUSTER_BATCH"] = str(batch)
+    if hv is not None:
+        os.environ["UGS_R2_HV"] = str(hv)          # (read at ugs_db_create, inside the call below)
     try:
         return capi.UgsCluster(p, r.seqs, r.offs, sort=c.get("sort"), labels=r.labels(), sizein=c.get("sizein", 0))
     finally:
         os.environ.pop("UGS_CLUSTER_BATCH", None)
+        os.environ.pop("UGS_R2_HV", None)
         if old is not None:
             os.environ["UGS_CLUSTER_BATCH"] = old
+        if old_hv is not None:
+            os.environ["UGS_R2_HV"] = old_hv
 
 
 @pytest.mark.parametrize("batch", [None, 37])
@@ -40,6 +46,39 @@ def test_gpu_cluster_fast_files_identical_to_reference(name, batch, tmp_path):
     res.write_centroids(labels, cp, sizein=c.get("sizein", 0), sizeout=c.get("sizeout", 0), minsize=c.get("minsize", 0))
     assert open(ucp).read() == uc
     assert open(cp).read() == cen
+
+
+@pytest.mark.parametrize("batch", [None, 37])
+@pytest.mark.parametrize("name", [n for n in G.cluster_cases() if "aa" not in n])
+def test_heavy_unit_kernel_ranks_every_big_phase_unit_files_identical_to_reference(name, batch, tmp_path):
+    """r6: UGS_R2_HV=2 makes the bitmap kernel's cluster_fast instantiation defer EVERY unit, so that the heavy-unit instantiation
+    (4-bit counters over k_rank's partitions, two passes per partition) ranks the whole Big phase of the run: same -uc / -centroids
+    text as the reference binary."""
+    c, r, uc, cen = G.load_cluster(name)
+    res = _cluster(c, r, batch, hv=2)
+    assert res.n_clusters == c["n_clusters"]
+    labels = r.labels()
+    ucp, cp = str(tmp_path / "o.uc"), str(tmp_path / "o.fa")
+    res.write_uc(labels, ucp)
+    res.write_centroids(labels, cp, sizein=c.get("sizein", 0), sizeout=c.get("sizeout", 0), minsize=c.get("minsize", 0))
+    assert open(ucp).read() == uc
+    assert open(cp).read() == cen
+
+
+def test_heavy_unit_kernel_equals_k_rank_and_the_oracle_on_abundant_species():
+    """a few species with thousands of near-identical centroids (-id 0.99 founds a centroid for most reads): the Big-phase units have
+    partitions with hundreds of multi-touch targets.  Default (the bitmap kernel defers what overflows its record lists, the heavy-unit
+    kernel takes those), every unit through the heavy-unit kernel, and no heavy-unit stage at all (k_rank) give the same clustering as
+    the oracle's serial loop; the heavy-unit kernel must have ranked units in the first two."""
+    r = synth.make_reads(611, 14000, n_species=3, p_sub=0.03)
+    c = dict(id=0.99, strand="plus", big=300)
+    o = orc.cluster_fast(orc.cluster_params(0.99, strand_both=False, big=300), r.seqs, r.offs)
+    runs = {}
+    for hv in (None, 2, 0):
+        res = _cluster(c, r, 2048, hv=hv)
+        _same(res, o)
+        runs[hv] = int(res.stats.units_heavy)
+    assert runs[0] == 0 and runs[2] > 5000 and runs[None] > 0, runs
 
 
 def _same(res, o):

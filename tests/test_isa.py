@@ -148,11 +148,12 @@ def test_rank2_ring_loads_live_in_accumulator_registers_and_nothing_spills():
     scratch access (a scratch store or load would sit in the same in-order VMEM queue), and (4) the ring is drained (vmcnt(0))
     before the slots are used again."""
     isa = _isa_of("ugs_rank2.hip")
-    for inst in ("k_rank2ILi4ELb0ELb0EE", "k_rank2ILi4ELb1ELb0EE"):  # the search kernel over 32-bit postings and its cluster_fast instantiation
+    # <D = 4, CL, P16, HV>: the search kernel over 32-bit postings, its cluster_fast instantiation, and the heavy-unit instantiation (r6)
+    for inst in ("k_rank2ILi4ELb0ELb0ELb0EE", "k_rank2ILi4ELb1ELb0ELb0EE", "k_rank2ILi4ELb1ELb0ELb1EE"):
         _check_rank2_ring(isa, inst)
     # <D = 4, CL = false, P16 = true>: the search kernel over 16-bit partition-relative postings (r6) - the same ring at half width:
     # 8-byte loads into a[2k : 2k+1], eight accumulator registers
-    _check_rank2_ring(isa, "k_rank2ILi4ELb0ELb1EE", half=True)
+    _check_rank2_ring(isa, "k_rank2ILi4ELb0ELb1ELb0EE", half=True)
 
 
 def _kernel_meta(isa, mangled_prefix):
@@ -199,8 +200,13 @@ def _check_rank2_ring(isa, inst, half=False):
                 assert a is None or int(a[1:]) >= 16, m.group(0)
     # every block of reads follows its own counted wait inside one asm statement
     assert len(re.findall(r"s_waitcnt vmcnt\(3\)\n\s*v_accvgpr_read_b32", body)) == 4
-    # the atomics of the bitmap are LDS instructions (not flat), with return
-    assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16 and "flat_atomic" not in body
+    assert "flat_atomic" not in body
+    if inst.endswith("Lb1ELb0ELb1EE"):
+        # the heavy-unit instantiation: pass 1 counts with adds that return nothing, pass 2 exchanges the counter for zero
+        assert len(re.findall(r"ds_add_u32 ", body)) >= 16 and len(re.findall(r"ds_and_rtn_b32", body)) >= 16
+    else:
+        # the atomics of the bitmap are LDS instructions (not flat), with return
+        assert len(re.findall(r"ds_or_rtn_b32", body)) >= 16
 
 
 def test_k_align_search_instantiations_use_no_scratch():

@@ -60,7 +60,7 @@ class BatchStats(C.Structure):
 
 class ClusterStats(C.Structure):
     """mirror of ugs_cluster_stats (include/ugs.h)"""
-    _fields_ = [("batches", C.c_uint32), ("batches_cut", C.c_uint32), ("max_batch", C.c_uint32), ("reserved_", C.c_uint32),
+    _fields_ = [("batches", C.c_uint32), ("batches_cut", C.c_uint32), ("max_batch", C.c_uint32), ("units_heavy", C.c_uint32),
                 ("queries_redone", C.c_uint64), ("inbatch_entries", C.c_uint64), ("pairs_in_batch", C.c_uint64),
                 ("hits_in_batch", C.c_uint64), ("pairs_frozen", C.c_uint64), ("postings", C.c_uint64),
                 ("ms_rank", C.c_float), ("ms_align", C.c_float)] + \

@@ -705,7 +705,7 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
     ++C->st.batches; C->st.pairs_in_batch += n_pairs; C->st.inbatch_entries += n_ent; C->st.queries_redone += B - done;
     C->st.max_batch = std::max<uint32_t>(C->st.max_batch, B);
     ugs_batch_stats bs;
-    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { uint64_t kh[6] = {0, 0, 0, 0, 0, 0}; if (profile) { (void)ugs_debug_kernel_hits(b, kh, 6); fprintf(stderr, "[ugs] batch %u: bitmap kernel %.3f ms, k_rank behind it %.3f ms ; T0..T7 %llu %llu %llu %llu %llu %llu %llu %llu\n", C->st.batches, kh[4] / 1000.0, kh[5] / 1000.0, b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5], b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]); } if (profile) fprintf(stderr, "[ugs] batch %u: n0 %u B %u done %u path %s ms_setup %.3f ms_rank %.3f ms_align %.3f pairs %llu | bitmap kernel: %s units %llu deferred %llu\n", C->st.batches, n0, B, done, small_path ? "small" : "big", bs.ms_rank_setup, bs.ms_rank, bs.ms_align, (unsigned long long)n_pairs, b->r2_ran ? "ran" : "-", b->ctr[UGS_CTR_R2_DONE], b->ctr[UGS_CTR_DEFER]);
+    if (ugs_batch_get_stats(b, &bs) == UGS_OK) { uint64_t kh[6] = {0, 0, 0, 0, 0, 0}; if (profile) { (void)ugs_debug_kernel_hits(b, kh, 6); fprintf(stderr, "[ugs] batch %u: bitmap kernel %.3f ms, k_rank behind it %.3f ms ; T0..T7 %llu %llu %llu %llu %llu %llu %llu %llu\n", C->st.batches, kh[4] / 1000.0, kh[5] / 1000.0, b->ctr[UGS_CTR_T0], b->ctr[UGS_CTR_T1], b->ctr[UGS_CTR_T2], b->ctr[UGS_CTR_T3], b->ctr[UGS_CTR_T4], b->ctr[UGS_CTR_T5], b->ctr[UGS_CTR_T6], b->ctr[UGS_CTR_T7]); } if (profile) fprintf(stderr, "[ugs] batch %u: n0 %u B %u done %u path %s ms_setup %.3f ms_rank %.3f ms_align %.3f pairs %llu | bitmap kernel: %s units %llu deferred %llu\n", C->st.batches, n0, B, done, small_path ? "small" : "big", bs.ms_rank_setup, bs.ms_rank, bs.ms_align, (unsigned long long)n_pairs, b->r2_ran ? "ran" : "-", b->ctr[UGS_CTR_R2_DONE], b->ctr[UGS_CTR_DEFER]); C->st.units_heavy += (uint32_t)b->ctr[UGS_CTR_HV_DONE]; if (profile) fprintf(stderr, "[ugs] batch %u: heavy-unit kernel ranked %llu of the deferred units, %llu went on to k_rank\n", C->st.batches, b->ctr[UGS_CTR_HV_DONE], b->ctr[UGS_CTR_DEFER2]);
       C->st.ms_rank += bs.ms_rank + bs.ms_rank_setup; C->st.ms_align += bs.ms_align; C->st.postings += bs.postings; C->st.pairs_frozen += bs.pairs_aligned; }
     next += done;
     B_prev = B; pairs_prev = n_pairs;

@@ -133,7 +133,8 @@ struct UgsBatchView {
   uint32_t *unit_order;      // [units] units by descending cost class
   uint32_t *order_hist;      // [512] units per cost class | cursors (zeroed by the launcher)
   uint32_t *defer_list;      // [units] units the bitmap ranking kernel (ugs_rank2.hip) hands on to k_rank; counters[UGS_CTR_DEFER] of them
-  uint32_t use_defer;        // k_rank (HOT instantiation): take the units from defer_list instead of 0 .. units-1
+  uint32_t use_defer;        // k_rank (HOT instantiation): take the units from defer_list instead of 0 .. units-1 (1: counters[UGS_CTR_DEFER] of
+                             // them; 2: counters[UGS_CTR_DEFER2] - the list the heavy-unit kernel leaves behind, cluster_fast)
   // deep walks (UGS_A_DEEP: max_accepts + max_rejects - 1 > UGS_KMAX, or one of them unlimited; ugs_deep.hip).  First pass: a walk that
   // used up a FULL list of K candidates without meeting a limit is parked - its counters in walk_state, its unit in open_list
   // (counters[UGS_CTR_OPEN] of them).  Continuation pass (walk_units != null): k_align takes unit walk_units[i], restores the counters
@@ -153,7 +154,8 @@ struct UgsWalkState { uint32_t nacc, nrej, nvis, xhead, xcur, pad0, pad1, pad2; 
 #define UGS_A_DEEP 0x400u     // internal: walks may need more than the UGS_KMAX candidates a ranking pass keeps (see UgsBatchView::walk_state)
 
 enum { UGS_CTR_POSTINGS = 0, UGS_CTR_TLETTERS, UGS_CTR_PAIRS, UGS_CTR_CELLS, UGS_CTR_HITS, UGS_CTR_ERR,
-       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_GROUPED, UGS_CTR_OPEN, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
+       UGS_CTR_T0, UGS_CTR_T1, UGS_CTR_T2, UGS_CTR_T3, UGS_CTR_T4, UGS_CTR_T5, UGS_CTR_T6, UGS_CTR_T7, UGS_CTR_NEXT_UNIT, UGS_CTR_NEXT_RANK, UGS_CTR_NEXT_SETUP, UGS_CTR_EMIT_MAX, UGS_CTR_NEXT_RANK2, UGS_CTR_DEFER, UGS_CTR_R2_DONE, UGS_CTR_GROUPED, UGS_CTR_OPEN,
+       UGS_CTR_NEXT_HEAVY, UGS_CTR_DEFER2, UGS_CTR_HV_DONE, UGS_CTR_N };  // T*: phase clocks (profiling); EMIT_MAX: most keys one wave emitted for one unit (set when UGS_ERR_EMIT is)
 enum { UGS_ERR_NS = 1, UGS_ERR_HSPCAP = 2, UGS_ERR_RUNS = 4, UGS_ERR_EMIT = 8, UGS_ERR_LOCAL = 16, UGS_ERR_LOCAL_HITS = 32, UGS_ERR_PAIRCAP = 64, UGS_ERR_XHITS = 128 };   // XHITS: the overflow hit blocks of a deep walk ran out (the host grows the pool and runs the pass again)
 
 // usearch_local (ugs_local.hip): x-drop tables and scratch, per-query score gates
@@ -192,7 +194,8 @@ int ugs_rank_blocks_per_cu(int threads, size_t lds, int big, int bits, int fast8
   X(8, SMALL_DENSE, "small 8/16-bit dense") X(9, SMALL_DENSE_LONG, "small 8/16-bit dense, long rows") \
   X(12, BIG4_WIDE, "HOT, 64-bit offsets") X(13, BIG4_LONG_WIDE, "long rows, 64-bit offsets") \
   X(14, R2, "k_rank2 (bitmap)") X(15, R2G, "k_rank2g (bitmap, sparse index)") X(16, R2_CL, "k_rank2, cluster_fast instantiation") \
-  X(17, R3G, "k_rank3g (two filter passes, sparse index)") X(18, R2_P16, "k_rank2 over 16-bit postings")
+  X(17, R3G, "k_rank3g (two filter passes, sparse index)") X(18, R2_P16, "k_rank2 over 16-bit postings") \
+  X(19, R2_HV, "k_rank2, heavy units of cluster_fast (4-bit counters, two passes)")
 #define UGS_RANK_INST_ENUM(i, n, s) UGS_RI_##n = i,
 enum { UGS_RANK_INST_TABLE(UGS_RANK_INST_ENUM) UGS_RI_END };
 unsigned long long ugs_rank_instances_seen(unsigned long long *compiled);

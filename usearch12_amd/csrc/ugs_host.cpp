@@ -290,6 +290,7 @@ UgsTune ugs_tune_read()
   t.r2_waves = env_int("UGS_R2_WAVES", 1, 32, 0);
   t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
   t.r2_p16 = env_int("UGS_R2_P16", 0, 1, -1);
+  t.r2_hv = env_int("UGS_R2_HV", 0, 2, -1);
   t.r3 = env_int("UGS_R3", 0, 1, -1);
   t.r3_sp = env_int("UGS_R3_SP", 1, 63, 0);
   t.r3_pps = env_int("UGS_R3_PPS", 64, 1 << 20, 0);
@@ -616,7 +617,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)hipDeviceSynchronize();        // (device-wide, as ugs_db_destroy says)
   (void)ugs_free(b->d_qseqs); (void)ugs_free(b->d_qoffs); (void)ugs_free(b->d_cand); (void)ugs_free(b->d_cand_cnt); (void)ugs_free(b->d_cand_n);
   (void)ugs_free(b->d_hit_n); (void)ugs_free(b->d_cigar); (void)ugs_free(b->d_runs); (void)ugs_free(b->d_hits); (void)ugs_free(b->d_emit); (void)ugs_free(b->d_tb);
-  (void)ugs_free(b->d_unit_ns); (void)ugs_free(b->d_unit_slots); (void)ugs_free(b->d_defer); (void)ugs_free(b->d_qpk);
+  (void)ugs_free(b->d_unit_ns); (void)ugs_free(b->d_unit_slots); (void)ugs_free(b->d_defer); (void)ugs_free(b->d_defer2); (void)ugs_free(b->d_qpk);
   (void)ugs_free(b->d_qkey); (void)ugs_free(b->d_qsize);
   (void)ugs_free(b->d_qthr); (void)ugs_free(b->d_ltb); (void)ugs_free(b->d_lrow); (void)ugs_free(b->d_lruns);
   (void)ugs_free(b->d_cigar_used); (void)ugs_free(b->d_ctr);
@@ -851,7 +852,7 @@ static int plan_launch(ugs_batch *b)
   // sampled rows for the typical query (4-bit count field; a longer query is deferred per unit), uniform rows.  Units outside its
   // envelope come back through k_rank (HOT instantiation), which runs right behind it over the deferred list.
   b->r2_grid = 0;
-  b->r2.gather = 0; b->r2.post16 = nullptr;
+  b->r2.gather = 0; b->r2.post16 = nullptr; b->r2.defer2 = nullptr; b->r2.hv_grid = 0; b->r2.hv_lds = 0; b->r2.force_defer = 0;
   // (k_rank2g reads a sub-row as at most 255 postings and 256 quads per partition: an index with long rows keeps k_rank there.  k_rank3g has
   // no such limit - a heavy super-partition is halved, a unit it cannot take is deferred - so a skewed protein dictionary stays with it)
   if (db->v.part2 && db->r2_gather && bits <= 8 && ns_typ <= 63 && (!b->rl.longrows || db->tune.r3 != 0) && b->K <= 64) {
@@ -918,6 +919,17 @@ static int plan_launch(ugs_batch *b)
     }
     int wcu = std::max(1, std::min(ugs_rank2_blocks_per_cu(b->r2.lds, 0, b->cl_mode ? 1 : 0, b->r2.post16 ? 1 : 0), 32));
     if (db->tune.r2_waves) wcu = std::min(wcu, db->tune.r2_waves);
+    // cluster_fast: the units the CL instantiation defers (a partition with more second touches than its record list: reads of abundant
+    // species) go through the heavy-unit instantiation (4-bit counters over k_rank's partitions, two passes) before k_rank sees the rest
+    if (b->cl_mode && db->tune.r2_hv != 0 && db->v.np <= 1024u && (db->v.gsize & 63u) == 0 && db->v.gsize <= 65536u && b->K + 64u <= b->r2.kcap) {
+      const size_t hl = ugs_rank2_hv_lds(db->v.gsize, b->r2.kcap, b->r2.clcap);
+      if (hl <= 64u * 1024u) {
+        if (!b->d_defer2) HIPCHK(ugs_malloc(&b->d_defer2, std::max<uint64_t>((uint64_t)b->max_queries * b->nstrand, 1) * 4));
+        const int hw = std::max(1, std::min(ugs_rank2_blocks_per_cu(hl, 0, 1, 0, 1), 32));
+        b->r2.defer2 = b->d_defer2; b->r2.hv_lds = (uint32_t)hl; b->r2.force_defer = db->tune.r2_hv == 2 ? 1u : 0u;
+        b->r2.hv_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(units, (uint64_t)db->num_cu * hw));
+      }
+    }
     b->r2_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((units + 3) / 4, (uint64_t)db->num_cu * wcu));
   }
   if (p.local) return plan_local(b);
@@ -1441,6 +1453,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
   if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];
+  if (n >= 9) out[8] = b->ctr[UGS_CTR_HV_DONE];
   if (n >= 8) out[7] = !b->r2_ran ? 0u : b->r2.gather == 2u ? 3u : b->r2.gather ? 2u : b->v.cand_key ? 4u : (b->r2.post16 ? 5u : 1u);
   return UGS_OK;
 }

@@ -25,6 +25,7 @@ struct UgsTune {
   int align_group;              // UGS_ALIGN_GROUP            -1 unset (= 1), 0 off, n: rejects of a unit after which k_align tests its candidates four at a time
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
+  int r2_hv;                    // UGS_R2_HV                  -1 unset (= on), 0: cluster_fast's deferred units go straight to k_rank (A/B), 2: every unit through the heavy-unit kernel (tests)
   int r2_p16;                   // UGS_R2_P16                 -1 unset (= on), 0: the bitmap kernel streams the 32-bit postings (A/B)
   int r3, r3_sp, r3_pps;        // UGS_R3 / UGS_R3_SP / UGS_R3_PPS  sparse index: -1 unset (= k_rank3g), 0 = k_rank2g; k_rank3g: partitions per super-partition
                                 //                            (0 unset = per unit, from its postings), postings per super-partition aimed at (0 unset = 4096)
@@ -73,6 +74,7 @@ struct ugs_batch {
   uint32_t *d_unit_ns, *d_unit_slots; uint64_t unit_slots_alloc;
   void *d_qpk; uint64_t qpk_alloc; uint32_t qpk_stride;          // packed query planes (nt), see UgsBatchView::qpk
   uint32_t *d_defer;                // units the bitmap ranking kernel hands on to k_rank
+  uint32_t *d_defer2;               // cluster_fast: ... and the ones the heavy-unit kernel behind it hands on (allocated on first use)
   UgsRank2Params r2; int r2_grid;   // its launch (r2_grid == 0: not used for this batch)
   // usearch_local
   uint32_t hit_slots;               // hit table entries per unit

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256, (!SMALL && !BATCH && !FAST8 && !WIDE) ? (LONG 
   const UgsTables *tab = db.tab;
   // Big path: behind a bitmap kernel (ugs_rank2.hip) this kernel takes the units that one deferred, from its list
   const bool deferred = !SMALL && bv.use_defer != 0;
-  const uint32_t units = deferred ? (uint32_t)bv.counters[UGS_CTR_DEFER] : bv.nq * bv.nstrand;
+  const uint32_t units = deferred ? (uint32_t)bv.counters[bv.use_defer == 2u ? UGS_CTR_DEFER2 : UGS_CTR_DEFER] : bv.nq * bv.nstrand;
   const uint32_t K = bv.K;
   const int W = db.word_len;
   constexpr bool small_path = SMALL;
@@ -1944,7 +1944,7 @@ unsigned long long ugs_rank_instances_seen(unsigned long long *compiled)
 {
 #define UGS_RI_BIT(i, n, s) | (1ull << (i))
 #ifdef UGS_ONLY_HOT
-  if (compiled) *compiled = (1ull << UGS_RI_BIG4) | (1ull << UGS_RI_R2) | (1ull << UGS_RI_R2G) | (1ull << UGS_RI_R2_CL) | (1ull << UGS_RI_R3G) | (1ull << UGS_RI_R2_P16);
+  if (compiled) *compiled = (1ull << UGS_RI_BIG4) | (1ull << UGS_RI_R2) | (1ull << UGS_RI_R2G) | (1ull << UGS_RI_R2_CL) | (1ull << UGS_RI_R3G) | (1ull << UGS_RI_R2_P16) | (1ull << UGS_RI_R2_HV);
 #else
   if (compiled) *compiled = 0ull UGS_RANK_INST_TABLE(UGS_RI_BIT);
 #endif
@@ -2021,11 +2021,13 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
   }
   int ordinal = 0;
   const void *fn = rank_kernel(db.big, L.bits, L.fast8, L.longrows, L.wide, &ordinal);
-  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather == 2u ? UGS_RI_R3G : r2->gather ? UGS_RI_R2G : (b.cand_key ? UGS_RI_R2_CL : (r2->post16 ? UGS_RI_R2_P16 : UGS_RI_R2)))) : 0ull));
+  g_rank_seen.fetch_or((1ull << ordinal) | (r2 ? (1ull << (r2->gather == 2u ? UGS_RI_R3G : r2->gather ? UGS_RI_R2G : (b.cand_key ? UGS_RI_R2_CL : (r2->post16 ? UGS_RI_R2_P16 : UGS_RI_R2)))) : 0ull) |
+                       ((r2 && r2->hv_grid > 0 && r2->defer2 && b.cand_key && !r2->gather) ? (1ull << UGS_RI_R2_HV) : 0ull));
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   {
     UgsDbView a0 = db; UgsBatchView a1 = b; uint32_t a2 = L.ns_max, a3 = tbl_words, a4 = L.part_words;
     a1.use_defer = r2 ? 1u : 0u;
+    if (r2 && r2->hv_grid > 0 && r2->defer2 && b.cand_key && !r2->gather) { a1.use_defer = 2u; a1.defer_list = r2->defer2; }      // (behind the heavy-unit kernel)
     void *args[] = {&a0, &a1, &a2, &a3, &a4};
     if (ugs_kernel_log) ugs_before_launch("k_rank");
     HIPCHK(hipLaunchKernel(fn, grid, block, args, L.lds, st));

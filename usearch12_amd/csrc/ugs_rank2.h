@@ -12,13 +12,19 @@ struct UgsRank2Params {
   uint32_t lds;        // dynamic LDS bytes per wave
   const uint16_t *post16; // k_rank2 only, null otherwise: the postings as 16-bit offsets inside their partition (target mod G) at the SAME element
                        //    positions as UgsDbView::postings - the kernel then streams these (np <= 512)
+  uint32_t *defer2;    // cluster_fast only, null otherwise: behind the CL instantiation the heavy-unit instantiation (HV) takes the deferred units
+                       //    and lists the ones IT cannot take here (counters[UGS_CTR_DEFER2] of them) for k_rank
+  uint32_t hv_lds;     // its dynamic LDS bytes per wave, hv_grid its grid (0: no such stage)
+  int hv_grid;
+  uint32_t force_defer; // tests (UGS_R2_HV=2): the CL instantiation defers EVERY unit, so that the heavy-unit kernel ranks a whole batch
   uint32_t gather;     // 1: k_rank2g (sparse index: one chunk = the sub-rows of all sampled rows of a partition); 2: k_rank3g (sparse index,
                        //    two filter passes per super-partition, ugs_rank3.hip)
 };
 
 size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl = 0);
+size_t ugs_rank2_hv_lds(uint32_t gsize, uint32_t kcap, uint32_t clcap);      // the heavy-unit instantiation: 4-bit counters for gsize targets
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np);
-int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl = 0, int p16 = 0);      // cl: the cluster_fast instantiation (walk records); p16: 16-bit postings
+int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl = 0, int p16 = 0, int hv = 0);      // cl: the cluster_fast instantiation (walk records); p16: 16-bit postings
 int ugs_build_post16(const uint32_t *d_postings, uint64_t n, uint32_t G, uint16_t *d_out, hipStream_t st);   // out[i] = postings[i] mod G
 // k_rank3g (ugs_rank3.hip)
 size_t ugs_rank3g_lds(uint32_t kcap);

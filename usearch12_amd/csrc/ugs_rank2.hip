@@ -72,6 +72,10 @@ __host__ __device__ constexpr uint32_t r2_fixed_words(bool cl) { return (cl ? R2
 #define R2D_PART16(m) (((m) >> 13) & 511u)
 #define R2D_LEAD16(m) (((m) >> 22) & 3u)
 #define R2_P16_MAXNP 512u
+// HV (the heavy-unit instantiation, r6): 10 bits of partition, bit 23 = the chunk belongs to the partition's SECOND pass
+#define R2D_PART_HV(m) (((m) >> 13) & 1023u)
+#define R2D_PASS2_HV(m) (((m) >> 23) & 1u)
+#define R2_HV_MAXNP 1024u
 
 // LDS byte address of target t's bitmap word: ((t >> 5) << 2) + nsub8 as a shift and ONE v_lshl_add_u32 (the compiler's own choice
 // for the expression is shift, and, add)
@@ -95,17 +99,32 @@ struct R2Stage { uint32_t old[4], bit[4], t[4]; };
 // P16: the scan streams UgsRank2Params::post16 - the index's postings as 16-bit offsets inside their partition (target mod G), same
 // element positions as UgsDbView::postings - instead of the 32-bit targets: half the bytes of the dominant stream, four postings per
 // 8-byte load and lane (the same lane occupancy and instruction count per posting as the 16-byte loads of four 32-bit targets).
-template <int D, bool CL, bool P16>
+// HV (r6): the instantiation for the HEAVY units of cluster_fast - the units the CL instantiation gave up because a partition held more
+// second touches than its record list (a read of an abundant species: hundreds to thousands of centroids share most of its words).
+// Records do not scale there (a target with count c leaves c - 1 of them); this instantiation COUNTS instead:
+//   * partitions of UgsDbView::gsize targets (k_rank's table, ~ 9 000 targets), a 4-bit counter per target in LDS (counts <= ns <= 15);
+//   * every partition is streamed twice through the same ring: pass 1 adds 1 to the counter of every posting (ds_add, nothing comes
+//     back), pass 2 - rows in ASCENDING order - exchanges the counter for zero (ds_and_rtn): the first posting of a target that still
+//     finds its count is the target's first touch (row, target), later ones find 0; the table is clean again when the pass ends;
+//   * a first touch with count c >= 2 is a key [15 - c][row][target] as above.  Inside a pass the keys of one count value arrive in
+//     ascending order, so the FIRST key of a count value in a partition is the partition's smallest for that value (all the prefix maxima
+//     need: lane c keeps the minimum over the partitions); a key is kept only while it is below the K-th smallest kept so far (the kept
+//     list is compacted to its K smallest whenever it fills, as in the CL instantiation) - no record list, nothing grows with the family.
+// It takes its units from the CL instantiation's deferred list and hands the ones it cannot take (more than 15 sampled rows, a window that
+// does not fit the chunk list) on to k_rank through UgsRank2Params::defer2.  udbusortedsearcherbig.cpp:82-110, countsort.cpp:110-191.
+template <int D, bool CL, bool P16, bool HV = false>
 __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatchView bv, UgsRank2Params prm)
 {
   static_assert(!(P16 && CL), "the cluster_fast instantiation reads the 32-bit postings (its index grows batch by batch)");
   static_assert(!P16 || R2_V2, "16-bit postings exist for the v2 ring only");
+  static_assert(!HV || (CL && R2_V2 && !P16), "the heavy-unit instantiation is a variant of the cluster_fast one");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x;
   const uint32_t lane4 = lane * 4u;
   // ---- LDS carve (the bitmap sits at offset 0 so that a posting's word address needs no add)
-  const uint32_t G = prm.G, np = prm.np, K = bv.K, kcap = prm.kcap;
-  const uint32_t bm_bytes = G / 8u;
+  const uint32_t G = HV ? db.gsize : prm.G, np = HV ? db.np : prm.np, K = bv.K, kcap = prm.kcap;
+  const uint32_t bm_bytes = HV ? G / 2u : G / 8u;                       // (HV: a 4-bit counter per target instead of one bit)
+  const uint32_t *const ptab = HV ? db.part : db.part2;                 // the partition table that goes with G
   constexpr uint32_t SCAP = CL ? R2_SCAP_CL : R2_SCAP;                 // records of one partition the grouping handles
   uint32_t *s_stg = (uint32_t *)(smem + bm_bytes);                      // [SCAP] records of the partition being scanned
   uint32_t *s_hba = s_stg + SCAP;                                       // [R2_HB_BITS / 32] hash filter of the grouping
@@ -120,10 +139,13 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
   const uint32_t clcap = prm.clcap;
   uint32_t *s_kl = (uint32_t *)(s_cl + clcap);                          // [kcap + 4] kept keys
   const uint32_t amax = bm_bytes - 4u;                                  // last word of the bitmap (G need not be a power of two)
-  const uint32_t units = bv.nq * bv.nstrand;
+  const uint32_t units = HV ? (uint32_t)bv.counters[UGS_CTR_DEFER] : bv.nq * bv.nstrand;      // (HV: the deferred list of the kernel in front)
   const uint32_t ns_max = prm.ns_max;
   const uint32_t *postings = db.postings;
   unsigned long long n_done_local = 0;
+  if constexpr (HV) {                                                   // the counter table starts clean and every pass 2 leaves it clean
+    for (uint32_t k = lane * 4u; k < bm_bytes; k += 256u) *(uint32_t *)(smem + k) = 0u;
+  }
 #ifdef R2_CLOCKS
   unsigned long long tc_pre = 0, tc_scan = 0, tc_fin = 0, tc_sel = 0;
 #define R2_CLK(...) __VA_ARGS__
@@ -145,18 +167,20 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
   uint32_t ubase = 0, uidx = 4, ugot = 4;
   for (;;) {
     if (uidx == ugot) {
-      const uint32_t want = (ubase + ugot < coarse_end) ? 4u : 1u;        // (ubase + ugot: the counter was at least there)
+      const uint32_t want = (!HV && ubase + ugot < coarse_end) ? 4u : 1u;   // (ubase + ugot: the counter was at least there; heavy units singly)
       uint32_t v = 0;
-      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[UGS_CTR_NEXT_RANK2], (unsigned long long)want);
+      if (lane == 0) v = (uint32_t)atomicAdd(&bv.counters[HV ? UGS_CTR_NEXT_HEAVY : UGS_CTR_NEXT_RANK2], (unsigned long long)want);
       ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
       uidx = 0; ugot = want;
     }
     uint32_t unit = ubase + uidx;
     ++uidx;
     if (unit >= units) break;
-    if constexpr (CL) { if (bv.unit_order) unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_order[unit]); }     // (heaviest first)
+    if constexpr (HV) unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.defer_list[unit]);
+    else if constexpr (CL) { if (bv.unit_order) unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_order[unit]); }     // (heaviest first)
     const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.unit_ns[unit]);
     bool bad = ns > 15u;                                                  // 4-bit count field of the keys
+    if constexpr (CL && !HV) { if (prm.force_defer) bad = true; }
 #ifdef R2_DEFER_STATS
     if (bad && lane == 0) atomicAdd(&bv.counters[UGS_CTR_T4], 1ull);
 #endif
@@ -358,9 +382,13 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
       // (as many partitions per window as the chunk list holds for this unit's row count: a multiple of 4)
       uint32_t W = ((clcap - 16u) / ((ns + 4u) & ~3u)) & ~3u;
       W = W < 4u ? 4u : (W > prm.W ? prm.W : W);
+      // HV: W counts VIRTUAL partitions - every partition appears twice in the chunk list, pass 1 then pass 2 (W / 2 partitions per window)
+      uint32_t hv_seen = 0, hv_kth = R2_KEY_INF;                         // count values met in the running pass 2 | the K-th smallest kept key
+      uint32_t hv_fk = R2_KEY_INF;                                       // lane c: smallest key of count c over the partitions scanned
+      (void)hv_seen; (void)hv_kth; (void)hv_fk;
       R2_CLK(tpre = clock64() - tk0;)                                     // (the unit's prologue: row descriptors)
       for (uint32_t p0 = 0; p0 < np && !bad; ) {
-        const uint32_t Wn = np - p0 < W ? np - p0 : W;
+        const uint32_t Wn = HV ? ((np - p0) * 2u < W ? (np - p0) * 2u : W) : (np - p0 < W ? np - p0 : W);      // (HV: virtual partitions)
         R2_CLK(const unsigned long long tw0 = clock64();)
         // (1) the window's chunk list -> LDS.  Lane = (partition of the window: lane >> 4, row: ns - 1 - (lane & 15)), so lane order is the
         // scan order (partition ascending, row DESCENDING); a sub-row's bounds are two adjacent words of the row's partition-table
@@ -372,9 +400,11 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         for (uint32_t pl0 = 0; pl0 < Wn; pl0 += 4u) {
           const uint32_t grp = lane >> 4, pl = pl0 + grp, rr = lane & 15u;
           const bool valid = rr < ns && pl < Wn;
-          const uint32_t r = valid ? ns - 1u - rr : 0u, p = p0 + pl;
+          // (HV: virtual partition pl = partition pl / 2, pass pl % 2; rows in ASCENDING order - the first posting that still finds its
+          //  target's count in pass 2 is the target's first touch)
+          const uint32_t r = valid ? (HV ? rr : ns - 1u - rr) : 0u, p = HV ? p0 + (pl >> 1) : p0 + pl;
           u32x2 lh; lh.x = 0; lh.y = 0;
-          if (valid) __builtin_memcpy(&lh, db.part2 + (uint64_t)s_slots[r] * (np + 1u) + p, 8);
+          if (valid) __builtin_memcpy(&lh, ptab + (uint64_t)s_slots[r] * (np + 1u) + p, 8);
           const uint32_t len = lh.y - lh.x;
           const uint64_t a0 = s_rs[r] + lh.x;
           // (P16: chunks start at multiples of four elements; the sub-row's first chunk begins up to three elements early)
@@ -397,6 +427,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
               const uint32_t n = spanall - j * 256u < 256u ? spanall - j * 256u : 256u;
               uint2 e; e.x = (uint32_t)a; e.y = n | (r << 9) | (p << 13) | ((uint32_t)(a >> 32) << 24);
               if constexpr (P16) { if (j == 0u) e.y |= lead << 22; }
+              if constexpr (HV) e.y |= (pl & 1u) << 23;
               s_cl[base + j] = e;
             }
           }
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
           if (rr == 15u && pl < 32u) s_pe[pl] = mybase + mypad;           // list index at which this partition ends
           nch = gbase;
         }
-        if (nch == 0) { p0 += Wn; continue; }
+        if (nch == 0) { p0 += HV ? Wn >> 1 : Wn; continue; }
         any_posting = true;
         R2_CLK(tpre += clock64() - tw0;)
         // padding entries: the ring below issues exactly one load per stage (its counted waits depend on it) and looks D chunks ahead
@@ -413,7 +444,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 #endif
         constexpr uint32_t PADN = (R2_V2 ? 3u : 2u) * (uint32_t)D;     // empty descriptors behind the list (v2 reads a loop body further ahead)
         if (nch + PADN > clcap) {                                      // a window with more chunks than the list holds: very long rows
-          if constexpr (CL) { if (W > 1u) { W = W > 4u ? 4u : W >> 1; continue; } }     // (cluster_fast: the window is cut down to one partition before the unit is given up)
+          if constexpr (CL) { if (W > (HV ? 2u : 1u)) { W = W > 4u ? 4u : W >> 1; continue; } }     // (cluster_fast: the window is cut down to one partition before the unit is given up)
           bad = true; break;
         }
         for (uint32_t i = nch + lane; i < nch + PADN; i += 64u) { uint2 e; e.x = 0; e.y = 0; s_cl[i] = e; }
@@ -456,6 +487,35 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         uint32_t e_bit[4] = {0, 0, 0, 0}, e_t[4] = {0, 0, 0, 0}, e_meta = 0;
         auto count2 = [&](uint32_t meta, const uint32_t (&t)[4]) {
           const int vlen = (int)R2D_N(meta) - (int)lane4;
+          if constexpr (HV) {
+            // 4-bit counters: target t of partition p lives in nibble (t - p G) % 8 of word (t - p G) / 8
+            const uint32_t sub = R2D_PART_HV(meta) * G;
+            const bool second = R2D_PASS2_HV(meta) != 0u;
+            e_meta = meta;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e_bit[j] = 0u; e_t[j] = t[j]; }
+            if (vlen > 0) {
+              uint32_t ad[4], sh[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const uint32_t idx = t[j] - sub;
+                const bool ok = j < vlen;
+                ad[j] = ok ? (idx >> 3) << 2 : 0u;
+                sh[j] = (idx & 7u) << 2;
+                e_bit[j] = (second && ok) ? (0x80000000u | sh[j]) : 0u;  // (what the emission needs: "valid" and the nibble's shift)
+              }
+              if (!second) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) (void)__hip_atomic_fetch_add((lds32)(uintptr_t)ad[j], j < vlen ? (1u << sh[j]) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              } else {
+                o0 = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[0], 0 < vlen ? ~(15u << sh[0]) : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                o1 = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[1], 1 < vlen ? ~(15u << sh[1]) : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                o2 = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[2], 2 < vlen ? ~(15u << sh[2]) : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                o3 = __hip_atomic_fetch_and((lds32)(uintptr_t)ad[3], 3 < vlen ? ~(15u << sh[3]) : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+            return;
+          }
           if constexpr (P16) {
             // t[0], t[1] = four 16-bit postings (offsets inside the partition).  Validity: element 4 lane + j of the chunk counts when
             // lead <= 4 lane + j < span - the lead only ever concerns lane 0
@@ -495,6 +555,45 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         auto emit2 = [&]() {
           const uint32_t rtag = R2D_ROW(e_meta) << 24;
           const uint32_t old[4] = {o0, o1, o2, o3};
+          if constexpr (HV) {
+            // the first touches of the pass-2 chunk counted one stage ago: postings that still found their target's count
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool on = (e_bit[j] & 0x80000000u) != 0u;
+              const uint32_t c = on ? (old[j] >> (e_bit[j] & 31u)) & 15u : 0u;
+              const uint32_t key = ((15u - c) << 28) | rtag | e_t[j];
+              const bool cand = c >= 2u;
+              uint64_t mc = r2_ballot(cand);
+              if (mc) {
+                // (1) the first key of a count value in this pass is the partition's smallest for it (keys ascend inside a pass)
+                uint64_t mn = r2_ballot(cand && ((hv_seen >> c) & 1u) == 0u);
+                while (mn) {
+                  const int L = __ffsll((long long)mn) - 1;
+                  const uint32_t cL = (uint32_t)__builtin_amdgcn_readlane((int)c, L), kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+                  if (lane == cL) hv_fk = kL < hv_fk ? kL : hv_fk;
+                  hv_seen |= 1u << cL;
+                  mn &= ~r2_ballot(c == cL);
+                }
+                // (2) a key stays while it is below the K-th smallest kept so far
+                uint64_t mk = r2_ballot(cand && key < hv_kth);
+                if (mk) {
+                  if (nk + (uint32_t)__popcll(mk) > kcap) {
+                    compact_kept();                                     // (nk = min(nk, K), the kept keys in rank order)
+                    hv_kth = nk >= K ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_kl[K - 1u]) : R2_KEY_INF;
+                    mk = r2_ballot(cand && key < hv_kth);
+                  }
+                  if (mk) {
+                    const uint32_t pos = nk + r2_mbcnt(mk);
+                    if (cand && key < hv_kth) s_kl[pos] = key;
+                    nk += (uint32_t)__popcll(mk);
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e_bit[j] = 0;
+            return;
+          }
           const uint32_t psub = P16 ? R2D_PART16(e_meta) * G : 0u;        // (P16: the partition's first target, added back to the offsets)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -540,11 +639,14 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
             // a partition ended with the previous loop body: its last chunk's records, then its grouping
             R2_CLK(const unsigned long long tf0 = clock64();)
             emit2();
-            if (c != 0) { finalize(); if (bad) break; }
+            if constexpr (!HV) { if (c != 0) { finalize(); if (bad) break; } }
             // (the next partition's end index was read where this one began: no LDS round trip at the boundary)
             do { pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)pe_next); ++pi; pe_next = s_pe[pi]; } while (pend == c);      // (partitions without a posting)
+            if constexpr (HV) hv_seen = 0u;                               // (a pass begins: pass 2 left the counter table clean, nothing to zero)
+            else {
             if constexpr (!P16) nsub8 = 0u - R2D_PART(mt[0]) * (G >> 3);  // (a partition's first chunk is never padding)
             zero_bitmap();
+            }
             R2_CLK(tfin += clock64() - tf0;)
           }
           R2_STAGE2(0, false) R2_STAGE2(1, false) R2_STAGE2(2, false) R2_STAGE2(3, true)
@@ -553,7 +655,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
         if (!bad) {
           R2_CLK(const unsigned long long tf0 = clock64();)
           emit2();
-          finalize();
+          if constexpr (!HV) finalize();
           R2_CLK(tfin += clock64() - tf0;)
         }
 #else
@@ -609,14 +711,30 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 #endif
         // every load of the ring has landed before the next window (or unit) issues into the same slots
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        p0 += Wn;
+        p0 += HV ? Wn >> 1 : Wn;
+      }
+      if constexpr (HV) {
+        // the smallest key of every count value, as the CL instantiation's groupings leave it in s_fpk (index 15 - count)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane >= 2u && lane <= 15u) s_fpk[15u - lane] = hv_fk;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
     if (bad) {
       // outside this kernel's envelope: the general kernel takes the unit (it writes cand / cand_cnt / cand_n)
       if (lane == 0) {
-        const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
-        bv.defer_list[idx] = unit;
+        if constexpr (HV) {
+          const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER2], 1ull);
+          prm.defer2[idx] = unit;
+        } else {
+          const unsigned long long idx = atomicAdd(&bv.counters[UGS_CTR_DEFER], 1ull);
+          bv.defer_list[idx] = unit;
+        }
+      }
+      if constexpr (HV) {                                                 // (a pass 1 may have been cut short: the table must be clean for the next unit)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t k = lane * 4u; k < bm_bytes; k += 256u) *(uint32_t *)(smem + k) = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
       continue;
     }
@@ -740,7 +858,7 @@ __global__ __launch_bounds__(64, CL ? 3 : 4) void k_rank2(UgsDbView db, UgsBatch
 #ifdef R2_CLOCKS
   if (lane == 0) { atomicAdd(&bv.counters[UGS_CTR_T0], tc_pre); atomicAdd(&bv.counters[UGS_CTR_T1], tc_scan); atomicAdd(&bv.counters[UGS_CTR_T2], tc_fin); atomicAdd(&bv.counters[UGS_CTR_T3], tc_sel); }
 #endif
-  if (lane == 0 && n_done_local) atomicAdd(&bv.counters[UGS_CTR_R2_DONE], n_done_local);
+  if (lane == 0 && n_done_local) atomicAdd(&bv.counters[HV ? UGS_CTR_HV_DONE : UGS_CTR_R2_DONE], n_done_local);
 }
 
 // ================================================================================================================================
@@ -1108,8 +1226,9 @@ int ugs_build_post16(const uint32_t *d_postings, uint64_t n, uint32_t G, uint16_
   return UGS_OK;
 }
 
-static const void *rank2_kernel(int gather = 0, int cl = 0, int p16 = 0)
+static const void *rank2_kernel(int gather = 0, int cl = 0, int p16 = 0, int hv = 0)
 {
+  if (hv) return (const void *)k_rank2<UGS_R2_DEPTH, true, false, true>;
   return gather ? (const void *)k_rank2g : cl ? (const void *)k_rank2<UGS_R2_DEPTH, true, false>
                 : p16 ? (const void *)k_rank2<UGS_R2_DEPTH, false, true> : (const void *)k_rank2<UGS_R2_DEPTH, false, false>;
 }
@@ -1119,15 +1238,20 @@ size_t ugs_rank2_lds(uint32_t G, uint32_t kcap, uint32_t clcap, int cl)
   return (size_t)G / 8 + (size_t)r2_fixed_words(cl != 0) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;       // (the kernel's own carve)
 }
 
+size_t ugs_rank2_hv_lds(uint32_t gsize, uint32_t kcap, uint32_t clcap)
+{
+  return (size_t)gsize / 2 + (size_t)r2_fixed_words(true) * 4 + (size_t)clcap * 8 + ((size_t)kcap + 4) * 4;      // (the kernel's own carve, bm_bytes = gsize / 2)
+}
+
 size_t ugs_rank2g_lds(uint32_t G, uint32_t kcap, uint32_t np)
 {
   return (size_t)G / 8 + ((size_t)R2_SCAP + 64 + R2G_HB_BITS / 32 + 64 * 3) * 4 + (size_t)R2G_DCAP * 8 + ((size_t)kcap + 2) * 8 + (size_t)np * 64;      // (must mirror the kernel's carve)
 }
 
-int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl, int p16)
+int ugs_rank2_blocks_per_cu(size_t lds, int gather, int cl, int p16, int hv)
 {
   int n = 0;
-  const void *fn = rank2_kernel(gather, cl, p16);
+  const void *fn = rank2_kernel(gather, cl, p16, hv);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess || n < 1) n = 1;
   return n;
@@ -1149,5 +1273,18 @@ int ugs_launch_rank2(const UgsDbView &db, const UgsBatchView &b, const UgsRank2P
   HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(64), args, prm.lds, st));
   if (ugs_kernel_log) ugs_after_launch("k_rank2 / k_rank2g", st);
   HIPCHK(hipGetLastError());
+  if (cl && prm.hv_grid > 0 && prm.defer2) {
+    // the heavy units of cluster_fast: the deferred list of the kernel above goes through the counting instantiation; what that cannot take
+    // (defer2) is k_rank's (ugs_launch_rank: use_defer = 2)
+    if (db.np > R2_HV_MAXNP || (db.gsize & 63u) || db.gsize > 65536u) { ugs_set_error("heavy-unit ranking kernel: partition table outside its envelope"); return UGS_E_ENVELOPE; }
+    const size_t need_hv = ugs_rank2_hv_lds(db.gsize, prm.kcap, prm.clcap);
+    if (prm.hv_lds < need_hv) { ugs_set_error("heavy-unit ranking kernel: %u bytes of LDS per wave, its carve needs %zu", prm.hv_lds, need_hv); return UGS_E_ENVELOPE; }
+    const void *fh = rank2_kernel(0, 1, 0, 1);
+    HIPCHK(hipFuncSetAttribute(fh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prm.hv_lds));
+    if (ugs_kernel_log) ugs_before_launch("k_rank2<HV>");
+    HIPCHK(hipLaunchKernel(fh, dim3(prm.hv_grid), dim3(64), args, prm.hv_lds, st));
+    if (ugs_kernel_log) ugs_after_launch("k_rank2<HV>", st);
+    HIPCHK(hipGetLastError());
+  }
   return UGS_OK;
 }
