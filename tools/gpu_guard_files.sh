@@ -8,7 +8,7 @@ tag=$1; shift
 files=("$@")
 if [ ${#files[@]} -eq 0 ]; then files=(tests/test_gpu_*.py tests/test_udb.py tests/test_zz_gpu_coverage.py); fi
 mkdir -p gpurun_out
-export UGS_GUARD_ALLOC=${UGS_GUARD_ALLOC:-1} UGS_ABORT_BT=stderr HSA_ENABLE_IPC_MODE_LEGACY=0 UGS_DEBUG_SYNC=1
+export UGS_GUARD_ALLOC=${UGS_GUARD_ALLOC:-1} UGS_ABORT_BT=stderr HSA_ENABLE_IPC_MODE_LEGACY=0 UGS_DEBUG_SYNC=${UGS_DEBUG_SYNC:-1}
 : > gpurun_out/${tag}_summary.txt
 for f in "${files[@]}"; do
   b=$(basename $f .py)
