@@ -283,17 +283,26 @@ def other_config(capi, synth, name, device, parity=True):
         out = {"workload": "C3: cluster_fast 5000000 x 300 nt reads -id 0.97 (UCLUST centroid path), one MI355X", "value": r.n / dt, "unit": "reads/s",
                "seconds": dt, "clusters": int(res.n_clusters), "uniques": int(res.n_unique),
                "kernel_ms": {"ranking (all batches)": st.ms_rank, "k_align (all batches)": st.ms_align},
-               "kernel": "k_rank2<cluster_fast> + k_rank over its deferred units", "algorithmic_bytes": 4 * int(st.postings),
+               "kernel": "k_rank2<cluster_fast>, k_rank2<HV> over the units that defers (%d of them ranked there), k_rank behind both and on the small path" % int(st.units_heavy),
+               "units_ranked_by_the_heavy_unit_kernel": int(st.units_heavy), "algorithmic_bytes": 4 * int(st.postings),
                "frac": 4 * st.postings / max(st.ms_rank * 1e-3, 1e-9) / (HBM_PEAK_GBS * 1e9), "gen_s": gen_s}
         res.close()
         if parity:
             out["parity_sample"] = ref_parity_cluster(capi, r, 0.97, 150_000, device)
         return out
-    if name != "C5":
+    if name == "ID90":
+        # the C2 shape at -id 0.9 (not a BASELINE configuration): ~ 41 sampled index rows per query instead of ~ 11 - the
+        # general ranking kernel's mid-identity instantiation (8-bit counters), outside the bitmap kernel's 15 rows
+        db = synth.make_db(2, 1_000_000, 250); qs = synth.make_queries(2, db, 1_000_000, 250)
+        p = capi.params(is_nucleo=True, id=0.9)
+        wl = "ID90: usearch_global 1000000 x 250 nt queries vs 1000000-seq DB, -id 0.9 (mid-identity: ~41 sampled rows per query), one MI355X"
+        parity = False
+    elif name == "C5":
+        db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 1_000_000, 300, aa=True)
+        p = capi.params(is_nucleo=False, id=0.8)
+        wl = "C5: usearch_global protein 1000000 x 300 aa queries vs 2000000-seq aa DB, -id 0.8, one MI355X"
+    else:
         raise ValueError("unknown configuration %r" % name)
-    db = synth.make_db(5, 2_000_000, 300, aa=True); qs = synth.make_queries(5, db, 1_000_000, 300, aa=True)
-    p = capi.params(is_nucleo=False, id=0.8)
-    wl = "C5: usearch_global protein 1000000 x 300 aa queries vs 2000000-seq aa DB, -id 0.8, one MI355X"
     gen_s = time.time() - t0
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=device)
     bats = [capi.UgsBatch(gdb, qs.n, int(qs.offs[-1])) for _ in range(2)]
@@ -390,7 +399,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48_000, help="queries of every point of the CPU thread sweep")
     ap.add_argument("--parity-sample", type=int, default=384_000, help="queries the reference binary searches with its -blast6out kept: the GPU's "
                     "hits for the same queries are formatted and compared with it (0 = off)")
-    ap.add_argument("--other-configs", default="auto", help="comma list of C5,C4,C3 run once each after the timed region (detail.other_configs); "
+    ap.add_argument("--other-configs", default="auto", help="comma list of C5,C4,C3,ID90 run once each after the timed region (detail.other_configs); "
                     "auto = all three on a default one-GPU C2 run, none otherwise")
     ap.add_argument("--emulate-world", type=int, default=8, help="one-GPU C2 runs: strong-scaling proxy - rank 0's step at 1/N of the batch with the "
                     "N-rank gather (loopback transport), detail.strong_scaling_proxy; 0 = off")
@@ -733,7 +742,7 @@ def main():
             for c in comms:
                 c.close()
         # ---- the other named configurations, once each (driver-visible)
-        which = [] if args.other_configs == "none" else (["C5", "C4", "C3"] if args.other_configs == "auto" else [x for x in args.other_configs.split(",") if x])
+        which = [] if args.other_configs == "none" else (["C5", "C4", "C3", "ID90"] if args.other_configs == "auto" else [x for x in args.other_configs.split(",") if x])
         if which:
             for b in bats:
                 b.close()
@@ -852,7 +861,7 @@ def main():
             # one entry per configuration that was compared with the reference BINARY's own output on this box (C2: 384 k queries, C5: 100 k
             # protein queries, C3: the -uc of a 150 k-read prefix at -threads 1)
             "parity_sample": ([dict(parity, config="C2")] if parity else []) +
-                             [dict(o["parity_sample"], config=o["workload"][:2]) for o in (others or []) if isinstance(o, dict) and o.get("parity_sample")],
+                             [dict(o["parity_sample"], config=o["workload"].split(":")[0]) for o in (others or []) if isinstance(o, dict) and o.get("parity_sample")],
             "detail": {"csrc_sha16": csrc_sha, "runtime_libs": all_libs, "other_configs": others, "strong_scaling_proxy": proxy,
                        "ms_rank": ms_rank, "ms_rank_setup": ms_setup, "ms_align": ms_align, "hits_per_step": n_hits,
                        "postings_per_query": st["postings"] / max(qs.n, 1),

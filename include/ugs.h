@@ -317,6 +317,7 @@ int ugs_debug_alloc_stats(unsigned long long out[5]);
  *   UGS_WIDE_OFFSETS=1      k_rank's Big-path 4-bit kernels with 64-bit table / row offsets (chosen by themselves for an index that needs them)
  *   UGS_RANK2=0|1           bitmap ranking kernel off / on wherever the index allows it (default: on for dense Big-path indexes)
  *   UGS_R2_G=n UGS_R2_KCAP=n UGS_R2_WAVES=n   its partition size (multiple of 8192), kept-key capacity, waves per CU
+ *   UGS_SETUP_STREAM=1      the unit set-up kernel of a search runs on a second stream, beside the kernels of the batch enqueued in front (A/B)
  *   UGS_R2_HV=0             cluster_fast: the units the bitmap kernel defers go straight to the general kernel (no heavy-unit stage; A/B); 2: EVERY unit is deferred to the heavy-unit stage (tests)
  *   UGS_R2_P16=0            the bitmap kernel streams the 32-bit postings instead of the 16-bit partition-relative copy (A/B)
  *   UGS_R3=0|1 UGS_R3_SP=n UGS_R3_PPS=n       sparse (protein) Big-path index: 0 = k_rank2g instead of k_rank3g; k_rank3g's partitions per

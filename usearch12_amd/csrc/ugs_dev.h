@@ -223,8 +223,11 @@ int ugs_launch_deep(const UgsDbView &db, const UgsBatchView &b, const UgsDeepArg
 int ugs_deep_sort(uint64_t *d_keys, uint64_t *d_sorted, uint64_t total, uint32_t segments, const uint64_t *d_off, void **d_tmp, size_t *tmp_bytes, hipStream_t st);
 size_t ugs_compact_tmp_bytes(uint32_t nq);
 struct UgsRank2Params;
+// st_setup (optional): the stream the unit set-up kernels run on - when it differs from st, the ranking kernels on st wait for
+// ev_setup_done; ev_rank_start (optional) is recorded on st where the ranking kernels begin
 int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
-                    const UgsRank2Params *r2 = nullptr, int r2_grid = 0, hipEvent_t ev_r2_done = nullptr);
+                    const UgsRank2Params *r2 = nullptr, int r2_grid = 0, hipEvent_t ev_r2_done = nullptr,
+                    hipStream_t st_setup = nullptr, hipEvent_t ev_rank_start = nullptr);
 int ugs_launch_align(const UgsDbView &db, const UgsBatchView &b, const UgsAlignLaunch &L, hipStream_t st);
 size_t ugs_local_wave_lds(uint32_t W, uint32_t max_qlen, uint32_t max_tlen, uint32_t seed_cap);
 int ugs_local_blocks_per_cu(int threads, size_t lds);

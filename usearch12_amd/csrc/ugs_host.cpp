@@ -246,6 +246,7 @@ extern "C" void ugs_db_destroy(ugs_db *db)
   (void)ugs_free(db->d_row_off2); (void)ugs_free(db->d_postings2);
   (void)ugs_free(db->d_step); (void)ugs_free(db->d_tab); (void)ugs_free(db->d_xsub2); (void)ugs_free(db->d_xcls); (void)ugs_free(db->d_tkey); (void)ugs_free(db->d_tsize);
   if (db->stream) (void)hipStreamDestroy(db->stream);
+  if (db->setup_stream) (void)hipStreamDestroy(db->setup_stream);
   delete db;
 }
 
@@ -291,6 +292,7 @@ UgsTune ugs_tune_read()
   t.r2_clcap = env_int("UGS_R2_CLCAP", 48, 4096, 0);
   t.r2_p16 = env_int("UGS_R2_P16", 0, 1, -1);
   t.r2_hv = env_int("UGS_R2_HV", 0, 2, -1);
+  t.setup_stream = env_int("UGS_SETUP_STREAM", 0, 1, 0);
   t.r3 = env_int("UGS_R3", 0, 1, -1);
   t.r3_sp = env_int("UGS_R3_SP", 1, 63, 0);
   t.r3_pps = env_int("UGS_R3_PPS", 64, 1 << 20, 0);
@@ -448,11 +450,12 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   db->d_seqs = nullptr; db->d_offs = nullptr; db->d_row_off = nullptr; db->d_postings = nullptr; db->d_part = nullptr;
   db->d_pk = nullptr; db->pack_cap = 0;
   db->d_row_off2 = nullptr; db->d_postings2 = nullptr; db->post_cap2 = 0; db->gsize_limit = 0;
-  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
+  db->d_step = nullptr; db->d_tab = nullptr; db->stream = nullptr; db->setup_stream = nullptr; db->d_xsub2 = nullptr; db->d_xcls = nullptr; db->d_tkey = nullptr; db->d_tsize = nullptr; db->have_tkey = db->have_tsize = false; db->sparse = false;
   memset(&db->lv, 0, sizeof(db->lv));
   int rc = UGS_OK;
   auto fail = [&](int code) { ugs_db_destroy(db); return code; };
   if (hipStreamCreate(&db->stream) != hipSuccess) { ugs_set_error("hipStreamCreate failed"); return fail(UGS_E_HIP); }
+  if (db->tune.setup_stream && hipStreamCreateWithFlags(&db->setup_stream, hipStreamNonBlocking) != hipSuccess) { ugs_set_error("hipStreamCreate failed"); return fail(UGS_E_HIP); }
   const uint64_t nletters = offs[nseq];
   uint32_t max_tlen = 0;
   for (uint32_t t = 0; t < nseq; ++t) {
@@ -624,6 +627,7 @@ extern "C" void ugs_batch_destroy(ugs_batch *b)
   (void)ugs_free(b->d_walk_state); (void)ugs_free(b->d_open_list); (void)ugs_free(b->d_deepU); (void)ugs_free(b->d_deepR); (void)ugs_free(b->d_keyn); (void)ugs_free(b->d_koff);
   (void)ugs_free(b->d_keys); (void)ugs_free(b->d_keys_sorted); (void)ugs_free(b->d_sort_tmp); (void)ugs_free(b->d_xpool); (void)ugs_free(b->d_xnext); (void)ugs_free(b->d_xblocks_used);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev0m) (void)hipEventDestroy(b->ev0m);
   if (b->ev0s) (void)hipEventDestroy(b->ev0s);
   if (b->ev0r) (void)hipEventDestroy(b->ev0r);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -677,6 +681,7 @@ extern "C" int ugs_batch_create(ugs_db *db, uint32_t max_queries, uint64_t max_l
   BCHK(ugs_malloc(&b->d_cigar_used, 8));
   BCHK(hipMemset(b->d_cigar_used, 0, 8));
   BCHK(ugs_malloc(&b->d_ctr, UGS_CTR_N * 8));
+  BCHK(hipEventCreate(&b->ev0m));
   BCHK(hipEventCreate(&b->ev0)); BCHK(hipEventCreate(&b->ev0s)); BCHK(hipEventCreate(&b->ev0r)); BCHK(hipEventCreate(&b->ev1)); BCHK(hipEventCreate(&b->ev2));
   BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
   BCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
@@ -1228,13 +1233,17 @@ extern "C" int ugs_batch_search(ugs_batch *b)
     }
   }
   b->v.K = b->K;
-  HIPCHK(hipStreamWaitEvent(bstream(b), b->ev_up, 0));          // the batch's letters and offsets have arrived
-  HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, bstream(b)));
-  if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, bstream(b)));
-  HIPCHK(hipEventRecord(b->ev0, bstream(b)));
+  // UGS_SETUP_STREAM=1: the counters' reset and the unit set-up of this search run on a stream of their own - beside the kernels of the batch
+  // enqueued in front (the set-up is a latency-bound kernel of dependent loads) - and the ranking kernels wait for its event
+  hipStream_t s0 = (db->setup_stream && b->nq && !b->cl_mode) ? db->setup_stream : bstream(b);
+  HIPCHK(hipStreamWaitEvent(s0, b->ev_up, 0));                   // the batch's letters and offsets have arrived
+  HIPCHK(hipMemsetAsync(b->d_ctr, 0, UGS_CTR_N * 8, s0));
+  if (is_deep(b)) HIPCHK(hipMemsetAsync(b->d_xblocks_used, 0, 8, s0));
+  HIPCHK(hipEventRecord(b->ev0, s0));
   // (cluster_fast's walk records - cand_key / cl_ev - are k_rank's: the bitmap kernel is for plain searches)
   const bool r2 = b->r2_grid > 0 && (b->v.cand_key ? (b->cl_mode && !b->r2.gather && b->v.cl_ev && b->v.cl_info) : !b->v.cl_ev);
-  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, bstream(b), b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r)); else HIPCHK(hipEventRecord(b->ev0s, bstream(b)));
+  if (b->nq) RCCHK(ugs_launch_rank(db->v, b->v, b->rl, bstream(b), b->ev0s, r2 ? &b->r2 : nullptr, b->r2_grid, b->ev0r, s0, b->ev0m));
+  else { HIPCHK(hipEventRecord(b->ev0s, bstream(b))); HIPCHK(hipEventRecord(b->ev0m, bstream(b))); }
   b->r2_ran = r2 && b->nq;
   HIPCHK(hipEventRecord(b->ev1, bstream(b)));
   const bool dbg = db->tune.debug_sync != 0;             // fault isolation: finish each stage before the next
@@ -1399,7 +1408,7 @@ extern "C" int ugs_batch_get_stats(ugs_batch *b, ugs_batch_stats *st)
   HIPCHK(hipSetDevice(b->db->device));
   memset(st, 0, sizeof(*st));
   HIPCHK(hipEventElapsedTime(&st->ms_rank_setup, b->ev0, b->ev0s));
-  HIPCHK(hipEventElapsedTime(&st->ms_rank, b->ev0s, b->ev1));
+  HIPCHK(hipEventElapsedTime(&st->ms_rank, b->ev0m, b->ev1));
   HIPCHK(hipEventElapsedTime(&st->ms_align, b->ev1, b->ev2));
   HIPCHK(hipEventElapsedTime(&st->ms_total, b->ev0, b->ev2));
   st->postings = b->ctr[UGS_CTR_POSTINGS];
@@ -1449,7 +1458,7 @@ extern "C" int ugs_debug_kernel_hits(const ugs_batch *b, uint64_t *out, int n)
   out[3] = b->r2_ran ? 1 : 0;
   if (n >= 6) {
     float a = 0, c = 0;
-    if (b->r2_ran) { if (hipEventElapsedTime(&a, b->ev0s, b->ev0r) != hipSuccess) a = 0; if (hipEventElapsedTime(&c, b->ev0r, b->ev1) != hipSuccess) c = 0; (void)hipGetLastError(); }    // (a diagnostic: an event not yet complete reads as 0, never an error)
+    if (b->r2_ran) { if (hipEventElapsedTime(&a, b->ev0m, b->ev0r) != hipSuccess) a = 0; if (hipEventElapsedTime(&c, b->ev0r, b->ev1) != hipSuccess) c = 0; (void)hipGetLastError(); }    // (a diagnostic: an event not yet complete reads as 0, never an error)
     out[4] = (uint64_t)(a * 1000.0f + 0.5f); out[5] = (uint64_t)(c * 1000.0f + 0.5f);
   }
   if (n >= 7) out[6] = b->ctr[UGS_CTR_GROUPED];

@@ -25,6 +25,7 @@ struct UgsTune {
   int align_group;              // UGS_ALIGN_GROUP            -1 unset (= 1), 0 off, n: rejects of a unit after which k_align tests its candidates four at a time
   int r2_g, r2_kcap, r2_waves; // UGS_R2_G / UGS_R2_KCAP / UGS_R2_WAVES  partition size, kept-key capacity, waves per CU of the bitmap kernel (0 unset)
   int r2_clcap;                 // UGS_R2_CLCAP               chunk descriptors per window of the bitmap kernel (0 unset)
+  int setup_stream;             // UGS_SETUP_STREAM=1         k_rank_setup of a search on a second stream (overlaps the kernels of the batch in front)
   int r2_hv;                    // UGS_R2_HV                  -1 unset (= on), 0: cluster_fast's deferred units go straight to k_rank (A/B), 2: every unit through the heavy-unit kernel (tests)
   int r2_p16;                   // UGS_R2_P16                 -1 unset (= on), 0: the bitmap kernel streams the 32-bit postings (A/B)
   int r3, r3_sp, r3_pps;        // UGS_R3 / UGS_R3_SP / UGS_R3_PPS  sparse index: -1 unset (= k_rank3g), 0 = k_rank2g; k_rank3g: partitions per super-partition
@@ -37,6 +38,7 @@ struct ugs_db {
   UgsTune tune;                     // the environment's debug switches as they stood at ugs_db_create
   int device;
   hipStream_t stream;
+  hipStream_t setup_stream;         // UGS_SETUP_STREAM=1: the unit set-up kernels of a search run here, beside the kernels of the batch in front (null otherwise)
   int num_cu;
   UgsDbView v;
   // owned device memory
@@ -87,6 +89,7 @@ struct ugs_batch {
   uint64_t emit_limit;              // keys per workgroup the candidate buffer is sized for (grown on demand by ugs_batch_sync)
   int rank_grid_alloc, align_waves_alloc;
   UgsRankLaunch rl; UgsAlignLaunch al;
+  hipEvent_t ev0m;                  // the ranking kernels begin (= ev0s unless the set-up runs on a stream of its own)
   hipEvent_t ev0, ev0s, ev0r, ev1, ev2;   // ev0r: end of the bitmap ranking kernel (before k_rank takes the deferred units)
   bool r2_ran;
   bool cl_mode;                     // the batch of a cluster_fast loop (ugs_cluster.cpp): its searches leave walk records, the bitmap kernel runs its CL instantiation

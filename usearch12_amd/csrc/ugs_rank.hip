@@ -1985,9 +1985,11 @@ size_t ugs_rank_fixed_lds(uint32_t ns_max, uint32_t max_qlen, uint32_t part_word
   return (off + 15) & ~(size_t)15;
 }
 
-int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st, hipEvent_t ev_setup_done,
-                    const UgsRank2Params *r2, int r2_grid, hipEvent_t ev_r2_done)
+int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLaunch &L, hipStream_t st_rank, hipEvent_t ev_setup_done,
+                    const UgsRank2Params *r2, int r2_grid, hipEvent_t ev_r2_done, hipStream_t st_setup, hipEvent_t ev_rank_start)
 {
+  const bool split = st_setup != nullptr && st_setup != st_rank && ev_setup_done != nullptr;
+  hipStream_t st = split ? st_setup : st_rank;                  // (stage 1 below; the ranking kernels run on st_rank)
   const uint32_t tbl_words = (uint32_t)(((uint64_t)db.gsize * L.bits) / 32);
   dim3 grid(L.grid), block(64 * L.wpb);
   {   // stage 1: sampled rows of every unit (one wavefront per unit, as many workgroups as fit)
@@ -2008,6 +2010,9 @@ int ugs_launch_rank(const UgsDbView &db, const UgsBatchView &b, const UgsRankLau
       HIPCHK(hipGetLastError());
     }
     if (ev_setup_done) HIPCHK(hipEventRecord(ev_setup_done, st));
+    if (split) HIPCHK(hipStreamWaitEvent(st_rank, ev_setup_done, 0));
+    st = st_rank;
+    if (ev_rank_start) HIPCHK(hipEventRecord(ev_rank_start, st));
     if (L.debug_sync) { HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[ugs] k_rank_setup done (grid %u, lds %zu); k_rank grid %d x %d lds %zu bits %d ns_max %u tbl_words %u\n", sgrid, slds, L.grid, L.wpb, L.lds, L.bits, L.ns_max, tbl_words); }
   }
 #ifdef UGS_ONLY_HOT
