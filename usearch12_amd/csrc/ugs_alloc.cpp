@@ -15,7 +15,7 @@
 // The ROCr runtime reports a GPU memory fault or a queue error by printing one line to fd 2 and calling abort() on one of ITS
 // threads; glibc does the same for a corrupted heap; a test harness that captures fd 2 swallows the line, and a Python-level
 // fault handler only shows the main thread.  This handler names the thread that died.
-#include "ugs_dev.h"
+#include "ugs_host.h"
 #include <execinfo.h>
 #include <signal.h>
 #include <fcntl.h>
@@ -134,6 +134,51 @@ extern "C" int ugs_debug_alloc_stats(unsigned long long out[5])
   std::lock_guard<std::mutex> lk(g_mu);
   out[0] = (unsigned long long)guard_mode(); out[1] = g_n_alloc; out[2] = g_n_free; out[3] = g_bytes_live; out[4] = g_bytes_peak;
   return UGS_OK;
+}
+
+// ---------------------------------------------------------------- ugs_h2d (ugs_host.h)
+namespace {
+constexpr size_t STAGE_BYTES = 8ull << 20;      // per slot
+struct Stage {
+  void *p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int dev = -1; unsigned next = 0;
+  ~Stage() { /* released with the process: the device may be gone when thread-locals are destroyed */ }
+};
+thread_local Stage g_stage;
+}  // namespace
+
+hipError_t ugs_h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+  if (!bytes) return hipSuccess;
+  {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged))
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);          // page-locked already: true DMA from the caller's buffer
+    (void)hipGetLastError();                                                       // (plain pageable memory is "invalid value" to the query)
+  }
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  Stage &sg = g_stage;
+  if (sg.dev != dev) {                                                             // first use on this thread / another device: new slots (the old ones stay)
+    for (int k = 0; k < 2; ++k) {
+      sg.p[k] = nullptr; sg.ev[k] = nullptr; sg.busy[k] = false;
+      if ((e = hipHostMalloc(&sg.p[k], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&sg.ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    sg.dev = dev; sg.next = 0;
+  }
+  const char *s = (const char *)src; char *d = (char *)dst;
+  for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+    const unsigned k = sg.next++ & 1u;
+    const size_t n = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+    if (sg.busy[k] && (e = hipEventSynchronize(sg.ev[k])) != hipSuccess) return e; // the slot's previous chunk has left it
+    memcpy(sg.p[k], s + off, n);
+    if ((e = hipMemcpyAsync(d + off, sg.p[k], n, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipEventRecord(sg.ev[k], st)) != hipSuccess) return e;
+    sg.busy[k] = true;
+  }
+  return hipSuccess;
 }
 
 // ---------------------------------------------------------------- UGS_KERNEL_LOG

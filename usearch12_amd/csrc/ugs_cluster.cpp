@@ -84,7 +84,7 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(ugs_free(db->d_offs)); db->d_offs = p; db->off_cap = cap;
   }
-  if (add) HIPCHK(hipMemcpyAsync(db->d_seqs + db->nletters, seqs + offs[0], add, hipMemcpyHostToDevice, st));
+  if (add) HIPCHK(ugs_h2d(db->d_seqs + db->nletters, seqs + offs[0], add, st));
   if (db->p.is_nucleo) {                          // the packed letters follow: every word the new letters touch is packed again from the bytes
     const uint64_t need = (db->nletters + add + 64) / 16 + 8;
     if (need > db->pack_cap) {
@@ -99,13 +99,13 @@ extern "C" int ugs_db_append(ugs_db *db, const char *seqs, const uint64_t *offs,
     }
     RCCHK(ugs_launch_pack(db->d_tab, db->d_seqs, db->nletters / 16, (db->nletters + add + 15) / 16, db->d_pk, st));
   }
-  HIPCHK(hipMemcpyAsync(db->d_offs + old_n, abs_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(ugs_h2d(db->d_offs + old_n, abs_off.data(), ((size_t)n + 1) * 8, st));
   struct Tmp {                                    // released on every way out, error returns included
     uint64_t *rel = nullptr, *drow = nullptr; uint32_t *dpost = nullptr, *dmax = nullptr;
     ~Tmp() { (void)ugs_free(rel); (void)ugs_free(drow); (void)ugs_free(dpost); (void)ugs_free(dmax); }
   } t;
   HIPCHK(ugs_malloc(&t.rel, ((size_t)n + 1) * 8));
-  HIPCHK(hipMemcpyAsync(t.rel, rel_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(ugs_h2d(t.rel, rel_off.data(), ((size_t)n + 1) * 8, st));
   // index of the new sequences on their own (targets 0..n-1), then row-wise append
   uint64_t n_dpost = 0; uint32_t dmax = 0;
   int rc = ugs_build_index(db->d_tab, db->d_seqs + db->nletters, t.rel, n, add, db->p.word_len, db->v.alpha, db->v.slots, &t.drow,

@@ -258,7 +258,8 @@ static int db_step_table(ugs_db *db, uint32_t n)
   for (size_t i = old; i < n; ++i) db->step[i] = query_step(db->p, (uint32_t)i);
   if (db->d_step) HIPCHK(ugs_free(db->d_step));
   HIPCHK(ugs_malloc(&db->d_step, n * sizeof(uint32_t)));
-  HIPCHK(hipMemcpy(db->d_step, db->step.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(ugs_h2d(db->d_step, db->step.data(), n * sizeof(uint32_t), db->stream));
+  HIPCHK(hipStreamSynchronize(db->stream));
   db->v.step_tab = db->d_step; db->v.step_n = (uint32_t)n;
   return UGS_OK;
 }
@@ -468,11 +469,11 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
   if ((rc = build_tables(*p, T)) != UGS_OK) return fail(rc);
 #define DBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return fail(UGS_E_HIP); } } while (0)
   DBCHK(ugs_malloc(&db->d_tab, sizeof(UgsTables)));
-  DBCHK(hipMemcpy(db->d_tab, &T, sizeof(T), hipMemcpyHostToDevice));
+  DBCHK(ugs_h2d(db->d_tab, &T, sizeof(T), db->stream));
   DBCHK(ugs_malloc(&db->d_seqs, nletters + 64));          // padded: the aligner prefetches letters as unaligned dwords
   DBCHK(ugs_malloc(&db->d_offs, ((size_t)nseq + 1) * sizeof(uint64_t)));
-  if (nletters) DBCHK(hipMemcpy(db->d_seqs, seqs, nletters, hipMemcpyHostToDevice));
-  DBCHK(hipMemcpy(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (nletters) DBCHK(ugs_h2d(db->d_seqs, seqs, nletters, db->stream));      // (through the library's page-locked staging buffer: ugs_host.h)
+  DBCHK(ugs_h2d(db->d_offs, offs, ((size_t)nseq + 1) * sizeof(uint64_t), db->stream));
   if (p->dbmask < 0 || p->dbmask > 3) { ugs_set_error("dbmask must be 0..3"); return fail(UGS_E_ARG); }
   if ((rc = ugs_launch_mask(db->d_seqs, db->d_offs, nseq, p->dbmask == 3 ? (1 | ((p->is_nucleo ? 'N' : 'X') << 8)) : p->dbmask, db->stream)) != UGS_OK) return fail(rc);
   if (p->is_nucleo) {                                       // the masked letters packed 2 bits each (UgsDbView::pk)
@@ -526,8 +527,8 @@ extern "C" int ugs_db_create(const ugs_params *p, const char *seqs, const uint64
     int8_t xsub2[1024]; uint8_t xcls[256];
     ugs_xdrop_tables(p->is_nucleo, p->match * 2.0f, p->mismatch * 2.0f, xsub2, xcls);
     if (ugs_malloc(&db->d_xsub2, 1024) != hipSuccess || ugs_malloc(&db->d_xcls, 256) != hipSuccess ||
-        hipMemcpy(db->d_xsub2, xsub2, 1024, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_xcls, xcls, 256, hipMemcpyHostToDevice) != hipSuccess) { ugs_set_error("x-drop tables: HIP error"); return fail(UGS_E_HIP); }
+        ugs_h2d(db->d_xsub2, xsub2, 1024, db->stream) != hipSuccess ||
+        ugs_h2d(db->d_xcls, xcls, 256, db->stream) != hipSuccess || hipStreamSynchronize(db->stream) != hipSuccess) { ugs_set_error("x-drop tables: HIP error"); return fail(UGS_E_HIP); }
     UgsLocalView &lv = db->lv;
     lv.sub2 = db->d_xsub2; lv.cls = db->d_xcls;
     lv.open2 = (int)(p->local_open * 2.0f); lv.ext2 = (int)(p->local_ext * 2.0f);
@@ -545,7 +546,7 @@ static int upload_keys(uint32_t **d, const uint32_t *h, size_t n, bool *have, hi
   *have = false;
   if (!h) return UGS_OK;
   if (!*d) HIPCHK(ugs_malloc(d, std::max<size_t>(n, 1) * 4));
-  if (n) HIPCHK(hipMemcpyAsync(*d, h, n * 4, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(ugs_h2d(*d, h, n * 4, st));
   HIPCHK(hipStreamSynchronize(st));
   *have = true;
   return UGS_OK;

@@ -9,6 +9,15 @@
 
 static const size_t LDS_MAX = 160 * 1024;
 
+// Caller-owned host memory -> device WITHOUT handing a pageable caller pointer to the runtime (ugs_alloc.cpp).  hipMemcpy from pageable
+// memory makes the runtime page-lock the caller's pages on the fly and lets the GPU read them in place; the one reproduction of round 5's
+// silent abort (round 6, the round-5 tree on torch's bundled ROCm 7.0 runtime, 1 of 6 full suites) was a GPU memory fault at an address
+// inside the HOST heap while the main thread was in ugs_db_create - i.e. in such a copy.  The library's own uploads of caller memory
+// (database letters and offsets, tables, pair keys, ugs_db_append) therefore go through a page-locked staging buffer the library owns:
+// memcpy on the host, DMA from the staging buffer, two slots in flight.  A source that IS page-locked (ugs_host_register, hipHostMalloc)
+// is copied directly.  Ordered on `st`; the source may be reused when the call returns.
+hipError_t ugs_h2d(void *dst, const void *src, size_t bytes, hipStream_t st);
+
 // Debug / tuning switches, read from the environment ONCE per database handle, at ugs_db_create (never inside a search call).  Not part of the ABI: they exist
 // for A/B measurements and fault isolation; the test-suite runs with none of them set unless a test names one.
 struct UgsTune {
