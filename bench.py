@@ -3,7 +3,7 @@
 
 One "step" = one pass of the hot path over one batch of synthetic queries: H2D upload of the batch, ranking +
 alignment kernels, hit table back on the host.  The upload of step i+1's batch is issued while step i's kernels
-run (two batches in flight, a copy stream per batch), and every step searches a batch that differs from the one
+run (two batch objects in flight, a copy stream per batch), and every step searches a batch that differs from the one
 before it; both are inside the timed region.
 
   every N  BASELINE.json configs[1] (C2), the configuration the metric is quoted on: every GPU searches its own batch of
@@ -391,6 +391,9 @@ def main():
                     "shards (125 k queries per GPU at N = 8: set-up, launch gaps and the gather are then a visible share of a step)")
     ap.add_argument("--force-gather", action="store_true", help="--gpus 1 only: run the N > 1 step (C++ gather through a communicator "
                     "of one rank) instead of the plain fetch - exercises that code on a one-GPU box")
+    ap.add_argument("--batches", type=int, default=2, help="batch objects of the pipeline (searches enqueued ahead = batches - 1).  Measured in r6 with "
+                    "three (the host's gather of step i then never delays the enqueue of a later step): C2 48.5 instead of 45.9 ms per step, the strong-"
+                    "scaling proxy 8.1 instead of 8.2 ms - the proxy's 1.3 ms outside the search kernels is GPU-side work of the emulated peers, not host latency")
     ap.add_argument("--db", type=int, default=0, help="DB sequences (default: the workload's)")
     ap.add_argument("--queries", type=int, default=0, help="queries per step: per GPU for C2 (weak), over all GPUs for C4 (default: the workload's)")
     ap.add_argument("--length", type=int, default=250)
@@ -499,7 +502,7 @@ def main():
     gdb = capi.UgsDB(p, db.seqs, db.offs, device=local_rank)
     t_index = time.time() - t0
     max_letters = max(int(q.offs[-1]) for q in qsets)
-    bats = [capi.UgsBatch(gdb, shard_n, max_letters) for _ in range(2)]
+    bats = [capi.UgsBatch(gdb, shard_n, max_letters) for _ in range(max(2, args.batches))]
     for q in qsets:                                                 # page-locked once: uploads are then true async DMA
         capi._chk(capi.lib().ugs_host_register(q.seqs.ctypes.data, q.seqs.nbytes))
     if world > 1:
@@ -540,8 +543,9 @@ def main():
         for a in gbuf:
             capi._chk(capi.lib().ugs_host_register(a.ctypes.data, a.nbytes))
     t0 = time.time()
-    bats[0].upload(qsets[0].seqs, qsets[0].offs)                    # the first batch of the pipeline
-    bats[0].search(); bats[0].sync()                                # (also sizes the scratch buffers)
+    for k, b in enumerate(bats):                                    # one search per batch object: sizes its scratch buffers outside the timed region
+        b.upload(qsets[k % 2].seqs, qsets[k % 2].offs)
+        b.search(); b.sync()
     t_upload = time.time() - t0
 
     def barrier():
@@ -585,44 +589,48 @@ def main():
         t_parts["gather"] += time.time() - tg
         return multigpu.merge_tables(*got) if rank == 0 else None
 
-    def step(last):
-        """step i of a run: the search of step i + 1 is enqueued BEHIND step i's kernels before the host waits for step i (the GPU never
-        waits for the host between steps), then step i's hit table travels (to the host; for N > 1 first GPU to GPU to rank 0) while
-        step i + 1's kernels run, then the batch of step i + 2 is uploaded into the batch object that has just been drained."""
-        i = state["i"]
-        state["i"] = i + 1
-        cur, nxt = bats[i % 2], bats[(i + 1) % 2]
+    def step(i, n):
+        """step i of a run of n: the searches of the next NB - 1 steps are already enqueued BEHIND step i's kernels when the host waits
+        for step i (the GPU never waits for the host between steps - with three batch objects not even while step i's hit table
+        travels: r6, a trace of the strong-scaling proxy showed the GPU idle for the host's gather + upload with two), then step i's
+        hit table travels (to the host; for N > 1 first GPU to GPU to rank 0) while the next steps' kernels run, then the batch of step
+        i + NB is uploaded into the batch object that has just been drained."""
+        NB = len(bats)
+        cur = bats[i % NB]
         ta = time.time()
-        if not last:
-            nxt.search()                                            # enqueue: waits (on the GPU) for nxt's upload and for cur's kernels
+        if i + NB - 1 < n:
+            bats[(i + NB - 1) % NB].search()                        # enqueue: waits (on the GPU) for its upload and for the kernels in front
         tw = time.time()
         cur.sync()
         t_parts["sync_wait"] += time.time() - tw                    # the host waiting for step i's kernels
         out = collect(cur)
         st, kh = cur.stats(), cur.kernel_hits()                     # (this step's counters and event times: the upload below starts a new batch)
         tu = time.time()
-        if not last:
-            cur.upload(qsets[i % 2].seqs, qsets[i % 2].offs)        # step i + 2's batch travels while step i + 1's kernels run
+        if i + NB < n:
+            q = qsets[(i + NB) % 2]
+            cur.upload(q.seqs, q.offs)                              # step i + NB's batch travels while the steps in between run
         t_parts["upload_issue"] += time.time() - tu
         t_parts["search_sync"] += time.time() - ta
         return out, st, kh
 
     def run_steps(n, timed):
-        """both batches uploaded (inputs resident in HBM), then - between barriers when timed - the first search enqueued and EXACTLY n steps"""
-        state.clear(); state["i"] = 0
-        bats[0].upload(qsets[0].seqs, qsets[0].offs)
-        bats[1].upload(qsets[1].seqs, qsets[1].offs)
-        bats[0].sync_upload(); bats[1].sync_upload()
+        """every batch object uploaded (inputs resident in HBM), then - between barriers when timed - the first NB - 1 searches enqueued and
+        EXACTLY n steps; step j searches batch object j % NB, which holds query set j % 2 (a batch different from the one before)"""
+        NB = len(bats)
+        for k, b in enumerate(bats):
+            b.upload(qsets[k % 2].seqs, qsets[k % 2].offs)
+        for b in bats:
+            b.sync_upload()
         for k in t_parts:
             t_parts[k] = 0.0
         if timed:
             barrier()
         t0 = time.time()
         stats, khits, out = [], [], None
-        if n:
-            bats[0].search()
+        for j in range(min(NB - 1, n)):
+            bats[j].search()
         for i in range(n):
-            out, st, kh = step(i == n - 1)
+            out, st, kh = step(i, n)
             stats.append(st)
             khits.append(kh)
         if timed:
@@ -694,7 +702,7 @@ def main():
                 pb.set_query_base(r * n8)
                 peers.append(pb)
             psteps, pwarm = max(args.steps, 10), 2
-            small = [capi.UgsBatch(gdb, n8, max(int(q.offs[-1]) for q in sub_sets)) for _ in range(2)]
+            small = [capi.UgsBatch(gdb, n8, max(int(q.offs[-1]) for q in sub_sets)) for _ in range(len(bats))]
             # (the shard's letters are views of the page-locked full batches)
             from usearch12_amd.abi import HIT_DTYPE
             cap_h = shard_n * (p.max_accepts or 64) + 1
