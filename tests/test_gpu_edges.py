@@ -166,3 +166,38 @@ def test_fully_redundant_database_in_one_partition(limit, monkeypatch):
     for big in (0, 100):
         g = both(db, qs, ident=0.97, big=big, max_accepts=4, max_rejects=8)
         assert g[1][0] == 4
+
+
+def test_guard_allocator_and_abort_handler_are_alive():
+    """The fault-isolation switches of round 6 (usearch12_amd/csrc/ugs_alloc.cpp) keep working: a child process with UGS_GUARD_ALLOC=2 (every
+    device buffer a mapping of its own, right-aligned against an unmapped page), UGS_ABORT_BT and UGS_KERNEL_LOG runs a small search on both
+    ranking paths bit-exactly against the oracle, reports guarded allocations, names its kernels - and no kernel steps outside its buffers."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, ctypes
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+import numpy as np
+from usearch12_amd import capi, synth
+import orc
+for big in (100, 100000):
+    db = synth.make_db(77, 4000, 250); qs = synth.make_queries(77, db, 300, 250)
+    kw = dict(is_nucleo=True, id=0.97, big=big)
+    h, nh, pool = capi.UgsDB(capi.params(**kw), db.seqs, db.offs, device=0).search(qs.seqs, qs.offs)
+    oh, onh, opool = orc.OrcDB(orc.params(**kw), db.seqs, db.offs).search(qs.seqs, qs.offs)
+    assert np.array_equal(nh, onh)
+    for f in h.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(h[f], oh[f]), f
+out = (ctypes.c_ulonglong * 5)()
+capi.lib().ugs_debug_alloc_stats(out)
+print("ALLOC", list(out))
+''' % (ROOT, ROOT)
+    env = dict(os.environ, UGS_GUARD_ALLOC="2", UGS_ABORT_BT="stderr", UGS_KERNEL_LOG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    st = [int(x) for x in r.stdout.split("ALLOC")[1].strip().strip("[]").split(",")]
+    assert st[0] == 2 and st[1] > 40 and st[2] > 10 and st[4] > 0, st
+    assert "[ugs] kernel k_align launched" in r.stderr and "[ugs] kernel k_align done" in r.stderr and "Memory access fault" not in r.stderr

@@ -893,6 +893,7 @@ static int plan_launch(ugs_batch *b)
     // after the index changed; cluster_fast's index grows batch by batch and keeps the 32-bit stream.
     b->r2.post16 = nullptr;
     if (!b->cl_mode && db->tune.r2_p16 != 0 && db->v.np2 <= 512u && db->v.gsize2 <= 65536u && db->n_postings) {
+      std::lock_guard<std::mutex> lk(db->post16_mu);
       if (!db->d_post16 || db->post16_gen != db->index_gen) {
         const uint64_t want = db->n_postings + 512;                 // (a chunk reads up to 256 + 3 elements past a sub-row's start)
         if (!db->d_post16 || want > db->post16_cap) {

@@ -3,6 +3,7 @@
 #include "ugs_dev.h"
 #include "ugs_rank2.h"
 #include <vector>
+#include <mutex>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ugs_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return UGS_E_HIP; } } while (0)
 #define RCCHK(x) do { int rc_ = (x); if (rc_ != UGS_OK) return rc_; } while (0)
@@ -54,6 +55,7 @@ struct ugs_db {
   uint8_t *d_seqs; uint64_t *d_offs; uint64_t *d_row_off; uint32_t *d_postings; uint32_t *d_part;
   uint32_t *d_part2; uint64_t part2_cap;   // dense Big-path indexes: the partition table of the bitmap ranking kernel (ugs_rank2.hip)
   uint16_t *d_post16; uint64_t post16_cap; // ... and the postings as 16-bit offsets inside their partition (built on first use by a plain search: plan_launch)
+  std::mutex post16_mu;                    // (the copy is made inside a search plan: two host threads may plan batches of one handle)
   uint64_t index_gen, post16_gen;          // the index as it stands (counts ugs_db_replan calls) / the one d_post16 was made from
   uint2 *d_pk; uint64_t pack_cap;   // nt: 2-bit letters + "other" bits, one uint2 per 16 letters (ugs_dev.h UgsDbView::pk)
   uint32_t *d_step; UgsTables *d_tab;
