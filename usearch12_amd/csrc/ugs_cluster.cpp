@@ -39,7 +39,9 @@ int ugs_index_merge(const uint64_t *old_off, const uint32_t *old_post, const uin
                     uint32_t slots, uint32_t base_target, uint64_t *new_off, uint32_t *new_post, uint64_t n_total,
                     uint32_t *d_max_row, hipStream_t st);
 int ugs_launch_inbatch(const UgsBatchView &bv, const uint64_t *brow_off, const uint32_t *bpost, uint32_t ns_max, int small_path,
-                       uint32_t max_rej, int num_cu, uint32_t *ent_n, const uint32_t *ent_off, uint2 *ent, hipStream_t st);
+                       uint32_t max_rej, int num_cu, uint32_t *ent_n, const uint32_t *ent_off, uint2 *ent, hipStream_t st,
+                       uint32_t slot_cap, const uint32_t *list, uint32_t n_list);
+#define INBATCH_SLOTS 16u        // entries per unit the first in-batch launch delivers (a unit has about one; the few with more get a second launch)
 
 #define POS_BITS 44
 #define CMAXV 4095u
@@ -450,6 +452,8 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
   const uint64_t umax = (uint64_t)Bmax * ns;
   DevBuf d_ucost, d_uorder, d_ohist;
   RCCHK(d_ucost.need(umax * 4)); RCCHK(d_uorder.need(umax * 4)); RCCHK(d_ohist.need(512 * 4));
+  DevBuf d_slots, d_elist;
+  std::vector<uint2> h_slots, h_over; std::vector<uint32_t> h_elist, h_ooff;
   DevBuf d_ckey, d_clev, d_clinfo, d_walk, d_entn, d_entoff, d_ent, d_pmap, d_pcand, d_pcandn, d_phitn, d_phits, d_pcompact, d_pqn, d_pqoff, d_scan;
   RCCHK(d_ckey.need(umax * K * 8)); RCCHK(d_clev.need(umax * UGS_CL_EV * 8)); RCCHK(d_clinfo.need(umax * 16)); RCCHK(d_walk.need(umax * 4));
   RCCHK(d_entn.need(umax * 4)); RCCHK(d_entoff.need(umax * 4));
@@ -498,20 +502,42 @@ extern "C" int ugs_cluster_fast_sorted(const ugs_params *pp, const char *seqs, c
     uint64_t *d_brow = nullptr; uint32_t *d_bpost = nullptr; uint64_t n_bpost = 0; uint32_t bmax = 0;
     RCCHK(ugs_build_index(db->d_tab, b->d_qseqs, b->d_qoffs, B, stage.size(), p.word_len, db->v.alpha, db->v.slots, &d_brow, &d_bpost, &n_bpost, &bmax, st));
     struct FreeIdx { uint64_t *a; uint32_t *b; ~FreeIdx() { (void)ugs_free(a); (void)ugs_free(b); } } free_idx{d_brow, d_bpost};
-    RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, nullptr, nullptr, st));
+    // (r6) ONE launch settles nearly every unit: its count and its first INBATCH_SLOTS entries; the few units with more entries (reads
+    // without a frozen hit among many relatives in their own batch) get a second launch over their list with exact offsets.  Before: a
+    // count-only launch, a host scan and a second FULL launch - the kernel ran twice over every unit (0.9 s of C3's GPU time).
+    RCCHK(d_slots.need((size_t)units * INBATCH_SLOTS * 8));
+    RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, nullptr, (uint2 *)d_slots.p, st,
+                             INBATCH_SLOTS, nullptr, 0));
     H.nq = B; H.ns = ns; H.K = K;
     H.ent_n.resize(units); H.ent_off.resize(units);
+    h_slots.resize((size_t)units * INBATCH_SLOTS);
     HIPCHK(hipMemcpyAsync(H.ent_n.data(), d_entn.p, (size_t)units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_slots.data(), d_slots.p, (size_t)units * INBATCH_SLOTS * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    uint64_t n_ent = 0;
-    for (uint32_t u = 0; u < units; ++u) { H.ent_off[u] = (uint32_t)n_ent; n_ent += H.ent_n[u]; }
+    uint64_t n_ent = 0, n_over = 0;
+    h_elist.clear(); h_ooff.assign(units, 0);
+    for (uint32_t u = 0; u < units; ++u) {
+      H.ent_off[u] = (uint32_t)n_ent; n_ent += H.ent_n[u];
+      if (H.ent_n[u] > INBATCH_SLOTS) { h_elist.push_back(u); h_ooff[u] = (uint32_t)n_over; n_over += H.ent_n[u]; }
+    }
     if (n_ent > 0x7fffffffull) { ugs_set_error("in-batch candidate list overflow"); return UGS_E_ENVELOPE; }
     H.ent.resize(n_ent);
-    if (n_ent) {
-      RCCHK(d_ent.need(n_ent * 8));
-      HIPCHK(hipMemcpyAsync(d_entoff.p, H.ent_off.data(), (size_t)units * 4, hipMemcpyHostToDevice, st));
-      RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, (const uint32_t *)d_entoff.p, (uint2 *)d_ent.p, st));
-      HIPCHK(hipMemcpyAsync(H.ent.data(), d_ent.p, n_ent * 8, hipMemcpyDeviceToHost, st));
+    h_over.resize(n_over);
+    if (n_over) {
+      RCCHK(d_ent.need(n_over * 8));
+      RCCHK(d_elist.need(h_elist.size() * 4));
+      HIPCHK(hipMemcpyAsync(d_entoff.p, h_ooff.data(), (size_t)units * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(d_elist.p, h_elist.data(), h_elist.size() * 4, hipMemcpyHostToDevice, st));
+      RCCHK(ugs_launch_inbatch(b->v, d_brow, d_bpost, b->rl.ns_max, small_path, (uint32_t)p.max_rejects, db->num_cu, (uint32_t *)d_entn.p, (const uint32_t *)d_entoff.p, (uint2 *)d_ent.p, st,
+                               0, (const uint32_t *)d_elist.p, (uint32_t)h_elist.size()));
+      HIPCHK(hipMemcpyAsync(h_over.data(), d_ent.p, n_over * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    for (uint32_t u = 0; u < units; ++u) {
+      const uint32_t n = H.ent_n[u];
+      if (!n) continue;
+      const uint2 *src = n > INBATCH_SLOTS ? h_over.data() + h_ooff[u] : h_slots.data() + (size_t)u * INBATCH_SLOTS;
+      memcpy(H.ent.data() + H.ent_off[u], src, (size_t)n * 8);
     }
     HIPCHK(hipStreamSynchronize(st));
     C->st.s_inbatch += (float)(now_s() - tq); tq = now_s();

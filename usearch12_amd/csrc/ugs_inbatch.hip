@@ -79,11 +79,14 @@ template <int CB> struct CTbl {
 //   pass 2: rows in scan order; a posting's counter is read and cleared at once, so only the first touch of a target sees
 //           its count; kept: (count, first position) sorts before the key at which the frozen walk ended (`tkey`) - nothing
 //           behind it can be reached by the merged walk (ugs_cluster.cpp).
-// ent == null: count only (ent_n[unit]); else write (j, count | row << 16) at ent_off[unit] in scan order.
+// Entries (j, count | row << 16) in scan order.  Two launch shapes (r6; before: a count-only launch, a host scan, a second full launch):
+//   slot_cap > 0  every unit: its count into ent_n[unit] and its first slot_cap entries into ent[unit * slot_cap ..] - a unit has about
+//                 one entry on average (C3: 5.3 M entries for 5 M reads), so this one launch settles nearly all units;
+//   slot_cap == 0 only the units of `list` (the ones that had more): all their entries at ent_off[unit].
 template <int CB>
 __global__ __launch_bounds__(256) void k_inbatch(UgsBatchView bv, const uint64_t *brow_off, const uint32_t *bpost, uint32_t ns_max,
                                                  uint32_t small_path, uint32_t max_rej, uint32_t tbl_words, uint32_t *ent_n,
-                                                 const uint32_t *ent_off, uint2 *ent)
+                                                 const uint32_t *ent_off, uint2 *ent, uint32_t slot_cap, const uint32_t *list, uint32_t n_list)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;      // (wave index in an SGPR)
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256) void k_inbatch(UgsBatchView bv, const uint64_t
   uint32_t *tbl = (uint32_t *)(smem + (size_t)wave * wave_bytes);
   uint32_t *ra = tbl + tbl_words + 64, *re = ra + ns_max;
   for (uint32_t k = lane; k < tbl_words + 64; k += 64) tbl[k] = 0;
-  const uint32_t units = bv.nq * bv.nstrand, K = bv.K;
-  for (uint32_t unit = blockIdx.x * wpb + wave; unit < units; unit += gridDim.x * wpb) {
+  const uint32_t units = list ? n_list : bv.nq * bv.nstrand, K = bv.K;
+  for (uint32_t ui = blockIdx.x * wpb + wave; ui < units; ui += gridDim.x * wpb) {
+    const uint32_t unit = list ? list[ui] : ui;
     const uint32_t qi = unit / bv.nstrand;
     const uint32_t ns = bv.unit_ns[unit];
     uint32_t n_out = 0;
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(256) void k_inbatch(UgsBatchView bv, const uint64_t
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // pass 2
-      const uint32_t off = ent ? ent_off[unit] : 0u;
+      const uint32_t off = slot_cap ? unit * slot_cap : ent_off[unit];
+      const uint32_t cap = slot_cap ? slot_cap : 0xffffffffu;
       for (uint32_t r = 0; r < ns; ++r) {
         const uint32_t a = ra[r], e = re[r];
         for (uint32_t k0 = a; k0 < e; k0 += 64) {
@@ -131,21 +136,24 @@ __global__ __launch_bounds__(256) void k_inbatch(UgsBatchView bv, const uint64_t
           const uint64_t key = ((uint64_t)(CL_CMAXV - c) << CL_POS_BITS) | pos;
           const bool keep = c != 0 && key < tkey;
           const uint64_t m = __ballot(keep);
-          if (keep && ent) ent[(uint64_t)off + n_out + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(j, c | (r << 16));
+          const uint32_t at = n_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (keep && at < cap) ent[(uint64_t)off + at] = make_uint2(j, c | (r << 16));
           n_out += (uint32_t)__popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
-    if (lane == 0 && !ent) ent_n[unit] = n_out;
+    if (lane == 0 && slot_cap) ent_n[unit] = n_out;
   }
 }
 
 int ugs_launch_inbatch(const UgsBatchView &bv, const uint64_t *brow_off, const uint32_t *bpost, uint32_t ns_max, int small_path,
-                       uint32_t max_rej, int num_cu, uint32_t *ent_n, const uint32_t *ent_off, uint2 *ent, hipStream_t st)
+                       uint32_t max_rej, int num_cu, uint32_t *ent_n, const uint32_t *ent_off, uint2 *ent, hipStream_t st,
+                       uint32_t slot_cap, const uint32_t *list, uint32_t n_list)
 {
-  const uint32_t units = bv.nq * bv.nstrand;
+  const uint32_t units = list ? n_list : bv.nq * bv.nstrand;
   if (!units) return UGS_OK;
+  if (!ent || (slot_cap == 0) != (list != nullptr)) { ugs_set_error("in-batch counts: slots for every unit, or a list of units with offsets"); return UGS_E_ARG; }
   const int bits = ns_max <= 15 ? 4 : (ns_max <= 255 ? 8 : 16);
   const uint32_t tbl_words = (uint32_t)(((uint64_t)bv.nq * bits + 31) / 32);
   const size_t wave_bytes = ((size_t)tbl_words + 64) * 4 + (size_t)ns_max * 8;
@@ -159,7 +167,7 @@ int ugs_launch_inbatch(const UgsBatchView &bv, const uint64_t *brow_off, const u
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * wpb, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + wpb - 1) / wpb, (uint64_t)num_cu * per_cu));
   UgsBatchView a0 = bv; uint32_t a3 = ns_max, a4 = (uint32_t)small_path, a5 = max_rej, a6 = tbl_words;
-  void *args[] = {&a0, &brow_off, &bpost, &a3, &a4, &a5, &a6, &ent_n, &ent_off, &ent};
+  void *args[] = {&a0, &brow_off, &bpost, &a3, &a4, &a5, &a6, &ent_n, &ent_off, &ent, &slot_cap, &list, &n_list};
   if (ugs_kernel_log) ugs_before_launch("k_inbatch");
   HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(64 * wpb), args, lds, st));
   if (ugs_kernel_log) ugs_after_launch("k_inbatch", st);
