@@ -556,7 +556,6 @@ def main():
             capi._chk(capi.lib().ugs_device_synchronize(local_rank))
 
     t_parts = {"search_sync": 0.0, "fetch": 0.0, "gather": 0.0, "upload_issue": 0.0, "sync_wait": 0.0, "gather_exchange": 0.0, "gather_d2h": 0.0}
-    state = {"i": 0}
 
     def collect(b):
         """the hit table of a synced batch to the host: plain fetch (one GPU), the C++ gather to rank 0 (N ranks over RCCL),
