@@ -140,10 +140,11 @@ extern "C" int ugs_debug_alloc_stats(unsigned long long out[5])
 namespace {
 constexpr size_t STAGE_BYTES = 8ull << 20;      // per slot
 struct Stage {
-  void *p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int dev = -1; unsigned next = 0;
+  void *p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; bool ready = false; unsigned next = 0;
   ~Stage() { /* released with the process: the device may be gone when thread-locals are destroyed */ }
 };
-thread_local Stage g_stage;
+constexpr int STAGE_DEVS = 16;
+thread_local Stage g_stage[STAGE_DEVS];      // one pair of slots per (host thread, device): a thread that walks over the devices keeps them all
 }  // namespace
 
 hipError_t ugs_h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
@@ -159,14 +160,18 @@ hipError_t ugs_h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  Stage &sg = g_stage;
-  if (sg.dev != dev) {                                                             // first use on this thread / another device: new slots (the old ones stay)
+  if (dev < 0 || dev >= STAGE_DEVS) {                                              // (no slots for such a device: the plain synchronous copy)
+    if ((e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+  }
+  Stage &sg = g_stage[dev];
+  if (!sg.ready) {                                                                 // first use of this device on this thread
     for (int k = 0; k < 2; ++k) {
-      sg.p[k] = nullptr; sg.ev[k] = nullptr; sg.busy[k] = false;
-      if ((e = hipHostMalloc(&sg.p[k], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&sg.ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+      if (!sg.p[k] && (e = hipHostMalloc(&sg.p[k], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) return e;
+      if (!sg.ev[k] && (e = hipEventCreateWithFlags(&sg.ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+      sg.busy[k] = false;
     }
-    sg.dev = dev; sg.next = 0;
+    sg.ready = true; sg.next = 0;
   }
   const char *s = (const char *)src; char *d = (char *)dst;
   for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
