@@ -84,3 +84,25 @@ def test_cli_refuses_what_the_device_path_does_not_implement():
     for opt in ("-quicksort", "-nosuchoption"):
         r = subprocess.run([cli, "-usearch_global", "/nonexistent.fa", "-db", "/nonexistent2.fa", "-id", "0.97", opt], capture_output=True, text=True)
         assert r.returncode != 0 and "unknown option" in r.stderr
+
+
+def test_no_process_that_loads_libugs_imports_torch():
+    """torch's wheel bundles a HIP runtime, an HSA runtime and an RCCL under the system libraries' SONAMEs: a process that holds torch AND
+    libugs.so runs the product on torch's ROCm 7.0 runtime (torch first) or maps two runtimes and corrupts its heap (libugs first) - round 5's
+    silent abort lived there (DESIGN.md section 4 "The crash").  So: nothing that a test process, bench.py or the package imports may import
+    torch; the one file that does (tests/gloo_worker.py, a child process of the gloo tests) must never load the library."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tests", "*.py")) + glob.glob(os.path.join(root, "usearch12_amd", "*.py")) + \
+        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    offenders = []
+    for f in files:
+        tree = ast.parse(open(f).read())
+        for node in ast.walk(tree):
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+            if any(n == "torch" or n.startswith("torch.") for n in names):
+                offenders.append(os.path.relpath(f, root))
+    assert sorted(set(offenders)) == ["tests/gloo_worker.py"], offenders
+    worker = open(os.path.join(root, "tests", "gloo_worker.py")).read()
+    assert "capi" not in worker.replace('"usearch12_amd.capi" not in sys.modules', "")
